@@ -1,0 +1,197 @@
+"""Python face of the CPU oracle.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg, never by the product package.
+
+Two layers:
+  * an independent pure-numpy restatement of the reference's index function and
+    golden convention (used to pin the C oracle), and
+  * ctypes bindings to oracle/libxeng_oracle.so (xeng_oracle.c), which is what
+    the GPU parity tests compare the HIP path against at full size.
+Citations are relative to /root/reference/pipeline.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    """gcc-compile xeng_oracle.c -> libxeng_oracle.so (no-op when up to date)."""
+    so = os.path.join(HERE, "libxeng_oracle.so")
+    src = os.path.join(HERE, "xeng_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", HERE, "-B", "libxeng_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(HERE, "libxeng_oracle.so")
+        if not os.path.exists(so):
+            build()
+        L = ctypes.CDLL(so)
+        vp, i, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+        L.orc_num_threads.restype = i
+        L.orc_xgpu_per_chan.restype = i64
+        L.orc_xgpu_per_chan.argtypes = [i, i]
+        L.orc_regtile_index.restype = i64
+        L.orc_regtile_index.argtypes = [i, i, i]
+        L.orc_xgpu_correlate.argtypes = [vp, vp, i, i, i, i]
+        L.orc_xgpu_get_order.argtypes = [vp, vp, vp, i, i]
+        L.orc_xgpu_reorder.argtypes = [vp, vp, vp, vp, i, i, i]
+        L.orc_xgpu_subselect.argtypes = [vp, vp, vp, vp, i, i, i, i, i]
+        L.orc_map_i32.argtypes = [vp, vp, ctypes.c_size_t, i]
+        L.orc_map_i32.restype = None
+        L.orc_beamform.argtypes = [vp, vp, vp, i, i, i, i]
+        L.orc_beamform_integrate.argtypes = [vp, vp, i, i, i, i]
+        L.orc_beamform_integrate_single.argtypes = [vp, vp, i, i, i, i, i]
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+# ----------------------------------------------------------------------------
+# numpy restatement (independent of the C code)
+# ----------------------------------------------------------------------------
+def decode(u8):
+    """corr_block.py:270-275 / make_golden_inputs.py:145-149."""
+    u8 = np.asarray(u8, dtype=np.uint8)
+    re = (u8 >> 4).astype(np.int16)
+    re[re > 7] -= 16
+    im = (u8 & 0xF).astype(np.int16)
+    im[im > 7] -= 16
+    return re, im
+
+
+def per_chan(nstand, npol=2):
+    """corr_block.py:231."""
+    return (nstand // 2 + 1) * (nstand // 4) * npol * npol * 4
+
+
+def tri_index(i, j):
+    """corr_block.py:27-28."""
+    return (i * (i + 1)) // 2 + j
+
+
+def regtile_index(in0, in1, nstand):
+    """corr_block.py:37-58 (valid for in1 >= in0)."""
+    a0, a1, p0, p1 = in0 >> 1, in1 >> 1, in0 & 1, in1 & 1
+    quadrant_index = tri_index(a1 // 2, a0 // 2)
+    quadrant = 2 * (a0 & 1) + (a1 & 1)
+    quadrant_size = (nstand // 2 + 1) * nstand // 4
+    return (quadrant * quadrant_size + quadrant_index) * 4 + 2 * p1 + p0
+
+
+def golden_corr(vin):
+    """make_golden_inputs.py:150-158: out[c,s0,s1,p0,p1] = sum_t x[t,c,s0,p0]*conj(x[t,c,s1,p1]).
+    vin uint8[T,C,S,P] -> (re, im) int64 arrays."""
+    re, im = decode(vin)
+    re = re.astype(np.int64)
+    im = im.astype(np.int64)
+    rr = np.einsum("tcap,tcbq->cabpq", re, re) + np.einsum("tcap,tcbq->cabpq", im, im)
+    ii = np.einsum("tcap,tcbq->cabpq", im, re) - np.einsum("tcap,tcbq->cabpq", re, im)
+    return rr, ii
+
+
+def xgpu_lookup_numpy(planar, nstand, nchan):
+    """xgpu_test.py:99-133 in reverse: read the planar xGPU buffer through
+    regtile_index for every s1 >= s0 and return (re, im)[c,s0,s1,p0,p1] of
+    conj(x[s0,p0]) * x[s1,p1] (zero for s1 < s0)."""
+    pc = per_chan(nstand)
+    planar = np.asarray(planar, dtype=np.int32).reshape(2, nchan, pc)
+    s0, s1, p0, p1 = np.meshgrid(np.arange(nstand), np.arange(nstand), [0, 1], [0, 1], indexing="ij")
+    idx = regtile_index(2 * s0 + p0, 2 * s1 + p1, nstand)
+    valid = s1 >= s0
+    idx = np.where(valid, idx, 0)
+    re = np.where(valid, planar[0][:, idx], 0)
+    im = np.where(valid, planar[1][:, idx], 0)
+    return re, im
+
+
+# ----------------------------------------------------------------------------
+# C oracle wrappers
+# ----------------------------------------------------------------------------
+def xgpu_correlate(vin, nstand, nchan, acc=None):
+    """vin uint8[T,C,nstand,2] (any shape with that many bytes).  Returns/updates
+    the planar int32[2*matlen] accumulator (xgpu_test.py:76-83 semantics: call
+    with acc=None for the first gulp, pass acc back for the following ones)."""
+    vin = np.ascontiguousarray(vin, dtype=np.uint8)
+    ntime = vin.size // (nchan * nstand * 2)
+    assert ntime * nchan * nstand * 2 == vin.size
+    accumulate = acc is not None
+    if acc is None:
+        acc = np.empty(2 * per_chan(nstand) * nchan, dtype=np.int32)
+    rc = lib().orc_xgpu_correlate(_p(vin), _p(acc), ntime, nchan, nstand, int(accumulate))
+    assert rc == 0, rc
+    return acc
+
+
+def xgpu_get_order(antpol_to_input):
+    a = np.ascontiguousarray(antpol_to_input, dtype=np.int32)
+    nstand, npol = a.shape
+    bl = np.zeros((nstand, nstand, npol, npol), dtype=np.int32)
+    cj = np.zeros_like(bl)
+    lib().orc_xgpu_get_order(_p(a), _p(bl), _p(cj), nstand, npol)
+    return bl, cj
+
+
+def xgpu_reorder(planar, bl, cj, nchan):
+    nstand, _, npol, _ = bl.shape
+    planar = np.ascontiguousarray(planar, dtype=np.int32)
+    out = np.zeros((nstand, nstand, npol, npol, nchan, 2), dtype=np.int32)
+    lib().orc_xgpu_reorder(_p(planar), _p(out), _p(np.ascontiguousarray(bl)), _p(np.ascontiguousarray(cj)),
+                           nstand, npol, nchan)
+    return out
+
+
+def xgpu_subselect(planar, vismap, conj, nchan, nchan_sum, nstand, npol=2):
+    planar = np.ascontiguousarray(planar, dtype=np.int32)
+    vismap = np.ascontiguousarray(vismap, dtype=np.int32)
+    conj = np.ascontiguousarray(conj, dtype=np.int32)
+    out = np.zeros((nchan // nchan_sum, vismap.size, 2), dtype=np.int32)
+    rc = lib().orc_xgpu_subselect(_p(planar), _p(out), _p(vismap), _p(conj), vismap.size, nchan, nchan_sum, nstand, npol)
+    assert rc == 0
+    return out
+
+
+def map_i32(a, b, add):
+    assert a.dtype == np.int32 and b.dtype == np.int32 and a.size == b.size
+    lib().orc_map_i32(_p(a), _p(b), a.size, int(add))
+    return a
+
+
+def beamform(vin, weights, ntime, nchan, ninput, nbeam):
+    vin = np.ascontiguousarray(vin, dtype=np.uint8)
+    w = np.ascontiguousarray(weights, dtype=np.complex64)
+    assert vin.size == ntime * nchan * ninput and w.size == nchan * nbeam * ninput
+    out = np.zeros((nchan, nbeam, ntime), dtype=np.complex64)
+    lib().orc_beamform(_p(vin), _p(w), _p(out), ntime, nchan, ninput, nbeam)
+    return out
+
+
+def beamform_integrate(beams, ntime_sum):
+    b = np.ascontiguousarray(beams, dtype=np.complex64)
+    nchan, nbeam, ntime = b.shape
+    out = np.zeros((nbeam // 2, ntime // ntime_sum, nchan, 4), dtype=np.float32)
+    rc = lib().orc_beamform_integrate(_p(b), _p(out), nchan, nbeam, ntime, ntime_sum)
+    assert rc == 0
+    return out
+
+
+def beamform_integrate_single(beams, ntime_sum, beam):
+    b = np.ascontiguousarray(beams, dtype=np.complex64)
+    nchan, nbeam, ntime = b.shape
+    out = np.zeros((ntime // ntime_sum, nchan, 4), dtype=np.float32)
+    rc = lib().orc_beamform_integrate_single(_p(b), _p(out), nchan, nbeam, ntime, ntime_sum, beam)
+    assert rc == 0
+    return out

@@ -1,0 +1,182 @@
+"""Pin the CPU oracle (oracle/xeng_oracle.c) against the reference's golden vectors.
+
+The golden files in tests/golden/ were produced by the reference's own
+pipeline/verification/make_golden_inputs.py (see oracle/make_golden.py) and by
+the reference's SoftwareBf functions (oracle/make_golden_beamform.py).
+"""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import xeng_oracle as orc
+
+
+def load_dat(path):
+    with open(path, "rb") as fh:
+        meta = json.loads(fh.readline().decode())
+        raw = fh.read()
+    dt = np.uint8 if "uint8" in meta["dtype"] else np.complex128
+    return meta, np.frombuffer(raw, dtype=dt).reshape(meta["shape"])
+
+
+def golden_sets(golden_dir):
+    out = []
+    for tag in ("deadbeef", "chanramp"):
+        mi, vin = load_dat(os.path.join(golden_dir, "in_8t_4c_16s_2p_%s.dat" % tag))
+        mc, corr = load_dat(os.path.join(golden_dir, "corr_8t_4a_4c_16s_2p_%s.dat" % tag))
+        out.append((tag, vin, np.round(corr.real).astype(np.int64), np.round(corr.imag).astype(np.int64), mc["acc_len"]))
+    z = np.load(os.path.join(golden_dir, "golden_64t_32a_8c_32s_2p_deadbeef.npz"))
+    out.append(("64in", z["vin"], z["corr_re"].astype(np.int64), z["corr_im"].astype(np.int64), 32))
+    return out
+
+
+def test_decode_all_bytes():
+    b = np.arange(256, dtype=np.uint8)
+    re = np.empty(256, np.int8)
+    im = np.empty(256, np.int8)
+    orc.lib().orc_decode(b.ctypes.data_as(ctypes.c_void_p), re.ctypes.data_as(ctypes.c_void_p),
+                         im.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(256))
+    nre, nim = orc.decode(b)
+    assert np.array_equal(re, nre) and np.array_equal(im, nim)
+    assert re.min() == -8 and re.max() == 7 and im.min() == -8 and im.max() == 7
+    assert re[0x88] == -8 and im[0x88] == -8 and re[0x7f] == 7 and im[0x7f] == -1
+
+
+def test_regtile_index_c_vs_numpy():
+    for nstand in (4, 16, 32, 352):
+        rng = np.random.default_rng(nstand)
+        for _ in range(2000):
+            i0, i1 = sorted(rng.integers(0, 2 * nstand, 2))
+            assert orc.lib().orc_regtile_index(int(i0), int(i1), nstand) == orc.regtile_index(int(i0), int(i1), nstand)
+        assert orc.lib().orc_xgpu_per_chan(nstand, 2) == orc.per_chan(nstand)
+    assert orc.per_chan(352) == 249216 and orc.per_chan(16) == 576
+
+
+def test_regtile_addresses_are_unique_and_count():
+    # measured property: 4*(n/2) words per plane per channel are never addressed
+    nstand = 32
+    s0, s1, p0, p1 = np.meshgrid(np.arange(nstand), np.arange(nstand), [0, 1], [0, 1], indexing="ij")
+    m = s1 >= s0
+    idx = orc.regtile_index(2 * s0 + p0, 2 * s1 + p1, nstand)[m]
+    assert len(np.unique(idx)) == len(idx)
+    assert orc.per_chan(nstand) - len(idx) == 4 * (nstand // 2)
+    assert idx.max() < orc.per_chan(nstand)
+
+
+def test_oracle_matches_reference_golden(golden_dir):
+    """C oracle -> GetOrder -> Reorder == make_golden_inputs.py output, exactly
+    (the check corr_output_full_block.py:550-603 does, for s1 >= s0)."""
+    for tag, vin, gre, gim, acc_len in golden_sets(golden_dir):
+        T, C, S, P = vin.shape
+        a2i = np.arange(S * P, dtype=np.int32).reshape(S, P)
+        bl, cj = orc.xgpu_get_order(a2i)
+        for blk in range(T // acc_len):
+            planar = orc.xgpu_correlate(vin[blk * acc_len:(blk + 1) * acc_len], S, C)
+            ro = orc.xgpu_reorder(planar, bl, cj, C)          # [s0,s1,p0,p1,c,2]
+            for s0 in range(S):
+                for s1 in range(s0, S):
+                    assert np.array_equal(ro[s0, s1, :, :, :, 0], np.moveaxis(gre[blk, :, s0, s1], 0, -1)), (tag, s0, s1)
+                    assert np.array_equal(ro[s0, s1, :, :, :, 1], np.moveaxis(gim[blk, :, s0, s1], 0, -1)), (tag, s0, s1)
+
+
+def test_oracle_matches_xgpu_test_convention(golden_dir):
+    """xgpu_test.py:99-133: buffer[regtile_index(2*s0+p0, 2*s1+p1)] == sum conj(x[s0,p0]) * x[s1,p1]."""
+    for tag, vin, gre, gim, acc_len in golden_sets(golden_dir):
+        T, C, S, P = vin.shape
+        planar = orc.xgpu_correlate(vin[:acc_len], S, C)
+        re, im = orc.xgpu_lookup_numpy(planar, S, C)
+        m = (np.arange(S)[:, None] <= np.arange(S)[None, :])[None, :, :, None, None]
+        # golden = x0 conj(x1); stored = conj(x0) x1 = conj(golden)
+        assert np.array_equal(re * m, gre[0] * m), tag
+        assert np.array_equal(im * m, -gim[0] * m), tag
+
+
+def test_accumulate_then_dump_semantics(golden_dir):
+    """xgpu_test.py:76-83: G calls, dump on the last == one call over G*ntime samples."""
+    tag, vin, gre, gim, acc_len = golden_sets(golden_dir)[2]
+    T, C, S, P = vin.shape
+    whole = orc.xgpu_correlate(vin, S, C)
+    acc = None
+    for g in range(4):
+        acc = orc.xgpu_correlate(vin[g * (T // 4):(g + 1) * (T // 4)], S, C, acc)
+    assert np.array_equal(whole, acc)
+
+
+def test_numpy_golden_restatement(golden_dir):
+    for tag, vin, gre, gim, acc_len in golden_sets(golden_dir):
+        rr, ii = orc.golden_corr(vin[:acc_len])
+        assert np.array_equal(rr, gre[0]) and np.array_equal(ii, gim[0])
+
+
+def test_input_permutation_get_order(golden_dir):
+    """GetOrder with a shuffled antpol_to_input still reorders to golden of the permuted inputs."""
+    tag, vin, gre, gim, acc_len = golden_sets(golden_dir)[0]
+    T, C, S, P = vin.shape
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(S * P).astype(np.int32).reshape(S, P)   # [s,p] -> correlator input
+    planar = orc.xgpu_correlate(vin[:acc_len], S, C)
+    bl, cj = orc.xgpu_get_order(perm)
+    ro = orc.xgpu_reorder(planar, bl, cj, C)
+    flat_re = gre[0].transpose(0, 1, 3, 2, 4).reshape(C, S * P, S * P)   # [c, in0, in1]
+    flat_im = gim[0].transpose(0, 1, 3, 2, 4).reshape(C, S * P, S * P)
+    for s0 in range(S):
+        for s1 in range(S):
+            for p0 in range(P):
+                for p1 in range(P):
+                    i0, i1 = perm[s0, p0], perm[s1, p1]
+                    assert np.array_equal(ro[s0, s1, p0, p1, :, 0], flat_re[:, i0, i1])
+                    assert np.array_equal(ro[s0, s1, p0, p1, :, 1], flat_im[:, i0, i1])
+
+
+def test_subselect_matches_golden(golden_dir):
+    """test_corr_part_rx.py:49-85: subselected, channel-summed vis == golden[s0,s1,p0,p1] summed."""
+    tag, vin, gre, gim, acc_len = golden_sets(golden_dir)[2]
+    T, C, S, P = vin.shape
+    planar = orc.xgpu_correlate(vin[:acc_len], S, C)
+    bl, cj = orc.xgpu_get_order(np.arange(S * P, dtype=np.int32).reshape(S, P))
+    rng = np.random.default_rng(9)
+    sel = [((int(a), int(b)), (int(c), int(d))) for a, b, c, d in
+           zip(rng.integers(0, S, 50), rng.integers(0, 2, 50), rng.integers(0, S, 50), rng.integers(0, 2, 50))]
+    vismap = np.array([bl[s0, s1, p0, p1] for (s0, p0), (s1, p1) in sel], dtype=np.int32)
+    conj = np.array([cj[s0, s1, p0, p1] for (s0, p0), (s1, p1) in sel], dtype=np.int32)
+    out = orc.xgpu_subselect(planar, vismap, conj, C, 4, S)
+    for v, ((s0, p0), (s1, p1)) in enumerate(sel):
+        assert np.array_equal(out[:, v, 0], gre[0][:, s0, s1, p0, p1].reshape(C // 4, 4).sum(1))
+        assert np.array_equal(out[:, v, 1], gim[0][:, s0, s1, p0, p1].reshape(C // 4, 4).sum(1))
+
+
+def test_map_i32():
+    rng = np.random.default_rng(1)
+    a = rng.integers(-2**31, 2**31 - 1, 1000, dtype=np.int64).astype(np.int32)
+    b = rng.integers(-2**31, 2**31 - 1, 1000, dtype=np.int64).astype(np.int32)
+    exp = (a.astype(np.int64) + b.astype(np.int64)).astype(np.int32)   # wraps
+    a2 = a.copy()
+    orc.map_i32(a2, b, add=True)
+    assert np.array_equal(a2, exp)
+    orc.map_i32(a2, b, add=False)
+    assert np.array_equal(a2, b)
+
+
+@pytest.mark.parametrize("tag", ["small", "tile"])
+def test_beamform_matches_reference_functions(golden_dir, tag):
+    """oracle beamformer / power sums vs outputs of the reference's own SoftwareBf functions
+    (which accumulate in complex64, so the tolerance is the reference's own,
+    beamformer_test.py:109 / beamformer_sum_test.py:104, scaled to the data)."""
+    z = np.load(os.path.join(golden_dir, "beamform_%s.npz" % tag))
+    vin, w, beams, power = z["vin"], z["weights"], z["beams"], z["power"]
+    ntime, nchan, ninput = vin.shape
+    nbeam = w.shape[1]
+    re, im = orc.decode(vin)
+    assert np.array_equal((re + 1j * im).astype(np.complex64), z["decoded"])
+    ob = orc.beamform(vin, w, ntime, nchan, ninput, nbeam)
+    scale = np.sqrt(np.mean(np.abs(beams) ** 2))
+    assert np.max(np.abs(ob - beams)) / scale < 1e-5
+    assert np.all(np.isclose(ob, beams, rtol=1e-4, atol=1e-4 * scale))
+    op = orc.beamform_integrate(beams, int(z["ntime_sum"]))
+    assert op.shape == power.shape
+    assert np.all(np.isclose(op, power, rtol=1e-5, atol=1e-4))
+    for b in range(nbeam // 2):
+        assert np.array_equal(orc.beamform_integrate_single(beams, int(z["ntime_sum"]), b), op[b])
