@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X X-engine (BASELINE.json metric).
+
+Workload (config.workload): BASELINE.json configs[1] -- 704 inputs (352 stands x 2 pol),
+96 channels, 4+4-bit -> int32 correlator on one MI355X.  One *step* = one short integration
+as lwa352-pipeline.py runs it: acc_len 2400 = 5 gulps of 480 samples fed through the C ABI
+(xengXgpuKernel*, dump on the 5th), on synthetic F-engine voltages already resident in HBM
+(a replay ring of pre-generated gulps; make_golden_inputs.py's generator, seed 0xdeadbeef).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): frequency channels shard
+embarrassingly, 96 channels per GPU (configs[2]); there is no data-path collective -- the
+process group (gloo) is only used for the barriers and the max-over-ranks of the wall time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NSTAND, NPOL, NCHAN, NTIME_GULP, ACC_LEN = 352, 2, 96, 480, 2400
+NINPUT = NSTAND * NPOL
+CMAC_PER_UNIT = NINPUT * (NINPUT + 1) // 2           # 248160
+OPS_PER_UNIT = 8 * CMAC_PER_UNIT                      # 1 985 280 int8 ops
+PEAK_CUS, PEAK_CLK_HZ = 256, 2.4e9                    # MI355X_MICROARCH.md chip-level parameters
+PEAK_INT8_OPS = PEAK_CUS * 8192 * PEAK_CLK_HZ         # 5.03e15 dense int8 MFMA ops/s
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(budget_s=12.0):
+    """The CPU oracle (oracle/xeng_oracle.c, OpenMP over channels) on the host cores: a bounded
+    sample of the same workload (whole 480-sample x 96-channel x 704-input gulps)."""
+    from oracle import xeng_oracle as orc
+    orc.build()
+    vin = np.random.RandomState(0xdeadbeef).randint(0, 255, size=(NTIME_GULP, NCHAN, NSTAND, NPOL), dtype=np.uint8)
+    acc = None
+    t0 = time.time()
+    ngulp = 0
+    while True:
+        acc = orc.xgpu_correlate(vin, NSTAND, NCHAN, acc)
+        ngulp += 1
+        el = time.time() - t0
+        if el > budget_s or ngulp >= 64:
+            break
+    units = ngulp * NTIME_GULP * NCHAN
+    return {"value": round(8 * NINPUT * units / el / 1e9, 4), "unit": "Gb/s",
+            "cores": int(orc.lib().orc_num_threads()), "kind": "port",
+            "cmac_per_s": units * CMAC_PER_UNIT / el,
+            "sample": "%d gulps of %d samples x %d chan x %d inputs (%.1f s)" % (ngulp, NTIME_GULP, NCHAN, NINPUT, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--ring-gulps", type=int, default=10, help="device-resident replay ring depth (gulps)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-per-call", action="store_true",
+                    help="time the drop-in synchronous xengXgpuKernel instead of the pipelined enqueue")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # plumbing only: barrier + max-reduce of the wall time
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    import caltech_bifrost_dsp_amd  # noqa: F401
+    from caltech_bifrost_dsp_amd import ffi
+
+    gpu = local_rank
+    ffi.call("xengSetDevice", gpu)
+    info = ffi.device_info(gpu)
+    gulps_per_step = ACC_LEN // NTIME_GULP
+    ffi.call("xengXgpuConfigure", NSTAND, NPOL, NCHAN, NTIME_GULP, gulps_per_step)
+    ffi.call("xengXgpuInitialize", gpu)
+    gulp_bytes = NTIME_GULP * NCHAN * NINPUT
+    matlen = NCHAN * 249216
+
+    # device-resident replay ring of synthetic F-engine voltages (chan0 = 96*rank; seed + rank)
+    ring = ffi.DeviceBuffer(args.ring_gulps * gulp_bytes)
+    rs = np.random.RandomState(0xdeadbeef + rank)
+    for g in range(args.ring_gulps):
+        ring.upload(rs.randint(0, 255, size=gulp_bytes, dtype=np.uint8), offset=g * gulp_bytes)
+    out = ffi.DeviceBuffer(2 * matlen * 4)
+    kern = "xengXgpuKernel" if args.sync_per_call else "xengXgpuKernelAsync"
+    L = ffi.lib()
+    kfn = getattr(L, kern)
+
+    gi = [0]
+
+    def step():
+        for g in range(gulps_per_step):
+            rc = kfn(ring.ptr + (gi[0] % args.ring_gulps) * gulp_bytes, out.ptr, int(g == gulps_per_step - 1))
+            if rc:
+                ffi.check(kern, rc)
+            gi[0] += 1
+        if not args.sync_per_call:
+            rc = L.xengXgpuSync()            # output complete before the span would be committed
+            if rc:
+                ffi.check("xengXgpuSync", rc)
+
+    def barrier():
+        ffi.call("xengDeviceSynchronize")
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    ffi.call("xengXgpuSetProfiling", 1)
+    tm = (ctypes.c_double * 2)()
+    cn = (ctypes.c_int * 2)()
+    ffi.call("xengXgpuGetTimes", tm, cn)       # clear
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ffi.call("xengDeviceSynchronize")
+    el = time.perf_counter() - t0
+    ffi.call("xengXgpuGetTimes", tm, cn)
+    ffi.call("xengXgpuSetProfiling", 0)
+    if dist is not None:
+        import torch
+        t = torch.tensor([el], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+        dist.barrier()
+
+    units_per_step = ACC_LEN * NCHAN
+    total_units = units_per_step * args.steps * world
+    gbps = 8 * NINPUT * total_units / el / 1e9
+    cmacs = CMAC_PER_UNIT * total_units / el
+    ct_ms = tm[0] / max(cn[0], 1)
+    mm_ms = tm[1] / max(cn[1], 1)
+    ops_per_launch = OPS_PER_UNIT * units_per_step
+    achieved = ops_per_launch / (mm_ms * 1e-3) / 1e12 if mm_ms > 0 else 0.0
+    ct_bytes = 2 * gulp_bytes
+    res = {
+        "metric": "xengine_ingest_gbps_704in_96ch", "value": round(gbps, 2), "unit": "Gb/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "int8 (4+4-bit samples) -> int32", "data": "synthetic",
+        "config": {"workload": "704-input (352 ant x 2 pol), %d chan/GPU, 4+4b->int32 correlator, acc_len %d = %d gulps x %d"
+                               % (NCHAN, ACC_LEN, gulps_per_step, NTIME_GULP),
+                   "nchan_total": NCHAN * world, "sharding": "channels, %d per GPU, no collective" % NCHAN,
+                   "call_mode": "sync-per-call" if args.sync_per_call else "enqueue gulps, sync per integration",
+                   "input": "device-resident replay ring, %d gulps" % args.ring_gulps},
+        "cmac_per_s": cmacs,
+        "mfma_peak_frac_end_to_end": round(8 * cmacs / (PEAK_INT8_OPS * world), 4),
+        "design_rate_x": round(gbps / world / 12.94, 1),
+        "roofline": {"kernel": "xcorr_mfma_kernel", "bound": "mfma", "achieved": round(achieved, 1),
+                     "peak": round(PEAK_INT8_OPS / 1e12, 1), "unit": "TFLOP/s",
+                     "frac": round(achieved / (PEAK_INT8_OPS / 1e12), 4), "traffic": None,
+                     "note": "int8 TOP/s; algorithmic ops = 8*704*705/2 per (sample,chan) x %d units per launch; "
+                             "avg launch %.1f us over %d launches (HIP events on the X-engine stream)"
+                             % (units_per_step, mm_ms * 1e3, cn[1])},
+        "corner_turn": {"bound": "hbm", "avg_us": round(ct_ms * 1e3, 2), "launches": int(cn[0]),
+                        "achieved_GBs": round(ct_bytes / (ct_ms * 1e-3) / 1e9, 1) if ct_ms > 0 else 0.0,
+                        "peak_GBs": HBM_PEAK_GBS, "bytes_per_launch": ct_bytes},
+        "device": info,
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res))
+    ffi.call("xengXgpuDestroy")
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

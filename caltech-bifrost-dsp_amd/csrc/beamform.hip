@@ -1,0 +1,151 @@
+// Host side of the beamformer: process-global context + C ABI.
+// Replaces _bf.bfBeamformInitialize / Run / Integrate / IntegrateSingleBeam
+// (beamform_block.py:251-253,449; beamform_sum_beams_block.py:245;
+//  beamform_sum_single_beam_block.py:114).
+#include <mutex>
+
+#include "beamform_kernels.h"
+#include "xeng_common.h"
+
+namespace xeng {
+
+struct BeamContext {
+    bool live = false;
+    int gpu = 0, ninput = 0, nchan = 0, ntime = 0, nbeam = 0, ntime_blocks = 0;
+    float* scratch = nullptr;  // voltage beams for the ntime_blocks>0 ("integrated") mode
+    hipStream_t stream = nullptr;
+    EventTimer timer;
+};
+static std::mutex g_bmu;
+static BeamContext g_b;
+
+static int beam_destroy_locked() {
+    if (!g_b.live) return XENG_STATUS_SUCCESS;
+    (void)hipSetDevice(g_b.gpu);
+    if (g_b.stream) (void)hipStreamSynchronize(g_b.stream);
+    if (g_b.scratch) (void)hipFree(g_b.scratch);
+    g_b.timer.destroy();
+    g_b = BeamContext();
+    return XENG_STATUS_SUCCESS;
+}
+
+static int run_locked(const void* in, float* out, const void* w) {
+    BeamContext& x = g_b;
+    dim3 grid((x.ntime + BF_NT - 1) / BF_NT, x.nchan, (x.nbeam + 31) / 32);
+    int slot = x.timer.begin(x.stream, 0);
+    hipLaunchKernelGGL(beamform_f32_kernel, grid, dim3(256), 0, x.stream, (const uint8_t*)in, (const float*)w, out,
+                       x.ntime, x.nchan, x.ninput, x.nbeam);
+    x.timer.end(x.stream, slot);
+    XENG_HIP(hipGetLastError());
+    return XENG_STATUS_SUCCESS;
+}
+
+static int integrate_locked(const void* in, void* out, int ntime_sum, int pair0, int npair) {
+    BeamContext& x = g_b;
+    if (ntime_sum <= 0 || x.ntime % ntime_sum) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Integrate: ntime %d not a multiple of ntime_sum %d", x.ntime, ntime_sum);
+    if (x.nbeam % 2) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Integrate: nbeam %d must be even (X/Y pairs)", x.nbeam);
+    dim3 grid((x.nchan + 3) / 4, npair);
+    int slot = x.timer.begin(x.stream, 1);
+    hipLaunchKernelGGL(beam_integrate_kernel, grid, dim3(256), 0, x.stream, (const float2*)in, (float4*)out, x.nchan,
+                       x.nbeam, x.ntime, ntime_sum, pair0, npair);
+    x.timer.end(x.stream, slot);
+    XENG_HIP(hipGetLastError());
+    return XENG_STATUS_SUCCESS;
+}
+
+}  // namespace xeng
+
+using namespace xeng;
+
+extern "C" {
+
+int xengBeamformInitialize(int gpu, int ninput, int nchan, int ntime, int nbeam, int ntime_blocks) {
+    if (ninput <= 0 || ninput % 4 || nchan <= 0 || ntime <= 0 || nbeam <= 0 || ntime_blocks < 0)
+        XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Beamform: bad sizes ninput=%d nchan=%d ntime=%d nbeam=%d ntime_blocks=%d",
+                  ninput, nchan, ntime, nbeam, ntime_blocks);
+    if (ntime_blocks > 0 && ntime % ntime_blocks)
+        XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Beamform: ntime %d not a multiple of ntime_blocks %d", ntime, ntime_blocks);
+    std::lock_guard<std::mutex> lk(g_bmu);
+    beam_destroy_locked();
+    BeamContext& x = g_b;
+    x.gpu = gpu < 0 ? 0 : gpu;
+    XENG_HIP(hipSetDevice(x.gpu));
+    x.ninput = ninput; x.nchan = nchan; x.ntime = ntime; x.nbeam = nbeam; x.ntime_blocks = ntime_blocks;
+    if (ntime_blocks > 0) XENG_HIP(hipMalloc((void**)&x.scratch, (size_t)nchan * nbeam * ntime * 8));
+    int rc = get_stream(STREAM_BEAM, &x.stream);
+    if (rc) return rc;
+    x.live = true;
+    return XENG_STATUS_SUCCESS;
+}
+
+int xengBeamformDestroy(void) {
+    std::lock_guard<std::mutex> lk(g_bmu);
+    return beam_destroy_locked();
+}
+
+int xengBeamformRun(const void* in_dev, void* out_dev, const void* weights_dev) {
+    std::lock_guard<std::mutex> lk(g_bmu);
+    BeamContext& x = g_b;
+    if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "Beamform: not initialized (call xengBeamformInitialize)");
+    if (!in_dev || !out_dev || !weights_dev) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Beamform: null buffer");
+    if (((uintptr_t)weights_dev & 15) || ((uintptr_t)out_dev & 15) || ((uintptr_t)in_dev & 3))
+        XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Beamform: weights/out must be 16-byte, in 4-byte aligned");
+    XENG_HIP(hipSetDevice(x.gpu));
+    if (x.ntime_blocks == 0) return run_locked(in_dev, (float*)out_dev, weights_dev);
+    int rc = run_locked(in_dev, x.scratch, weights_dev);
+    if (rc) return rc;
+    return integrate_locked(x.scratch, out_dev, x.ntime / x.ntime_blocks, 0, x.nbeam / 2);
+}
+
+int xengBeamformIntegrate(const void* in_dev, void* out_dev, int ntime_sum) {
+    std::lock_guard<std::mutex> lk(g_bmu);
+    BeamContext& x = g_b;
+    if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "Beamform: not initialized (the Beamform block initializes the shared context)");
+    if (!in_dev || !out_dev) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Integrate: null buffer");
+    XENG_HIP(hipSetDevice(x.gpu));
+    return integrate_locked(in_dev, out_dev, ntime_sum, 0, x.nbeam / 2);
+}
+
+int xengBeamformIntegrateSingleBeam(const void* in_dev, void* out_dev, int ntime_sum, int beam_id) {
+    std::lock_guard<std::mutex> lk(g_bmu);
+    BeamContext& x = g_b;
+    if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "Beamform: not initialized");
+    if (!in_dev || !out_dev) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Integrate: null buffer");
+    if (beam_id < 0 || beam_id >= x.nbeam / 2) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "IntegrateSingleBeam: beam %d out of range", beam_id);
+    XENG_HIP(hipSetDevice(x.gpu));
+    return integrate_locked(in_dev, out_dev, ntime_sum, beam_id, 1);
+}
+
+int xengBeamformSync(void) {
+    std::lock_guard<std::mutex> lk(g_bmu);
+    BeamContext& x = g_b;
+    if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "Beamform: not initialized");
+    XENG_HIP(hipSetDevice(x.gpu));
+    XENG_HIP(hipStreamSynchronize(x.stream));
+    x.timer.drain();
+    return XENG_STATUS_SUCCESS;
+}
+
+int xengBeamformSetProfiling(int enable) {
+    std::lock_guard<std::mutex> lk(g_bmu);
+    g_b.timer.enabled = enable != 0;
+    return XENG_STATUS_SUCCESS;
+}
+
+int xengBeamformGetTimes(double ms[2], int count[2]) {
+    std::lock_guard<std::mutex> lk(g_bmu);
+    BeamContext& x = g_b;
+    if (x.live && x.stream) {
+        XENG_HIP(hipStreamSynchronize(x.stream));
+        x.timer.drain();
+    }
+    for (int k = 0; k < 2; k++) {
+        if (ms) ms[k] = x.timer.total_ms[k];
+        if (count) count[k] = x.timer.count[k];
+        x.timer.total_ms[k] = 0;
+        x.timer.count[k] = 0;
+    }
+    return XENG_STATUS_SUCCESS;
+}
+
+}  // extern "C"

@@ -1,0 +1,424 @@
+// Host side of the X-engine: process-global context, work-group tiling, C ABI.
+// Replaces _bf.bfXgpuInitialize/Kernel/Correlate/GetOrder/SubSelect/Reorder
+// (call sites: corr_block.py:251-256,445,317-333; corr_subsel_block.py:298;
+//  corr_output_full_block.py:669; verification/xgpu_test.py:76-89).
+#include <algorithm>
+#include <cstdlib>
+#include <mutex>
+#include <vector>
+
+#include "xcorr_kernels.h"
+#include "xeng_common.h"
+
+namespace xeng {
+
+// --------------------------------------------------------------------------------------
+// Triangular tiling of the nblk64 x nblk64 grid of 64x64-input wave tiles onto work-groups
+// of 4 waves that share at most 4 staged 64-input blocks (hard part 2).
+//   * off-diagonal 128x128 squares: 4 tiles, 4 blocks
+//   * diagonal pairs: 3 tiles (+1 tile of the unpaired last block row when nblk64 is odd)
+//   * what is left of the last block row is packed 3-4 tiles per work-group
+// 704 inputs -> 11 blocks -> 66 tiles in 17 work-groups (97 % of wave slots busy).
+// --------------------------------------------------------------------------------------
+static std::vector<WgDesc> build_wg_descs(int nblk64) {
+    std::vector<WgDesc> out;
+    auto blank = []() {
+        WgDesc d;
+        memset(&d, 0, sizeof(d));
+        for (int w = 0; w < 4; w++) d.wave_a[w] = d.wave_b[w] = 0xFF;
+        return d;
+    };
+    auto finish = [&](WgDesc d, int nslot) {
+        for (int s = nslot; s < XC_NSLOT; s++) d.slot_blk[s] = d.slot_blk[0];  // harmless duplicate loads
+        out.push_back(d);
+    };
+    const int np = nblk64 / 2;
+    const int L = (nblk64 & 1) ? nblk64 - 1 : -1;
+    std::vector<int> left;  // column blocks j of the remaining tiles (L, j)
+    if (L >= 0)
+        for (int j = 0; j <= L; j++) left.push_back(j);
+    for (int k = 1; k < np; k++)
+        for (int m = 0; m < k; m++) {
+            WgDesc d = blank();
+            d.slot_blk[0] = 2 * k; d.slot_blk[1] = 2 * k + 1; d.slot_blk[2] = 2 * m; d.slot_blk[3] = 2 * m + 1;
+            const uint8_t wa[4] = {0, 0, 1, 1}, wb[4] = {2, 3, 2, 3};
+            for (int w = 0; w < 4; w++) { d.wave_a[w] = wa[w]; d.wave_b[w] = wb[w]; }
+            d.nwave = 4;
+            finish(d, 4);
+        }
+    for (int k = 0; k < np; k++) {
+        WgDesc d = blank();
+        d.slot_blk[0] = 2 * k; d.slot_blk[1] = 2 * k + 1;
+        d.wave_a[0] = 0; d.wave_b[0] = 0;
+        d.wave_a[1] = 1; d.wave_b[1] = 0;
+        d.wave_a[2] = 1; d.wave_b[2] = 1;
+        d.nwave = 3;
+        int nslot = 2;
+        auto it = std::find(left.begin(), left.end(), 2 * k);
+        if (it != left.end()) {
+            left.erase(it);
+            d.slot_blk[2] = (uint8_t)L; nslot = 3;
+            d.wave_a[3] = 2; d.wave_b[3] = 0;
+            d.nwave = 4;
+        }
+        finish(d, nslot);
+    }
+    while (!left.empty()) {
+        WgDesc d = blank();
+        d.slot_blk[0] = (uint8_t)L;
+        int nslot = 1, nw = 0;
+        for (size_t q = 0; q < left.size() && nw < 4;) {
+            const int j = left[q];
+            int slot = -1;
+            if (j == L) slot = 0;
+            else if (nslot < XC_NSLOT) { slot = nslot; d.slot_blk[nslot++] = (uint8_t)j; }
+            if (slot < 0) { q++; continue; }
+            d.wave_a[nw] = 0; d.wave_b[nw] = (uint8_t)slot; nw++;
+            left.erase(left.begin() + q);
+        }
+        d.nwave = (uint8_t)nw;
+        finish(d, nslot);
+    }
+    return out;
+}
+
+struct XgpuConfig {
+    int nstand = 352, npol = 2, nchan = 96, ntime_gulp = 480, max_gulps = 0;
+};
+
+struct XgpuContext {
+    bool live = false;
+    int gpu = 0;
+    XgpuConfig cfg;
+    int ninput = 0, nblk64 = 0, gkt = 0, cap_kt = 0, cap_gulps = 0, kt_stage = 1;
+    int64_t per_chan = 0, matlen = 0;
+    uint8_t* stash = nullptr;
+    size_t stash_bytes = 0;
+    WgDesc* descs_dev = nullptr;
+    int nwg = 0;
+    hipStream_t stream = nullptr;
+    // integration state
+    int nfilled = 0;           // gulps staged since the last flush
+    bool acc_started = false;  // out already holds a partial sum of the current integration
+    void* acc_out = nullptr;   // where that partial sum lives
+    // host staging for xengXgpuCorrelate
+    uint8_t* in_dev = nullptr;
+    int32_t* out_dev = nullptr;
+    EventTimer timer;
+};
+
+static std::mutex g_mu;
+static XgpuConfig g_cfg;
+static XgpuContext g_ctx;
+
+static int destroy_locked() {
+    XgpuContext& x = g_ctx;
+    if (!x.live) return XENG_STATUS_SUCCESS;
+    (void)hipSetDevice(x.gpu);
+    if (x.stream) (void)hipStreamSynchronize(x.stream);
+    if (x.stash) (void)hipFree(x.stash);
+    if (x.descs_dev) (void)hipFree(x.descs_dev);
+    if (x.in_dev) (void)hipFree(x.in_dev);
+    if (x.out_dev) (void)hipFree(x.out_dev);
+    x.timer.destroy();
+    x = XgpuContext();
+    return XENG_STATUS_SUCCESS;
+}
+
+static int pick_kt_stage(int gkt) {
+    if (const char* e = getenv("XENG_KT_STAGE")) {
+        int v = atoi(e);
+        if ((v == 1 || v == 3 || v == 5) ) return v;
+    }
+    if (gkt % 3 == 0) return 3;
+    if (gkt % 5 == 0) return 5;
+    return 1;
+}
+
+template <int KT>
+static void launch_xcorr(const XcorrParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_mfma_kernel<KT>), dim3(p.nchan * p.nwg), dim3(256), 0, s, p);
+}
+
+// contracts the staged gulps into `out`; caller holds g_mu
+static int flush_locked(void* out, bool dump) {
+    XgpuContext& x = g_ctx;
+    if (x.nfilled == 0) return XENG_STATUS_SUCCESS;
+    if (x.acc_started && x.acc_out != out)
+        XENG_FAIL(XENG_STATUS_INVALID_STATE,
+                  "xgpu: output buffer changed inside one integration (partial sums live in %p, got %p)",
+                  x.acc_out, out);
+    int nkt = x.nfilled * x.gkt;
+    const int rem = nkt % x.kt_stage;
+    if (rem) {  // zero-fill the K padding of every (channel, block) row of the stash
+        const int padk = x.kt_stage - rem;
+        XENG_HIP(hipMemset2DAsync(x.stash + (size_t)nkt * KT_BYTES, (size_t)x.cap_kt * KT_BYTES, 0,
+                                  (size_t)padk * KT_BYTES, (size_t)x.cfg.nchan * x.nblk64, x.stream));
+        nkt += padk;
+    }
+    XcorrParams p;
+    p.stash = x.stash; p.out = (int32_t*)out; p.descs = x.descs_dev;
+    p.nwg = x.nwg; p.nchan = x.cfg.nchan; p.nblk64 = x.nblk64; p.cap_kt = x.cap_kt; p.nkt = nkt;
+    p.nstand = x.cfg.nstand; p.per_chan = x.per_chan; p.matlen = x.matlen;
+    p.accumulate = x.acc_started ? 1 : 0;
+    int slot = x.timer.begin(x.stream, 1);
+    switch (x.kt_stage) {
+        case 3: launch_xcorr<3>(p, x.stream); break;
+        case 5: launch_xcorr<5>(p, x.stream); break;
+        default: launch_xcorr<1>(p, x.stream); break;
+    }
+    x.timer.end(x.stream, slot);
+    XENG_HIP(hipGetLastError());
+    x.nfilled = 0;
+    x.acc_started = !dump;
+    x.acc_out = dump ? nullptr : out;
+    return XENG_STATUS_SUCCESS;
+}
+
+static int kernel_locked(const void* in_dev, void* out_dev, int doDump, bool sync) {
+    XgpuContext& x = g_ctx;
+    if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized (call xengXgpuInitialize)");
+    if (!in_dev || !out_dev) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "xgpu: null buffer");
+    if (((uintptr_t)out_dev & 15) || ((uintptr_t)in_dev & 3))
+        XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "xgpu: out must be 16-byte and in 4-byte aligned");
+    XENG_HIP(hipSetDevice(x.gpu));
+    int slot = x.timer.begin(x.stream, 0);
+    hipLaunchKernelGGL(corner_turn_kernel, dim3(x.gkt, x.cfg.nchan), dim3(256), 0, x.stream,
+                       (const uint8_t*)in_dev, x.stash, x.cfg.ntime_gulp, x.cfg.nchan, x.ninput, x.nblk64,
+                       x.cap_kt, x.nfilled * x.gkt);
+    x.timer.end(x.stream, slot);
+    XENG_HIP(hipGetLastError());
+    x.nfilled++;
+    if (doDump || x.nfilled == x.cap_gulps) {
+        int rc = flush_locked(out_dev, doDump != 0);
+        if (rc) return rc;
+    } else if (x.acc_started && x.acc_out != out_dev) {
+        XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: output buffer changed inside one integration");
+    }
+    if (sync) {
+        XENG_HIP(hipStreamSynchronize(x.stream));
+        x.timer.drain();
+    }
+    return XENG_STATUS_SUCCESS;
+}
+
+}  // namespace xeng
+
+using namespace xeng;
+
+extern "C" {
+
+int xengXgpuConfigure(int nstand, int npol, int nchan, int ntime_gulp, int max_gulps_per_flush) {
+    if (npol != 2) XENG_FAIL(XENG_STATUS_UNSUPPORTED, "xgpu: npol must be 2 (got %d)", npol);
+    if (nstand <= 0 || nstand % 4) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "xgpu: nstand must be a positive multiple of 4 (got %d)", nstand);
+    if (nstand * npol > 255 * 64) XENG_FAIL(XENG_STATUS_UNSUPPORTED, "xgpu: too many inputs (%d)", nstand * npol);
+    if (nchan <= 0 || ntime_gulp <= 0 || max_gulps_per_flush < 0)
+        XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "xgpu: bad sizes nchan=%d ntime_gulp=%d max_gulps=%d", nchan, ntime_gulp, max_gulps_per_flush);
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_cfg.nstand = nstand; g_cfg.npol = npol; g_cfg.nchan = nchan; g_cfg.ntime_gulp = ntime_gulp;
+    g_cfg.max_gulps = max_gulps_per_flush;
+    return XENG_STATUS_SUCCESS;
+}
+
+int xengXgpuInitialize(int gpu) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    destroy_locked();
+    XgpuContext& x = g_ctx;
+    x.cfg = g_cfg;
+    x.gpu = gpu < 0 ? 0 : gpu;
+    XENG_HIP(hipSetDevice(x.gpu));
+    x.ninput = x.cfg.nstand * x.cfg.npol;
+    x.nblk64 = (x.ninput + 63) / 64;
+    x.gkt = (x.cfg.ntime_gulp + 31) / 32;
+    x.kt_stage = pick_kt_stage(x.gkt);
+    // staging depth: default ~4800 samples (two 2400-sample integrations' worth never needed at once;
+    // the X-engine flushes early when full).  K per launch must stay <= 65535 samples (int32 bound).
+    int cap = x.cfg.max_gulps > 0 ? x.cfg.max_gulps : std::max(1, 4800 / (x.gkt * 32));
+    cap = std::min(cap, std::max(1, 65535 / (x.gkt * 32)));
+    x.cap_gulps = cap;
+    x.cap_kt = ((cap * x.gkt + x.kt_stage - 1) / x.kt_stage) * x.kt_stage;
+    x.per_chan = (int64_t)(x.cfg.nstand / 2 + 1) * (x.cfg.nstand / 4) * x.cfg.npol * x.cfg.npol * 4;
+    x.matlen = x.per_chan * x.cfg.nchan;
+    x.stash_bytes = (size_t)x.cfg.nchan * x.nblk64 * x.cap_kt * KT_BYTES;
+    XENG_HIP(hipMalloc((void**)&x.stash, x.stash_bytes));
+    XENG_HIP(hipMemset(x.stash, 0, x.stash_bytes));
+    std::vector<WgDesc> descs = build_wg_descs(x.nblk64);
+    x.nwg = (int)descs.size();
+    XENG_HIP(hipMalloc((void**)&x.descs_dev, descs.size() * sizeof(WgDesc)));
+    XENG_HIP(hipMemcpy(x.descs_dev, descs.data(), descs.size() * sizeof(WgDesc), hipMemcpyHostToDevice));
+    int rc = get_stream(STREAM_XGPU, &x.stream);
+    if (rc) return rc;
+    x.live = true;
+    return XENG_STATUS_SUCCESS;
+}
+
+int xengXgpuDestroy(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return destroy_locked();
+}
+
+int xengXgpuKernel(const void* in_dev, void* out_dev, int doDump) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return kernel_locked(in_dev, out_dev, doDump, true);
+}
+
+int xengXgpuKernelAsync(const void* in_dev, void* out_dev, int doDump) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return kernel_locked(in_dev, out_dev, doDump, false);
+}
+
+int xengXgpuSync(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    XgpuContext& x = g_ctx;
+    if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized");
+    XENG_HIP(hipSetDevice(x.gpu));
+    XENG_HIP(hipStreamSynchronize(x.stream));
+    x.timer.drain();
+    return XENG_STATUS_SUCCESS;
+}
+
+int xengXgpuCorrelate(const void* in_host, void* out_host, int doDump) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    XgpuContext& x = g_ctx;
+    if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized");
+    if (!in_host || !out_host) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "xgpu: null buffer");
+    XENG_HIP(hipSetDevice(x.gpu));
+    const size_t in_bytes = (size_t)x.cfg.ntime_gulp * x.cfg.nchan * x.ninput;
+    const size_t out_bytes = (size_t)x.matlen * 2 * sizeof(int32_t);
+    if (!x.in_dev) XENG_HIP(hipMalloc((void**)&x.in_dev, in_bytes));
+    if (!x.out_dev) XENG_HIP(hipMalloc((void**)&x.out_dev, out_bytes));
+    XENG_HIP(hipMemcpyAsync(x.in_dev, in_host, in_bytes, hipMemcpyHostToDevice, x.stream));
+    int rc = kernel_locked(x.in_dev, x.out_dev, doDump, true);
+    if (rc) return rc;
+    if (doDump) {
+        XENG_HIP(hipMemcpyAsync(out_host, x.out_dev, out_bytes, hipMemcpyDeviceToHost, x.stream));
+        XENG_HIP(hipStreamSynchronize(x.stream));
+    }
+    return XENG_STATUS_SUCCESS;
+}
+
+static inline int64_t regtile_index_host(int in0, int in1, int nstand) {
+    // corr_block.py:37-58
+    const int a0 = in0 >> 1, a1 = in1 >> 1, p0 = in0 & 1, p1 = in1 & 1;
+    const int64_t qi = ((int64_t)(a1 / 2) * (a1 / 2 + 1)) / 2 + a0 / 2;
+    const int64_t quadrant = 2 * (a0 & 1) + (a1 & 1);
+    const int64_t qs = ((int64_t)(nstand / 2 + 1) * nstand) / 4;
+    return (quadrant * qs + qi) * 4 + 2 * p1 + p0;
+}
+
+int xengXgpuGetOrder(const int32_t* antpol_to_input, int32_t* antpol_to_bl, int32_t* is_conj) {
+    XgpuConfig cfg;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        cfg = g_ctx.live ? g_ctx.cfg : g_cfg;
+    }
+    if (!antpol_to_input || !antpol_to_bl || !is_conj) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "GetOrder: null array");
+    const int ns = cfg.nstand, np = cfg.npol, ninput = ns * np;
+    for (int k = 0; k < ninput; k++)
+        if (antpol_to_input[k] < 0 || antpol_to_input[k] >= ninput)
+            XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "GetOrder: input id %d out of range at [%d]", antpol_to_input[k], k);
+    for (int s0 = 0; s0 < ns; s0++)
+        for (int s1 = 0; s1 < ns; s1++)
+            for (int p0 = 0; p0 < np; p0++)
+                for (int p1 = 0; p1 < np; p1++) {
+                    const int i0 = antpol_to_input[s0 * np + p0], i1 = antpol_to_input[s1 * np + p1];
+                    const size_t k = (((size_t)s0 * ns + s1) * np + p0) * np + p1;
+                    // stored word at regtile_index(lo,hi) is conj(x[lo])*x[hi] (xgpu_test.py:111-131);
+                    // the consumer wants x[s0,p0]*conj(x[s1,p1]) (corr_output_full_block.py:582-591)
+                    if (i1 >= i0) { antpol_to_bl[k] = (int32_t)regtile_index_host(i0, i1, ns); is_conj[k] = 1; }
+                    else          { antpol_to_bl[k] = (int32_t)regtile_index_host(i1, i0, ns); is_conj[k] = 0; }
+                }
+    return XENG_STATUS_SUCCESS;
+}
+
+int xengXgpuSubSelect(const void* in_dev, void* out_dev, const int32_t* vismap_dev, const int32_t* conj_dev,
+                      int nvis, int nchan_sum) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    XgpuContext& x = g_ctx;
+    if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized");
+    if (!in_dev || !out_dev || !vismap_dev || !conj_dev) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "SubSelect: null buffer");
+    if (nvis <= 0 || nchan_sum <= 0 || x.cfg.nchan % nchan_sum)
+        XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "SubSelect: nvis=%d nchan_sum=%d nchan=%d", nvis, nchan_sum, x.cfg.nchan);
+    XENG_HIP(hipSetDevice(x.gpu));
+    hipLaunchKernelGGL(subselect_kernel, dim3((nvis + 255) / 256, x.cfg.nchan / nchan_sum), dim3(256), 0, x.stream,
+                       (const int32_t*)in_dev, (int32_t*)out_dev, vismap_dev, conj_dev, nvis, nchan_sum,
+                       x.per_chan, x.matlen);
+    XENG_HIP(hipGetLastError());
+    XENG_HIP(hipStreamSynchronize(x.stream));
+    return XENG_STATUS_SUCCESS;
+}
+
+int xengXgpuReorder(const void* in_host, void* out_host, const int32_t* bl, const int32_t* conj) {
+    XgpuConfig cfg;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        cfg = g_ctx.live ? g_ctx.cfg : g_cfg;
+    }
+    if (!in_host || !out_host || !bl || !conj) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Reorder: null buffer");
+    const int64_t per_chan = (int64_t)(cfg.nstand / 2 + 1) * (cfg.nstand / 4) * cfg.npol * cfg.npol * 4;
+    const int64_t matlen = per_chan * cfg.nchan;
+    const int32_t* xg = (const int32_t*)in_host;
+    int32_t* out = (int32_t*)out_host;
+    const size_t nbl = (size_t)cfg.nstand * cfg.nstand * cfg.npol * cfg.npol;
+    for (size_t k = 0; k < nbl; k++) {
+        if (bl[k] < 0 || bl[k] >= per_chan) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Reorder: baseline index %d out of range", bl[k]);
+        int32_t* o = out + k * cfg.nchan * 2;
+        for (int c = 0; c < cfg.nchan; c++) {
+            const int64_t w = (int64_t)c * per_chan + bl[k];
+            o[2 * c] = xg[w];
+            o[2 * c + 1] = conj[k] ? -xg[matlen + w] : xg[matlen + w];
+        }
+    }
+    return XENG_STATUS_SUCCESS;
+}
+
+int xengXgpuGetInfo(int* nstand, int* npol, int* nchan, int* ntime_gulp, int64_t* matlen, int* max_gulps) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    XgpuContext& x = g_ctx;
+    if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized");
+    if (nstand) *nstand = x.cfg.nstand;
+    if (npol) *npol = x.cfg.npol;
+    if (nchan) *nchan = x.cfg.nchan;
+    if (ntime_gulp) *ntime_gulp = x.cfg.ntime_gulp;
+    if (matlen) *matlen = x.matlen;
+    if (max_gulps) *max_gulps = x.cap_gulps;
+    return XENG_STATUS_SUCCESS;
+}
+
+int xengXgpuSetProfiling(int enable) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_ctx.timer.enabled = enable != 0;
+    return XENG_STATUS_SUCCESS;
+}
+
+int xengXgpuGetTimes(double ms[2], int count[2]) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    XgpuContext& x = g_ctx;
+    if (x.live && x.stream) {
+        XENG_HIP(hipStreamSynchronize(x.stream));
+        x.timer.drain();
+    }
+    for (int k = 0; k < 2; k++) {
+        if (ms) ms[k] = x.timer.total_ms[k];
+        if (count) count[k] = x.timer.count[k];
+        x.timer.total_ms[k] = 0;
+        x.timer.count[k] = 0;
+    }
+    return XENG_STATUS_SUCCESS;
+}
+
+// debug/test hook (not part of the drop-in surface): copy the staging area to the host
+int xengXgpuDebugReadStash(void* host, size_t nbytes, int* cap_kt, int* nblk64) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    XgpuContext& x = g_ctx;
+    if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized");
+    if (cap_kt) *cap_kt = x.cap_kt;
+    if (nblk64) *nblk64 = x.nblk64;
+    if (host) {
+        XENG_HIP(hipStreamSynchronize(x.stream));
+        XENG_HIP(hipMemcpy(host, x.stash, std::min(nbytes, x.stash_bytes), hipMemcpyDeviceToHost));
+    }
+    return XENG_STATUS_SUCCESS;
+}
+
+}  // extern "C"

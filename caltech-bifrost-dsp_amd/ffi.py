@@ -1,0 +1,143 @@
+"""ctypes binding of libxeng.so (include/xeng.h) -- the product's only route to the GPU.
+
+This plays the role of `from bifrost.libbifrost import _bf` in the reference blocks
+(corr_block.py:5, beamform_block.py:5).  There is no CPU fallback: if the HIP library is
+missing or fails to load, importing `lib()` raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libxeng.so")
+
+STATUS_SUCCESS = 0
+SPACE_SYSTEM, SPACE_CUDA, SPACE_CUDA_HOST = 1, 2, 3
+
+_lib = None
+
+
+class XengError(RuntimeError):
+    def __init__(self, fn, status, msg):
+        super().__init__("%s returned %d: %s" % (fn, status, msg))
+        self.status = status
+
+
+class XENGarray(ctypes.Structure):
+    """Mirror of include/xeng.h XENGarray (= bifrost BFarray)."""
+    _fields_ = [("data", ctypes.c_void_p), ("space", ctypes.c_int), ("dtype", ctypes.c_int),
+                ("ndim", ctypes.c_int), ("shape", ctypes.c_long * 8), ("strides", ctypes.c_long * 8),
+                ("immutable", ctypes.c_int), ("big_endian", ctypes.c_int), ("conjugated", ctypes.c_int)]
+
+
+# every symbol include/xeng.h declares: name -> argtypes (all return int unless noted)
+_vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+_pi = ctypes.POINTER(ctypes.c_int)
+_pa = ctypes.POINTER(XENGarray)
+SYMBOLS = {
+    "xengGetDeviceCount": [_pi], "xengSetDevice": [_i], "xengGetDevice": [_pi], "xengDeviceSynchronize": [],
+    "xengGetDeviceInfo": [_i, _pi, _pi, ctypes.POINTER(_sz), ctypes.c_char_p, _i],
+    "xengMalloc": [ctypes.POINTER(_vp), _sz, _i], "xengFree": [_vp, _i], "xengMemcpy": [_vp, _vp, _sz],
+    "xengMemcpyAsync": [_vp, _vp, _sz], "xengMemset": [_vp, _i, _sz], "xengStreamSynchronize": [],
+    "xengXgpuConfigure": [_i, _i, _i, _i, _i], "xengXgpuInitialize": [_i], "xengXgpuDestroy": [],
+    "xengXgpuKernel": [_vp, _vp, _i], "xengXgpuKernelAsync": [_vp, _vp, _i], "xengXgpuSync": [],
+    "xengXgpuCorrelate": [_vp, _vp, _i], "xengXgpuGetOrder": [_vp, _vp, _vp],
+    "xengXgpuSubSelect": [_vp, _vp, _vp, _vp, _i, _i], "xengXgpuReorder": [_vp, _vp, _vp, _vp],
+    "xengXgpuGetInfo": [_pi, _pi, _pi, _pi, ctypes.POINTER(ctypes.c_int64), _pi],
+    "xengXgpuSetProfiling": [_i], "xengXgpuGetTimes": [ctypes.POINTER(ctypes.c_double), _pi],
+    "xengMapAssignI32": [_vp, _vp, _sz], "xengMapAddI32": [_vp, _vp, _sz],
+    "xengBeamformInitialize": [_i, _i, _i, _i, _i, _i], "xengBeamformDestroy": [],
+    "xengBeamformRun": [_vp, _vp, _vp], "xengBeamformIntegrate": [_vp, _vp, _i],
+    "xengBeamformIntegrateSingleBeam": [_vp, _vp, _i, _i], "xengBeamformSync": [],
+    "xengBeamformSetProfiling": [_i], "xengBeamformGetTimes": [ctypes.POINTER(ctypes.c_double), _pi],
+    "bfXgpuInitialize": [_pa, _pa, _i], "bfXgpuKernel": [_pa, _pa, _i], "bfXgpuCorrelate": [_pa, _pa, _i],
+    "bfXgpuGetOrder": [_pa, _pa, _pa], "bfXgpuSubSelect": [_pa, _pa, _pa, _pa, _i, _i],
+    "bfXgpuReorder": [_pa, _pa, _pa, _pa], "bfBeamformInitialize": [_i, _i, _i, _i, _i, _i],
+    "bfBeamformRun": [_pa, _pa, _pa], "bfBeamformIntegrate": [_pa, _pa, _i],
+    "bfBeamformIntegrateSingleBeam": [_pa, _pa, _i, _i],
+}
+STRING_SYMBOLS = ["xengGetLastError", "xengVersion"]
+
+
+def lib():
+    """Load libxeng.so (once).  Raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(or make -C caltech-bifrost-dsp_amd/csrc). There is no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, args in SYMBOLS.items():
+            f = getattr(L, name)
+            f.argtypes = args
+            f.restype = ctypes.c_int
+        for name in STRING_SYMBOLS:
+            getattr(L, name).restype = ctypes.c_char_p
+            getattr(L, name).argtypes = []
+        _lib = L
+    return _lib
+
+
+def check(name, status):
+    if status != STATUS_SUCCESS:
+        raise XengError(name, status, lib().xengGetLastError().decode())
+
+
+def call(name, *args):
+    check(name, getattr(lib(), name)(*args))
+
+
+class DeviceBuffer:
+    """A HIP allocation (space 'cuda') or pinned host allocation ('cuda_host')."""
+
+    def __init__(self, nbytes, space=SPACE_CUDA):
+        self.nbytes = int(nbytes)
+        self.space = space
+        p = ctypes.c_void_p()
+        call("xengMalloc", ctypes.byref(p), self.nbytes, space)
+        self.ptr = p.value
+
+    def free(self):
+        if self.ptr:
+            call("xengFree", self.ptr, self.space)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def upload(self, arr, offset=0):
+        arr = np.ascontiguousarray(arr)
+        assert offset + arr.nbytes <= self.nbytes
+        call("xengMemcpy", self.ptr + offset, arr.ctypes.data, arr.nbytes)
+        return self
+
+    def download(self, dtype, count=None, offset=0):
+        dtype = np.dtype(dtype)
+        if count is None:
+            count = (self.nbytes - offset) // dtype.itemsize
+        out = np.empty(count, dtype=dtype)
+        call("xengMemcpy", out.ctypes.data, self.ptr + offset, out.nbytes)
+        return out
+
+    def as_host_array(self, dtype):
+        assert self.space == SPACE_CUDA_HOST
+        dtype = np.dtype(dtype)
+        buf = (ctypes.c_char * self.nbytes).from_address(self.ptr)
+        return np.frombuffer(buf, dtype=dtype)
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    call("xengGetDeviceCount", ctypes.byref(n))
+    return n.value
+
+
+def device_info(gpu=0):
+    cu, clk, mem = ctypes.c_int(), ctypes.c_int(), ctypes.c_size_t()
+    name = ctypes.create_string_buffer(128)
+    call("xengGetDeviceInfo", gpu, ctypes.byref(cu), ctypes.byref(clk), ctypes.byref(mem), name, 128)
+    return {"num_cu": cu.value, "clock_khz": clk.value, "total_mem": mem.value, "name": name.value.decode()}

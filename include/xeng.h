@@ -1,0 +1,183 @@
+/*
+ * xeng.h -- C ABI of the MI355X-native LWA-352 X-engine library (libxeng.so).
+ *
+ * This is the drop-in boundary for the hot path of realtimeradio/caltech-bifrost-dsp:
+ * the functions below are what the reference's Python blocks reach through
+ * `from bifrost.libbifrost import _bf` (ctypes).  Every entry point cites the
+ * reference call site it replaces (paths relative to
+ * /root/reference/pipeline/lwa352_pipeline/blocks unless stated).
+ *
+ * Conventions (same as the reference's BFstatus convention, corr_block.py:254):
+ *   - every function returns int, 0 (XENG_STATUS_SUCCESS) on success, non-zero
+ *     on error; nothing throws across the ABI; xengGetLastError() returns a
+ *     thread-local message for the last failure.
+ *   - the caller owns every data buffer; the library owns contexts and scratch.
+ *   - contexts are process-global singletons like the reference's (one xGPU
+ *     context: corr_block.py:249-256; one beamformer context shared by Beamform
+ *     and BeamformSumBeams: beamform_sum_beams_block.py:186-187).
+ *   - plain pointers and sizes only; "dev" pointers are HIP device pointers,
+ *     "host" pointers are ordinary (ideally pinned) host memory.
+ *
+ * Two layers are exported:
+ *   xeng*   raw-pointer functions (sizes are runtime arguments of Configure /
+ *           Initialize; xGPU's were compile-time, install_xgpu.sh:5), and
+ *   bf*     adapters with bifrost's names and BFarray* argument shapes, so a
+ *           bifrost build could bind them 1:1.
+ */
+#ifndef XENG_H_
+#define XENG_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XENG_STATUS_SUCCESS            0
+#define XENG_STATUS_INVALID_ARGUMENT   1
+#define XENG_STATUS_INVALID_STATE      2
+#define XENG_STATUS_DEVICE_ERROR       3
+#define XENG_STATUS_UNSUPPORTED        4
+#define XENG_STATUS_MEM_ALLOC_FAILED   5
+
+/* memory spaces, numbered as bifrost's BFspace [from memory of bifrost/src/bifrost/memory.h] */
+#define XENG_SPACE_AUTO       0
+#define XENG_SPACE_SYSTEM     1
+#define XENG_SPACE_CUDA       2   /* device memory (HIP) -- keeps bifrost's name for the space */
+#define XENG_SPACE_CUDA_HOST  3   /* pinned host memory */
+
+/* mirrors bifrost's BFarray (bifrost/src/bifrost/array.h) [struct layout from memory, unverifiable here] */
+#define XENG_MAX_DIMS 8
+typedef struct XENGarray_ {
+    void *data;
+    int   space;
+    int   dtype;
+    int   ndim;
+    long  shape[XENG_MAX_DIMS];
+    long  strides[XENG_MAX_DIMS];
+    int   immutable;
+    int   big_endian;
+    int   conjugated;
+} XENGarray;
+
+const char *xengGetLastError(void);
+const char *xengVersion(void);
+
+/* ---------------------------------------------------------------- device / memory plumbing
+ * replaces bifrost.device.set_device / stream_synchronize and BFArray(space='cuda'|'cuda_host')
+ * + copy_array (corr_acc_block.py:315-317, beamform_block.py:433, copy_block.py:146). */
+int xengGetDeviceCount(int *count);
+int xengSetDevice(int gpu);
+int xengGetDevice(int *gpu);
+int xengDeviceSynchronize(void);
+int xengGetDeviceInfo(int gpu, int *num_cu, int *clock_khz, size_t *total_mem, char *name, int name_len);
+int xengMalloc(void **ptr, size_t nbytes, int space);          /* XENG_SPACE_CUDA or XENG_SPACE_CUDA_HOST */
+int xengFree(void *ptr, int space);
+int xengMemcpy(void *dst, const void *src, size_t nbytes);     /* any direction, synchronous on return */
+int xengMemcpyAsync(void *dst, const void *src, size_t nbytes);/* on the library's copy stream */
+int xengMemset(void *dst, int value, size_t nbytes);
+int xengStreamSynchronize(void);                               /* all library streams of the current device */
+
+/* ---------------------------------------------------------------- X-engine (Corr)
+ * replaces _bf.bfXgpuInitialize / bfXgpuKernel / bfXgpuCorrelate / bfXgpuGetOrder /
+ * bfXgpuSubSelect / bfXgpuReorder. */
+
+/* Sizes the next xengXgpuInitialize will use (xGPU compile-time NSTATION/NFREQUENCY/NTIME,
+ * install_xgpu.sh:5; block args corr_block.py:221-231).  max_gulps_per_flush bounds the
+ * device staging area (gulps are corner-turned into HBM and contracted in one launch at
+ * dump time); 0 picks a default.  Defaults before any call: 352, 2, 96, 480. */
+int xengXgpuConfigure(int nstand, int npol, int nchan, int ntime_gulp, int max_gulps_per_flush);
+
+/* corr_block.py:251-256, xgpu_test.py:76.  Creates (or re-creates) the process-global context on `gpu`. */
+int xengXgpuInitialize(int gpu);
+int xengXgpuDestroy(void);
+
+/* corr_block.py:445, xgpu_test.py:81-83.  in_dev: uint8[ntime_gulp][nchan][nstand][npol] 4+4 bit
+ * (hi nibble real, lo nibble imag).  out_dev: int32[2][nchan][per_chan] planar re|im in xGPU
+ * register-tile order (corr_block.py:27-58).  Gulps accumulate until a call with doDump=1, after
+ * which out_dev holds the sum over all gulps since the previous dump and the accumulation restarts.
+ * The same out_dev must be passed for every gulp of one integration (as Corr.main does: one
+ * WriteSpan per integration, corr_block.py:433-435).  Synchronous: on return the input has been
+ * consumed and, if doDump, the output is complete. */
+int xengXgpuKernel(const void *in_dev, void *out_dev, int doDump);
+
+/* Same, but enqueue only: the caller must keep in_dev valid and call xengXgpuSync before reading
+ * out_dev or recycling in_dev.  (No reference counterpart; used to pipeline gulps of one integration.) */
+int xengXgpuKernelAsync(const void *in_dev, void *out_dev, int doDump);
+int xengXgpuSync(void);
+
+/* xgpu_test.py:86-89: host-buffer variant (H2D, kernel, D2H on dump). */
+int xengXgpuCorrelate(const void *in_host, void *out_host, int doDump);
+
+/* corr_block.py:317-333.  Host arrays: antpol_to_input int32[nstand][npol];
+ * antpol_to_bl, is_conj int32[nstand][nstand][npol][npol] indexed [s0][s1][p0][p1]
+ * (corr_subsel_block.py:248-250).  is_conj=1: negate the stored imaginary part to obtain
+ * x[s0,p0]*conj(x[s1,p1]) (corr_output_full_block.py:582-591). */
+int xengXgpuGetOrder(const int32_t *antpol_to_input, int32_t *antpol_to_bl, int32_t *is_conj);
+
+/* corr_subsel_block.py:298.  in_dev: planar xGPU buffer; out_dev: int32[nchan/nchan_sum][nvis][2];
+ * vismap_dev/conj_dev: int32[nvis] device arrays. */
+int xengXgpuSubSelect(const void *in_dev, void *out_dev, const int32_t *vismap_dev,
+                      const int32_t *conj_dev, int nvis, int nchan_sum);
+
+/* corr_output_full_block.py:669.  Host: planar xGPU buffer -> int32[nstand][nstand][npol][npol][nchan][2]. */
+int xengXgpuReorder(const void *in_host, void *out_host, const int32_t *antpol_to_bl, const int32_t *is_conj);
+
+/* sizes of the current context */
+int xengXgpuGetInfo(int *nstand, int *npol, int *nchan, int *ntime_gulp, int64_t *matlen, int *max_gulps);
+
+/* profiling: HIP events around each kernel on the context's stream.  GetTimes returns and clears
+ * the totals (ms) and launch counts since the last call: [0]=corner-turn, [1]=MFMA X-engine. */
+int xengXgpuSetProfiling(int enable);
+int xengXgpuGetTimes(double ms[2], int count[2]);
+
+/* ---------------------------------------------------------------- CorrAcc
+ * replaces bifrost.map "a = b" / "a += b" on int32 (corr_acc_block.py:304,306).  Device pointers;
+ * enqueued on the library's map stream; xengStreamSynchronize() (corr_acc_block.py:317) completes it. */
+int xengMapAssignI32(void *a_dev, const void *b_dev, size_t nwords);
+int xengMapAddI32(void *a_dev, const void *b_dev, size_t nwords);
+
+/* ---------------------------------------------------------------- Beamformer
+ * replaces _bf.bfBeamformInitialize / Run / Integrate / IntegrateSingleBeam. */
+
+/* beamform_block.py:251-253.  ntime_blocks==0: voltage mode.  >0: "integrated power" mode the reference
+ * marks experimental (beamform_block.py:108-110) -- implemented as Run then Integrate (parity unpinned). */
+int xengBeamformInitialize(int gpu, int ninput, int nchan, int ntime, int nbeam, int ntime_blocks);
+int xengBeamformDestroy(void);
+
+/* beamform_block.py:446-449.  in_dev uint8[ntime][nchan][ninput] 4+4 bit; weights_dev
+ * cf32[nchan][nbeam][ninput] interleaved; out_dev cf32[nchan][nbeam][ntime]:
+ * out[c,b,t] = sum_i w[c,b,i]*x[t,c,i] (beamformer_test.py:76-84).  Asynchronous on the beamformer
+ * stream; xengBeamformSync()/xengStreamSynchronize() is the BFSync() of beamform_block.py:450. */
+int xengBeamformRun(const void *in_dev, void *out_dev, const void *weights_dev);
+
+/* beamform_sum_beams_block.py:243-246.  in_dev cf32[nchan][nbeam][ntime];
+ * out_dev f32[nbeam/2][ntime/ntime_sum][nchan][4] = [XX, YY, Re XY*, Im XY*]. */
+int xengBeamformIntegrate(const void *in_dev, void *out_dev, int ntime_sum);
+
+/* beamform_sum_single_beam_block.py:114: one dual-pol beam -> f32[ntime/ntime_sum][nchan][4]. */
+int xengBeamformIntegrateSingleBeam(const void *in_dev, void *out_dev, int ntime_sum, int beam_id);
+int xengBeamformSync(void);
+int xengBeamformSetProfiling(int enable);
+int xengBeamformGetTimes(double ms[2], int count[2]);   /* [0]=Run, [1]=Integrate */
+
+/* ---------------------------------------------------------------- bifrost-named adapters
+ * Exact argument shapes of the reference's call sites; data pointers are taken from the
+ * BFarray-like structs, sizes from the configured context. */
+int bfXgpuInitialize(XENGarray *in, XENGarray *out, int gpu_dev);                      /* corr_block.py:253 */
+int bfXgpuKernel(XENGarray *in, XENGarray *out, int doDump);                           /* corr_block.py:445 */
+int bfXgpuCorrelate(XENGarray *in, XENGarray *out, int doDump);                        /* xgpu_test.py:86-89 */
+int bfXgpuGetOrder(XENGarray *antpol_to_input, XENGarray *antpol_to_bl, XENGarray *is_conj); /* corr_block.py:331-333 */
+int bfXgpuSubSelect(XENGarray *in, XENGarray *out, XENGarray *vismap, XENGarray *conj,
+                    int nchan_sum, int unused);                                         /* corr_subsel_block.py:298 */
+int bfXgpuReorder(XENGarray *in, XENGarray *out, XENGarray *baselines, XENGarray *is_conj); /* corr_output_full_block.py:669 */
+int bfBeamformInitialize(int gpu, int ninput, int nchan, int ntime, int nbeam, int ntime_blocks); /* beamform_block.py:251 */
+int bfBeamformRun(XENGarray *in, XENGarray *out, XENGarray *weights);                  /* beamform_block.py:449 */
+int bfBeamformIntegrate(XENGarray *in, XENGarray *out, int ntime_sum);                 /* beamform_sum_beams_block.py:245 */
+int bfBeamformIntegrateSingleBeam(XENGarray *in, XENGarray *out, int ntime_sum, int beam_id); /* beamform_sum_single_beam_block.py:114 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XENG_H_ */

@@ -1,0 +1,218 @@
+"""GPU parity tests of the X-engine (Corr) path, through the C ABI, against the CPU oracle.
+Integer work: the bar is bit-exact on every word of both planes."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import xeng_oracle as orc  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from tests import gpu_util
+    assert gpu_util.ffi.device_count() >= 1
+    return gpu_util
+
+
+def oracle_run(vin, nstand, nchan, ntime_gulp):
+    acc = None
+    v = vin.reshape(-1, ntime_gulp, nchan, nstand, 2)
+    for g in range(v.shape[0]):
+        acc = orc.xgpu_correlate(v[g], nstand, nchan, acc)
+    return acc
+
+
+def test_corner_turn_layout(gpu):
+    """Stage 1 in isolation: the staging area holds, for (c, ib, kt, sub, lane=(h,r)), the 16
+    samples kt*32+16h+[0,16) of input ib*64+sub*32+r (as a set: the order inside a fragment is free)."""
+    nstand, nchan, ntime = 48, 3, 80      # 96 inputs -> 2 blocks (second half padded); 80 = 2.5 K tiles
+    x = gpu.Xgpu(nstand, nchan, ntime, max_gulps=2)
+    vin = gpu.synth_voltages(ntime, nchan, nstand, "full", seed=3)
+    x.inbuf = gpu.ffi.DeviceBuffer(vin.size).upload(vin)
+    gpu.ffi.call("xengXgpuKernelAsync", x.inbuf.ptr, x.out.ptr, 0)
+    gpu.ffi.call("xengXgpuSync")
+    L = gpu.ffi.lib()
+    L.xengXgpuDebugReadStash.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    cap_kt, nblk = ctypes.c_int(), ctypes.c_int()
+    assert L.xengXgpuDebugReadStash(None, 0, ctypes.byref(cap_kt), ctypes.byref(nblk)) == 0
+    cap_kt, nblk = cap_kt.value, nblk.value
+    assert nblk == 2
+    stash = np.zeros(nchan * nblk * cap_kt * 2048, dtype=np.uint8)
+    assert L.xengXgpuDebugReadStash(stash.ctypes.data, stash.nbytes, None, None) == 0
+    stash = stash.reshape(nchan, nblk, cap_kt, 2, 2, 32, 16)   # c, ib, kt, sub, h, r, 16
+    flat = vin.reshape(ntime, nchan, nstand * 2)
+    gkt = (ntime + 31) // 32
+    for c in range(nchan):
+        for ib in range(nblk):
+            for kt in range(gkt):
+                for sub in range(2):
+                    for h in range(2):
+                        for r in range(32):
+                            i = ib * 64 + sub * 32 + r
+                            t0 = kt * 32 + 16 * h
+                            exp = np.zeros(16, np.uint8)
+                            if i < nstand * 2:
+                                n = max(0, min(16, ntime - t0))
+                                exp[:n] = flat[t0:t0 + n, c, i]
+                            got = stash[c, ib, kt, sub, h, r]
+                            assert np.array_equal(np.sort(got), np.sort(exp)), (c, ib, kt, sub, h, r)
+                            assert np.array_equal(got, exp)   # this implementation also keeps time order
+    x.close()
+
+
+def _load_dat(path):
+    with open(path, "rb") as fh:
+        meta = json.loads(fh.readline().decode())
+        raw = fh.read()
+    dt = np.uint8 if "uint8" in meta["dtype"] else np.complex128
+    return meta, np.frombuffer(raw, dtype=dt).reshape(meta["shape"])
+
+
+@pytest.mark.parametrize("tag", ["deadbeef", "chanramp"])
+def test_golden_cfg1(gpu, golden_dir, tag):
+    """BASELINE config 1 shapes (16 stands x 2 pol, 4 chan) against the reference's golden file:
+    HIP X-engine -> GetOrder -> Reorder (both through the C ABI) == make_golden_inputs.py output."""
+    _, vin = _load_dat(os.path.join(golden_dir, "in_8t_4c_16s_2p_%s.dat" % tag))
+    meta, corr = _load_dat(os.path.join(golden_dir, "corr_8t_4a_4c_16s_2p_%s.dat" % tag))
+    T, C, S, P = vin.shape
+    acc_len = meta["acc_len"]
+    x = gpu.Xgpu(S, C, acc_len)
+    a2i = np.arange(S * P, dtype=np.int32).reshape(S, P)
+    bl = np.zeros((S, S, P, P), np.int32)
+    cj = np.zeros_like(bl)
+    gpu.ffi.call("xengXgpuGetOrder", a2i.ctypes.data, bl.ctypes.data, cj.ctypes.data)
+    obl, ocj = orc.xgpu_get_order(a2i)
+    assert np.array_equal(bl, obl) and np.array_equal(cj, ocj)
+    for blk in range(T // acc_len):
+        planar = x.run(vin[blk * acc_len:(blk + 1) * acc_len])
+        assert np.array_equal(planar, orc.xgpu_correlate(vin[blk * acc_len:(blk + 1) * acc_len], S, C))
+        ro = np.zeros((S, S, P, P, C, 2), np.int32)
+        gpu.ffi.call("xengXgpuReorder", planar.ctypes.data, ro.ctypes.data, bl.ctypes.data, cj.ctypes.data)
+        for s0 in range(S):
+            for s1 in range(s0, S):
+                g = corr[blk, :, s0, s1]                      # [c, p0, p1]
+                assert np.array_equal(ro[s0, s1, :, :, :, 0], np.moveaxis(g.real, 0, -1).astype(np.int32))
+                assert np.array_equal(ro[s0, s1, :, :, :, 1], np.moveaxis(g.imag, 0, -1).astype(np.int32))
+    x.close()
+
+
+def test_golden_64input(gpu, golden_dir):
+    z = np.load(os.path.join(golden_dir, "golden_64t_32a_8c_32s_2p_deadbeef.npz"))
+    vin = z["vin"]
+    T, C, S, P = vin.shape
+    x = gpu.Xgpu(S, C, 32)
+    for blk in range(2):
+        planar = x.run(vin[blk * 32:(blk + 1) * 32])
+        re, im = orc.xgpu_lookup_numpy(planar, S, C)
+        m = (np.arange(S)[:, None] <= np.arange(S)[None, :])[None, :, :, None, None]
+        assert np.array_equal(re * m, z["corr_re"][blk] * m)
+        assert np.array_equal(im * m, -z["corr_im"][blk] * m)     # stored = conj(golden), xgpu_test.py:111
+    x.close()
+
+
+@pytest.mark.parametrize("nstand,nchan,ntime,ngulp,kind", [
+    (16, 4, 8, 1, "full"),          # one half-empty 64-input block, K tile mostly padding
+    (32, 8, 32, 3, "full"),         # exactly one block
+    (48, 5, 96, 2, "random"),       # 2 blocks (one diagonal work-group), nchan not a multiple of 8
+    (80, 8, 480, 2, "full"),        # 3 blocks: odd count -> leftover row packing; the reference gulp length
+    (96, 3, 160, 2, "88"),          # every nibble -8: largest magnitudes, exercises the x16 scaling / P-Q split
+    (176, 2, 64, 1, "full"),        # 6 blocks: off-diagonal squares
+    (208, 1, 100, 3, "full"),       # 7 blocks (odd), ntime not a multiple of 32 (padded K tile per gulp)
+])
+def test_parity_vs_oracle(gpu, nstand, nchan, ntime, ngulp, kind):
+    x = gpu.Xgpu(nstand, nchan, ntime)
+    vin = gpu.synth_voltages(ntime * ngulp, nchan, nstand, kind, seed=nstand + ntime)
+    got = x.run(vin)
+    exp = oracle_run(vin, nstand, nchan, ntime)
+    assert got.shape == exp.shape
+    assert np.array_equal(got, exp)
+    # async enqueue + one sync gives the same answer
+    assert np.array_equal(x.run(vin, use_async=True), exp)
+    x.close()
+
+
+def test_mid_integration_flush_accumulates(gpu):
+    """Staging depth 2 with 5 gulps: the library flushes early (overwrite), later flushes
+    read-modify-write the caller's buffer; the dumped result is still the 5-gulp sum, and the
+    next integration starts from zero again (xgpu_test.py:76-83 semantics)."""
+    nstand, nchan, ntime = 48, 8, 64
+    x = gpu.Xgpu(nstand, nchan, ntime, max_gulps=2)
+    v1 = gpu.synth_voltages(ntime * 5, nchan, nstand, "full", seed=11)
+    v2 = gpu.synth_voltages(ntime * 3, nchan, nstand, "full", seed=12)
+    assert np.array_equal(x.run(v1), oracle_run(v1, nstand, nchan, ntime))
+    assert np.array_equal(x.run(v2, poison=False), oracle_run(v2, nstand, nchan, ntime))
+    x.close()
+
+
+def test_output_buffer_change_inside_integration_is_an_error(gpu):
+    nstand, nchan, ntime = 16, 8, 32
+    x = gpu.Xgpu(nstand, nchan, ntime, max_gulps=1)
+    vin = gpu.synth_voltages(ntime, nchan, nstand, "random")
+    x.inbuf = gpu.ffi.DeviceBuffer(vin.size).upload(vin)
+    other = gpu.ffi.DeviceBuffer(x.out.nbytes)
+    gpu.ffi.call("xengXgpuKernel", x.inbuf.ptr, x.out.ptr, 0)       # flushed into x.out (depth 1)
+    with pytest.raises(gpu.ffi.XengError):
+        gpu.ffi.call("xengXgpuKernel", x.inbuf.ptr, other.ptr, 1)
+    x.close()
+    other.free()
+
+
+def test_host_buffer_correlate(gpu):
+    """bfXgpuCorrelate shape (xgpu_test.py:86-89): host in, host out on dump."""
+    nstand, nchan, ntime = 32, 8, 64
+    gpu.ffi.call("xengXgpuConfigure", nstand, 2, nchan, ntime, 0)
+    gpu.ffi.call("xengXgpuInitialize", 0)
+    vin = gpu.synth_voltages(ntime * 2, nchan, nstand, "full", seed=4)
+    out = np.zeros(2 * orc.per_chan(nstand) * nchan, np.int32)
+    flat = vin.reshape(2, -1)
+    gpu.ffi.call("xengXgpuCorrelate", flat[0].ctypes.data, out.ctypes.data, 0)
+    gpu.ffi.call("xengXgpuCorrelate", flat[1].ctypes.data, out.ctypes.data, 1)
+    assert np.array_equal(out, oracle_run(vin, nstand, nchan, ntime))
+    gpu.ffi.call("xengXgpuDestroy")
+
+
+def test_subselect(gpu):
+    nstand, nchan, ntime = 32, 8, 64
+    x = gpu.Xgpu(nstand, nchan, ntime)
+    vin = gpu.synth_voltages(ntime, nchan, nstand, "full", seed=8)
+    planar = x.run(vin)
+    bl, cj = orc.xgpu_get_order(np.arange(nstand * 2, dtype=np.int32).reshape(nstand, 2))
+    rng = np.random.default_rng(2)
+    nvis = 300
+    s0, s1 = rng.integers(0, nstand, nvis), rng.integers(0, nstand, nvis)
+    p0, p1 = rng.integers(0, 2, nvis), rng.integers(0, 2, nvis)
+    vismap = bl[s0, s1, p0, p1].astype(np.int32)
+    conj = cj[s0, s1, p0, p1].astype(np.int32)
+    dv = gpu.ffi.DeviceBuffer(vismap.nbytes).upload(vismap)
+    dc = gpu.ffi.DeviceBuffer(conj.nbytes).upload(conj)
+    do = gpu.ffi.DeviceBuffer((nchan // 4) * nvis * 8)
+    gpu.ffi.call("xengXgpuSubSelect", x.out.ptr, do.ptr, dv.ptr, dc.ptr, nvis, 4)
+    got = do.download(np.int32).reshape(nchan // 4, nvis, 2)
+    assert np.array_equal(got, orc.xgpu_subselect(planar, vismap, conj, nchan, 4, nstand))
+    x.close()
+
+
+def test_config2_full_size(gpu):
+    """BASELINE config 2: 704 inputs, 96 channels, 5 gulps of 480 (acc_len 2400), bit-exact vs the
+    C oracle on every word of both planes -- random bytes (the golden generator), then all-0x88."""
+    nstand, nchan, ntime, ngulp = 352, 96, 480, 5
+    x = gpu.Xgpu(nstand, nchan, ntime)
+    vin = gpu.synth_voltages(ntime * ngulp, nchan, nstand, "random")
+    got = x.run(vin)
+    exp = oracle_run(vin, nstand, nchan, ntime)
+    assert np.array_equal(got, exp)
+    # size-independent properties at full size: autos are real and positive, planes have the xGPU length
+    matlen = 96 * 249216                       # per_chan = 249216 words per plane per channel
+    assert got.size == 2 * matlen
+    auto = orc.regtile_index(2 * 7, 2 * 7, nstand)
+    assert got[auto] > 0 and got[matlen + auto] == 0
+    v88 = gpu.synth_voltages(ntime, nchan, nstand, "88")
+    g88 = x.run(v88)
+    # every product is (-8-8j)*conj(-8-8j) = 128: all words 128*ntime (re) / 0 (im), incl. the unaddressed ones
+    assert np.all(g88[:matlen] == 128 * ntime) and np.all(g88[matlen:] == 0)
+    x.close()
