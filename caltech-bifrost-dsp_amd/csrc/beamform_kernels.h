@@ -90,8 +90,8 @@ __global__ __launch_bounds__(256) void beamform_f32_kernel(const uint8_t* __rest
                 for (int z = 0; z < 2; z++) {
                     const int sh = 8 * (e + z);
                     // hi nibble = real, lo nibble = imag, two's complement (beamformer_test.py:69-73)
-                    const float xr = (float)__builtin_amdgcn_sbfe(xw, sh + 4, 4);
-                    const float xi = (float)__builtin_amdgcn_sbfe(xw, sh, 4);
+                    const float xr = (float)(int)__builtin_amdgcn_sbfe((int)xw, sh + 4, 4);
+                    const float xi = (float)(int)__builtin_amdgcn_sbfe((int)xw, sh, 4);
                     const float wr = z ? wv.z : wv.x, wi = z ? wv.w : wv.y;
                     acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(wr, xr, acc_r, 0, 0, 0);
                     acc_i = __builtin_amdgcn_mfma_f32_32x32x2f32(wr, xi, acc_i, 0, 0, 0);
