@@ -1,0 +1,77 @@
+"""The object the blocks call where the reference calls `_bf` / `bifrost.device` / `bifrost.map`.
+
+`HipBackend` forwards to libxeng.so (include/xeng.h) and is the only backend the product ships:
+constructing it without the HIP library or without a GPU raises.  Tests may inject a different
+object with the same methods (tests/fake_backend.py wraps the CPU oracle) to exercise the block
+state machines without a GPU -- that is test infrastructure, never a fallback.
+"""
+from . import ffi
+
+
+class HipBackend:
+    BF_STATUS_SUCCESS = ffi.STATUS_SUCCESS
+    space_in = "cuda"          # memory space the compute entry points expect
+
+    def __init__(self):
+        self._lib = ffi.lib()   # raises ImportError if libxeng.so has not been built
+
+    # ---- device plumbing (bifrost.device.set_device / get_device / stream_synchronize)
+    def set_device(self, gpu):
+        ffi.call("xengSetDevice", int(gpu))
+
+    def get_device(self):
+        import ctypes
+        g = ctypes.c_int()
+        ffi.call("xengGetDevice", ctypes.byref(g))
+        return g.value
+
+    def stream_synchronize(self):
+        ffi.call("xengStreamSynchronize")
+
+    # ---- X-engine (corr_block.py:253,331,445)
+    def xgpu_configure(self, nstand, npol, nchan, ntime_gulp, max_gulps=0):
+        """xGPU's compile-time NSTATION/NFREQUENCY/NTIME (install_xgpu.sh:5) are runtime here."""
+        return self._lib.xengXgpuConfigure(nstand, npol, nchan, ntime_gulp, max_gulps)
+
+    def bfXgpuInitialize(self, in_arr, out_arr, gpu):
+        return self._lib.bfXgpuInitialize(in_arr, out_arr, int(gpu))
+
+    def bfXgpuKernel(self, in_arr, out_arr, do_dump):
+        return self._lib.bfXgpuKernel(in_arr, out_arr, int(do_dump))
+
+    def bfXgpuGetOrder(self, antpol_to_input, antpol_to_bl, is_conj):
+        return self._lib.bfXgpuGetOrder(antpol_to_input, antpol_to_bl, is_conj)
+
+    def xgpu_reset(self):
+        """Drop staged gulps / partial sums of an aborted integration (no reference counterpart)."""
+        return self._lib.xengXgpuReset()
+
+    # ---- CorrAcc (corr_acc_block.py:304,306: BFMap "a = b" / "a += b")
+    def map_assign_i32(self, a, b):
+        return self._lib.xengMapAssignI32(a.ptr, b.ptr, a.nbytes // 4)
+
+    def map_add_i32(self, a, b):
+        return self._lib.xengMapAddI32(a.ptr, b.ptr, a.nbytes // 4)
+
+    # ---- beamformer (beamform_block.py:251,449; beamform_sum_beams_block.py:245)
+    def bfBeamformInitialize(self, gpu, ninput, nchan, ntime, nbeam, ntime_blocks):
+        return self._lib.bfBeamformInitialize(int(gpu), ninput, nchan, ntime, nbeam, ntime_blocks)
+
+    def bfBeamformRun(self, in_arr, out_arr, weights):
+        return self._lib.bfBeamformRun(in_arr, out_arr, weights)
+
+    def bfBeamformIntegrate(self, in_arr, out_arr, ntime_sum):
+        return self._lib.bfBeamformIntegrate(in_arr, out_arr, int(ntime_sum))
+
+    def last_error(self):
+        return self._lib.xengGetLastError().decode()
+
+
+_default = None
+
+
+def default_backend():
+    global _default
+    if _default is None:
+        _default = HipBackend()
+    return _default

@@ -1,0 +1,9 @@
+"""Hot-path blocks with the reference's Block + ring interface."""
+from .block_base import Block, COMMAND_OK, COMMAND_NOT_RECOGNIZED, COMMAND_WRONG_TYPE, COMMAND_INVALID
+from .corr_block import Corr, regtile_index, tri_index
+from .corr_acc_block import CorrAcc
+from .beamform_block import Beamform
+from .beamform_sum_beams_block import BeamformSumBeams
+
+__all__ = ["Block", "Corr", "CorrAcc", "Beamform", "BeamformSumBeams", "regtile_index", "tri_index",
+           "COMMAND_OK", "COMMAND_NOT_RECOGNIZED", "COMMAND_WRONG_TYPE", "COMMAND_INVALID"]

@@ -1,0 +1,182 @@
+"""Beamform: voltage beams from 4+4-bit F-engine data on the GPU.
+
+Drop-in counterpart of pipeline/lwa352_pipeline/blocks/beamform_block.py (class Beamform,
+constructor :208, command handling :269-362, main :364-461): same constructor signature, the
+`coeffs` command key with its two payload types (`calgains`, `beamcoeffs`), the three-stage
+gain buffers (new -> cpu -> gpu) with per-beam timed activation (`load_sample`, :416-434), the
+output header rewrite (:403-409) and one `_bf.bfBeamformRun` per gulp (:449) -- which here is
+libxeng's fused nibble-decode + fp32-MFMA beamformer (csrc/beamform_kernels.h).
+
+out[c, b, t] = sum_i gains[c, b, i] * x[t, c, i], cf32 [nchan, nbeam, ntime_gulp]
+(beamformer_test.py:76-84).
+"""
+import json
+import time
+
+import numpy as np
+
+from ..backend import default_backend
+from ..ndarray import XArray
+from ..proclog import cpu_affinity
+from .block_base import Block, COMMAND_INVALID, COMMAND_OK
+
+
+class Beamform(Block):
+    def __init__(self, log, iring, oring, nchan=256, nbeam=1, ninput=352 * 2, ntime_gulp=2500, ntime_sum=None,
+                 guarantee=True, core=-1, gpu=-1, etcd_client=None, backend=None):
+        super(Beamform, self).__init__(log, iring, oring, guarantee, core, etcd_client=etcd_client)
+        self._bf = backend if backend is not None else default_backend()
+        self.ntime_gulp = ntime_gulp
+        self.gpu = gpu
+        self.ntime_sum = ntime_sum
+        if ntime_sum is not None:
+            assert ntime_gulp % ntime_sum == 0
+            self.ntime_blocks = ntime_gulp // ntime_sum
+        else:
+            self.ntime_blocks = ntime_gulp
+        self.nchan, self.nbeam, self.ninput = nchan, nbeam, ninput
+        self.freqs = np.zeros(self.nchan, dtype=np.float32)
+        if self.gpu != -1:
+            self._bf.set_device(self.gpu)
+        # gains: latest commanded (new) -> waiting for its load time (cpu) -> on the device (gpu)
+        self.cal_gains = np.ones((nchan, nbeam, ninput), dtype=np.complex64)
+        self.gains_cpu_new = np.zeros((nchan, nbeam, ninput), dtype=np.complex64)
+        self.gains_cpu = np.zeros((nchan, nbeam, ninput), dtype=np.complex64)
+        self.gains_gpu = XArray(shape=(nchan, nbeam, ninput), dtype=np.complex64, space=self._bf.space_in)
+        self.gains_load_sample = np.zeros(nbeam)
+        self.define_command_key('coeffs', type=dict, initial_val={})
+        for b in range(self.nbeam):
+            self.update_stats({'cal_gains%d' % b: [False, ] * ninput})
+        if ntime_sum is not None:
+            self.log.warning("Running Beamform block with ntime_sum != None is experimental!")
+            rv = self._bf.bfBeamformInitialize(self.gpu, self.ninput, self.nchan, self.ntime_gulp, self.nbeam, self.ntime_blocks)
+        else:
+            rv = self._bf.bfBeamformInitialize(self.gpu, self.ninput, self.nchan, self.ntime_gulp, self.nbeam, 0)
+        if rv != self._bf.BF_STATUS_SUCCESS:
+            raise RuntimeError("bfBeamformInitialize returned %d: %s" % (rv, self._bf.last_error()))
+
+    def _etcd_callback(self, watchresponse):
+        """Every command is enacted immediately (all coefficient commands share one key, so a later
+        one must not overwrite an earlier one before it is processed; beamform_block.py:269-318)."""
+        cpu_affinity.set_core(self.core)
+        self.acquire_control_lock()
+        try:
+            for event in watchresponse.events:
+                try:
+                    seq_id, kwargs = self._parse_event(event)
+                except ValueError:
+                    self.log.exception("BEAMFORM >> Failed to JSON-decode event %s" % str(event.value))
+                    self._send_command_response("0", False, "JSON-decode failed!")
+                    continue
+                if kwargs is None:
+                    continue
+                try:
+                    proc_ok = self._process_commands(kwargs, set_pending_flag=False)
+                except Exception:
+                    proc_ok = COMMAND_INVALID
+                self.update_stats({'last_cmd_response': proc_ok})
+                self.update_command_vals()
+                self._send_command_response(seq_id, proc_ok == COMMAND_OK, str(proc_ok))
+        finally:
+            self.release_control_lock()
+
+    def update_command_vals(self):
+        """Apply pending `coeffs` commands (called with the control lock held; :320-362)."""
+        cpu_affinity.set_core(self.core)
+        self.command_vals.update(self._pending_command_vals)
+        update_beam_cal_state = False
+        for k, v in self._pending_command_vals.items():
+            try:
+                if not v:
+                    continue
+                if v['type'] == 'calgains':
+                    i, b = v['input_id'], v['beam_id']
+                    data = np.array(v['data'])
+                    self.cal_gains[:, b, i] = data[0::2] + 1j * data[1::2]      # freq x beam x input
+                    self.stats['cal_gains%d' % b][i] = True
+                    update_beam_cal_state = True
+                if v['type'] == 'beamcoeffs':
+                    b = v['beam_id']
+                    delays_ns = np.array(v['data']['delays'])
+                    amps = np.array(v['data']['amps'])
+                    phases = np.exp(1j * 2 * np.pi * self.freqs[:, None] * delays_ns * 1e-9)   # freq x input
+                    self.gains_cpu_new[:, b, :] = amps * phases * self.cal_gains[:, b, :]
+                    self.gains_load_sample[b] = v.get('load_sample', -1)        # default: load immediately
+                    self.update_pending = True      # only beam coefficients trigger a device update
+            except KeyError:
+                self.log.error("BEAMFORM >> Failed to parse command")
+        self.update_stats(self.command_vals)
+        if update_beam_cal_state:
+            self.update_stats({'cal_gains%d' % b: self.stats['cal_gains%d' % b] for b in range(self.nbeam)})
+
+    def main(self):
+        cpu_affinity.set_core(self.core)
+        if self.gpu != -1:
+            self._bf.set_device(self.gpu)
+        self.bind_proclog.update({'ncore': 1, 'core0': cpu_affinity.get_core(), 'ngpu': 1,
+                                  'gpu0': self._bf.get_device()})
+        igulp_size = self.ntime_gulp * self.nchan * self.ninput           # 4+4 bit
+        ogulp_size = self.ntime_blocks * self.nchan * self.nbeam * 8      # complex64
+        self.oring.resize(ogulp_size)
+        with self.oring.begin_writing() as oring:
+            for iseq in self.iring.read(guarantee=self.guarantee):
+                # frequencies may have changed: rebuild and re-upload coefficients on every sequence
+                self.update_pending = True
+                copy_pending = True
+                ihdr = json.loads(iseq.header.tostring())
+                self.sequence_proclog.update(ihdr)
+                this_gulp_time = ihdr['seq0']
+                nchan, nstand, npol = ihdr['nchan'], ihdr['nstand'], ihdr['npol']
+                chan_bw = ihdr['bw_hz'] / nchan
+                assert nchan == self.nchan
+                assert self.ninput == nstand * npol
+                self.freqs = ihdr['sfreq'] + chan_bw * np.arange(nchan)
+                ohdr = ihdr.copy()
+                ohdr['nstand'] = self.nbeam
+                ohdr['nbit'] = 32
+                ohdr['npol'] = 1            # single-polarisation beams
+                ohdr['complex'] = True
+                ohdr['nbeam'] = self.nbeam
+                prev_time = time.time()
+                with oring.begin_sequence(time_tag=iseq.time_tag, header=json.dumps(ohdr)) as oseq:
+                    for ispan in iseq.read(igulp_size):
+                        self.update_stats({'curr_sample': this_gulp_time})
+                        if ispan.size < igulp_size:
+                            continue
+                        if self.update_pending:
+                            self.acquire_control_lock()
+                            for b in range(self.nbeam):
+                                if self.gains_load_sample[b] == 0:      # 0 = nothing pending for this beam
+                                    continue
+                                if this_gulp_time >= self.gains_load_sample[b]:
+                                    self.gains_cpu[:, b, :] = self.gains_cpu_new[:, b, :]
+                                    self.gains_load_sample[b] = 0
+                                    copy_pending = True
+                            if self.gains_load_sample.sum() == 0:
+                                self.update_pending = False
+                            self.stats['update_pending'] = self.update_pending
+                            self.stats['last_cmd_proc_time'] = time.time()
+                            self.release_control_lock()
+                        if copy_pending:
+                            self.gains_gpu[...] = self.gains_cpu
+                            copy_pending = False
+                        curr_time = time.time()
+                        acquire_time = curr_time - prev_time
+                        prev_time = curr_time
+                        with oseq.reserve(ogulp_size) as ospan:
+                            curr_time = time.time()
+                            reserve_time = curr_time - prev_time
+                            prev_time = curr_time
+                            idata = ispan.data_view('i8')
+                            odata = ospan.data_view(np.float32)
+                            rv = self._bf.bfBeamformRun(idata.as_BFarray(), odata.as_BFarray(), self.gains_gpu.as_BFarray())
+                            if rv != self._bf.BF_STATUS_SUCCESS:
+                                raise RuntimeError("bfBeamformRun returned %d: %s" % (rv, self._bf.last_error()))
+                            self._bf.stream_synchronize()
+                        this_gulp_time += self.ntime_gulp
+                        curr_time = time.time()
+                        process_time = curr_time - prev_time
+                        prev_time = curr_time
+                        self.perf_proclog.update({'acquire_time': acquire_time, 'reserve_time': reserve_time,
+                                                  'process_time': process_time,
+                                                  'gbps': 8 * igulp_size / max(process_time, 1e-9) / 1e9})

@@ -1,0 +1,84 @@
+"""BeamformSumBeams: dual-polarisation power beams from pairs of voltage beams.
+
+Drop-in counterpart of pipeline/lwa352_pipeline/blocks/beamform_sum_beams_block.py
+(constructor :161-163, main :189-260).  Beams 2b / 2b+1 are treated as X / Y; every `ntime_sum`
+samples it emits [XX, YY, Re(XY*), Im(XY*)] per channel, f32 [nbeam/2, ntime/ntime_sum, nchan, 4]
+(:220-222; math beamformer_sum_test.py:64-77).  The beamformer context is the process-global
+one the Beamform block created (:186-187): this block does not initialise it.
+"""
+import json
+import time
+
+import numpy as np
+
+from ..backend import default_backend
+from ..ndarray import XArray
+from ..proclog import cpu_affinity
+from .block_base import Block
+
+
+class BeamformSumBeams(Block):
+    def __init__(self, log, iring, oring, nchan=256,
+                 ntime_gulp=2500, ntime_sum=24, guarantee=True, core=-1, gpu=-1,
+                 etcd_client=None, backend=None):
+        super(BeamformSumBeams, self).__init__(log, iring, oring, guarantee, core, etcd_client=etcd_client)
+        self._bf = backend if backend is not None else default_backend()
+        self.ntime_gulp = ntime_gulp
+        self.gpu = gpu
+        self.ntime_sum = ntime_sum
+        assert ntime_gulp % ntime_sum == 0
+        self.ntime_blocks = ntime_gulp // ntime_sum
+        self.nchan = nchan
+        if self.gpu != -1:
+            self._bf.set_device(self.gpu)
+
+    def main(self):
+        cpu_affinity.set_core(self.core)
+        if self.gpu != -1:
+            self._bf.set_device(self.gpu)
+        self.bind_proclog.update({'ncore': 1, 'core0': cpu_affinity.get_core(), 'ngpu': 1,
+                                  'gpu0': self._bf.get_device()})
+        with self.oring.begin_writing() as oring:
+            for iseq in self.iring.read(guarantee=self.guarantee):
+                ihdr = json.loads(iseq.header.tostring())
+                self.sequence_proclog.update(ihdr)
+                nchan, nbeam = ihdr['nchan'], ihdr['nbeam']
+                assert nchan == self.nchan
+                ohdr = ihdr.copy()
+                ohdr['nbeam'] = nbeam // 2      # single-pol beams -> dual-pol
+                ohdr['nbit'] = 32
+                ohdr['complex'] = True
+                ohdr['acc_len'] = self.ntime_sum
+                ohdr['npol'] = 2
+                self.bf_output = XArray(shape=(ohdr['nbeam'], self.ntime_blocks, nchan, 4), dtype=np.float32,
+                                        space=self._bf.space_in)
+                igulp_size = self.ntime_gulp * nchan * nbeam * 2 * 32 // 8
+                ogulp_size = self.ntime_blocks * nchan * ohdr['nbeam'] * 4 * 4
+                # output gulps are small: size the ring in units of input gulps (:225-228)
+                self.oring.resize(ogulp_size * self.ntime_sum * 4)
+                prev_time = time.time()
+                with oring.begin_sequence(time_tag=iseq.time_tag, header=json.dumps(ohdr)) as oseq:
+                    for ispan in iseq.read(igulp_size):
+                        if ispan.size < igulp_size:
+                            continue
+                        curr_time = time.time()
+                        acquire_time = curr_time - prev_time
+                        prev_time = curr_time
+                        with oseq.reserve(ogulp_size) as ospan:
+                            curr_time = time.time()
+                            reserve_time = curr_time - prev_time
+                            prev_time = curr_time
+                            idata = ispan.data_view(np.float32)
+                            odata = ospan.data_view(np.float32).reshape(self.bf_output.shape)
+                            rv = self._bf.bfBeamformIntegrate(idata.as_BFarray(), self.bf_output.as_BFarray(), self.ntime_sum)
+                            if rv != self._bf.BF_STATUS_SUCCESS:
+                                raise RuntimeError("bfBeamformIntegrate returned %d: %s" % (rv, self._bf.last_error()))
+                            self._bf.stream_synchronize()
+                            odata[...] = self.bf_output
+                            self._bf.stream_synchronize()
+                        curr_time = time.time()
+                        process_time = curr_time - prev_time
+                        prev_time = curr_time
+                        self.perf_proclog.update({'acquire_time': acquire_time, 'reserve_time': reserve_time,
+                                                  'process_time': process_time,
+                                                  'gbps': 8 * igulp_size / max(process_time, 1e-9) / 1e9})

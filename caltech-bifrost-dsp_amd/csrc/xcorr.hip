@@ -277,6 +277,19 @@ int xengXgpuSync(void) {
     return XENG_STATUS_SUCCESS;
 }
 
+int xengXgpuReset(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    XgpuContext& x = g_ctx;
+    if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized");
+    XENG_HIP(hipSetDevice(x.gpu));
+    XENG_HIP(hipStreamSynchronize(x.stream));
+    x.timer.drain();
+    x.nfilled = 0;
+    x.acc_started = false;
+    x.acc_out = nullptr;
+    return XENG_STATUS_SUCCESS;
+}
+
 int xengXgpuCorrelate(const void* in_host, void* out_host, int doDump) {
     std::lock_guard<std::mutex> lk(g_mu);
     XgpuContext& x = g_ctx;

@@ -1,0 +1,45 @@
+"""Stand-ins for bifrost.proclog.ProcLog and bifrost.affinity used by the blocks
+(block_base.py:113-119, corr_block.py:336).  ProcLog keeps the latest dict per log name in
+memory (PROCLOGS) and, when XENG_PROCLOG_DIR is set, also writes bifrost-style `key : value`
+files there so a monitor can poll them like /dev/shm/bifrost."""
+import os
+import threading
+
+PROCLOGS = {}
+_lock = threading.Lock()
+
+
+class ProcLog:
+    def __init__(self, name):
+        self.name = name
+        with _lock:
+            PROCLOGS.setdefault(name, {})
+
+    def update(self, contents, *args, **kwargs):
+        with _lock:
+            PROCLOGS[self.name] = dict(contents)
+        d = os.environ.get("XENG_PROCLOG_DIR")
+        if d:
+            path = os.path.join(d, str(os.getpid()), self.name)
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            with open(path, "w") as fh:
+                for k, v in contents.items():
+                    fh.write("%s : %s\n" % (k, v))
+
+
+class cpu_affinity:
+    @staticmethod
+    def set_core(core):
+        if core is not None and core >= 0 and hasattr(os, "sched_setaffinity"):
+            try:
+                os.sched_setaffinity(0, {int(core)})
+            except OSError:
+                pass
+
+    @staticmethod
+    def get_core():
+        try:
+            cores = sorted(os.sched_getaffinity(0))
+            return cores[0] if len(cores) == 1 else -1
+        except (AttributeError, OSError):
+            return -1

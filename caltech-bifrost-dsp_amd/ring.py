@@ -1,0 +1,316 @@
+"""A minimal ring buffer implementing exactly the protocol the hot-path blocks use.
+
+The reference blocks sit on `bifrost.ring.Ring`.  They only need this method set (enumerated
+from corr_block.py, corr_acc_block.py, beamform_block.py, beamform_sum_beams_block.py;
+SURVEY.md section 8b):
+
+    Ring(name=, space=) .name .resize(contig_bytes, total_span=)
+    ring.begin_writing() ctx -> .begin_sequence(time_tag=, header=<json str>, nringlet=) (ctx or .end())
+    oseq.reserve(nbytes) ctx -> ospan.data / ospan.data_view(dtype[, shape]);  oseq.ring
+    WriteSpan(oseq.ring, nbytes, nonblocking=False) + .close()
+    ring.read(guarantee=) -> iseq.header(.tostring()/.tobytes()) .time_tag .nringlet
+    iseq.read(gulp_nbytes) -> ispan.size / ispan.data / ispan.data_view(dtype)
+
+The blocks are duck-typed against this protocol, so they accept a real bifrost Ring or this one.
+This implementation is a single-writer / multi-reader byte stream per sequence, with the data
+held as committed spans in the ring's space ('system' = numpy memory, so config 1 runs with no
+GPU; 'cuda' / 'cuda_host' = HIP allocations through libxeng).  Readers that ask for
+`guarantee=True` apply back-pressure once `total_span` bytes are outstanding.
+"""
+import threading
+
+import numpy as np
+
+from .ndarray import XArray, copy_array, to_dtype
+
+
+class _Header(bytes):
+    """Sequence header bytes; the blocks call .tostring() (bifrost arrays) on it."""
+
+    def tostring(self):
+        return bytes(self)
+
+    def tobytes(self):
+        return bytes(self)
+
+
+class _Chunk:
+    __slots__ = ("offset", "nbytes", "data")
+
+    def __init__(self, offset, nbytes, data):
+        self.offset, self.nbytes, self.data = offset, nbytes, data
+
+
+class _Sequence:
+    def __init__(self, ring, index, time_tag, header, nringlet):
+        self.ring, self.index = ring, index
+        self.time_tag, self.nringlet = time_tag, nringlet
+        self.header = _Header(header.encode() if isinstance(header, str) else bytes(header))
+        self.chunks = []          # committed spans, in order
+        self.committed = 0        # bytes committed so far
+        self.ended = False
+
+
+class WriteSequence:
+    """Writer-side handle of a sequence (what begin_sequence returns)."""
+
+    def __init__(self, seq):
+        self._seq = seq
+        self.ring = seq.ring      # the blocks pass `oseq.ring` to WriteSpan
+
+    def reserve(self, nbytes, nonblocking=False):
+        return WriteSpan(self.ring, nbytes, nonblocking=nonblocking, _seq=self._seq)
+
+    def end(self):
+        self.ring._end_sequence(self._seq)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.end()
+        return False
+
+
+class WriteSpan:
+    """`WriteSpan(oseq.ring, nbytes, nonblocking=False)` (corr_block.py:435) -- reserved output
+    memory in the ring's space; `.close()` (or leaving the `with`) commits all of it."""
+
+    def __init__(self, ring, nbytes, nonblocking=False, _seq=None):
+        self.ring = ring
+        self._seq = _seq if _seq is not None else ring._open_seq
+        if self._seq is None or self._seq.ended:
+            raise RuntimeError("WriteSpan: no open sequence on ring %r" % ring.name)
+        self.size = int(nbytes)
+        ring._wait_for_room(self.size, nonblocking)
+        self.data = XArray(shape=(self.size,), dtype=np.uint8, space=ring.space)
+        self._closed = False
+
+    def data_view(self, dtype=np.uint8, shape=None):
+        v = self.data.view(dtype)
+        return v.reshape(shape) if shape is not None else v
+
+    def commit(self, nbytes=None):
+        if self._closed:
+            return
+        self._closed = True
+        n = self.size if nbytes is None else int(nbytes)
+        if n > 0:
+            self.ring._commit(self._seq, self.data if n == self.size else self.data.byte_slice(0, n), n)
+
+    def close(self):
+        self.commit()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+
+class ReadSpan:
+    def __init__(self, data, size):
+        self.data, self.size = data, size
+
+    def data_view(self, dtype=np.uint8, shape=None):
+        v = self.data.view(dtype)
+        return v.reshape(shape) if shape is not None else v
+
+
+class ReadSequence:
+    def __init__(self, seq, reader):
+        self._seq, self._reader = seq, reader
+        self.header = seq.header
+        self.time_tag, self.nringlet = seq.time_tag, seq.nringlet
+        self.ring = seq.ring
+
+    def read(self, gulp_nbytes):
+        """Yield full gulps as they become available; a short final gulp (size < gulp_nbytes) is
+        yielded once when the sequence ends, as bifrost does (the blocks skip it:
+        corr_block.py:389-391)."""
+        ring, seq, rd = self.ring, self._seq, self._reader
+        gulp_nbytes = int(gulp_nbytes)
+        while True:
+            with ring._cond:
+                while seq.committed - rd.offset < gulp_nbytes and not seq.ended:
+                    ring._cond.wait(0.5)
+                avail = seq.committed - rd.offset
+                n = min(avail, gulp_nbytes)
+                if n <= 0:
+                    return
+                data = ring._assemble(seq, rd.offset, n)
+            yield ReadSpan(data, n)
+            with ring._cond:
+                rd.offset += n
+                ring._gc()
+                ring._cond.notify_all()
+            if n < gulp_nbytes:
+                return
+
+
+class _Reader:
+    def __init__(self, guarantee):
+        self.guarantee = guarantee
+        self.seq_index = 0
+        self.offset = 0
+
+
+class _Writer:
+    def __init__(self, ring):
+        self.ring = ring
+
+    def begin_sequence(self, time_tag=0, header="", nringlet=1, name=None):
+        return self.ring._begin_sequence(time_tag, header, nringlet)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.ring._end_writing()
+        return False
+
+
+class Ring:
+    def __init__(self, name="", space="system", core=None):
+        self.name, self.space = name, space
+        self._cond = threading.Condition()
+        self._seqs = []
+        self._open_seq = None
+        self._writing_ended = False
+        self._readers = []
+        self._capacity = 0
+        self._live_bytes = 0
+
+    # ------------------------------------------------------------------ writer side
+    def resize(self, contig_bytes, total_span=None, nringlet=1):
+        want = int(total_span) if total_span else 4 * int(contig_bytes)
+        with self._cond:
+            self._capacity = max(self._capacity, want, int(contig_bytes))
+
+    def begin_writing(self):
+        return _Writer(self)
+
+    def _begin_sequence(self, time_tag, header, nringlet):
+        with self._cond:
+            if self._open_seq is not None and not self._open_seq.ended:
+                self._open_seq.ended = True
+            seq = _Sequence(self, len(self._seqs), time_tag, header, nringlet)
+            self._seqs.append(seq)
+            self._open_seq = seq
+            self._cond.notify_all()
+        return WriteSequence(seq)
+
+    def _end_sequence(self, seq):
+        with self._cond:
+            seq.ended = True
+            if self._open_seq is seq:
+                self._open_seq = None
+            self._cond.notify_all()
+
+    def _end_writing(self):
+        with self._cond:
+            if self._open_seq is not None:
+                self._open_seq.ended = True
+                self._open_seq = None
+            self._writing_ended = True
+            self._cond.notify_all()
+
+    def _wait_for_room(self, nbytes, nonblocking):
+        with self._cond:
+            if self._capacity == 0:
+                self._capacity = 4 * nbytes
+            while self._live_bytes + nbytes > max(self._capacity, nbytes):
+                self._gc()
+                if self._live_bytes + nbytes <= max(self._capacity, nbytes):
+                    break
+                if not any(r.guarantee for r in self._readers):
+                    self._drop_oldest()           # nobody applies back-pressure: overwrite, like bifrost
+                    continue
+                if nonblocking:
+                    raise BlockingIOError("ring %r full" % self.name)
+                self._cond.wait(0.5)
+
+    def _commit(self, seq, data, nbytes):
+        with self._cond:
+            seq.chunks.append(_Chunk(seq.committed, nbytes, data))
+            seq.committed += nbytes
+            self._live_bytes += nbytes
+            self._cond.notify_all()
+
+    # ------------------------------------------------------------------ bookkeeping (hold _cond)
+    def _gc(self):
+        """Free committed spans every registered reader has moved past."""
+        if not self._readers:
+            return
+        lo_seq = min(r.seq_index for r in self._readers)
+        for seq in self._seqs[:lo_seq + 1]:
+            lo_off = None
+            if seq.index == lo_seq:
+                lo_off = min(r.offset for r in self._readers if r.seq_index == lo_seq)
+            for ch in seq.chunks:
+                if ch.data is not None and (lo_off is None or ch.offset + ch.nbytes <= lo_off):
+                    ch.data = None
+                    self._live_bytes -= ch.nbytes
+
+    def _drop_oldest(self):
+        for seq in self._seqs:
+            for ch in seq.chunks:
+                if ch.data is not None:
+                    ch.data = None
+                    self._live_bytes -= ch.nbytes
+                    return
+        self._live_bytes = 0
+
+    def _assemble(self, seq, offset, nbytes):
+        """Bytes [offset, offset+nbytes) of a sequence as one array: a zero-copy window when they
+        lie inside one committed span, else a gathered copy in the ring's space."""
+        pieces = []
+        for ch in seq.chunks:
+            lo, hi = max(offset, ch.offset), min(offset + nbytes, ch.offset + ch.nbytes)
+            if lo < hi:
+                if ch.data is None:
+                    raise RuntimeError("ring %r: data at %d was overwritten before it was read" % (self.name, lo))
+                pieces.append(ch.data.byte_slice(lo - ch.offset, hi - lo))
+        if len(pieces) == 1:
+            return pieces[0]
+        out = XArray(shape=(nbytes,), dtype=np.uint8, space=self.space)
+        pos = 0
+        for p in pieces:
+            copy_array(out.byte_slice(pos, p.nbytes), p)
+            pos += p.nbytes
+        return out
+
+    # ------------------------------------------------------------------ reader side
+    def read(self, guarantee=True):
+        """Iterate over sequences.  The reader is registered when read() is called (not at the first
+        next()), so data written between the call and the first iteration is kept for it."""
+        rd = _Reader(guarantee)
+        with self._cond:
+            self._readers.append(rd)
+        return self._read_sequences(rd)
+
+    def _read_sequences(self, rd):
+        try:
+            while True:
+                with self._cond:
+                    while len(self._seqs) <= rd.seq_index and not self._writing_ended:
+                        self._cond.wait(0.5)
+                    if len(self._seqs) <= rd.seq_index:
+                        return
+                    seq = self._seqs[rd.seq_index]
+                    rd.offset = 0
+                yield ReadSequence(seq, rd)
+                with self._cond:
+                    rd.seq_index += 1
+                    rd.offset = 0
+                    self._gc()
+                    self._cond.notify_all()
+        finally:
+            with self._cond:
+                if rd in self._readers:
+                    self._readers.remove(rd)
+                self._cond.notify_all()
+
+
+__all__ = ["Ring", "WriteSpan", "to_dtype"]

@@ -107,6 +107,12 @@ int xengXgpuKernel(const void *in_dev, void *out_dev, int doDump);
 int xengXgpuKernelAsync(const void *in_dev, void *out_dev, int doDump);
 int xengXgpuSync(void);
 
+/* Drop the gulps staged and the partial sums accumulated since the last dump (an integration that
+ * is abandoned, e.g. when a new start_time command interrupts it: corr_block.py:392-404 resets
+ * `start` mid-integration).  No reference counterpart: xGPU would silently carry the partial sums
+ * into the next integration. */
+int xengXgpuReset(void);
+
 /* xgpu_test.py:86-89: host-buffer variant (H2D, kernel, D2H on dump). */
 int xengXgpuCorrelate(const void *in_host, void *out_host, int doDump);
 

@@ -1,0 +1,107 @@
+"""TEST INFRASTRUCTURE: a backend object with the same methods as
+caltech_bifrost_dsp_amd.backend.HipBackend, implemented with the CPU oracle on 'system'-space
+arrays.  It lets the not-gpu tests drive the block state machines (BASELINE config 1: "CPU ring
+vs numpy, no GPU").  It is injected explicitly by tests; the product never falls back to it."""
+import ctypes
+
+import numpy as np
+
+from oracle import xeng_oracle as orc
+
+
+def _np(pa, dtype, count):
+    a = pa.contents if hasattr(pa, "contents") else pa
+    buf = (ctypes.c_char * (count * np.dtype(dtype).itemsize)).from_address(a.data)
+    return np.frombuffer(buf, dtype=dtype, count=count)
+
+
+class OracleBackend:
+    BF_STATUS_SUCCESS = 0
+    space_in = "system"
+
+    def __init__(self):
+        self.cfg = None
+        self.acc = None
+        self.kernel_calls = []
+        self.resets = 0
+        self.beam = None
+        self.device = 0
+
+    def set_device(self, gpu):
+        self.device = gpu
+
+    def get_device(self):
+        return self.device
+
+    def stream_synchronize(self):
+        pass
+
+    def last_error(self):
+        return ""
+
+    # X-engine
+    def xgpu_configure(self, nstand, npol, nchan, ntime_gulp, max_gulps=0):
+        self.cfg = dict(nstand=nstand, npol=npol, nchan=nchan, ntime=ntime_gulp)
+        return 0
+
+    def bfXgpuInitialize(self, i, o, gpu):
+        self.acc = None
+        return 0
+
+    def bfXgpuKernel(self, in_arr, out_arr, do_dump):
+        c = self.cfg
+        n = c["ntime"] * c["nchan"] * c["nstand"] * c["npol"]
+        vin = _np(in_arr, np.uint8, n)
+        self.acc = orc.xgpu_correlate(vin, c["nstand"], c["nchan"], self.acc)
+        self.kernel_calls.append(int(do_dump))
+        if do_dump:
+            out = _np(out_arr, np.int32, self.acc.size)
+            out[...] = self.acc
+            self.acc = None
+        return 0
+
+    def xgpu_reset(self):
+        self.acc = None
+        self.resets += 1
+        return 0
+
+    def bfXgpuGetOrder(self, a2i, bl, cj):
+        c = self.cfg
+        ns, npol = c["nstand"], c["npol"]
+        a = _np(a2i, np.int32, ns * npol).reshape(ns, npol)
+        obl, ocj = orc.xgpu_get_order(a)
+        _np(bl, np.int32, obl.size)[...] = obl.ravel()
+        _np(cj, np.int32, ocj.size)[...] = ocj.ravel()
+        return 0
+
+    # CorrAcc
+    def map_assign_i32(self, a, b):
+        orc.map_i32(a.numpy().reshape(-1), b.numpy().reshape(-1), add=False)
+        return 0
+
+    def map_add_i32(self, a, b):
+        orc.map_i32(a.numpy().reshape(-1), b.numpy().reshape(-1), add=True)
+        return 0
+
+    # beamformer
+    def bfBeamformInitialize(self, gpu, ninput, nchan, ntime, nbeam, ntime_blocks):
+        self.beam = dict(ninput=ninput, nchan=nchan, ntime=ntime, nbeam=nbeam, ntime_blocks=ntime_blocks)
+        OracleBackend.shared_beam = self.beam       # process-global context, as in the reference
+        return 0
+
+    def bfBeamformRun(self, in_arr, out_arr, weights):
+        b = self.beam
+        vin = _np(in_arr, np.uint8, b["ntime"] * b["nchan"] * b["ninput"])
+        w = _np(weights, np.complex64, b["nchan"] * b["nbeam"] * b["ninput"])
+        out = orc.beamform(vin, w, b["ntime"], b["nchan"], b["ninput"], b["nbeam"])
+        _np(out_arr, np.complex64, out.size)[...] = out.ravel()
+        return 0
+
+    def bfBeamformIntegrate(self, in_arr, out_arr, ntime_sum):
+        b = getattr(OracleBackend, "shared_beam", None)
+        if b is None:
+            return 2
+        beams = _np(in_arr, np.complex64, b["nchan"] * b["nbeam"] * b["ntime"]).reshape(b["nchan"], b["nbeam"], b["ntime"])
+        out = orc.beamform_integrate(beams, ntime_sum)
+        _np(out_arr, np.float32, out.size)[...] = out.ravel()
+        return 0

@@ -1,0 +1,80 @@
+"""The C-ABI library loads on a machine without a GPU and exports every symbol include/xeng.h
+declares; entry points fail loudly (status + message), never silently, when there is no device."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import caltech_bifrost_dsp_amd  # noqa: F401
+from caltech_bifrost_dsp_amd import ffi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "xeng.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b((?:xeng|bf)[A-Z]\w*)\s*\(", src)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    names = declared_functions()
+    assert len(names) >= 40
+    L = ctypes.CDLL(ffi.LIB_PATH)
+    for n in names:
+        assert hasattr(L, n), "libxeng.so does not export %s" % n
+    bound = set(ffi.SYMBOLS) | set(ffi.STRING_SYMBOLS)
+    assert set(names) == bound, (set(names) ^ bound)
+
+
+def test_version_and_error_strings():
+    L = ffi.lib()
+    assert b"gfx950" in L.xengVersion()
+    assert isinstance(L.xengGetLastError(), bytes)
+
+
+def test_no_cpu_fallback_without_device():
+    """Without a GPU the compute entry points return an error status with a message."""
+    n = ctypes.c_int(-1)
+    rc = ffi.lib().xengGetDeviceCount(ctypes.byref(n))
+    if rc == 0 and n.value > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(ffi.XengError) as ei:
+        ffi.call("xengXgpuInitialize", 0)
+    assert ei.value.status != 0 and str(ei.value)
+    with pytest.raises(ffi.XengError):
+        ffi.call("xengXgpuKernel", 16, 16, 1)          # not initialised -> INVALID_STATE, no compute
+    with pytest.raises(ffi.XengError):
+        ffi.call("xengBeamformRun", 16, 16, 16)
+
+
+def test_argument_validation_needs_no_gpu():
+    with pytest.raises(ffi.XengError):
+        ffi.call("xengXgpuConfigure", 351, 2, 96, 480, 0)     # nstand not a multiple of 4
+    with pytest.raises(ffi.XengError):
+        ffi.call("xengXgpuConfigure", 352, 1, 96, 480, 0)     # npol != 2
+    ffi.call("xengXgpuConfigure", 352, 2, 96, 480, 0)
+    with pytest.raises(ffi.XengError):
+        ffi.call("xengBeamformInitialize", 0, 703, 96, 960, 32, 0)
+
+
+def test_get_order_and_reorder_are_host_functions():
+    """GetOrder / Reorder are host code (corr_block.py:317-333, corr_output_full_block.py:669):
+    they run without a GPU and agree with the oracle."""
+    import numpy as np
+    from oracle import xeng_oracle as orc
+    ns, nchan = 16, 4
+    ffi.call("xengXgpuConfigure", ns, 2, nchan, 8, 0)
+    rng = np.random.default_rng(0)
+    a2i = rng.permutation(ns * 2).astype(np.int32).reshape(ns, 2)
+    bl = np.zeros((ns, ns, 2, 2), np.int32)
+    cj = np.zeros_like(bl)
+    ffi.call("xengXgpuGetOrder", a2i.ctypes.data, bl.ctypes.data, cj.ctypes.data)
+    obl, ocj = orc.xgpu_get_order(a2i)
+    assert np.array_equal(bl, obl) and np.array_equal(cj, ocj)
+    planar = rng.integers(-1000, 1000, 2 * orc.per_chan(ns) * nchan).astype(np.int32)
+    out = np.zeros((ns, ns, 2, 2, nchan, 2), np.int32)
+    ffi.call("xengXgpuReorder", planar.ctypes.data, out.ctypes.data, bl.ctypes.data, cj.ctypes.data)
+    assert np.array_equal(out, orc.xgpu_reorder(planar, bl, cj, nchan))
+    ffi.call("xengXgpuConfigure", 352, 2, 96, 480, 0)

@@ -1,0 +1,280 @@
+"""Host logic of the hot-path blocks on CPU rings (no GPU): BASELINE config 1 -- "16-ant x 2pol,
+4 chan, correlate+accumulate on a CPU ring vs numpy (pipeline/verification)".  The compute calls
+go to tests/fake_backend.OracleBackend (the CPU oracle behind the backend interface); what is
+under test here is the Block/ring/state-machine code the product ships."""
+import json
+import logging
+import os
+
+import numpy as np
+import pytest
+
+import caltech_bifrost_dsp_amd  # noqa: F401
+from caltech_bifrost_dsp_amd.blocks import (Beamform, BeamformSumBeams, Block, Corr, CorrAcc, regtile_index,
+                                            COMMAND_INVALID, COMMAND_NOT_RECOGNIZED, COMMAND_OK, COMMAND_WRONG_TYPE)
+from caltech_bifrost_dsp_amd.ring import Ring
+from oracle import xeng_oracle as orc
+from tests.fake_backend import OracleBackend
+from tests.pipeline_util import LOG, Sink, Source, run_blocks, source_header
+
+
+def load_dat(path):
+    with open(path, "rb") as fh:
+        meta = json.loads(fh.readline().decode())
+        raw = fh.read()
+    dt = np.uint8 if "uint8" in meta["dtype"] else np.complex128
+    return meta, np.frombuffer(raw, dtype=dt).reshape(meta["shape"])
+
+
+def cmd(idx, **kwargs):
+    return json.dumps({"cmd": "update", "val": {"kwargs": kwargs}, "id": str(idx)})
+
+
+# ----------------------------------------------------------------------------------------------
+def test_regtile_index_matches_oracle():
+    for ns in (16, 352):
+        rng = np.random.default_rng(ns)
+        for _ in range(500):
+            i0, i1 = sorted(int(v) for v in rng.integers(0, 2 * ns, 2))
+            assert regtile_index(i0, i1, ns) == orc.regtile_index(i0, i1, ns)
+
+
+@pytest.mark.parametrize("tag", ["deadbeef", "chanramp"])
+@pytest.mark.parametrize("ntime_gulp", [4, 2])
+def test_config1_corr_on_cpu_ring_vs_golden(golden_dir, tag, ntime_gulp):
+    """Golden input replayed through Corr on a system-space ring; the xGPU-order output spans,
+    reordered with the block's own antpol_to_bl / bl_is_conj maps, equal the reference's golden
+    visibilities exactly (the check of corr_output_full_block.py:550-603)."""
+    _, vin = load_dat(os.path.join(golden_dir, "in_8t_4c_16s_2p_%s.dat" % tag))
+    meta, corr = load_dat(os.path.join(golden_dir, "corr_8t_4a_4c_16s_2p_%s.dat" % tag))
+    T, C, S, P = vin.shape
+    acc_len = meta["acc_len"]
+    iring, oring = Ring("gpu-input"), Ring("corr-output")
+    be = OracleBackend()
+    hdr = source_header(C, S, P, seq0=0)
+    blk = Corr(LOG, iring, oring, ntime_gulp=ntime_gulp, nchan=C, npol=P, nstand=S, acc_len=acc_len,
+               autostartat=0, ant_to_input=hdr['ant_to_input'], backend=be, test=True)
+    sink = Sink(oring, blk.ogulp_size)
+    run_blocks([blk], Source(iring, [(hdr, vin, ntime_gulp * C * S * P)]), [sink])
+    assert len(sink.sequences) == 1
+    ohdr, time_tag, spans = sink.sequences[0]
+    assert time_tag == 1 and ohdr['seq0'] == 0 and ohdr['acc_len'] == acc_len
+    assert 'ant_to_input' not in ohdr and 'input_to_ant' not in ohdr and ohdr['nchan'] == C
+    assert len(spans) == T // acc_len
+    assert be.kernel_calls == ([0] * (acc_len // ntime_gulp - 1) + [1]) * (T // acc_len)
+    bl, cj = blk.antpol_to_bl.numpy(), blk.bl_is_conj.numpy()
+    for k, sp in enumerate(spans):
+        ro = orc.xgpu_reorder(sp.view(np.int32), bl, cj, C)
+        for s0 in range(S):
+            for s1 in range(s0, S):
+                g = corr[k, :, s0, s1]
+                assert np.array_equal(ro[s0, s1, :, :, :, 0], np.moveaxis(g.real, 0, -1).astype(np.int32))
+                assert np.array_equal(ro[s0, s1, :, :, :, 1], np.moveaxis(g.imag, 0, -1).astype(np.int32))
+    assert blk.stats['test_match'] is True           # the block's own --testcorr self-check (corr_block.py:265-315)
+    assert blk.stats['state'] == 'running' and blk.stats['last_end_sample'] == T - ntime_gulp
+
+
+def _corr_scenario(nseq_gulps, ntime_gulp=2, acc_len=4, autostartat=0, seq0s=None, commands=None, C=2, S=4):
+    """Run Corr over sequences of random data; returns (sink sequences, backend, per-sequence inputs)."""
+    rng = np.random.default_rng(1)
+    iring, oring = Ring("in"), Ring("out")
+    be = OracleBackend()
+    blk = Corr(LOG, iring, oring, ntime_gulp=ntime_gulp, nchan=C, npol=2, nstand=S, acc_len=acc_len,
+               autostartat=autostartat, backend=be)
+    for c in (commands or []):
+        blk.process_command_strings(c)
+    seqs, data = [], []
+    for k, ng in enumerate(nseq_gulps):
+        seq0 = (seq0s[k] if seq0s else 0)
+        d = rng.integers(0, 256, (ng * ntime_gulp, C, S, 2), dtype=np.uint8)
+        data.append(d)
+        seqs.append((source_header(C, S, 2, seq0=seq0), d, ntime_gulp * C * S * 2))
+    sink = Sink(oring, blk.ogulp_size)
+    run_blocks([blk], Source(iring, seqs), [sink])
+    return sink.sequences, be, data, blk
+
+
+def test_corr_start_time_in_future_and_short_tail():
+    # start at sample 6; 11 gulps of 2 (samples 0..21) plus a short tail -> integrations [6,10) [10,14) [14,18) [18,22)
+    seqs, be, data, blk = _corr_scenario([11], autostartat=6)
+    (ohdr, tag, spans), = seqs
+    assert ohdr['seq0'] == 6 and ohdr['acc_len'] == 4 and len(spans) == 4
+    for k, sp in enumerate(spans):
+        exp = orc.xgpu_correlate(data[0][6 + 4 * k:10 + 4 * k], 4, 2)
+        assert np.array_equal(sp.view(np.int32), exp)
+
+
+def test_corr_start_minus_one_rounds_up_to_acc_len():
+    # corr_block.py:397-398: -1 -> next multiple of acc_len after the current gulp; seq0 = 2 -> start at 4
+    seqs, be, data, blk = _corr_scenario([8], autostartat=-1, seq0s=[2])
+    (ohdr, tag, spans), = seqs
+    assert ohdr['seq0'] == 4
+    assert np.array_equal(spans[0].view(np.int32), orc.xgpu_correlate(data[0][2:6], 4, 2))   # samples 4..7 = rows 2..5
+
+
+def test_corr_recovery_after_new_sequence_skips_ten_integrations():
+    # corr_block.py:360-371: new upstream sequence while running -> start = last_start + (missed+10)*acc_len
+    seqs, be, data, blk = _corr_scenario([4, 30], seq0s=[0, 8])
+    assert [s[0]['seq0'] for s in seqs] == [0, 0 + (8 // 4 + 10) * 4]
+    assert [s[1] for s in seqs] == [1, 2]                    # time_tag counts output sequences
+    assert len(seqs[0][2]) == 2
+    first_new = (48 - 8)                                       # row offset of sample 48 in sequence 2
+    assert np.array_equal(seqs[1][2][0].view(np.int32), orc.xgpu_correlate(data[1][first_new:first_new + 4], 4, 2))
+
+
+def test_corr_command_validation_and_update():
+    iring, oring = Ring("i"), Ring("o")
+    blk = Corr(LOG, iring, oring, ntime_gulp=2, nchan=2, npol=2, nstand=4, acc_len=4, backend=OracleBackend())
+    blk.process_command_strings(cmd(1, acc_len=3))            # not a multiple of the gulp
+    assert blk.stats['last_cmd_response'] == COMMAND_INVALID and blk.last_response['val']['status'] == 'error'
+    blk.process_command_strings(cmd(2, acc_len="8"))
+    assert blk.stats['last_cmd_response'] == COMMAND_WRONG_TYPE
+    blk.process_command_strings(cmd(3, bogus=1))
+    assert blk.stats['last_cmd_response'] == COMMAND_NOT_RECOGNIZED
+    blk.process_command_strings(json.dumps({"cmd": "nope", "val": {}, "id": "4"}))
+    assert blk.last_response['val']['response'] == "Invalid command"
+    blk.process_command_strings(cmd(5, acc_len=8, start_time=-1))
+    assert blk.stats['last_cmd_response'] == COMMAND_OK and blk.update_pending
+    assert blk.command_vals['acc_len'] == 4                   # active values only change in main()
+    blk.update_command_vals()
+    assert blk.command_vals['acc_len'] == 8 and blk.command_vals['start_time'] == -1 and not blk.update_pending
+    assert blk.command_key.endswith('/Corr/%d' % blk.instance_id)
+
+
+def test_corr_acc_len_zero_is_a_clean_stop():
+    seqs, be, data, blk = _corr_scenario([6], commands=[cmd(1, acc_len=0)])
+    assert seqs == [] and be.kernel_calls == [] and blk.stats['state'] == 'stopped'
+
+
+# ----------------------------------------------------------------------------------------------
+def test_corr_then_corracc_chain():
+    """Corr (acc 4) -> CorrAcc (acc 8, start -1 = "now"): each long integration is the sum of two
+    short ones; header carries upstream_acc_len (corr_acc_block.py:216)."""
+    C, S, g = 2, 8, 2
+    rng = np.random.default_rng(3)
+    vin = rng.integers(0, 256, (32, C, S, 2), dtype=np.uint8)
+    r0, r1, r2 = Ring("gpu-input"), Ring("corr-output"), Ring("corr-slow-output")
+    be = OracleBackend()
+    corr = Corr(LOG, r0, r1, ntime_gulp=g, nchan=C, npol=2, nstand=S, acc_len=4, autostartat=0, backend=be)
+    cacc = CorrAcc(LOG, r1, r2, nchan=C, npol=2, nstand=S, acc_len=8, autostartat=-1, backend=be)
+    sink = Sink(r2, cacc.ogulp_size)
+    run_blocks([corr, cacc], Source(r0, [(source_header(C, S, 2), vin, g * C * S * 2)]), [sink])
+    (ohdr, tag, spans), = sink.sequences
+    assert ohdr['upstream_acc_len'] == 4 and ohdr['acc_len'] == 8 and ohdr['seq0'] == 0 and tag == 1
+    assert len(spans) == 4
+    for k, sp in enumerate(spans):
+        assert np.array_equal(sp.view(np.int32), orc.xgpu_correlate(vin[8 * k:8 * k + 8], S, C))
+    assert cacc.stats['state'] == 'running' and cacc.stats['last_end_sample'] == 28
+
+
+def test_corracc_start_time_and_stop():
+    C, S = 2, 4
+    matlen = C * orc.per_chan(S)
+    rng = np.random.default_rng(4)
+    blocks = rng.integers(-1000, 1000, (10, 2 * matlen)).astype(np.int32)
+    r1, r2 = Ring("a"), Ring("b")
+    cacc = CorrAcc(LOG, r1, r2, nchan=C, npol=2, nstand=S, acc_len=12, autostartat=8, backend=OracleBackend())
+    hdr = dict(source_header(C, S, 2, seq0=0), acc_len=4)
+    sink = Sink(r2, cacc.ogulp_size)
+    run_blocks([cacc], Source(r1, [(hdr, blocks, 2 * matlen * 4)]), [sink])
+    (ohdr, tag, spans), = sink.sequences
+    assert ohdr['seq0'] == 8 and len(spans) == 2              # [8,20) and [20,32): upstream blocks 2-4, 5-7
+    assert np.array_equal(spans[0].view(np.int32), blocks[2:5].sum(0, dtype=np.int32))
+    assert np.array_equal(spans[1].view(np.int32), blocks[5:8].sum(0, dtype=np.int32))
+
+
+# ----------------------------------------------------------------------------------------------
+def _beam_cmds(nchan, nbeam, ninput, rng, load_sample=None):
+    """Command stream as beamformer_test.py:152-183 sends it: cal gains per (beam,input), then beam coeffs."""
+    cmds, cal, delays, amps = [], {}, {}, {}
+    k = 0
+    for b in range(nbeam):
+        for i in range(ninput):
+            g = rng.uniform(-1, 1, 2 * nchan)
+            cal[b, i] = g[0::2] + 1j * g[1::2]
+            cmds.append(cmd(k, coeffs={'type': 'calgains', 'input_id': i, 'beam_id': b, 'data': g.tolist()}))
+            k += 1
+    for b in range(nbeam):
+        delays[b], amps[b] = rng.uniform(0, 12, ninput), rng.uniform(10, 17, ninput)
+        c = {'type': 'beamcoeffs', 'beam_id': b, 'data': {'delays': delays[b].tolist(), 'amps': amps[b].tolist()}}
+        if load_sample is not None:
+            c['load_sample'] = load_sample
+        cmds.append(cmd(k, coeffs=c))
+        k += 1
+    return cmds, cal, delays, amps
+
+
+def test_beamform_and_sum_beams_chain():
+    """DummySource-style input -> Beamform (weights commanded as the control library does) ->
+    BeamformSumBeams; voltage beams and power beams equal the oracle with the weights of
+    beamform_block.py:343-350; headers rewritten as beamform_block.py:403-409 /
+    beamform_sum_beams_block.py:211-216."""
+    nchan, nstand, nbeam, g, ntime_sum = 3, 6, 4, 8, 4
+    ninput = nstand * 2
+    rng = np.random.default_rng(0xaabbccdd)
+    vin = rng.integers(0, 256, (3 * g, nchan, ninput), dtype=np.uint8)
+    sfreq, chan_bw = 50e6, 23925.78125
+    r0, r1, r2 = Ring("gpu-input"), Ring("bf-output"), Ring("bf-pow-output")
+    be = OracleBackend()
+    bf = Beamform(LOG, r0, r1, nchan=nchan, nbeam=nbeam, ninput=ninput, ntime_gulp=g, backend=be)
+    sb = BeamformSumBeams(LOG, r1, r2, nchan=nchan, ntime_gulp=g, ntime_sum=ntime_sum, backend=be)
+    cmds, cal, delays, amps = _beam_cmds(nchan, nbeam, ninput, rng)
+    hdr = source_header(nchan, nstand, 2, seq0=0, sfreq=sfreq, chan_bw=chan_bw)
+    # commands are processed against the sequence's frequencies: inject them once main() has the header
+    bf.freqs = sfreq + chan_bw * np.arange(nchan)
+    bf.process_command_strings(cmds)
+    s1, s2 = Sink(r1, g * nchan * nbeam * 8), Sink(r2, (nbeam // 2) * (g // ntime_sum) * nchan * 16)
+    run_blocks([bf, sb], Source(r0, [(hdr, vin, g * nchan * ninput)], wait_readers=1), [s1, s2])
+    freqs = sfreq + chan_bw * np.arange(nchan)
+    w = np.zeros((nchan, nbeam, ninput), np.complex64)
+    for b in range(nbeam):
+        calb = np.stack([cal[b, i] for i in range(ninput)], axis=1)            # [chan, input]
+        w[:, b, :] = amps[b] * np.exp(1j * 2 * np.pi * freqs[:, None] * delays[b] * 1e-9) * calb
+    assert np.allclose(bf.gains_cpu, w, rtol=1e-6, atol=1e-6)
+    (h1, _, spans1), = s1.sequences
+    assert h1['nstand'] == nbeam and h1['npol'] == 1 and h1['nbit'] == 32 and h1['complex'] and h1['nbeam'] == nbeam
+    assert len(spans1) == 3
+    for k, sp in enumerate(spans1):
+        exp = orc.beamform(vin[k * g:(k + 1) * g], bf.gains_cpu, g, nchan, ninput, nbeam)
+        assert np.array_equal(sp.view(np.complex64).reshape(exp.shape), exp)
+    (h2, _, spans2), = s2.sequences
+    assert h2['nbeam'] == nbeam // 2 and h2['npol'] == 2 and h2['acc_len'] == ntime_sum
+    for k, sp in enumerate(spans2):
+        beams = spans1[k].view(np.complex64).reshape(nchan, nbeam, g)
+        exp = orc.beamform_integrate(beams, ntime_sum)
+        assert np.array_equal(sp.view(np.float32).reshape(exp.shape), exp)
+
+
+def test_beamform_timed_coefficient_load():
+    """load_sample: new coefficients take effect on the first gulp whose start time >= load_sample
+    (beamform_block.py:416-429); before that the beam has zero gains."""
+    nchan, nstand, nbeam, g = 2, 4, 2, 4
+    ninput = nstand * 2
+    rng = np.random.default_rng(7)
+    vin = rng.integers(0, 256, (4 * g, nchan, ninput), dtype=np.uint8)
+    r0, r1 = Ring("i"), Ring("o")
+    bf = Beamform(LOG, r0, r1, nchan=nchan, nbeam=nbeam, ninput=ninput, ntime_gulp=g, backend=OracleBackend())
+    bf.freqs = 1e6 + 1e3 * np.arange(nchan)
+    cmds, cal, delays, amps = _beam_cmds(nchan, nbeam, ninput, rng, load_sample=2 * g)
+    bf.process_command_strings(cmds)
+    hdr = source_header(nchan, nstand, 2, seq0=0, sfreq=1e6, chan_bw=1e3)
+    s1 = Sink(r1, g * nchan * nbeam * 8)
+    run_blocks([bf], Source(r0, [(hdr, vin, g * nchan * ninput)]), [s1])
+    (h1, _, spans), = s1.sequences
+    assert not spans[0].any() and not spans[1].any()
+    for k in (2, 3):
+        exp = orc.beamform(vin[k * g:(k + 1) * g], bf.gains_cpu_new, g, nchan, ninput, nbeam)
+        assert np.array_equal(spans[k].view(np.complex64).reshape(exp.shape), exp)
+
+
+def test_block_instance_ids_and_keys():
+    class A(Block):
+        pass
+
+    class B(Block):
+        pass
+    Block.set_id(3)
+    a0, a1, b0 = (k(LOG, Ring("x"), None, True, -1) for k in (A, A, B))
+    assert (a0.instance_id, a1.instance_id, b0.instance_id) == (0, 1, 0)
+    assert '/pipeline/3/A/1' in a1.command_key and a1.monitor_key.startswith('/mon/corr/x/')
+    Block.set_id(0)

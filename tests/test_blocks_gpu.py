@@ -1,0 +1,62 @@
+"""The blocks on device-space rings with the real HIP backend (libxeng): Corr -> CorrAcc and
+Beamform -> BeamformSumBeams as threads, one HIP stream each, against the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import caltech_bifrost_dsp_amd  # noqa: E402,F401
+from caltech_bifrost_dsp_amd.blocks import Beamform, BeamformSumBeams, Corr, CorrAcc  # noqa: E402
+from caltech_bifrost_dsp_amd.ring import Ring  # noqa: E402
+from oracle import xeng_oracle as orc  # noqa: E402
+from tests.pipeline_util import LOG, Sink, Source, run_blocks, source_header  # noqa: E402
+from tests.test_blocks_cpu import _beam_cmds  # noqa: E402
+
+
+def test_corr_corracc_on_device_rings():
+    """gpu-input (cuda) -> Corr -> corr-output (cuda) -> CorrAcc -> corr-slow-output (cuda_host),
+    the ring spaces of lwa352-pipeline.py:147-155; bit-exact vs the oracle."""
+    C, S, g, acc, lacc = 8, 48, 32, 64, 128
+    rng = np.random.default_rng(5)
+    vin = rng.integers(0, 256, (4 * lacc // 2, C, S, 2), dtype=np.uint8)      # 256 samples = 2 long integrations
+    r0, r1, r2 = Ring("gpu-input", space="cuda"), Ring("corr-output", space="cuda"), Ring("corr-slow-output", space="cuda_host")
+    corr = Corr(LOG, r0, r1, ntime_gulp=g, nchan=C, npol=2, nstand=S, acc_len=acc, autostartat=0, gpu=0, test=True)
+    cacc = CorrAcc(LOG, r1, r2, nchan=C, npol=2, nstand=S, acc_len=lacc, autostartat=0, gpu=0)
+    fast = Sink(r1, corr.ogulp_size)
+    slow = Sink(r2, cacc.ogulp_size)
+    run_blocks([corr, cacc], Source(r0, [(source_header(C, S, 2), vin, g * C * S * 2)], wait_readers=1), [fast, slow])
+    (h1, _, sp1), = fast.sequences
+    assert len(sp1) == 4 and h1['acc_len'] == acc
+    for k, sp in enumerate(sp1):
+        assert np.array_equal(sp.view(np.int32), orc.xgpu_correlate(vin[k * acc:(k + 1) * acc], S, C))
+    assert corr.stats['test_match'] is True
+    (h2, _, sp2), = slow.sequences
+    assert h2['upstream_acc_len'] == acc and h2['acc_len'] == lacc and len(sp2) == 2
+    for k, sp in enumerate(sp2):
+        assert np.array_equal(sp.view(np.int32), orc.xgpu_correlate(vin[k * lacc:(k + 1) * lacc], S, C))
+
+
+def test_beamform_sumbeams_on_device_rings():
+    nchan, nstand, nbeam, g, ns = 4, 32, 8, 96, 24
+    ninput = nstand * 2
+    rng = np.random.default_rng(0xaabbccdd)
+    vin = rng.integers(0, 256, (2 * g, nchan, ninput), dtype=np.uint8)
+    r0, r1, r2 = Ring("gpu-input", space="cuda"), Ring("bf-output", space="cuda"), Ring("bf-pow-output", space="cuda_host")
+    bf = Beamform(LOG, r0, r1, nchan=nchan, nbeam=nbeam, ninput=ninput, ntime_gulp=g, gpu=0)
+    sb = BeamformSumBeams(LOG, r1, r2, nchan=nchan, ntime_gulp=g, ntime_sum=ns, gpu=0)
+    sfreq, bw = 40e6, 23925.78125
+    bf.freqs = sfreq + bw * np.arange(nchan)
+    cmds, cal, delays, amps = _beam_cmds(nchan, nbeam, ninput, rng)
+    bf.process_command_strings(cmds)
+    s1, s2 = Sink(r1, g * nchan * nbeam * 8), Sink(r2, (nbeam // 2) * (g // ns) * nchan * 16)
+    run_blocks([bf, sb], Source(r0, [(source_header(nchan, nstand, 2, sfreq=sfreq, chan_bw=bw), vin, g * nchan * ninput)]), [s1, s2])
+    (h1, _, sp1), = s1.sequences
+    (h2, _, sp2), = s2.sequences
+    assert len(sp1) == 2 and len(sp2) == 2 and h2['nbeam'] == nbeam // 2
+    for k in range(2):
+        exp = orc.beamform(vin[k * g:(k + 1) * g], bf.gains_cpu, g, nchan, ninput, nbeam)
+        got = sp1[k].view(np.complex64).reshape(exp.shape)
+        assert np.max(np.abs(got - exp)) / np.sqrt(np.mean(np.abs(exp) ** 2)) <= 1e-5
+        pexp = orc.beamform_integrate(got, ns)
+        pgot = sp2[k].view(np.float32).reshape(pexp.shape)
+        assert np.all(np.isclose(pgot, pexp, rtol=1e-5, atol=1e-5 * np.abs(pexp).max()))
