@@ -64,7 +64,9 @@ def main():
     ap.add_argument("--ring-gulps", type=int, default=10, help="device-resident replay ring depth (gulps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-per-call", action="store_true",
-                    help="time the drop-in synchronous xengXgpuKernel instead of the pipelined enqueue")
+                    help="time the drop-in synchronous xengXgpuKernel (the reference's call semantics)")
+    ap.add_argument("--sync-per-integration", action="store_true",
+                    help="enqueue the gulps of one integration, then wait for its dump before the next")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -93,23 +95,34 @@ def main():
     rs = np.random.RandomState(0xdeadbeef + rank)
     for g in range(args.ring_gulps):
         ring.upload(rs.randint(0, 255, size=gulp_bytes, dtype=np.uint8), offset=g * gulp_bytes)
-    out = ffi.DeviceBuffer(2 * matlen * 4)
+    outs = [ffi.DeviceBuffer(2 * matlen * 4) for _ in range(2)]     # output spans alternate, as ring spans do
     kern = "xengXgpuKernel" if args.sync_per_call else "xengXgpuKernelAsync"
     L = ffi.lib()
     kfn = getattr(L, kern)
+    if args.sync_per_call:
+        call_mode = "sync-per-call (reference call semantics)"
+    elif args.sync_per_integration:
+        call_mode = "enqueue gulps, sync per integration"
+    else:
+        call_mode = "streaming: enqueue integration n+1, then wait for dump n (xengXgpuSyncLag(1))"
 
     gi = [0]
+    si = [0]
 
     def step():
+        out = outs[si[0] & 1]
+        si[0] += 1
         for g in range(gulps_per_step):
             rc = kfn(ring.ptr + (gi[0] % args.ring_gulps) * gulp_bytes, out.ptr, int(g == gulps_per_step - 1))
             if rc:
                 ffi.check(kern, rc)
             gi[0] += 1
-        if not args.sync_per_call:
-            rc = L.xengXgpuSync()            # output complete before the span would be committed
-            if rc:
-                ffi.check("xengXgpuSync", rc)
+        if args.sync_per_call:
+            return
+        # the span of dump n-1 (or n) is complete before it would be committed downstream
+        rc = L.xengXgpuSync() if args.sync_per_integration else L.xengXgpuSyncLag(1)
+        if rc:
+            ffi.check("xengXgpuSync", rc)
 
     def barrier():
         ffi.call("xengDeviceSynchronize")
@@ -154,7 +167,7 @@ def main():
         "config": {"workload": "704-input (352 ant x 2 pol), %d chan/GPU, 4+4b->int32 correlator, acc_len %d = %d gulps x %d"
                                % (NCHAN, ACC_LEN, gulps_per_step, NTIME_GULP),
                    "nchan_total": NCHAN * world, "sharding": "channels, %d per GPU, no collective" % NCHAN,
-                   "call_mode": "sync-per-call" if args.sync_per_call else "enqueue gulps, sync per integration",
+                   "call_mode": call_mode,
                    "input": "device-resident replay ring, %d gulps" % args.ring_gulps},
         "cmac_per_s": cmacs,
         "mfma_peak_frac_end_to_end": round(8 * cmacs / (PEAK_INT8_OPS * world), 4),

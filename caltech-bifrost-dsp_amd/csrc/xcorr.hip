@@ -92,11 +92,20 @@ struct XgpuContext {
     XgpuConfig cfg;
     int ninput = 0, nblk64 = 0, gkt = 0, cap_kt = 0, cap_gulps = 0, kt_stage = 1;
     int64_t per_chan = 0, matlen = 0;
-    uint8_t* stash = nullptr;
+    // Two staging areas and two streams: corner turns (HBM-bound) of integration n+1 run on `stream`
+    // while the MFMA contraction (power-bound) of integration n runs on `stream_mm`.
+    uint8_t* stash[2] = {nullptr, nullptr};
     size_t stash_bytes = 0;
+    int cur = 0;                               // staging area being filled
     WgDesc* descs_dev = nullptr;
     int nwg = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;              // corner turns (+ H2D of the host-buffer variant)
+    hipStream_t stream_mm = nullptr;           // MFMA contraction (+ sub-selection, D2H)
+    hipEvent_t ev_ct = nullptr;                // staged gulps of the area about to be contracted are complete
+    hipEvent_t ev_mm[2] = {nullptr, nullptr};  // the contraction reading staging area b is complete
+    bool mm_used[2] = {false, false};
+    hipEvent_t ev_dump[4] = {nullptr, nullptr, nullptr, nullptr};   // completion of the last dumps
+    unsigned long long ndump = 0;
     // integration state
     int nfilled = 0;           // gulps staged since the last flush
     bool acc_started = false;  // out already holds a partial sum of the current integration
@@ -104,6 +113,7 @@ struct XgpuContext {
     // host staging for xengXgpuCorrelate
     uint8_t* in_dev = nullptr;
     int32_t* out_dev = nullptr;
+    unsigned long long* stamps = nullptr;   // diagnostic (XENG_DBG_STAMPS=1)
     EventTimer timer;
 };
 
@@ -116,28 +126,38 @@ static int destroy_locked() {
     if (!x.live) return XENG_STATUS_SUCCESS;
     (void)hipSetDevice(x.gpu);
     if (x.stream) (void)hipStreamSynchronize(x.stream);
-    if (x.stash) (void)hipFree(x.stash);
+    if (x.stream_mm) (void)hipStreamSynchronize(x.stream_mm);
+    for (int b = 0; b < 2; b++) {
+        if (x.stash[b]) (void)hipFree(x.stash[b]);
+        if (x.ev_mm[b]) (void)hipEventDestroy(x.ev_mm[b]);
+    }
+    if (x.ev_ct) (void)hipEventDestroy(x.ev_ct);
+    for (int k = 0; k < 4; k++)
+        if (x.ev_dump[k]) (void)hipEventDestroy(x.ev_dump[k]);
     if (x.descs_dev) (void)hipFree(x.descs_dev);
     if (x.in_dev) (void)hipFree(x.in_dev);
+    if (x.stamps) (void)hipFree(x.stamps);
     if (x.out_dev) (void)hipFree(x.out_dev);
     x.timer.destroy();
     x = XgpuContext();
     return XENG_STATUS_SUCCESS;
 }
 
-static int pick_kt_stage(int gkt) {
-    if (const char* e = getenv("XENG_KT_STAGE")) {
-        int v = atoi(e);
-        if ((v == 1 || v == 3 || v == 5) ) return v;
-    }
-    if (gkt % 3 == 0) return 3;
-    if (gkt % 5 == 0) return 5;
-    return 1;
+template <int ABL>
+static void launch_abl(const XcorrParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_mfma_kernel<ABL>), dim3(p.nchan * p.nwg), dim3(256), 0, s, p);
 }
-
-template <int KT>
 static void launch_xcorr(const XcorrParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_mfma_kernel<KT>), dim3(p.nchan * p.nwg), dim3(256), 0, s, p);
+    static const int abl = getenv("XENG_ABLATE") ? atoi(getenv("XENG_ABLATE")) : 0;   // timing experiments only
+    switch (abl) {
+        case 1: launch_abl<1>(p, s); break;
+        case 2: launch_abl<2>(p, s); break;
+        case 4: launch_abl<4>(p, s); break;
+        case 8: launch_abl<8>(p, s); break;
+        case 9: launch_abl<9>(p, s); break;
+        case 15: launch_abl<15>(p, s); break;
+        default: launch_abl<0>(p, s); break;
+    }
 }
 
 // contracts the staged gulps into `out`; caller holds g_mu
@@ -152,23 +172,30 @@ static int flush_locked(void* out, bool dump) {
     const int rem = nkt % x.kt_stage;
     if (rem) {  // zero-fill the K padding of every (channel, block) row of the stash
         const int padk = x.kt_stage - rem;
-        XENG_HIP(hipMemset2DAsync(x.stash + (size_t)nkt * KT_BYTES, (size_t)x.cap_kt * KT_BYTES, 0,
+        XENG_HIP(hipMemset2DAsync(x.stash[x.cur] + (size_t)nkt * KT_BYTES, (size_t)x.cap_kt * KT_BYTES, 0,
                                   (size_t)padk * KT_BYTES, (size_t)x.cfg.nchan * x.nblk64, x.stream));
         nkt += padk;
     }
     XcorrParams p;
-    p.stash = x.stash; p.out = (int32_t*)out; p.descs = x.descs_dev;
+    p.stash = x.stash[x.cur]; p.out = (int32_t*)out; p.descs = x.descs_dev;
     p.nwg = x.nwg; p.nchan = x.cfg.nchan; p.nblk64 = x.nblk64; p.cap_kt = x.cap_kt; p.nkt = nkt;
     p.nstand = x.cfg.nstand; p.per_chan = x.per_chan; p.matlen = x.matlen;
     p.accumulate = x.acc_started ? 1 : 0;
-    int slot = x.timer.begin(x.stream, 1);
-    switch (x.kt_stage) {
-        case 3: launch_xcorr<3>(p, x.stream); break;
-        case 5: launch_xcorr<5>(p, x.stream); break;
-        default: launch_xcorr<1>(p, x.stream); break;
-    }
-    x.timer.end(x.stream, slot);
+    p.stamps = x.stamps;
+    // the contraction starts when this area's corner turns are done and runs beside the next area's
+    XENG_HIP(hipEventRecord(x.ev_ct, x.stream));
+    XENG_HIP(hipStreamWaitEvent(x.stream_mm, x.ev_ct, 0));
+    int slot = x.timer.begin(x.stream_mm, 1);
+    launch_xcorr(p, x.stream_mm);
+    x.timer.end(x.stream_mm, slot);
     XENG_HIP(hipGetLastError());
+    XENG_HIP(hipEventRecord(x.ev_mm[x.cur], x.stream_mm));
+    x.mm_used[x.cur] = true;
+    if (dump) {
+        XENG_HIP(hipEventRecord(x.ev_dump[x.ndump & 3], x.stream_mm));
+        x.ndump++;
+    }
+    x.cur ^= 1;
     x.nfilled = 0;
     x.acc_started = !dump;
     x.acc_out = dump ? nullptr : out;
@@ -182,10 +209,29 @@ static int kernel_locked(const void* in_dev, void* out_dev, int doDump, bool syn
     if (((uintptr_t)out_dev & 15) || ((uintptr_t)in_dev & 3))
         XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "xgpu: out must be 16-byte and in 4-byte aligned");
     XENG_HIP(hipSetDevice(x.gpu));
+    if (x.nfilled == 0 && x.mm_used[x.cur])   // this staging area may still be read by an earlier contraction
+        XENG_HIP(hipStreamWaitEvent(x.stream, x.ev_mm[x.cur], 0));
+    uint8_t* const stash = x.stash[x.cur];
     int slot = x.timer.begin(x.stream, 0);
-    hipLaunchKernelGGL(corner_turn_kernel, dim3(x.gkt, x.cfg.nchan), dim3(256), 0, x.stream,
-                       (const uint8_t*)in_dev, x.stash, x.cfg.ntime_gulp, x.cfg.nchan, x.ninput, x.nblk64,
-                       x.cap_kt, x.nfilled * x.gkt);
+    const size_t lds_bytes = (((size_t)32 * x.ninput + 1023) & ~(size_t)1023) + (size_t)x.nblk64 * KT_BYTES;
+    static const int ct_mode = getenv("XENG_CT_MODE") ? atoi(getenv("XENG_CT_MODE")) : 2;   // 0 register-only, 1 LDS full tile, 2 LDS half tiles
+    if (x.ninput % 16 == 0 && lds_bytes <= 64 * 1024 && ct_mode == 1) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(corner_turn_lds_kernel<0>), dim3(x.cfg.nchan, x.gkt), dim3(256), lds_bytes, x.stream,
+                           (const uint8_t*)in_dev, stash, x.cfg.ntime_gulp, x.cfg.nchan, x.ninput, x.nblk64,
+                           x.cap_kt, x.nfilled * x.gkt);
+    } else if (x.ninput % 16 == 0 && lds_bytes <= 64 * 1024 && ct_mode == 2) {
+        const size_t half_bytes = (((size_t)16 * x.ninput + 1023) & ~(size_t)1023) + (size_t)x.nblk64 * KT_BYTES / 2;
+        const int thr = std::min(256, ((x.nblk64 * 16 + 63) / 64) * 64);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(corner_turn_lds_kernel<1>), dim3(x.cfg.nchan, x.gkt, 2), dim3(thr), half_bytes, x.stream,
+                           (const uint8_t*)in_dev, stash, x.cfg.ntime_gulp, x.cfg.nchan, x.ninput, x.nblk64,
+                           x.cap_kt, x.nfilled * x.gkt);
+    } else {
+        const int ct_items = 2 * x.nblk64 * 16;                   // (input quad, k-half) work items per (K-tile, channel)
+        const int ct_threads = std::min(1024, ((ct_items + 63) / 64) * 64);
+        hipLaunchKernelGGL(corner_turn_kernel, dim3(x.gkt, x.cfg.nchan), dim3(ct_threads), 0, x.stream,
+                           (const uint8_t*)in_dev, stash, x.cfg.ntime_gulp, x.cfg.nchan, x.ninput, x.nblk64,
+                           x.cap_kt, x.nfilled * x.gkt);
+    }
     x.timer.end(x.stream, slot);
     XENG_HIP(hipGetLastError());
     x.nfilled++;
@@ -196,8 +242,12 @@ static int kernel_locked(const void* in_dev, void* out_dev, int doDump, bool syn
         XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: output buffer changed inside one integration");
     }
     if (sync) {
+        // input consumed = its corner turn is done; on a dump the output must be complete too
         XENG_HIP(hipStreamSynchronize(x.stream));
-        x.timer.drain();
+        if (doDump) {
+            XENG_HIP(hipStreamSynchronize(x.stream_mm));
+            x.timer.drain();
+        }
     }
     return XENG_STATUS_SUCCESS;
 }
@@ -230,7 +280,7 @@ int xengXgpuInitialize(int gpu) {
     x.ninput = x.cfg.nstand * x.cfg.npol;
     x.nblk64 = (x.ninput + 63) / 64;
     x.gkt = (x.cfg.ntime_gulp + 31) / 32;
-    x.kt_stage = pick_kt_stage(x.gkt);
+    x.kt_stage = XC_KT;   // K is zero-padded to a whole number of stages at flush time
     // staging depth: default ~4800 samples (two 2400-sample integrations' worth never needed at once;
     // the X-engine flushes early when full).  K per launch must stay <= 65535 samples (int32 bound).
     int cap = x.cfg.max_gulps > 0 ? x.cfg.max_gulps : std::max(1, 4800 / (x.gkt * 32));
@@ -240,14 +290,25 @@ int xengXgpuInitialize(int gpu) {
     x.per_chan = (int64_t)(x.cfg.nstand / 2 + 1) * (x.cfg.nstand / 4) * x.cfg.npol * x.cfg.npol * 4;
     x.matlen = x.per_chan * x.cfg.nchan;
     x.stash_bytes = (size_t)x.cfg.nchan * x.nblk64 * x.cap_kt * KT_BYTES;
-    XENG_HIP(hipMalloc((void**)&x.stash, x.stash_bytes));
-    XENG_HIP(hipMemset(x.stash, 0, x.stash_bytes));
+    for (int b = 0; b < 2; b++) {
+        XENG_HIP(hipMalloc((void**)&x.stash[b], x.stash_bytes));
+        XENG_HIP(hipMemset(x.stash[b], 0, x.stash_bytes));
+        XENG_HIP(hipEventCreateWithFlags(&x.ev_mm[b], hipEventDisableTiming));
+    }
+    XENG_HIP(hipEventCreateWithFlags(&x.ev_ct, hipEventDisableTiming));
+    for (int k = 0; k < 4; k++) XENG_HIP(hipEventCreateWithFlags(&x.ev_dump[k], hipEventDisableTiming));
     std::vector<WgDesc> descs = build_wg_descs(x.nblk64);
     x.nwg = (int)descs.size();
     XENG_HIP(hipMalloc((void**)&x.descs_dev, descs.size() * sizeof(WgDesc)));
     XENG_HIP(hipMemcpy(x.descs_dev, descs.data(), descs.size() * sizeof(WgDesc), hipMemcpyHostToDevice));
     int rc = get_stream(STREAM_XGPU, &x.stream);
     if (rc) return rc;
+    rc = get_stream(STREAM_XGPU_MM, &x.stream_mm);
+    if (rc) return rc;
+    if (getenv("XENG_DBG_STAMPS")) {
+        XENG_HIP(hipMalloc((void**)&x.stamps, (size_t)x.cfg.nchan * x.nwg * 4 * 4 * sizeof(unsigned long long)));
+        XENG_HIP(hipMemset(x.stamps, 0, (size_t)x.cfg.nchan * x.nwg * 4 * 4 * sizeof(unsigned long long)));
+    }
     x.live = true;
     return XENG_STATUS_SUCCESS;
 }
@@ -273,6 +334,19 @@ int xengXgpuSync(void) {
     if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized");
     XENG_HIP(hipSetDevice(x.gpu));
     XENG_HIP(hipStreamSynchronize(x.stream));
+    XENG_HIP(hipStreamSynchronize(x.stream_mm));
+    x.timer.drain();
+    return XENG_STATUS_SUCCESS;
+}
+
+int xengXgpuSyncLag(int lag) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    XgpuContext& x = g_ctx;
+    if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized");
+    if (lag < 0 || lag > 3) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "SyncLag: lag must be 0..3 (got %d)", lag);
+    XENG_HIP(hipSetDevice(x.gpu));
+    if (x.ndump > (unsigned long long)lag)
+        XENG_HIP(hipEventSynchronize(x.ev_dump[(x.ndump - 1 - lag) & 3]));
     x.timer.drain();
     return XENG_STATUS_SUCCESS;
 }
@@ -283,6 +357,7 @@ int xengXgpuReset(void) {
     if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized");
     XENG_HIP(hipSetDevice(x.gpu));
     XENG_HIP(hipStreamSynchronize(x.stream));
+    XENG_HIP(hipStreamSynchronize(x.stream_mm));
     x.timer.drain();
     x.nfilled = 0;
     x.acc_started = false;
@@ -304,8 +379,8 @@ int xengXgpuCorrelate(const void* in_host, void* out_host, int doDump) {
     int rc = kernel_locked(x.in_dev, x.out_dev, doDump, true);
     if (rc) return rc;
     if (doDump) {
-        XENG_HIP(hipMemcpyAsync(out_host, x.out_dev, out_bytes, hipMemcpyDeviceToHost, x.stream));
-        XENG_HIP(hipStreamSynchronize(x.stream));
+        XENG_HIP(hipMemcpyAsync(out_host, x.out_dev, out_bytes, hipMemcpyDeviceToHost, x.stream_mm));
+        XENG_HIP(hipStreamSynchronize(x.stream_mm));
     }
     return XENG_STATUS_SUCCESS;
 }
@@ -353,11 +428,11 @@ int xengXgpuSubSelect(const void* in_dev, void* out_dev, const int32_t* vismap_d
     if (nvis <= 0 || nchan_sum <= 0 || x.cfg.nchan % nchan_sum)
         XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "SubSelect: nvis=%d nchan_sum=%d nchan=%d", nvis, nchan_sum, x.cfg.nchan);
     XENG_HIP(hipSetDevice(x.gpu));
-    hipLaunchKernelGGL(subselect_kernel, dim3((nvis + 255) / 256, x.cfg.nchan / nchan_sum), dim3(256), 0, x.stream,
+    hipLaunchKernelGGL(subselect_kernel, dim3((nvis + 255) / 256, x.cfg.nchan / nchan_sum), dim3(256), 0, x.stream_mm,
                        (const int32_t*)in_dev, (int32_t*)out_dev, vismap_dev, conj_dev, nvis, nchan_sum,
                        x.per_chan, x.matlen);
     XENG_HIP(hipGetLastError());
-    XENG_HIP(hipStreamSynchronize(x.stream));
+    XENG_HIP(hipStreamSynchronize(x.stream_mm));
     return XENG_STATUS_SUCCESS;
 }
 
@@ -409,6 +484,7 @@ int xengXgpuGetTimes(double ms[2], int count[2]) {
     XgpuContext& x = g_ctx;
     if (x.live && x.stream) {
         XENG_HIP(hipStreamSynchronize(x.stream));
+        XENG_HIP(hipStreamSynchronize(x.stream_mm));
         x.timer.drain();
     }
     for (int k = 0; k < 2; k++) {
@@ -417,6 +493,18 @@ int xengXgpuGetTimes(double ms[2], int count[2]) {
         x.timer.total_ms[k] = 0;
         x.timer.count[k] = 0;
     }
+    return XENG_STATUS_SUCCESS;
+}
+
+// diagnostic hook: per-wave clock stamps of the last MFMA launch (needs XENG_DBG_STAMPS=1 at Initialize)
+int xengXgpuDebugReadStamps(unsigned long long* host, size_t nwords, int* nwaves) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    XgpuContext& x = g_ctx;
+    if (!x.live || !x.stamps) XENG_FAIL(XENG_STATUS_INVALID_STATE, "stamps not enabled");
+    const size_t n = (size_t)x.cfg.nchan * x.nwg * 4 * 4;
+    if (nwaves) *nwaves = x.cfg.nchan * x.nwg * 4;
+    XENG_HIP(hipStreamSynchronize(x.stream_mm));
+    if (host) XENG_HIP(hipMemcpy(host, x.stamps, std::min(nwords, n) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return XENG_STATUS_SUCCESS;
 }
 
@@ -429,7 +517,7 @@ int xengXgpuDebugReadStash(void* host, size_t nbytes, int* cap_kt, int* nblk64) 
     if (nblk64) *nblk64 = x.nblk64;
     if (host) {
         XENG_HIP(hipStreamSynchronize(x.stream));
-        XENG_HIP(hipMemcpy(host, x.stash, std::min(nbytes, x.stash_bytes), hipMemcpyDeviceToHost));
+        XENG_HIP(hipMemcpy(host, x.stash[x.cur], std::min(nbytes, x.stash_bytes), hipMemcpyDeviceToHost));
     }
     return XENG_STATUS_SUCCESS;
 }

@@ -68,10 +68,11 @@ __device__ __forceinline__ void transpose4x4_bytes(uint32_t a, uint32_t b, uint3
     o3 = __builtin_amdgcn_perm(u1, t1, 0x07060302u);
 }
 
-// grid (gkt, nchan), 256 threads.  Each work item is (input quad q, k-half h): it reads
+// grid (gkt, nchan), one thread per work item (threads = 32*nblk64 rounded up to a wave, set by the
+// launcher) so every load of the tile is in flight at once.  Each work item is (input quad q, k-half h): it reads
 // 16 samples x 4 inputs as 16 coalesced dwords (a wave covers 256 contiguous bytes of one
 // [t][c] row per load) and writes the four inputs' 16-byte fragment entries (64 contiguous B).
-__global__ __launch_bounds__(256) void corner_turn_kernel(const uint8_t* __restrict__ in,
+__global__ __launch_bounds__(1024) void corner_turn_kernel(const uint8_t* __restrict__ in,
                                                           uint8_t* __restrict__ stash, int ntime,
                                                           int nchan, int ninput, int nblk64,
                                                           int cap_kt, int kt_off) {
@@ -104,6 +105,86 @@ __global__ __launch_bounds__(256) void corner_turn_kernel(const uint8_t* __restr
     }
 }
 
+// LDS-staged corner turn (used when ninput is a multiple of 16, e.g. 704): grid (gkt, nchan), 256 threads.
+//   phase 1  the raw tile (32 samples x ninput bytes) is copied HBM -> LDS by LDS-DMA, 16 B per lane; the
+//            LDS image is the tile's rows back to back, so each 1 KiB wave-instruction lands linearly
+//            while its per-lane source addresses walk the [t][c] rows of the input;
+//   phase 2  each thread transposes 16 samples x 4 inputs (16 conflict-free ds_read_b32, 32 v_perm_b32)
+//            and writes its four 16-byte fragment entries into an LDS image of the output;
+//   phase 3  the output image (2 KiB per 64-input block) is streamed out with fully contiguous
+//            1 KiB-per-wave stores.
+// HALF = 0: one block per (K tile, channel), 32 samples.  HALF = 1: one block per (K tile, channel,
+// k-half), 16 samples -- half the LDS per block, so twice the blocks overlap their phases per CU.
+template <int HALF>
+__global__ __launch_bounds__(256) void corner_turn_lds_kernel(const uint8_t* __restrict__ in,
+                                                              uint8_t* __restrict__ stash, int ntime,
+                                                              int nchan, int ninput, int nblk64,
+                                                              int cap_kt, int kt_off) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t ct_lds[];
+    constexpr int NROW = HALF ? 16 : 32;
+    // channel is the fastest grid index: blocks resident together read adjacent segments of the same [t] rows
+    const int c = blockIdx.x, kt = blockIdx.y, hz = HALF ? blockIdx.z : 0;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwave = blockDim.x >> 6;
+    const int in_bytes = NROW * ninput;                          // raw tile
+    const int out_bytes = nblk64 * KT_BYTES / (HALF ? 2 : 1);    // fragment image (or its k-half)
+    uint8_t* lin = ct_lds;
+    uint8_t* lout = ct_lds + ((in_bytes + 1023) & ~1023);
+    const size_t row_stride = (size_t)nchan * ninput;
+    const uint8_t* src_c = in + (size_t)c * ninput;
+    const int t_base = kt * 32 + 16 * hz;
+    const int t_valid = max(0, min(NROW, ntime - t_base));       // samples of this tile that exist
+
+    // phase 1: pieces of 1 KiB; lane L of piece n covers tile bytes n*1024 + 16L .. +15 = (t, i..i+15)
+    const int npiece = (in_bytes + 1023) >> 10;
+    for (int n = wave; n < npiece; n += nwave) {
+        const int off = n * 1024 + lane * 16;
+        int t = off / ninput, i = off - t * ninput;
+        if (t >= t_valid) { t = 0; i = 0; }           // past the tile / past ntime: any valid address (masked below)
+        const uint8_t* g = src_c + (size_t)(t_valid > 0 ? t_base + t : 0) * row_stride + i;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(lin + n * 1024), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // phase 2
+    const int nq = nblk64 * 16;
+    const int nitem = HALF ? nq : 2 * nq;
+    for (int item = tid; item < nitem; item += blockDim.x) {
+        const int h = HALF ? hz : item / nq, q = HALF ? item : item - h * nq;
+        const int i0 = q * 4;
+        uint32_t v[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int t = (HALF ? 0 : 16 * h) + j;
+            v[j] = (i0 < ninput && t < t_valid) ? *reinterpret_cast<const uint32_t*>(lin + t * ninput + i0) : 0u;
+        }
+        uint32_t o[4][4];
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+            transpose4x4_bytes(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3], o[0][g], o[1][g],
+                               o[2][g], o[3][g]);
+        // full image: (i0>>5)*1024 + h*512 + (i0&31)*16 ; half image: (i0>>5)*512 + (i0&31)*16
+        uint8_t* dst = HALF ? lout + (i0 >> 5) * 512 + (i0 & 31) * 16
+                            : lout + (i0 >> 5) * FRAG_BYTES + h * 512 + (i0 & 31) * 16;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            *reinterpret_cast<uint4*>(dst + 16 * j) = make_uint4(o[j][0], o[j][1], o[j][2], o[j][3]);
+    }
+    __syncthreads();
+
+    // phase 3: 1 KiB LDS pieces -> HBM (contiguous 1 KiB, or two contiguous 512 B runs for HALF)
+    const int nout = out_bytes >> 10;
+    for (int n = wave; n < nout; n += nwave) {
+        const uint4 val = *reinterpret_cast<const uint4*>(lout + n * 1024 + lane * 16);
+        const int f = HALF ? 2 * n + (lane >> 5) : n;            // 32-input fragment index = ib*2 + sub
+        const int within = HALF ? hz * 512 + (lane & 31) * 16 : lane * 16;
+        uint8_t* dst = stash + (((size_t)c * nblk64 + (f >> 1)) * cap_kt + (kt_off + kt)) * KT_BYTES + (f & 1) * FRAG_BYTES + within;
+        *reinterpret_cast<uint4*>(dst) = val;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // stage 2: int8-MFMA contraction + xGPU-order epilogue
 // ---------------------------------------------------------------------------------------
@@ -125,14 +206,41 @@ struct XcorrParams {
     int nwg, nchan, nblk64, cap_kt, nkt, nstand;
     int64_t per_chan, matlen;
     int accumulate;
+    unsigned long long* stamps;   // diagnostic only (null in production): per wave {d_memtime, d_memrealtime, loop cycles}
 };
 
-template <int KT_STAGE>
+struct Frags {   // the 8 unpacked int8 operand fragments of one 64x64 wave tile and one K-tile
+    v4i ar[2], ai[2], br[2], bi[2];
+};
+struct RawFrags {  // the same, still packed 4+4 bit (as read from LDS)
+    v4i a[2], b[2];
+};
+
+__device__ __forceinline__ Frags unpack_frags(const RawFrags& r) {
+    const v4i M = (v4i)(0xF0F0F0F0);
+    Frags u;
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+        u.ar[m] = r.a[m] & M;          // 16 * re  (hi nibble in place, two's complement)
+        u.ai[m] = (r.a[m] << 4) & M;   // 16 * im
+        u.br[m] = r.b[m] & M;
+        u.bi[m] = (r.b[m] << 4) & M;
+    }
+    return u;
+}
+
+constexpr int XC_KT = 3;      // K-tiles (32 samples each) per LDS stage
+constexpr int XC_RING = 4;    // LDS ring depth (stages)
+
+// ABL: timing-only ablation bits (results are wrong unless ABL == 0): 1 no LDS-DMA in the loop,
+// 2 no nibble unpack, 4 no LDS reads in the loop, 8 no barrier/vmcnt wait in the loop.
+template <int ABL>
 __global__ __launch_bounds__(256, 1) void xcorr_mfma_kernel(XcorrParams p) {
+    constexpr int KT_STAGE = XC_KT;
     constexpr int SLOT_BYTES = KT_STAGE * KT_BYTES;
     constexpr int STAGE_BYTES = XC_NSLOT * SLOT_BYTES;
     constexpr int NLOAD = 2 * KT_STAGE;  // 1 KiB LDS-DMA pieces per wave per stage
-    __shared__ __attribute__((aligned(16))) uint8_t lds[XC_NBUF * STAGE_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[XC_RING * STAGE_BYTES];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -162,14 +270,15 @@ __global__ __launch_bounds__(256, 1) void xcorr_mfma_kernel(XcorrParams p) {
         p.stash + ((size_t)c * p.nblk64 + dp->slot_blk[wave]) * (size_t)p.cap_kt * KT_BYTES + lane * 16;
     const int nstage = p.nkt / KT_STAGE;
 
-    auto issue = [&](int s, int buf) {
-        const uint8_t* g = gsrc + (size_t)s * SLOT_BYTES;
-        uint8_t* l = lds + buf * STAGE_BYTES + wave * SLOT_BYTES;
-#pragma unroll
-        for (int n = 0; n < NLOAD; n++)
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(g + n * FRAG_BYTES),
-                (__attribute__((address_space(3))) void*)(l + n * FRAG_BYTES), 16, 0, 0);
+    // one 1 KiB LDS-DMA piece n (0..NLOAD-1) of stage s into ring buffer s % XC_RING.  Stages past
+    // the end re-read the last real stage (never consumed): the issue stays unconditional, so every
+    // stage costs exactly NLOAD pieces on the vmcnt counter and the loop body is one scheduling region.
+    auto issue_piece = [&](int s, int n) {
+        const int ssrc = s < nstage ? s : nstage - 1;
+        const uint8_t* g = gsrc + (size_t)ssrc * SLOT_BYTES + n * FRAG_BYTES;
+        uint8_t* l = lds + (s & (XC_RING - 1)) * STAGE_BYTES + wave * SLOT_BYTES + n * FRAG_BYTES;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)l, 16, 0, 0);
     };
 
     v16i accR[2][2], accP[2][2], accQ[2][2];
@@ -188,56 +297,92 @@ __global__ __launch_bounds__(256, 1) void xcorr_mfma_kernel(XcorrParams p) {
     const int a_off = (active ? a_slot : 0) * SLOT_BYTES + lane * 16;
     const int b_off = (active ? b_slot : 0) * SLOT_BYTES + lane * 16;
 
-    auto compute = [&](int buf) {
-        const uint8_t* base = lds + buf * STAGE_BYTES;
-#pragma unroll
-        for (int k = 0; k < KT_STAGE; k++) {
-            const v4i a0 = *reinterpret_cast<const v4i*>(base + a_off + k * KT_BYTES);
-            const v4i a1 = *reinterpret_cast<const v4i*>(base + a_off + k * KT_BYTES + FRAG_BYTES);
-            const v4i b0 = *reinterpret_cast<const v4i*>(base + b_off + k * KT_BYTES);
-            const v4i b1 = *reinterpret_cast<const v4i*>(base + b_off + k * KT_BYTES + FRAG_BYTES);
-            const v4i M = (v4i)(0xF0F0F0F0);
-            v4i ar[2], ai[2], br[2], bi[2];
-            ar[0] = a0 & M; ai[0] = (a0 << 4) & M;
-            ar[1] = a1 & M; ai[1] = (a1 << 4) & M;
-            br[0] = b0 & M; bi[0] = (b0 << 4) & M;
-            br[1] = b1 & M; bi[1] = (b1 << 4) & M;
-#pragma unroll
-            for (int m = 0; m < 2; m++)
-#pragma unroll
-                for (int n = 0; n < 2; n++) {
-                    accR[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ar[m], br[n], accR[m][n], 0, 0, 0);
-                    accP[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ai[m], br[n], accP[m][n], 0, 0, 0);
-                    accQ[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ar[m], bi[n], accQ[m][n], 0, 0, 0);
-                    accR[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ai[m], bi[n], accR[m][n], 0, 0, 0);
-                }
-        }
+    // fragments of K-tile j (0..KT_STAGE-1) of stage s
+    auto load_raw = [&](int s, int j) {
+        const uint8_t* base = lds + (s & (XC_RING - 1)) * STAGE_BYTES + j * KT_BYTES;
+        RawFrags r;
+        r.a[0] = *reinterpret_cast<const v4i*>(base + a_off);
+        r.a[1] = *reinterpret_cast<const v4i*>(base + a_off + FRAG_BYTES);
+        r.b[0] = *reinterpret_cast<const v4i*>(base + b_off);
+        r.b[1] = *reinterpret_cast<const v4i*>(base + b_off + FRAG_BYTES);
+        return r;
     };
 
-    // 3-deep LDS ring, one barrier per stage.  At the top of stage s the wave's own pieces of
-    // stage s have landed (counted vmcnt leaves stage s+1 in flight); the barrier then proves
-    // everybody's have, and that every wave is done reading buffer (s-1)%3, which the
-    // LDS-DMA of stage s+2 overwrites next.
-    issue(0, 0);
-    if (nstage > 1) issue(1, 1);
-    int buf = 0;
-    int s = 0;
-    for (; s + 2 < nstage; s++) {
-        wait_vmcnt<NLOAD>();
-        __builtin_amdgcn_s_barrier();
-        issue(s + 2, buf >= 1 ? buf - 1 : XC_NBUF - 1);
-        compute(buf);
-        buf = (buf + 1 == XC_NBUF) ? 0 : buf + 1;
-    }
-    if (nstage > 1) {
-        wait_vmcnt<NLOAD>();
-        __builtin_amdgcn_s_barrier();
-        compute(buf);
-        buf = (buf + 1 == XC_NBUF) ? 0 : buf + 1;
-    }
-    wait_vmcnt<0>();
+    auto mfma_tile = [&](const Frags& u) {
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int n = 0; n < 2; n++) {
+                accR[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(u.ar[m], u.br[n], accR[m][n], 0, 0, 0);
+                accP[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(u.ai[m], u.br[n], accP[m][n], 0, 0, 0);
+                accQ[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(u.ar[m], u.bi[n], accQ[m][n], 0, 0, 0);
+                accR[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(u.ai[m], u.bi[n], accR[m][n], 0, 0, 0);
+            }
+    };
+
+    // ---- software pipeline over K-tiles g = s*KT_STAGE + j ------------------------------------
+    //   MFMA(g)  ||  unpack(g+1)  ||  LDS read(g+2)  ||  LDS-DMA of stage s+3
+    // 4-deep LDS ring.  At the end of stage s every wave waits until its own pieces of stage s+2
+    // have landed (counted vmcnt: stage s+3 stays in flight), then one barrier: stages s+1 and s+2
+    // are now visible to all waves (the LDS reads two K-tiles ahead cross into the next stage), and
+    // everybody is done reading stage s, whose buffer the DMA of stage s+4 overwrites.
+#pragma unroll
+    for (int st = 0; st < 3; st++)
+#pragma unroll
+        for (int n = 0; n < NLOAD; n++) issue_piece(st, n);
+    wait_vmcnt<NLOAD>();
     __builtin_amdgcn_s_barrier();
-    compute(buf);
+
+    Frags cur = unpack_frags(load_raw(0, 0));
+    RawFrags raw = load_raw(0, 1);
+    unsigned long long t_start = 0, r_start = 0;
+    if (p.stamps) {   // diagnostic build path: shader clock vs 100 MHz reference (MI355X_MICROARCH, DVFS item 6)
+        t_start = __builtin_amdgcn_s_memtime();
+        r_start = __builtin_amdgcn_s_memrealtime();
+    }
+    for (int s = 0; s < nstage; s++) {
+#pragma unroll
+        for (int j = 0; j < KT_STAGE; j++) {
+            if (!(ABL & 1)) {
+                issue_piece(s + 3, 2 * j);
+                issue_piece(s + 3, 2 * j + 1);
+            }
+            mfma_tile(cur);
+            if (ABL & 2) {
+#pragma unroll
+                for (int m = 0; m < 2; m++) { cur.ar[m] = raw.a[m]; cur.ai[m] = raw.a[m]; cur.br[m] = raw.b[m]; cur.bi[m] = raw.b[m]; }
+            } else {
+                cur = unpack_frags(raw);
+            }
+            // K-tile g+2: same stage for j < KT_STAGE-2, else the next stage (already visible; past the
+            // end of K the read lands in a valid ring buffer and is never used)
+            if (!(ABL & 4)) raw = (j + 2 < KT_STAGE) ? load_raw(s, j + 2) : load_raw(s + 1, j + 2 - KT_STAGE);
+            else { asm volatile("" : "+v"(raw.a[0]), "+v"(raw.a[1]), "+v"(raw.b[0]), "+v"(raw.b[1])); }
+            // pin the interleave: 1 MFMA : 3 VALU (the 48 mask/shift ops of the next K-tile hide under
+            // the 16 MFMAs of this one), the two DMA pieces early, the four LDS reads in the second half
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                   // VALU
+                if (i == 1 || i == 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read (LDS-DMA)
+                if (i >= 8 && i < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+            }
+        }
+        if (!(ABL & 8)) {
+            if (!(ABL & 1)) wait_vmcnt<NLOAD>();
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    wait_vmcnt<0>();   // no LDS-DMA may still be in flight when the wave ends
+    if (p.stamps) {
+        // wait for the last MFMA to retire before stamping (read one accumulator element)
+        asm volatile("" :: "v"(accR[1][1][15]), "v"(accQ[1][1][15]), "v"(accP[1][1][15]));
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime(), r_end = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+            unsigned long long* o = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 4;
+            o[0] = t_end - t_start; o[1] = r_end - r_start; o[2] = r_start; o[3] = r_end;
+        }
+    }
     if (!active) return;
 
     // ---- epilogue: D[i][j] = sum x_i conj(x_j), lane = column j, register = row i.

@@ -2,6 +2,7 @@
 // Replaces bifrost.device.set_device / stream_synchronize, BFArray(space='cuda'|'cuda_host')
 // allocation and copy_array for the hot-path blocks.
 #include <mutex>
+#include <utility>
 
 #include "xeng_common.h"
 
@@ -66,14 +67,24 @@ void EventTimer::end(hipStream_t s, int slot) {
     if (slot >= 0) (void)hipEventRecord(stop[slot], s);
 }
 int EventTimer::drain() {
+    // consume the pairs that have completed; keep the rest pending (streams may still be running)
+    int keep = 0;
     for (int i = 0; i < npend; i++) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, start[i], stop[i]) == hipSuccess) {
+        if (hipEventQuery(stop[i]) == hipSuccess && hipEventElapsedTime(&ms, start[i], stop[i]) == hipSuccess) {
             total_ms[kind[i]] += ms;
             count[kind[i]]++;
+        } else {
+            if (keep != i) {
+                std::swap(start[keep], start[i]);
+                std::swap(stop[keep], stop[i]);
+                std::swap(kind[keep], kind[i]);
+            }
+            keep++;
         }
     }
-    npend = 0;
+    npend = keep;
+    (void)hipGetLastError();   // hipEventQuery(not ready) is not an error
     return 0;
 }
 void EventTimer::destroy() {

@@ -106,6 +106,10 @@ int xengXgpuKernel(const void *in_dev, void *out_dev, int doDump);
  * out_dev or recycling in_dev.  (No reference counterpart; used to pipeline gulps of one integration.) */
 int xengXgpuKernelAsync(const void *in_dev, void *out_dev, int doDump);
 int xengXgpuSync(void);
+/* Wait until all but the last `lag` (0..3) dumps are complete -- lag 1 lets a streaming caller enqueue
+ * integration n+1 (into a different out_dev) before it waits for integration n, so the corner turns of
+ * n+1 overlap the contraction of n on the GPU.  lag 0 waits for the latest dump. */
+int xengXgpuSyncLag(int lag);
 
 /* Drop the gulps staged and the partial sums accumulated since the last dump (an integration that
  * is abandoned, e.g. when a new start_time command interrupts it: corr_block.py:392-404 resets

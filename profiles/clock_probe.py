@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Diagnostic: in-kernel shader clock of xcorr_mfma_kernel (s_memtime / s_memrealtime stamps per wave).
+Run with XENG_DBG_STAMPS=1 (set below).  Not a benchmark: the stamped build path is for shares/clocks only."""
+import ctypes, os, sys, time
+import numpy as np
+os.environ["XENG_DBG_STAMPS"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import caltech_bifrost_dsp_amd  # noqa
+from caltech_bifrost_dsp_amd import ffi
+NS, NC, NT, G = 352, 96, 480, 5
+ffi.call("xengXgpuConfigure", NS, 2, NC, NT, G)
+ffi.call("xengXgpuInitialize", 0)
+gb = NT * NC * NS * 2
+ring = ffi.DeviceBuffer(G * gb)
+rs = np.random.RandomState(1)
+for g in range(G):
+    ring.upload(rs.randint(0, 255, size=gb, dtype=np.uint8), offset=g * gb)
+out = ffi.DeviceBuffer(2 * NC * 249216 * 4)
+L = ffi.lib()
+t0 = time.time()
+n = 0
+while time.time() - t0 < float(sys.argv[1]) if len(sys.argv) > 1 else 2.0:     # >= 2 s of back-to-back launches
+    for g in range(G):
+        L.xengXgpuKernelAsync(ring.ptr + g * gb, out.ptr, int(g == G - 1))
+    n += 1
+    if n % 50 == 0:
+        L.xengXgpuSync()
+L.xengXgpuSync()
+L.xengXgpuDebugReadStamps.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)]
+nw = ctypes.c_int()
+L.xengXgpuDebugReadStamps(None, 0, ctypes.byref(nw))
+st = np.zeros(nw.value * 4, dtype=np.uint64)
+L.xengXgpuDebugReadStamps(st.ctypes.data, st.size, None)
+st = st.reshape(-1, 4).astype(np.float64)
+ok = st[:, 1] > 0
+clk = st[ok, 0] / st[ok, 1] * 100e6
+print("integrations run: %d" % n)
+print("waves stamped: %d; in-kernel clock GHz: median %.3f  p10 %.3f  p90 %.3f" % (ok.sum(), np.median(clk) / 1e9, np.percentile(clk, 10) / 1e9, np.percentile(clk, 90) / 1e9))
+print("loop cycles per wave: median %.0f (pure MFMA = 75*16*32 = 38400); loop time us: median %.2f" % (np.median(st[ok, 0]), np.median(st[ok, 1]) / 100.0))
+span = (st[ok, 3].max() - st[ok, 2].min()) / 100.0
+print("first loop start -> last loop end: %.1f us; sum of loop time / (1024 SIMDs * span) = %.3f" % (span, st[ok, 1].sum() / 100.0 / (1024 * span)))

@@ -1,0 +1,33 @@
+#!/bin/bash
+# Collect PMC counters for bench.py in separate passes (no tracing domains combined with --pmc).
+# usage: profiles/pmc_run.sh <outdir-under-gpurun_out> [bench args...]
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/$1; shift
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+i=0
+for set in \
+  "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_LDS_BANK_CONFLICT" \
+  "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_LDS_IDX_ACTIVE" \
+  "FETCH_SIZE" \
+  "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
+  i=$((i+1))
+  timeout -k 10 240 rocprofv3 --pmc $set --output-format csv -d $OUT/pass$i -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline "$@" > $OUT/pass$i.log 2>&1 || echo "pass $i failed" >> $OUT/fail.log
+done
+python3 - "$OUT" <<'PY'
+import csv, glob, sys, collections
+out = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        k = row["Kernel_Name"].split("(")[0][-40:]
+        a = agg[k][row["Counter_Name"]]
+        a[0] += float(row["Counter_Value"]); a[1] += 1
+with open(out + "/summary.txt", "w") as fh:
+    for k, d in agg.items():
+        fh.write(k + "\n")
+        for c, (tot, n) in sorted(d.items()):
+            fh.write("   %-32s per-dispatch %16.1f  (n=%d)\n" % (c, tot / max(n, 1), n))
+print(open(out + "/summary.txt").read())
+PY

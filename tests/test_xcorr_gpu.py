@@ -118,6 +118,7 @@ def test_golden_64input(gpu, golden_dir):
 @pytest.mark.parametrize("nstand,nchan,ntime,ngulp,kind", [
     (16, 4, 8, 1, "full"),          # one half-empty 64-input block, K tile mostly padding
     (32, 8, 32, 3, "full"),         # exactly one block
+    (36, 2, 64, 2, "full"),         # 72 inputs: not a multiple of 16 -> register-only corner turn
     (48, 5, 96, 2, "random"),       # 2 blocks (one diagonal work-group), nchan not a multiple of 8
     (80, 8, 480, 2, "full"),        # 3 blocks: odd count -> leftover row packing; the reference gulp length
     (96, 3, 160, 2, "88"),          # every nibble -8: largest magnitudes, exercises the x16 scaling / P-Q split
