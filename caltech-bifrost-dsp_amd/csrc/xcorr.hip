@@ -100,7 +100,10 @@ struct XgpuContext {
     WgDesc* descs_dev = nullptr;
     int nwg = 0;
     hipStream_t stream = nullptr;              // corner turns (+ H2D of the host-buffer variant)
-    hipStream_t stream_mm = nullptr;           // MFMA contraction (+ sub-selection, D2H)
+    hipStream_t stream_mm2[2] = {nullptr, nullptr};   // MFMA contraction of staging area b: alternating
+                                               // streams let the tail of one launch fill with the next
+    hipStream_t stream_mm = nullptr;           // = stream_mm2[0] (sub-selection, D2H)
+    void* last_out[2] = {nullptr, nullptr};    // output buffer of the last contraction on each stream
     hipEvent_t ev_ct = nullptr;                // staged gulps of the area about to be contracted are complete
     hipEvent_t ev_mm[2] = {nullptr, nullptr};  // the contraction reading staging area b is complete
     bool mm_used[2] = {false, false};
@@ -126,7 +129,8 @@ static int destroy_locked() {
     if (!x.live) return XENG_STATUS_SUCCESS;
     (void)hipSetDevice(x.gpu);
     if (x.stream) (void)hipStreamSynchronize(x.stream);
-    if (x.stream_mm) (void)hipStreamSynchronize(x.stream_mm);
+    for (int b = 0; b < 2; b++)
+        if (x.stream_mm2[b]) (void)hipStreamSynchronize(x.stream_mm2[b]);
     for (int b = 0; b < 2; b++) {
         if (x.stash[b]) (void)hipFree(x.stash[b]);
         if (x.ev_mm[b]) (void)hipEventDestroy(x.ev_mm[b]);
@@ -156,6 +160,7 @@ static void launch_xcorr(const XcorrParams& p, hipStream_t s) {
         case 8: launch_abl<8>(p, s); break;
         case 9: launch_abl<9>(p, s); break;
         case 15: launch_abl<15>(p, s); break;
+        case 16: launch_abl<16>(p, s); break;
         default: launch_abl<0>(p, s); break;
     }
 }
@@ -183,16 +188,22 @@ static int flush_locked(void* out, bool dump) {
     p.accumulate = x.acc_started ? 1 : 0;
     p.stamps = x.stamps;
     // the contraction starts when this area's corner turns are done and runs beside the next area's
+    hipStream_t smm = x.stream_mm2[x.cur];
     XENG_HIP(hipEventRecord(x.ev_ct, x.stream));
-    XENG_HIP(hipStreamWaitEvent(x.stream_mm, x.ev_ct, 0));
-    int slot = x.timer.begin(x.stream_mm, 1);
-    launch_xcorr(p, x.stream_mm);
-    x.timer.end(x.stream_mm, slot);
+    XENG_HIP(hipStreamWaitEvent(smm, x.ev_ct, 0));
+    // contractions that touch the same output (partial sums of one integration, or a caller that
+    // reuses one buffer for consecutive integrations) stay ordered; independent ones may overlap
+    if (x.mm_used[x.cur ^ 1] && (x.acc_started || x.last_out[x.cur ^ 1] == out))
+        XENG_HIP(hipStreamWaitEvent(smm, x.ev_mm[x.cur ^ 1], 0));
+    int slot = x.timer.begin(smm, 1);
+    launch_xcorr(p, smm);
+    x.timer.end(smm, slot);
     XENG_HIP(hipGetLastError());
-    XENG_HIP(hipEventRecord(x.ev_mm[x.cur], x.stream_mm));
+    XENG_HIP(hipEventRecord(x.ev_mm[x.cur], smm));
     x.mm_used[x.cur] = true;
+    x.last_out[x.cur] = out;
     if (dump) {
-        XENG_HIP(hipEventRecord(x.ev_dump[x.ndump & 3], x.stream_mm));
+        XENG_HIP(hipEventRecord(x.ev_dump[x.ndump & 3], smm));
         x.ndump++;
     }
     x.cur ^= 1;
@@ -245,7 +256,8 @@ static int kernel_locked(const void* in_dev, void* out_dev, int doDump, bool syn
         // input consumed = its corner turn is done; on a dump the output must be complete too
         XENG_HIP(hipStreamSynchronize(x.stream));
         if (doDump) {
-            XENG_HIP(hipStreamSynchronize(x.stream_mm));
+            XENG_HIP(hipStreamSynchronize(x.stream_mm2[0]));
+            XENG_HIP(hipStreamSynchronize(x.stream_mm2[1]));
             x.timer.drain();
         }
     }
@@ -303,11 +315,15 @@ int xengXgpuInitialize(int gpu) {
     XENG_HIP(hipMemcpy(x.descs_dev, descs.data(), descs.size() * sizeof(WgDesc), hipMemcpyHostToDevice));
     int rc = get_stream(STREAM_XGPU, &x.stream);
     if (rc) return rc;
-    rc = get_stream(STREAM_XGPU_MM, &x.stream_mm);
+    rc = get_stream(STREAM_XGPU_MM, &x.stream_mm2[0]);
     if (rc) return rc;
+    rc = get_stream(STREAM_XGPU_MM2, &x.stream_mm2[1]);
+    if (rc) return rc;
+    if (getenv("XENG_ONE_MM_STREAM")) x.stream_mm2[1] = x.stream_mm2[0];   // experiment: no tail overlap
+    x.stream_mm = x.stream_mm2[0];
     if (getenv("XENG_DBG_STAMPS")) {
-        XENG_HIP(hipMalloc((void**)&x.stamps, (size_t)x.cfg.nchan * x.nwg * 4 * 4 * sizeof(unsigned long long)));
-        XENG_HIP(hipMemset(x.stamps, 0, (size_t)x.cfg.nchan * x.nwg * 4 * 4 * sizeof(unsigned long long)));
+        XENG_HIP(hipMalloc((void**)&x.stamps, (size_t)x.cfg.nchan * x.nwg * 4 * 8 * sizeof(unsigned long long)));
+        XENG_HIP(hipMemset(x.stamps, 0, (size_t)x.cfg.nchan * x.nwg * 4 * 8 * sizeof(unsigned long long)));
     }
     x.live = true;
     return XENG_STATUS_SUCCESS;
@@ -334,7 +350,8 @@ int xengXgpuSync(void) {
     if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized");
     XENG_HIP(hipSetDevice(x.gpu));
     XENG_HIP(hipStreamSynchronize(x.stream));
-    XENG_HIP(hipStreamSynchronize(x.stream_mm));
+    XENG_HIP(hipStreamSynchronize(x.stream_mm2[0]));
+    XENG_HIP(hipStreamSynchronize(x.stream_mm2[1]));
     x.timer.drain();
     return XENG_STATUS_SUCCESS;
 }
@@ -357,7 +374,8 @@ int xengXgpuReset(void) {
     if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized");
     XENG_HIP(hipSetDevice(x.gpu));
     XENG_HIP(hipStreamSynchronize(x.stream));
-    XENG_HIP(hipStreamSynchronize(x.stream_mm));
+    XENG_HIP(hipStreamSynchronize(x.stream_mm2[0]));
+    XENG_HIP(hipStreamSynchronize(x.stream_mm2[1]));
     x.timer.drain();
     x.nfilled = 0;
     x.acc_started = false;
@@ -380,7 +398,8 @@ int xengXgpuCorrelate(const void* in_host, void* out_host, int doDump) {
     if (rc) return rc;
     if (doDump) {
         XENG_HIP(hipMemcpyAsync(out_host, x.out_dev, out_bytes, hipMemcpyDeviceToHost, x.stream_mm));
-        XENG_HIP(hipStreamSynchronize(x.stream_mm));
+        XENG_HIP(hipStreamSynchronize(x.stream_mm2[0]));
+    XENG_HIP(hipStreamSynchronize(x.stream_mm2[1]));
     }
     return XENG_STATUS_SUCCESS;
 }
@@ -432,7 +451,8 @@ int xengXgpuSubSelect(const void* in_dev, void* out_dev, const int32_t* vismap_d
                        (const int32_t*)in_dev, (int32_t*)out_dev, vismap_dev, conj_dev, nvis, nchan_sum,
                        x.per_chan, x.matlen);
     XENG_HIP(hipGetLastError());
-    XENG_HIP(hipStreamSynchronize(x.stream_mm));
+    XENG_HIP(hipStreamSynchronize(x.stream_mm2[0]));
+    XENG_HIP(hipStreamSynchronize(x.stream_mm2[1]));
     return XENG_STATUS_SUCCESS;
 }
 
@@ -484,7 +504,8 @@ int xengXgpuGetTimes(double ms[2], int count[2]) {
     XgpuContext& x = g_ctx;
     if (x.live && x.stream) {
         XENG_HIP(hipStreamSynchronize(x.stream));
-        XENG_HIP(hipStreamSynchronize(x.stream_mm));
+        XENG_HIP(hipStreamSynchronize(x.stream_mm2[0]));
+    XENG_HIP(hipStreamSynchronize(x.stream_mm2[1]));
         x.timer.drain();
     }
     for (int k = 0; k < 2; k++) {
@@ -501,9 +522,10 @@ int xengXgpuDebugReadStamps(unsigned long long* host, size_t nwords, int* nwaves
     std::lock_guard<std::mutex> lk(g_mu);
     XgpuContext& x = g_ctx;
     if (!x.live || !x.stamps) XENG_FAIL(XENG_STATUS_INVALID_STATE, "stamps not enabled");
-    const size_t n = (size_t)x.cfg.nchan * x.nwg * 4 * 4;
+    const size_t n = (size_t)x.cfg.nchan * x.nwg * 4 * 8;
     if (nwaves) *nwaves = x.cfg.nchan * x.nwg * 4;
-    XENG_HIP(hipStreamSynchronize(x.stream_mm));
+    XENG_HIP(hipStreamSynchronize(x.stream_mm2[0]));
+    XENG_HIP(hipStreamSynchronize(x.stream_mm2[1]));
     if (host) XENG_HIP(hipMemcpy(host, x.stamps, std::min(nwords, n) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return XENG_STATUS_SUCCESS;
 }

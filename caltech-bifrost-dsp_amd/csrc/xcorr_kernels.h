@@ -244,6 +244,7 @@ __global__ __launch_bounds__(256, 1) void xcorr_mfma_kernel(XcorrParams p) {
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned long long r_entry = p.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
     // block -> (channel, work-group).  Blocks b and b+8 share an XCD (round-robin dispatch),
     // so give each XCD whole channels: all tiles of a channel then stream the same stash
@@ -308,11 +309,18 @@ __global__ __launch_bounds__(256, 1) void xcorr_mfma_kernel(XcorrParams p) {
         return r;
     };
 
+    // Diagonal wave tiles (row block == column block) never store the upper-right 32x32 MFMA tile
+    // (rows 0-31 x columns 32-63: Rh < Ch): skip its 4 MFMAs.  Idle waves skip all of them.  Both
+    // conditions are wave-uniform; the chip is power-limited, so unspent MFMAs come back as clock.
+    const bool skip01 = __builtin_amdgcn_readfirstlane((int)(!active || blk_a == blk_b)) != 0;
+    const bool skipall = __builtin_amdgcn_readfirstlane((int)!active) != 0;
     auto mfma_tile = [&](const Frags& u) {
 #pragma unroll
         for (int m = 0; m < 2; m++)
 #pragma unroll
             for (int n = 0; n < 2; n++) {
+                if (m == 0 && n == 1) { if (skip01) continue; }
+                else if (ABL & 16) { if (skipall) continue; }
                 accR[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(u.ar[m], u.br[n], accR[m][n], 0, 0, 0);
                 accP[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(u.ai[m], u.br[n], accP[m][n], 0, 0, 0);
                 accQ[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(u.ar[m], u.bi[n], accQ[m][n], 0, 0, 0);
@@ -379,27 +387,41 @@ __global__ __launch_bounds__(256, 1) void xcorr_mfma_kernel(XcorrParams p) {
         asm volatile("" :: "v"(accR[1][1][15]), "v"(accQ[1][1][15]), "v"(accP[1][1][15]));
         const unsigned long long t_end = __builtin_amdgcn_s_memtime(), r_end = __builtin_amdgcn_s_memrealtime();
         if (lane == 0) {
-            unsigned long long* o = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 4;
-            o[0] = t_end - t_start; o[1] = r_end - r_start; o[2] = r_start; o[3] = r_end;
+            unsigned long long* o = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
+            o[0] = t_end - t_start; o[1] = r_end - r_start; o[2] = r_start; o[3] = r_end; o[4] = r_entry;
         }
     }
     if (!active) return;
 
     // ---- epilogue: D[i][j] = sum x_i conj(x_j), lane = column j, register = row i.
     // MFMA C/D map (32x32): col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-    const int64_t qs = ((int64_t)(p.nstand / 2 + 1) * p.nstand) / 4;
+    // Registers 4u..4u+3 of a lane are (station 2Rh, pol 0/1), (station 2Rh+1, pol 0/1) of one column
+    // (station C, pol = lane&1).  The even lane of a pair stores the cell of station 2Rh, the odd lane
+    // the cell of station 2Rh+1; the two words each is missing (the other polC) come from its partner
+    // lane by DPP (quad_perm [1,0,3,2]):
+    //   even: {v0, odd.v0, v1, odd.v1}     odd: {even.v2, v2, even.v3, v3}
+    const int qs = (int)(((int64_t)(p.nstand / 2 + 1) * p.nstand) / 4);
     int32_t* out_r = p.out + (int64_t)c * p.per_chan;
     int32_t* out_i = out_r + p.matlen;
     const int odd = lane & 1;
     const int cpar = (lane >> 1) & 1;          // C & 1 of this lane's column station
-    const int64_t quad = 2 * cpar + odd;       // quadrant of the cell this lane stores
+    const int quad = 2 * cpar + odd;           // quadrant of the cell this lane stores
+    auto cell = [&](int v0, int v1, int v2, int v3) {
+        const int g0 = dpp_xor1(odd ? v0 : v2), g1 = dpp_xor1(odd ? v1 : v3);
+        return odd ? make_int4(g0, v2, g1, v3) : make_int4(v0, g0, v1, g1);
+    };
+    // interior tiles (strictly below the block diagonal, no padded inputs) need no per-cell mask
+    const bool interior = __builtin_amdgcn_readfirstlane((int)(blk_a > blk_b && blk_a * 64 + 64 <= 2 * p.nstand)) != 0;
+    const bool accumulate = p.accumulate != 0;
 #pragma unroll
     for (int m = 0; m < 2; m++)
 #pragma unroll
         for (int n = 0; n < 2; n++) {
+            if (m == 0 && n == 1 && skip01) continue;      // never stored (and not computed) on diagonal tiles
             const int ibase = blk_a * 64 + m * 32, jbase = blk_b * 64 + n * 32;
             const int Ch = (jbase >> 2) + ((lane & 31) >> 2);
             const int C = 2 * Ch + cpar;
+            const int wcol = (quad * qs + Ch) * 4;
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int Rh = (ibase >> 2) + 2 * u + (lane >> 5);
@@ -410,17 +432,13 @@ __global__ __launch_bounds__(256, 1) void xcorr_mfma_kernel(XcorrParams p) {
                     vr[v] = accR[m][n][4 * u + v] >> 8;
                     vi[v] = (accP[m][n][4 * u + v] - accQ[m][n][4 * u + v]) >> 8;
                 }
-                // even lane keeps station R&1=0 (regs 0,1), odd lane station R&1=1 (regs 2,3);
-                // the partner lane (other polC) supplies the missing two words.
-                const int gr0 = dpp_xor1(odd ? vr[0] : vr[2]), gr1 = dpp_xor1(odd ? vr[1] : vr[3]);
-                const int gi0 = dpp_xor1(odd ? vi[0] : vi[2]), gi1 = dpp_xor1(odd ? vi[1] : vi[3]);
-                int4 cr = odd ? make_int4(gr0, vr[2], gr1, vr[3]) : make_int4(vr[0], gr0, vr[1], gr1);
-                int4 ci = odd ? make_int4(gi0, vi[2], gi1, vi[3]) : make_int4(vi[0], gi0, vi[1], gi1);
-                if (Rh >= Ch && R < p.nstand && C < p.nstand) {
-                    const int64_t w = (quad * qs + tri64(Rh, Ch)) * 4;
-                    int4* pr = reinterpret_cast<int4*>(out_r + w);
-                    int4* pi = reinterpret_cast<int4*>(out_i + w);
-                    if (p.accumulate) {
+                int4 cr = cell(vr[0], vr[1], vr[2], vr[3]);
+                int4 ci = cell(vi[0], vi[1], vi[2], vi[3]);
+                const int w = wcol + ((Rh * (Rh + 1)) >> 1) * 4;
+                int4* pr = reinterpret_cast<int4*>(out_r + w);
+                int4* pi = reinterpret_cast<int4*>(out_i + w);
+                if (interior || (Rh >= Ch && R < p.nstand && C < p.nstand)) {
+                    if (accumulate) {
                         const int4 o_r = *pr, o_i = *pi;
                         cr.x += o_r.x; cr.y += o_r.y; cr.z += o_r.z; cr.w += o_r.w;
                         ci.x += o_i.x; ci.y += o_i.y; ci.z += o_i.z; ci.w += o_i.w;
@@ -430,6 +448,7 @@ __global__ __launch_bounds__(256, 1) void xcorr_mfma_kernel(XcorrParams p) {
                 }
             }
         }
+    if (p.stamps && lane == 0) p.stamps[((size_t)blockIdx.x * 4 + wave) * 8 + 5] = __builtin_amdgcn_s_memrealtime();
 }
 
 // ---------------------------------------------------------------------------------------

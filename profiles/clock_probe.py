@@ -15,23 +15,22 @@ ring = ffi.DeviceBuffer(G * gb)
 rs = np.random.RandomState(1)
 for g in range(G):
     ring.upload(rs.randint(0, 255, size=gb, dtype=np.uint8), offset=g * gb)
-out = ffi.DeviceBuffer(2 * NC * 249216 * 4)
+outs = [ffi.DeviceBuffer(2 * NC * 249216 * 4) for _ in range(2)]
 L = ffi.lib()
 t0 = time.time()
 n = 0
 while time.time() - t0 < float(sys.argv[1]) if len(sys.argv) > 1 else 2.0:     # >= 2 s of back-to-back launches
     for g in range(G):
-        L.xengXgpuKernelAsync(ring.ptr + g * gb, out.ptr, int(g == G - 1))
+        L.xengXgpuKernelAsync(ring.ptr + g * gb, outs[n & 1].ptr, int(g == G - 1))
     n += 1
-    if n % 50 == 0:
-        L.xengXgpuSync()
+    L.xengXgpuSyncLag(1)
 L.xengXgpuSync()
 L.xengXgpuDebugReadStamps.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)]
 nw = ctypes.c_int()
 L.xengXgpuDebugReadStamps(None, 0, ctypes.byref(nw))
-st = np.zeros(nw.value * 4, dtype=np.uint64)
+st = np.zeros(nw.value * 8, dtype=np.uint64)
 L.xengXgpuDebugReadStamps(st.ctypes.data, st.size, None)
-st = st.reshape(-1, 4).astype(np.float64)
+st = st.reshape(-1, 8).astype(np.float64)
 ok = st[:, 1] > 0
 clk = st[ok, 0] / st[ok, 1] * 100e6
 print("integrations run: %d" % n)
@@ -39,3 +38,10 @@ print("waves stamped: %d; in-kernel clock GHz: median %.3f  p10 %.3f  p90 %.3f" 
 print("loop cycles per wave: median %.0f (pure MFMA = 75*16*32 = 38400); loop time us: median %.2f" % (np.median(st[ok, 0]), np.median(st[ok, 1]) / 100.0))
 span = (st[ok, 3].max() - st[ok, 2].min()) / 100.0
 print("first loop start -> last loop end: %.1f us; sum of loop time / (1024 SIMDs * span) = %.3f" % (span, st[ok, 1].sum() / 100.0 / (1024 * span)))
+pro = (st[ok, 2] - st[ok, 4]) / 100.0
+epi = (st[ok, 5] - st[ok, 3]) / 100.0
+tot = (st[ok, 5] - st[ok, 4]) / 100.0
+print("per wave us: prologue median %.2f p90 %.2f | loop %.2f | epilogue median %.2f p90 %.2f | total %.2f" % (
+    np.median(pro), np.percentile(pro, 90), np.median(st[ok, 1]) / 100.0, np.median(epi), np.percentile(epi, 90), np.median(tot)))
+kspan = (st[ok, 5].max() - st[ok, 4].min()) / 100.0
+print("kernel entry->exit span %.1f us; wave-resident fraction %.3f" % (kspan, tot.sum() / (1024 * kspan)))
