@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--ring-gulps", type=int, default=10, help="device-resident replay ring depth (gulps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--data", default="random", choices=["random", "zeros", "0x88"],
+                    help="diagnostic only: constant inputs show the DVFS give-back (the reported value uses random)")
     ap.add_argument("--sync-per-call", action="store_true",
                     help="time the drop-in synchronous xengXgpuKernel (the reference's call semantics)")
     ap.add_argument("--sync-per-integration", action="store_true",
@@ -94,7 +96,11 @@ def main():
     ring = ffi.DeviceBuffer(args.ring_gulps * gulp_bytes)
     rs = np.random.RandomState(0xdeadbeef + rank)
     for g in range(args.ring_gulps):
-        ring.upload(rs.randint(0, 255, size=gulp_bytes, dtype=np.uint8), offset=g * gulp_bytes)
+        if args.data == "random":
+            blk = rs.randint(0, 255, size=gulp_bytes, dtype=np.uint8)
+        else:
+            blk = np.full(gulp_bytes, 0 if args.data == "zeros" else 0x88, dtype=np.uint8)
+        ring.upload(blk, offset=g * gulp_bytes)
     outs = [ffi.DeviceBuffer(2 * matlen * 4) for _ in range(2)]     # output spans alternate, as ring spans do
     kern = "xengXgpuKernel" if args.sync_per_call else "xengXgpuKernelAsync"
     L = ffi.lib()
@@ -163,7 +169,8 @@ def main():
         "metric": "xengine_ingest_gbps_704in_96ch", "value": round(gbps, 2), "unit": "Gb/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "int8 (4+4-bit samples) -> int32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "int8 (4+4-bit samples) -> int32",
+        "data": "synthetic" if args.data == "random" else "synthetic-constant-%s (diagnostic, not a valid result)" % args.data,
         "config": {"workload": "704-input (352 ant x 2 pol), %d chan/GPU, 4+4b->int32 correlator, acc_len %d = %d gulps x %d"
                                % (NCHAN, ACC_LEN, gulps_per_step, NTIME_GULP),
                    "nchan_total": NCHAN * world, "sharding": "channels, %d per GPU, no collective" % NCHAN,

@@ -153,6 +153,10 @@ static void launch_abl(const XcorrParams& p, hipStream_t s) {
 }
 static void launch_xcorr(const XcorrParams& p, hipStream_t s) {
     static const int abl = getenv("XENG_ABLATE") ? atoi(getenv("XENG_ABLATE")) : 0;   // timing experiments only
+    if (abl == 100) {   // occupancy experiment (timing only)
+        hipLaunchKernelGGL(xcorr_occ2_experiment_kernel, dim3(p.nchan * p.nwg), dim3(256), 0, s, p);
+        return;
+    }
     switch (abl) {
         case 1: launch_abl<1>(p, s); break;
         case 2: launch_abl<2>(p, s); break;
