@@ -67,6 +67,8 @@ def main():
                     help="diagnostic only: constant inputs show the DVFS give-back (the reported value uses random)")
     ap.add_argument("--sync-per-call", action="store_true",
                     help="time the drop-in synchronous xengXgpuKernel (the reference's call semantics)")
+    ap.add_argument("--rehearse-on-gpu0", action="store_true",
+                    help="testing only: every rank uses GPU 0 (to rehearse the N>1 code path on a 1-GPU box)")
     ap.add_argument("--sync-per-integration", action="store_true",
                     help="enqueue the gulps of one integration, then wait for its dump before the next")
     args = ap.parse_args()
@@ -83,7 +85,7 @@ def main():
     import caltech_bifrost_dsp_amd  # noqa: F401
     from caltech_bifrost_dsp_amd import ffi
 
-    gpu = local_rank
+    gpu = 0 if args.rehearse_on_gpu0 else local_rank
     ffi.call("xengSetDevice", gpu)
     info = ffi.device_info(gpu)
     gulps_per_step = ACC_LEN // NTIME_GULP
@@ -148,6 +150,19 @@ def main():
     ffi.call("xengDeviceSynchronize")
     el = time.perf_counter() - t0
     ffi.call("xengXgpuGetTimes", tm, cn)
+    # outside the timed region: the same kernels launched one integration at a time (no overlap between
+    # launches), to document the stand-alone duration of each kernel next to the streaming one
+    iso_tm = (ctypes.c_double * 2)()
+    iso_cn = (ctypes.c_int * 2)()
+    if not args.sync_per_call and not args.sync_per_integration:
+        ffi.call("xengXgpuSync")
+        ffi.call("xengXgpuGetTimes", iso_tm, iso_cn)    # clear
+        for _ in range(20):
+            for g in range(gulps_per_step):
+                ffi.check(kern, kfn(ring.ptr + (gi[0] % args.ring_gulps) * gulp_bytes, outs[0].ptr, int(g == gulps_per_step - 1)))
+                gi[0] += 1
+            ffi.call("xengXgpuSync")
+        ffi.call("xengXgpuGetTimes", iso_tm, iso_cn)
     ffi.call("xengXgpuSetProfiling", 0)
     if dist is not None:
         import torch
@@ -165,6 +180,14 @@ def main():
     ops_per_launch = OPS_PER_UNIT * units_per_step
     achieved = ops_per_launch / (mm_ms * 1e-3) / 1e12 if mm_ms > 0 else 0.0
     ct_bytes = 2 * gulp_bytes
+    # HBM traffic of the dominant kernel from the committed PMC passes (profiles/pmc_run.sh:
+    # FETCH_SIZE x2 for the gfx950 wide-load under-count + WRITE_SIZE, per launch); null if absent
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as fh:
+            traffic = json.load(fh).get("xcorr_mfma_kernel_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
     res = {
         "metric": "xengine_ingest_gbps_704in_96ch", "value": round(gbps, 2), "unit": "Gb/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -181,7 +204,8 @@ def main():
         "design_rate_x": round(gbps / world / 12.94, 1),
         "roofline": {"kernel": "xcorr_mfma_kernel", "bound": "mfma", "achieved": round(achieved, 1),
                      "peak": round(PEAK_INT8_OPS / 1e12, 1), "unit": "TFLOP/s",
-                     "frac": round(achieved / (PEAK_INT8_OPS / 1e12), 4), "traffic": None,
+                     "frac": round(achieved / (PEAK_INT8_OPS / 1e12), 4), "traffic": traffic,
+                     "algorithmic_bytes_per_launch": units_per_step * NINPUT + 2 * matlen * 4,
                      "note": "int8 TOP/s; algorithmic ops = 8*704*705/2 per (sample,chan) x %d units per launch; "
                              "avg launch %.1f us over %d launches (HIP events on the X-engine stream)"
                              % (units_per_step, mm_ms * 1e3, cn[1])},
@@ -190,6 +214,16 @@ def main():
                         "peak_GBs": HBM_PEAK_GBS, "bytes_per_launch": ct_bytes},
         "device": info,
     }
+    if iso_cn[1] > 0:
+        iso_mm = iso_tm[1] / iso_cn[1]
+        iso_ach = ops_per_launch / (iso_mm * 1e-3) / 1e12
+        res["roofline_isolated_launches"] = {
+            "kernel": "xcorr_mfma_kernel", "avg_us": round(iso_mm * 1e3, 1), "achieved": round(iso_ach, 1),
+            "frac": round(iso_ach / (PEAK_INT8_OPS / 1e12), 4), "launches": int(iso_cn[1]),
+            "corner_turn_avg_us": round(iso_tm[0] / max(iso_cn[0], 1) * 1e3, 2),
+            "note": "same kernels, one integration at a time (outside the timed region): in the timed streaming "
+                    "region consecutive MFMA launches overlap each other and the corner turns, which lengthens "
+                    "each launch but shortens the step"}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
