@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--ring-gulps", type=int, default=10, help="device-resident replay ring depth (gulps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-h2d", dest="h2d", action="store_false", help="skip the PCIe-inclusive measurement")
     ap.add_argument("--data", default="random", choices=["random", "zeros", "0x88"],
                     help="diagnostic only: constant inputs show the DVFS give-back (the reported value uses random)")
     ap.add_argument("--sync-per-call", action="store_true",
@@ -116,6 +117,7 @@ def main():
 
     gi = [0]
     si = [0]
+    units_per_step_c = ACC_LEN * NCHAN
 
     def step():
         out = outs[si[0] & 1]
@@ -164,6 +166,28 @@ def main():
             ffi.call("xengXgpuSync")
         ffi.call("xengXgpuGetTimes", iso_tm, iso_cn)
     ffi.call("xengXgpuSetProfiling", 0)
+    # outside the timed region: PCIe-inclusive regime (SURVEY 8d "two reporting regimes", ii): gulps start in
+    # pinned host memory, are copied H2D (xengMemcpy, the Copy block's copy_array) and then correlated
+    pcie = None
+    if args.h2d and rank == 0:
+        nh = 2 * gulps_per_step
+        hostbuf = ffi.DeviceBuffer(nh * gulp_bytes, ffi.SPACE_CUDA_HOST)
+        hostbuf.as_host_array(np.uint8)[:] = np.random.RandomState(1).randint(0, 255, size=nh * gulp_bytes, dtype=np.uint8)
+        ffi.call("xengXgpuSync")
+        t1 = time.perf_counter()
+        nint = 6
+        for it in range(nint):
+            for g in range(gulps_per_step):
+                slot = (it * gulps_per_step + g) % nh
+                ffi.call("xengMemcpy", ring.ptr + slot * gulp_bytes, hostbuf.ptr + slot * gulp_bytes, gulp_bytes)
+                ffi.check(kern, kfn(ring.ptr + slot * gulp_bytes, outs[it & 1].ptr, int(g == gulps_per_step - 1)))
+            ffi.call("xengXgpuSyncLag", 1)
+        ffi.call("xengXgpuSync")
+        el2 = time.perf_counter() - t1
+        pcie = {"value": round(8 * NINPUT * units_per_step_c * nint / el2 / 1e9, 1), "unit": "Gb/s",
+                "h2d_GBs": round(gulp_bytes * gulps_per_step * nint / el2 / 1e9, 1),
+                "note": "pinned host -> H2D -> X-engine, %d integrations; link-bound (PCIe Gen5 x16)" % nint}
+        hostbuf.free()
     if dist is not None:
         import torch
         t = torch.tensor([el], dtype=torch.float64)
@@ -214,6 +238,8 @@ def main():
                         "peak_GBs": HBM_PEAK_GBS, "bytes_per_launch": ct_bytes},
         "device": info,
     }
+    if pcie is not None:
+        res["pcie_inclusive"] = pcie
     if iso_cn[1] > 0:
         iso_mm = iso_tm[1] / iso_cn[1]
         iso_ach = ops_per_launch / (iso_mm * 1e-3) / 1e12

@@ -42,6 +42,9 @@ class HipBackend:
     def bfXgpuGetOrder(self, antpol_to_input, antpol_to_bl, is_conj):
         return self._lib.bfXgpuGetOrder(antpol_to_input, antpol_to_bl, is_conj)
 
+    def bfXgpuSubSelect(self, in_arr, out_arr, vismap, conj, nchan_sum, unused=0):
+        return self._lib.bfXgpuSubSelect(in_arr, out_arr, vismap, conj, int(nchan_sum), int(unused))
+
     def xgpu_reset(self):
         """Drop staged gulps / partial sums of an aborted integration (no reference counterpart)."""
         return self._lib.xengXgpuReset()

@@ -4,6 +4,8 @@ from .corr_block import Corr, regtile_index, tri_index
 from .corr_acc_block import CorrAcc
 from .beamform_block import Beamform
 from .beamform_sum_beams_block import BeamformSumBeams
+from .copy_block import Copy
+from .corr_subsel_block import CorrSubsel
 
-__all__ = ["Block", "Corr", "CorrAcc", "Beamform", "BeamformSumBeams", "regtile_index", "tri_index",
+__all__ = ["Block", "Corr", "CorrAcc", "Beamform", "BeamformSumBeams", "Copy", "CorrSubsel", "regtile_index", "tri_index",
            "COMMAND_OK", "COMMAND_NOT_RECOGNIZED", "COMMAND_WRONG_TYPE", "COMMAND_INVALID"]

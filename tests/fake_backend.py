@@ -74,6 +74,16 @@ class OracleBackend:
         _np(cj, np.int32, ocj.size)[...] = ocj.ravel()
         return 0
 
+    def bfXgpuSubSelect(self, in_arr, out_arr, vismap, conj, nchan_sum, unused=0):
+        c = self.cfg
+        matlen = orc.per_chan(c["nstand"]) * c["nchan"]
+        nvis = int(vismap.contents.shape[0])
+        planar = _np(in_arr, np.int32, 2 * matlen)
+        out = orc.xgpu_subselect(planar, _np(vismap, np.int32, nvis), _np(conj, np.int32, nvis),
+                                 c["nchan"], nchan_sum, c["nstand"])
+        _np(out_arr, np.int32, out.size)[...] = out.ravel()
+        return 0
+
     # CorrAcc
     def map_assign_i32(self, a, b):
         orc.map_i32(a.numpy().reshape(-1), b.numpy().reshape(-1), add=False)

@@ -278,3 +278,53 @@ def test_block_instance_ids_and_keys():
     assert (a0.instance_id, a1.instance_id, b0.instance_id) == (0, 1, 0)
     assert '/pipeline/3/A/1' in a1.command_key and a1.monitor_key.startswith('/mon/corr/x/')
     Block.set_id(0)
+
+
+# ----------------------------------------------------------------------------------------------
+def test_copy_block_passes_headers_and_data():
+    from caltech_bifrost_dsp_amd.blocks import Copy
+    r0, r1 = Ring("capture"), Ring("gpu-input")
+    cp = Copy(LOG, r0, r1, ntime_gulp=4, nbyte_per_time=10, buffer_multiplier=2)
+    assert cp.igulp_size == 40 and cp.buf_size == 4 * 40 * 2
+    data = np.arange(100, dtype=np.uint8)                   # 2.5 gulps: the half gulp is dropped
+    hdr = source_header(1, 5, 2, seq0=7)
+    sink = Sink(r1, 40)
+    run_blocks([cp], Source(r0, [(hdr, data, 20)]), [sink])
+    (ohdr, tag, spans), = sink.sequences
+    assert ohdr == hdr and len(spans) == 2
+    assert np.array_equal(np.concatenate(spans), data[:80])
+
+
+def test_corr_then_subsel_chain(golden_dir):
+    """Corr -> CorrSubsel on CPU rings: the sub-selected, channel-summed visibilities equal the golden
+    x[s0,p0]*conj(x[s1,p1]) (verification/test_corr_part_rx.py:49-85), including after a `baselines`
+    command, which starts a new output sequence (corr_subsel_block.py:316-329)."""
+    from caltech_bifrost_dsp_amd.blocks import CorrSubsel
+    z = np.load(os.path.join(golden_dir, "golden_64t_32a_8c_32s_2p_deadbeef.npz"))
+    vin, gre, gim = z["vin"], z["corr_re"], z["corr_im"]
+    T, C, S, P = vin.shape
+    nvis, nsum = 12, 4
+    r0, r1, r2 = Ring("gpu-input"), Ring("corr-output"), Ring("corr-fast-output")
+    be = OracleBackend()
+    hdr = source_header(C, S, P, seq0=0)
+    corr = Corr(LOG, r0, r1, ntime_gulp=16, nchan=C, npol=P, nstand=S, acc_len=32, autostartat=0,
+                ant_to_input=hdr['ant_to_input'], backend=be)
+    sub = CorrSubsel(LOG, r1, r2, nchan=C, npol=P, nstand=S, nchan_sum=nsum, backend=be, nvis_out=nvis,
+                     antpol_to_bl=corr.antpol_to_bl.numpy(), bl_is_conj=corr.bl_is_conj.numpy())
+    rng = np.random.default_rng(6)
+    sel = [[[int(a), int(b)], [int(c), int(d)]] for a, b, c, d in
+           zip(rng.integers(0, S, nvis), rng.integers(0, 2, nvis), rng.integers(0, S, nvis), rng.integers(0, 2, nvis))]
+    sub.process_command_strings(cmd(1, baselines=sel))
+    sink = Sink(r2, sub.ogulp_size)
+    run_blocks([corr, sub], Source(r0, [(hdr, vin, 16 * C * S * P)]), [sink])
+    (ohdr, tag, spans), = sink.sequences
+    assert ohdr['nchan'] == C // nsum and ohdr['nvis'] == nvis and ohdr['nchan_sum'] == nsum and ohdr['baselines'] == sel
+    assert len(spans) == 2
+    for k, sp in enumerate(spans):
+        got = sp.view(np.int32).reshape(C // nsum, nvis, 2)
+        for v, ((s0, p0), (s1, p1)) in enumerate(sel):
+            assert np.array_equal(got[:, v, 0], gre[k][:, s0, s1, p0, p1].reshape(C // nsum, nsum).sum(1))
+            assert np.array_equal(got[:, v, 1], gim[k][:, s0, s1, p0, p1].reshape(C // nsum, nsum).sum(1))
+    # wrong-length selection lists are rejected (condition len == nvis_out)
+    sub.process_command_strings(cmd(2, baselines=sel[:-1]))
+    assert sub.stats['last_cmd_response'] == COMMAND_INVALID

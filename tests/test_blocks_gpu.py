@@ -60,3 +60,34 @@ def test_beamform_sumbeams_on_device_rings():
         pexp = orc.beamform_integrate(got, ns)
         pgot = sp2[k].view(np.float32).reshape(pexp.shape)
         assert np.all(np.isclose(pgot, pexp, rtol=1e-5, atol=1e-5 * np.abs(pexp).max()))
+
+
+def test_ingest_copy_corr_subsel_chain():
+    """The ingest side and the fast-visibility side of Corr: pinned host ring
+    -> Copy (H2D) -> gpu-input (cuda) -> Corr -> corr-output (cuda) -> CorrSubsel -> cuda_host ring."""
+    from caltech_bifrost_dsp_amd.blocks import Copy, CorrSubsel
+    C, S, g, acc, nvis, nsum = 8, 48, 32, 64, 40, 4
+    rng = np.random.default_rng(21)
+    vin = rng.integers(0, 256, (2 * acc, C, S, 2), dtype=np.uint8)
+    r_host = Ring("capture", space="cuda_host")
+    r_in, r_vis, r_fast = Ring("gpu-input", space="cuda"), Ring("corr-output", space="cuda"), Ring("corr-fast-output", space="cuda_host")
+    hdr = source_header(C, S, 2, seq0=0)
+    cp = Copy(LOG, r_host, r_in, ntime_gulp=g, nbyte_per_time=C * S * 2, gpu=0)
+    corr = Corr(LOG, r_in, r_vis, ntime_gulp=g, nchan=C, npol=2, nstand=S, acc_len=acc, autostartat=0, gpu=0,
+                ant_to_input=hdr['ant_to_input'])
+    sub = CorrSubsel(LOG, r_vis, r_fast, nchan=C, npol=2, nstand=S, nchan_sum=nsum, gpu=0, nvis_out=nvis,
+                     antpol_to_bl=corr.antpol_to_bl.numpy(), bl_is_conj=corr.bl_is_conj.numpy())
+    sel = [[[int(a), int(b)], [int(c), int(d)]] for a, b, c, d in
+           zip(rng.integers(0, S, nvis), rng.integers(0, 2, nvis), rng.integers(0, S, nvis), rng.integers(0, 2, nvis))]
+    sub.process_command_strings('{"cmd": "update", "val": {"kwargs": {"baselines": %s}}, "id": "1"}' % str(sel).replace("'", '"'))
+    sink = Sink(r_fast, sub.ogulp_size)
+    run_blocks([cp, corr, sub], Source(r_host, [(hdr, vin, g * C * S * 2)]), [sink])
+    (ohdr, _, spans), = sink.sequences
+    assert len(spans) == 2 and ohdr['nvis'] == nvis
+    bl, cj = orc.xgpu_get_order(np.arange(S * 2, dtype=np.int32).reshape(S, 2))
+    vismap = np.array([bl[s0, s1, p0, p1] for (s0, p0), (s1, p1) in sel], np.int32)
+    conj = np.array([cj[s0, s1, p0, p1] for (s0, p0), (s1, p1) in sel], np.int32)
+    for k, sp in enumerate(spans):
+        planar = orc.xgpu_correlate(vin[k * acc:(k + 1) * acc], S, C)
+        exp = orc.xgpu_subselect(planar, vismap, conj, C, nsum, S)
+        assert np.array_equal(sp.view(np.int32).reshape(exp.shape), exp)
