@@ -60,7 +60,12 @@ class HipBackend:
     def bfBeamformInitialize(self, gpu, ninput, nchan, ntime, nbeam, ntime_blocks):
         return self._lib.bfBeamformInitialize(int(gpu), ninput, nchan, ntime, nbeam, ntime_blocks)
 
-    def bfBeamformRun(self, in_arr, out_arr, weights):
+    def bfBeamformRun(self, in_arr, out_arr, weights, version=0):
+        """`version` != 0 lets the library reuse its bf16-split copy of the weights while the caller has
+        not changed them (the reference call shape has no such argument: version 0 = always re-split)."""
+        if version:
+            return self._lib.xengBeamformRunVersioned(in_arr.contents.data, out_arr.contents.data,
+                                                      weights.contents.data, int(version))
         return self._lib.bfBeamformRun(in_arr, out_arr, weights)
 
     def bfBeamformIntegrate(self, in_arr, out_arr, ntime_sum):

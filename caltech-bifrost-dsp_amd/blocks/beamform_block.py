@@ -44,6 +44,7 @@ class Beamform(Block):
         self.gains_cpu = np.zeros((nchan, nbeam, ninput), dtype=np.complex64)
         self.gains_gpu = XArray(shape=(nchan, nbeam, ninput), dtype=np.complex64, space=self._bf.space_in)
         self.gains_load_sample = np.zeros(nbeam)
+        self._gains_version = 0       # bumped whenever gains_gpu is rewritten
         self.define_command_key('coeffs', type=dict, initial_val={})
         for b in range(self.nbeam):
             self.update_stats({'cal_gains%d' % b: [False, ] * ninput})
@@ -159,6 +160,7 @@ class Beamform(Block):
                             self.release_control_lock()
                         if copy_pending:
                             self.gains_gpu[...] = self.gains_cpu
+                            self._gains_version += 1
                             copy_pending = False
                         curr_time = time.time()
                         acquire_time = curr_time - prev_time
@@ -169,7 +171,8 @@ class Beamform(Block):
                             prev_time = curr_time
                             idata = ispan.data_view('i8')
                             odata = ospan.data_view(np.float32)
-                            rv = self._bf.bfBeamformRun(idata.as_BFarray(), odata.as_BFarray(), self.gains_gpu.as_BFarray())
+                            rv = self._bf.bfBeamformRun(idata.as_BFarray(), odata.as_BFarray(), self.gains_gpu.as_BFarray(),
+                                                        version=self._gains_version)
                             if rv != self._bf.BF_STATUS_SUCCESS:
                                 raise RuntimeError("bfBeamformRun returned %d: %s" % (rv, self._bf.last_error()))
                             self._bf.stream_synchronize()

@@ -2,6 +2,7 @@
 // Replaces _bf.bfBeamformInitialize / Run / Integrate / IntegrateSingleBeam
 // (beamform_block.py:251-253,449; beamform_sum_beams_block.py:245;
 //  beamform_sum_single_beam_block.py:114).
+#include <cstdlib>
 #include <mutex>
 
 #include "beamform_kernels.h"
@@ -13,6 +14,12 @@ struct BeamContext {
     bool live = false;
     int gpu = 0, ninput = 0, nchan = 0, ntime = 0, nbeam = 0, ntime_blocks = 0;
     float* scratch = nullptr;  // voltage beams for the ntime_blocks>0 ("integrated") mode
+    uint8_t* wprep = nullptr;  // bf16x3-split weights (beam_weights_prep_kernel)
+    size_t wprep_bytes = 0;
+    int nchunk = 0, nbtile = 0;
+    const void* w_cached = nullptr;   // weights the prepared copy was made from ...
+    long long w_version = 0;          // ... and their caller-supplied version (0 = never reuse)
+    bool use_f32 = false;             // XENG_BEAM_F32=1: the fp32-MFMA kernel
     hipStream_t stream = nullptr;
     EventTimer timer;
 };
@@ -24,17 +31,35 @@ static int beam_destroy_locked() {
     (void)hipSetDevice(g_b.gpu);
     if (g_b.stream) (void)hipStreamSynchronize(g_b.stream);
     if (g_b.scratch) (void)hipFree(g_b.scratch);
+    if (g_b.wprep) (void)hipFree(g_b.wprep);
     g_b.timer.destroy();
     g_b = BeamContext();
     return XENG_STATUS_SUCCESS;
 }
 
-static int run_locked(const void* in, float* out, const void* w) {
+static int run_locked(const void* in, float* out, const void* w, long long version) {
     BeamContext& x = g_b;
-    dim3 grid((x.ntime + BF_NT - 1) / BF_NT, x.nchan, (x.nbeam + 31) / 32);
+    if (x.use_f32) {
+        dim3 grid((x.ntime + BF_NT - 1) / BF_NT, x.nchan, (x.nbeam + 31) / 32);
+        int slot = x.timer.begin(x.stream, 0);
+        hipLaunchKernelGGL(beamform_f32_kernel, grid, dim3(256), 0, x.stream, (const uint8_t*)in, (const float*)w, out,
+                           x.ntime, x.nchan, x.ninput, x.nbeam);
+        x.timer.end(x.stream, slot);
+        XENG_HIP(hipGetLastError());
+        return XENG_STATUS_SUCCESS;
+    }
+    // split the fp32 weights into three bf16 terms unless this exact (pointer, version) is already prepared
+    if (!(version != 0 && version == x.w_version && w == x.w_cached)) {
+        hipLaunchKernelGGL(beam_weights_prep_kernel, dim3(x.nchunk, x.nbtile, x.nchan), dim3(256), 0, x.stream,
+                           (const float*)w, x.wprep, x.nchan, x.nbeam, x.ninput, x.nchunk, x.nbtile);
+        XENG_HIP(hipGetLastError());
+        x.w_cached = w;
+        x.w_version = version;
+    }
+    dim3 grid(((x.ntime + BF3_NT - 1) / BF3_NT) * x.nchan * x.nbtile);
     int slot = x.timer.begin(x.stream, 0);
-    hipLaunchKernelGGL(beamform_f32_kernel, grid, dim3(256), 0, x.stream, (const uint8_t*)in, (const float*)w, out,
-                       x.ntime, x.nchan, x.ninput, x.nbeam);
+    hipLaunchKernelGGL(beamform_bf16x3_kernel, grid, dim3(BF3_NT * 2), 0, x.stream, (const uint8_t*)in, x.wprep, out,
+                       x.ntime, x.nchan, x.ninput, x.nbeam, x.nchunk, x.nbtile);
     x.timer.end(x.stream, slot);
     XENG_HIP(hipGetLastError());
     return XENG_STATUS_SUCCESS;
@@ -72,6 +97,13 @@ int xengBeamformInitialize(int gpu, int ninput, int nchan, int ntime, int nbeam,
     XENG_HIP(hipSetDevice(x.gpu));
     x.ninput = ninput; x.nchan = nchan; x.ntime = ntime; x.nbeam = nbeam; x.ntime_blocks = ntime_blocks;
     if (ntime_blocks > 0) XENG_HIP(hipMalloc((void**)&x.scratch, (size_t)nchan * nbeam * ntime * 8));
+    x.nchunk = (ninput + BF_KC - 1) / BF_KC;
+    x.nbtile = (nbeam + 31) / 32;
+    x.wprep_bytes = (size_t)nchan * x.nbtile * x.nchunk * BF3_WCHUNK;
+    XENG_HIP(hipMalloc((void**)&x.wprep, x.wprep_bytes));
+    XENG_HIP(hipMemset(x.wprep, 0, x.wprep_bytes));
+    // the bf16x3 kernel moves the packed voltages by 16-byte LDS-DMA columns: inputs must be a multiple of 16
+    x.use_f32 = getenv("XENG_BEAM_F32") != nullptr || (ninput % 16) != 0;
     int rc = get_stream(STREAM_BEAM, &x.stream);
     if (rc) return rc;
     x.live = true;
@@ -84,6 +116,10 @@ int xengBeamformDestroy(void) {
 }
 
 int xengBeamformRun(const void* in_dev, void* out_dev, const void* weights_dev) {
+    return xengBeamformRunVersioned(in_dev, out_dev, weights_dev, 0);
+}
+
+int xengBeamformRunVersioned(const void* in_dev, void* out_dev, const void* weights_dev, long long weights_version) {
     std::lock_guard<std::mutex> lk(g_bmu);
     BeamContext& x = g_b;
     if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "Beamform: not initialized (call xengBeamformInitialize)");
@@ -91,8 +127,8 @@ int xengBeamformRun(const void* in_dev, void* out_dev, const void* weights_dev) 
     if (((uintptr_t)weights_dev & 15) || ((uintptr_t)out_dev & 15) || ((uintptr_t)in_dev & 3))
         XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Beamform: weights/out must be 16-byte, in 4-byte aligned");
     XENG_HIP(hipSetDevice(x.gpu));
-    if (x.ntime_blocks == 0) return run_locked(in_dev, (float*)out_dev, weights_dev);
-    int rc = run_locked(in_dev, x.scratch, weights_dev);
+    if (x.ntime_blocks == 0) return run_locked(in_dev, (float*)out_dev, weights_dev, weights_version);
+    int rc = run_locked(in_dev, x.scratch, weights_dev, weights_version);
     if (rc) return rc;
     return integrate_locked(x.scratch, out_dev, x.ntime / x.ntime_blocks, 0, x.nbeam / 2);
 }

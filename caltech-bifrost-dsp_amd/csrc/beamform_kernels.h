@@ -114,6 +114,175 @@ __global__ __launch_bounds__(256) void beamform_f32_kernel(const uint8_t* __rest
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// bf16x3 beamformer (default).  The voltages (-8..7) are exact in bf16; every fp32 weight is split
+// exactly into three bf16 terms  w = w1 + w2 + w3 + O(2^-25 |w|)  by beam_weights_prep_kernel, and
+//   out = sum_i (w1 + w2 + w3) * x
+// runs on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: products are exact (8-bit x 4-bit
+// significands), so the only roundings are the fp32 adds of the accumulator, as in the fp32 path.
+// 12 bf16 MFMAs per 16 inputs replace 32 fp32 MFMAs (v_mfma_f32_32x32x2_f32) at 1/2 the cycles each.
+//
+// Prepared weights: Wp[c][beam tile][chunk][term 3][re|im][32 beams][64 inputs] bf16, rows padded to
+// 144 B so the ds_read_b128 of the A operand is bank-conflict-free; zero for beams/inputs past the end.
+// ---------------------------------------------------------------------------------------
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+
+// LDS-DMA issued from inline asm: hipcc tracks the builtin form as a pending LDS write and puts
+// `s_waitcnt vmcnt(0)` in front of the next ds_read of the array, which serialises the prefetch of
+// chunk n+1 with the compute of chunk n.  From asm the transfer is invisible to that bookkeeping; the
+// kernel's own `s_waitcnt vmcnt(0)` + barrier orders it (cdna_hip_programming.md 5.7, M0 recipe).
+__device__ __forceinline__ void lds_dma16(const void* gsrc, uint32_t lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
+    return (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
+constexpr int BF3_ROW = 144;                         // 64 bf16 + 16 B pad
+constexpr int BF3_WCHUNK = 3 * 2 * 32 * BF3_ROW;      // 27648 B of weights per 64-input chunk
+constexpr int BF3_NT = 128;                           // samples per work-group: 4 waves x 32, one per SIMD
+constexpr int BF3_XCHUNK = BF3_NT * BF_KC;            // 12288 B of packed voltages per chunk
+constexpr int BF3_STAGE = BF3_WCHUNK + BF3_XCHUNK;
+
+__device__ __forceinline__ uint32_t f32_to_bf16_rne(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;   // weights are finite
+}
+
+// grid (nchunk, nbtile, nchan), 256 threads: thread = (beam tid/8, 8 inputs (tid%8)*8)
+__global__ __launch_bounds__(256) void beam_weights_prep_kernel(const float* __restrict__ w, uint8_t* __restrict__ wp,
+                                                                int nchan, int nbeam, int ninput, int nchunk, int nbtile) {
+    const int ch = blockIdx.x, bt = blockIdx.y, c = blockIdx.z;
+    const int beam = threadIdx.x >> 3, k0 = (threadIdx.x & 7) * 8;
+    const int b = bt * 32 + beam;
+    uint32_t t[3][2][4];   // [term][re|im][4 dwords = 8 bf16]
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int i = ch * BF_KC + k0 + j;
+        float re = 0.f, im = 0.f;
+        if (b < nbeam && i < ninput) {
+            const float2 v = *reinterpret_cast<const float2*>(w + (((size_t)c * nbeam + b) * ninput + i) * 2);
+            re = v.x; im = v.y;
+        }
+        float r[2] = {re, im};
+#pragma unroll
+        for (int comp = 0; comp < 2; comp++) {
+            float rem = r[comp];
+#pragma unroll
+            for (int term = 0; term < 3; term++) {
+                const uint32_t hb = f32_to_bf16_rne(rem);
+                rem -= __uint_as_float(hb << 16);          // exact: the bf16 term cancels the leading bits
+                if (j & 1) t[term][comp][j >> 1] |= hb << 16; else t[term][comp][j >> 1] = hb;
+            }
+        }
+    }
+    uint8_t* base = wp + (((size_t)c * nbtile + bt) * nchunk + ch) * BF3_WCHUNK;
+#pragma unroll
+    for (int term = 0; term < 3; term++)
+#pragma unroll
+        for (int comp = 0; comp < 2; comp++)
+            *reinterpret_cast<uint4*>(base + ((term * 2 + comp) * 32 + beam) * BF3_ROW + k0 * 2) =
+                make_uint4(t[term][comp][0], t[term][comp][1], t[term][comp][2], t[term][comp][3]);
+    // the 16-byte pad of each row is never read
+}
+
+__device__ __forceinline__ v8bf as_v8bf(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    const v4u v = {a, b, c, d};
+    return __builtin_bit_cast(v8bf, v);
+}
+
+// grid nchan * nbtile * ceil(ntime/128) (1-D), 256 threads; wave w owns samples t0 + 32w .. +31.
+// One LDS stage (36 KB) per work-group: four work-groups per CU interleave, so one group's LDS-DMA
+// latency and barriers hide under the MFMAs of the other three (4 waves per SIMD, all SIMDs equal).
+__global__ __launch_bounds__(256, 4) void beamform_bf16x3_kernel(const uint8_t* __restrict__ in,
+                                                                 const uint8_t* __restrict__ wp,
+                                                                 float* __restrict__ out, int ntime, int nchan,
+                                                                 int ninput, int nbeam, int nchunk, int nbtile) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[BF3_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // 1-D grid of nchan*nbtile*nttile blocks.  Blocks b and b+8 share an XCD: give each XCD whole channels
+    // so the work-groups of a channel read its 304 KB of split weights through one L2 (speed only).
+    const int nttile = (ntime + BF3_NT - 1) / BF3_NT, per_c = nbtile * nttile;
+    int c, rem;
+    if ((nchan & 7) == 0) { const int b = blockIdx.x, slot = b >> 3; c = (b & 7) + 8 * (slot / per_c); rem = slot % per_c; }
+    else { c = blockIdx.x / per_c; rem = blockIdx.x % per_c; }
+    const int bt = rem / nttile, t0 = (rem % nttile) * BF3_NT;
+    const int h = lane >> 5, j = lane & 31;
+    const uint8_t* wsrc = wp + (((size_t)c * nbtile + bt) * nchunk) * BF3_WCHUNK + lane * 16;
+    // X piece n (1 KiB) of a chunk = samples 16n..16n+15, 64 B each; this lane: row 16n + lane/4, bytes (lane%4)*16
+    const size_t row_stride = (size_t)nchan * ninput;
+    constexpr int NWP = BF3_WCHUNK / 1024;            // 27 weight pieces per chunk
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
+    auto issue = [&](int ch, int buf) {
+        const uint32_t l = lds0 + buf * BF3_STAGE;
+        for (int n = wave; n < NWP; n += BF3_NT / 32)
+            lds_dma16(wsrc + (size_t)ch * BF3_WCHUNK + n * 1024, l + n * 1024);
+        for (int n = wave; n < BF3_NT / 16; n += BF3_NT / 32) {
+            int t = t0 + n * 16 + (lane >> 2);
+            int i = ch * BF_KC + (lane & 3) * 16;
+            if (t >= ntime) t = ntime - 1;             // rows past the end: any valid row (never stored)
+            if (i + 16 > ninput) i = 0;                // columns past the end meet zero weights
+            const uint8_t* g = in + (size_t)t * row_stride + (size_t)c * ninput + i;
+            lds_dma16(g, l + BF3_WCHUNK + n * 1024);
+        }
+    };
+    v16f acc_r = (v16f)(0.f), acc_i = (v16f)(0.f);
+    for (int ch = 0; ch < nchunk; ch++) {
+        const int buf = 0;
+        if (ch > 0) __builtin_amdgcn_s_barrier();      // everybody is done reading chunk ch-1
+        issue(ch, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                  // chunk ch landed for all waves
+        const uint8_t* lw = lds + buf * BF3_STAGE + j * BF3_ROW + h * 16;
+        const uint8_t* lx = lds + buf * BF3_STAGE + BF3_WCHUNK + (wave * 32 + j) * BF_KC + h * 8;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {                  // 16 inputs per step: this lane-half takes 8 of them
+            const uint2 xb = *reinterpret_cast<const uint2*>(lx + s * 16);
+            uint32_t xr[4], xi[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {              // bytes 2q, 2q+1 -> one dword of two bf16
+                const uint32_t wd = q < 2 ? xb.x : xb.y;
+                const int sh = 16 * (q & 1);
+                // hi nibble = real, lo nibble = imag, two's complement (beamformer_test.py:69-73);
+                // small integers convert exactly; bf16 = upper half of the fp32
+                const float r0 = (float)(int)__builtin_amdgcn_sbfe((int)wd, sh + 4, 4);
+                const float r1 = (float)(int)__builtin_amdgcn_sbfe((int)wd, sh + 12, 4);
+                const float i0 = (float)(int)__builtin_amdgcn_sbfe((int)wd, sh, 4);
+                const float i1 = (float)(int)__builtin_amdgcn_sbfe((int)wd, sh + 8, 4);
+                xr[q] = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+                xi[q] = __builtin_amdgcn_perm(__float_as_uint(i1), __float_as_uint(i0), 0x07060302u);
+            }
+            const v8bf Xr = as_v8bf(xr[0], xr[1], xr[2], xr[3]);
+            const v8bf Xi = as_v8bf(xi[0], xi[1], xi[2], xi[3]);
+            const v8bf nXi = as_v8bf(xi[0] ^ 0x80008000u, xi[1] ^ 0x80008000u, xi[2] ^ 0x80008000u, xi[3] ^ 0x80008000u);
+#pragma unroll
+            for (int term = 2; term >= 0; term--) {    // smallest term first
+                const uint4 a = *reinterpret_cast<const uint4*>(lw + ((term * 2 + 0) * 32) * BF3_ROW + s * 32);
+                const uint4 b = *reinterpret_cast<const uint4*>(lw + ((term * 2 + 1) * 32) * BF3_ROW + s * 32);
+                const v8bf Wr = as_v8bf(a.x, a.y, a.z, a.w), Wi = as_v8bf(b.x, b.y, b.z, b.w);
+                acc_r = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr, Xr, acc_r, 0, 0, 0);
+                acc_i = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr, Xi, acc_i, 0, 0, 0);
+                acc_r = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wi, nXi, acc_r, 0, 0, 0);
+                acc_i = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wi, Xr, acc_i, 0, 0, 0);
+            }
+        }
+    }
+    // C/D map: col (sample) = lane&31, row (beam) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const int t = t0 + wave * 32 + j;
+    if (t < ntime) {
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            const int b = bt * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+            if (b < nbeam)
+                *reinterpret_cast<float2*>(out + (((size_t)c * nbeam + b) * ntime + t) * 2) =
+                    make_float2(acc_r[g], acc_i[g]);
+        }
+    }
+}
+
 // beam power sums (beamformer_sum_test.py:64-77, cublas_beamform.cu:46-79).
 // in cf32[nchan][nbeam][ntime] -> out f32[npair][ntime/ntime_sum][nchan][4]; one wave per
 // (channel, beam pair): lanes stride the time blocks, 8-lane groups sweep one block's samples

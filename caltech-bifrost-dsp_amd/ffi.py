@@ -48,7 +48,7 @@ SYMBOLS = {
     "xengXgpuSetProfiling": [_i], "xengXgpuGetTimes": [ctypes.POINTER(ctypes.c_double), _pi],
     "xengMapAssignI32": [_vp, _vp, _sz], "xengMapAddI32": [_vp, _vp, _sz],
     "xengBeamformInitialize": [_i, _i, _i, _i, _i, _i], "xengBeamformDestroy": [],
-    "xengBeamformRun": [_vp, _vp, _vp], "xengBeamformIntegrate": [_vp, _vp, _i],
+    "xengBeamformRun": [_vp, _vp, _vp], "xengBeamformRunVersioned": [_vp, _vp, _vp, ctypes.c_longlong], "xengBeamformIntegrate": [_vp, _vp, _i],
     "xengBeamformIntegrateSingleBeam": [_vp, _vp, _i, _i], "xengBeamformSync": [],
     "xengBeamformSetProfiling": [_i], "xengBeamformGetTimes": [ctypes.POINTER(ctypes.c_double), _pi],
     "bfXgpuInitialize": [_pa, _pa, _i], "bfXgpuKernel": [_pa, _pa, _i], "bfXgpuCorrelate": [_pa, _pa, _i],

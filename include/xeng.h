@@ -161,6 +161,10 @@ int xengBeamformDestroy(void);
  * out[c,b,t] = sum_i w[c,b,i]*x[t,c,i] (beamformer_test.py:76-84).  Asynchronous on the beamformer
  * stream; xengBeamformSync()/xengStreamSynchronize() is the BFSync() of beamform_block.py:450. */
 int xengBeamformRun(const void *in_dev, void *out_dev, const void *weights_dev);
+/* Same, for callers that know when the weights change: the library re-splits the fp32 weights into the
+ * bf16 terms its MFMA kernel uses only when (weights_dev, weights_version) differs from the last call
+ * (version 0 = always re-split, which is what xengBeamformRun / bfBeamformRun do). */
+int xengBeamformRunVersioned(const void *in_dev, void *out_dev, const void *weights_dev, long long weights_version);
 
 /* beamform_sum_beams_block.py:243-246.  in_dev cf32[nchan][nbeam][ntime];
  * out_dev f32[nbeam/2][ntime/ntime_sum][nchan][4] = [XX, YY, Re XY*, Im XY*]. */

@@ -99,7 +99,7 @@ class OracleBackend:
         OracleBackend.shared_beam = self.beam       # process-global context, as in the reference
         return 0
 
-    def bfBeamformRun(self, in_arr, out_arr, weights):
+    def bfBeamformRun(self, in_arr, out_arr, weights, version=0):
         b = self.beam
         vin = _np(in_arr, np.uint8, b["ntime"] * b["nchan"] * b["ninput"])
         w = _np(weights, np.complex64, b["nchan"] * b["nbeam"] * b["ninput"])
