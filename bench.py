@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--ring-gulps", type=int, default=10, help="device-resident replay ring depth (gulps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d", dest="h2d", action="store_false", help="skip the PCIe-inclusive measurement")
+    ap.add_argument("--no-beamform", dest="beamform", action="store_false", help="skip the config-4 beamformer leg")
     ap.add_argument("--data", default="random", choices=["random", "zeros", "0x88"],
                     help="diagnostic only: constant inputs show the DVFS give-back (the reported value uses random)")
     ap.add_argument("--sync-per-call", action="store_true",
@@ -188,6 +189,50 @@ def main():
                 "h2d_GBs": round(gulp_bytes * gulps_per_step * nint / el2 / 1e9, 1),
                 "note": "pinned host -> H2D -> X-engine, %d integrations; link-bound (PCIe Gen5 x16)" % nint}
         hostbuf.free()
+    # outside the timed region: BASELINE config 4 -- Beamform (32 beams, 96 chan, 960 samples, fp32 weights)
+    # + BeamformSumBeams (16 dual-pol power beams, ntime_sum 24) on the same GPU
+    beam = None
+    if args.beamform and rank == 0:
+        ffi.call("xengXgpuSync")
+        NT_B, NB, NS = 960, 32, 24
+        ffi.call("xengBeamformInitialize", gpu, NINPUT, NCHAN, NT_B, NB, 0)
+        rng = np.random.default_rng(0xaabbccdd)
+        wts = (rng.uniform(-17, 17, NCHAN * NB * NINPUT) + 1j * rng.uniform(-17, 17, NCHAN * NB * NINPUT)).astype(np.complex64)
+        dw = ffi.DeviceBuffer(wts.nbytes).upload(wts)
+        dbeam = ffi.DeviceBuffer(NCHAN * NB * NT_B * 8)
+        dpow = ffi.DeviceBuffer((NB // 2) * (NT_B // NS) * NCHAN * 16)
+        btm = (ctypes.c_double * 2)()
+        bcn = (ctypes.c_int * 2)()
+
+        def bstep(i):
+            # two consecutive 480-sample ring gulps form one 960-sample beamformer gulp (GPU_NGULP = 2)
+            src = ring.ptr + ((2 * i) % (args.ring_gulps - 1)) * gulp_bytes
+            ffi.check("run", L.xengBeamformRunVersioned(src, dbeam.ptr, dw.ptr, 1))
+            ffi.check("int", L.xengBeamformIntegrate(dbeam.ptr, dpow.ptr, NS))
+        for i in range(5):
+            bstep(i)
+        ffi.call("xengBeamformSync")
+        ffi.call("xengBeamformSetProfiling", 1)
+        ffi.call("xengBeamformGetTimes", btm, bcn)
+        tb = time.perf_counter()
+        nb_it = 40
+        for i in range(nb_it):
+            bstep(i)
+        ffi.call("xengBeamformSync")
+        elb = time.perf_counter() - tb
+        ffi.call("xengBeamformGetTimes", btm, bcn)
+        run_us = btm[0] / max(bcn[0], 1) * 1e3
+        flop = NT_B * NCHAN * NB * NINPUT * 8
+        beam = {"workload": "704 inputs, 96 chan, 32 beams, 960 samples/gulp, then 16 dual-pol power beams (ntime_sum 24)",
+                "ingest_gbps": round(8 * NT_B * NCHAN * NINPUT / (elb / nb_it) / 1e9, 1),
+                "run_us": round(run_us, 1), "integrate_us": round(btm[1] / max(bcn[1], 1) * 1e3, 1),
+                "algorithmic_tflops": round(flop / run_us / 1e6, 1),
+                "roofline": {"kernel": "beamform_bf16x3_kernel", "bound": "mfma", "unit": "TFLOP/s",
+                             "achieved": round(3 * flop / run_us / 1e6, 1), "peak": 2500.0,
+                             "frac": round(3 * flop / run_us / 1e6 / 2500.0, 4),
+                             "note": "bf16 MFMA flops issued = 3 x 8 x nbeam x ninput per (sample, chan) (three bf16 terms "
+                                     "per fp32 weight); algorithmic fp32 flops are 1/3 of that"}}
+        ffi.call("xengBeamformDestroy")
     if dist is not None:
         import torch
         t = torch.tensor([el], dtype=torch.float64)
@@ -240,6 +285,8 @@ def main():
     }
     if pcie is not None:
         res["pcie_inclusive"] = pcie
+    if beam is not None:
+        res["beamform"] = beam
     if iso_cn[1] > 0:
         iso_mm = iso_tm[1] / iso_cn[1]
         iso_ach = ops_per_launch / (iso_mm * 1e-3) / 1e12
