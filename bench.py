@@ -232,6 +232,41 @@ def main():
                              "frac": round(3 * flop / run_us / 1e6 / 2500.0, 4),
                              "note": "bf16 MFMA flops issued = 3 x 8 x nbeam x ninput per (sample, chan) (three bf16 terms "
                                      "per fp32 weight); algorithmic fp32 flops are 1/3 of that"}}
+        # ---- BASELINE config 5 (one GPU's share): Corr + CorrAcc + Beamform + SumBeams concurrently, each on
+        # its own HIP stream, all fed from the same device-resident gulps
+        ffi.call("xengXgpuSync")
+        acc_long = ffi.DeviceBuffer(2 * matlen * 4)
+        outs3 = outs + [ffi.DeviceBuffer(2 * matlen * 4)]
+        ffi.call("xengBeamformSetProfiling", 0)
+        nfull = 60
+        bi = [0]
+
+        def full_step(n):
+            o = outs3[n % 3]
+            for g in range(gulps_per_step):
+                ffi.check(kern, kfn(ring.ptr + (gi[0] % args.ring_gulps) * gulp_bytes, o.ptr, int(g == gulps_per_step - 1)))
+                gi[0] += 1
+            for _ in range(2 + (n & 1)):            # 2.5 beamformer gulps of 960 samples per 2400-sample integration
+                bstep(bi[0])
+                bi[0] += 1
+            ffi.call("xengXgpuSyncLag", 1)          # dump n-1 is complete: add it to the long accumulation
+            if n >= 1:
+                ffi.call("xengMapSync")             # the previous add has released its source span
+                fn = L.xengMapAssignI32 if n == 1 else L.xengMapAddI32
+                ffi.check("map", fn(acc_long.ptr, outs3[(n - 1) % 3].ptr, 2 * matlen))
+        for n in range(6):
+            full_step(n)
+        ffi.call("xengDeviceSynchronize")
+        tf = time.perf_counter()
+        for n in range(6, 6 + nfull):
+            full_step(n)
+        ffi.call("xengDeviceSynchronize")
+        elf = time.perf_counter() - tf
+        beam["full_xengine_concurrent"] = {
+            "ingest_gbps": round(8 * NINPUT * units_per_step_c * nfull / elf / 1e9, 1),
+            "ms_per_integration": round(elf / nfull * 1e3, 4),
+            "note": "config 5 on one GPU: per 2400-sample integration 5 corner turns + 1 MFMA contraction (X-engine streams), "
+                    "2.5 beamformer gulps + power sums (beam stream), 1 CorrAcc int32 map over 191 MB (map stream)"}
         ffi.call("xengBeamformDestroy")
     if dist is not None:
         import torch

@@ -51,4 +51,11 @@ static int map_i32(void* a, const void* b, size_t nwords, bool add) {
 extern "C" {
 int xengMapAssignI32(void* a_dev, const void* b_dev, size_t nwords) { return xeng::map_i32(a_dev, b_dev, nwords, false); }
 int xengMapAddI32(void* a_dev, const void* b_dev, size_t nwords) { return xeng::map_i32(a_dev, b_dev, nwords, true); }
+int xengMapSync(void) {
+    hipStream_t s;
+    int rc = xeng::get_stream(xeng::STREAM_MAP, &s);
+    if (rc) return rc;
+    XENG_HIP(hipStreamSynchronize(s));
+    return XENG_STATUS_SUCCESS;
+}
 }

@@ -46,7 +46,7 @@ SYMBOLS = {
     "xengXgpuSubSelect": [_vp, _vp, _vp, _vp, _i, _i], "xengXgpuReorder": [_vp, _vp, _vp, _vp],
     "xengXgpuGetInfo": [_pi, _pi, _pi, _pi, ctypes.POINTER(ctypes.c_int64), _pi],
     "xengXgpuSetProfiling": [_i], "xengXgpuGetTimes": [ctypes.POINTER(ctypes.c_double), _pi],
-    "xengMapAssignI32": [_vp, _vp, _sz], "xengMapAddI32": [_vp, _vp, _sz],
+    "xengMapAssignI32": [_vp, _vp, _sz], "xengMapAddI32": [_vp, _vp, _sz], "xengMapSync": [],
     "xengBeamformInitialize": [_i, _i, _i, _i, _i, _i], "xengBeamformDestroy": [],
     "xengBeamformRun": [_vp, _vp, _vp], "xengBeamformRunVersioned": [_vp, _vp, _vp, ctypes.c_longlong], "xengBeamformIntegrate": [_vp, _vp, _i],
     "xengBeamformIntegrateSingleBeam": [_vp, _vp, _i, _i], "xengBeamformSync": [],

@@ -147,6 +147,7 @@ int xengXgpuGetTimes(double ms[2], int count[2]);
  * enqueued on the library's map stream; xengStreamSynchronize() (corr_acc_block.py:317) completes it. */
 int xengMapAssignI32(void *a_dev, const void *b_dev, size_t nwords);
 int xengMapAddI32(void *a_dev, const void *b_dev, size_t nwords);
+int xengMapSync(void);   /* wait for the map stream only */
 
 /* ---------------------------------------------------------------- Beamformer
  * replaces _bf.bfBeamformInitialize / Run / Integrate / IntegrateSingleBeam. */
