@@ -152,21 +152,21 @@ static void launch_abl(const XcorrParams& p, hipStream_t s) {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_mfma_kernel<ABL>), dim3(p.nchan * p.nwg), dim3(256), 0, s, p);
 }
 static void launch_xcorr(const XcorrParams& p, hipStream_t s) {
-    static const int abl = getenv("XENG_ABLATE") ? atoi(getenv("XENG_ABLATE")) : 0;   // timing experiments only
-    if (abl == 100) {   // occupancy experiment (timing only)
-        hipLaunchKernelGGL(xcorr_occ2_experiment_kernel, dim3(p.nchan * p.nwg), dim3(256), 0, s, p);
-        return;
-    }
+#ifdef XENG_DIAGNOSTICS
+    // timing-only ablations of the K loop (results are wrong): build with -DXENG_DIAGNOSTICS, select with
+    // XENG_ABLATE = 1 (no LDS-DMA) | 2 (no unpack) | 4 (no LDS reads) | 8 (no barrier); see profiles/r01/README.md
+    static const int abl = getenv("XENG_ABLATE") ? atoi(getenv("XENG_ABLATE")) : 0;
     switch (abl) {
-        case 1: launch_abl<1>(p, s); break;
-        case 2: launch_abl<2>(p, s); break;
-        case 4: launch_abl<4>(p, s); break;
-        case 8: launch_abl<8>(p, s); break;
-        case 9: launch_abl<9>(p, s); break;
-        case 15: launch_abl<15>(p, s); break;
-        case 16: launch_abl<16>(p, s); break;
-        default: launch_abl<0>(p, s); break;
+        case 1: launch_abl<1>(p, s); return;
+        case 2: launch_abl<2>(p, s); return;
+        case 4: launch_abl<4>(p, s); return;
+        case 8: launch_abl<8>(p, s); return;
+        case 9: launch_abl<9>(p, s); return;
+        case 15: launch_abl<15>(p, s); return;
+        default: break;
     }
+#endif
+    launch_abl<0>(p, s);
 }
 
 // contracts the staged gulps into `out`; caller holds g_mu

@@ -310,17 +310,14 @@ __global__ __launch_bounds__(256, 1) void xcorr_mfma_kernel(XcorrParams p) {
     };
 
     // Diagonal wave tiles (row block == column block) never store the upper-right 32x32 MFMA tile
-    // (rows 0-31 x columns 32-63: Rh < Ch): skip its 4 MFMAs.  Idle waves skip all of them.  Both
-    // conditions are wave-uniform; the chip is power-limited, so unspent MFMAs come back as clock.
+    // (rows 0-31 x columns 32-63: Rh < Ch): skip its 4 MFMAs (wave-uniform branch; idle waves too).
     const bool skip01 = __builtin_amdgcn_readfirstlane((int)(!active || blk_a == blk_b)) != 0;
-    const bool skipall = __builtin_amdgcn_readfirstlane((int)!active) != 0;
     auto mfma_tile = [&](const Frags& u) {
 #pragma unroll
         for (int m = 0; m < 2; m++)
 #pragma unroll
             for (int n = 0; n < 2; n++) {
-                if (m == 0 && n == 1) { if (skip01) continue; }
-                else if (ABL & 16) { if (skipall) continue; }
+                if (m == 0 && n == 1 && skip01) continue;
                 accR[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(u.ar[m], u.br[n], accR[m][n], 0, 0, 0);
                 accP[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(u.ai[m], u.br[n], accP[m][n], 0, 0, 0);
                 accQ[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(u.ar[m], u.bi[n], accQ[m][n], 0, 0, 0);
@@ -449,113 +446,6 @@ __global__ __launch_bounds__(256, 1) void xcorr_mfma_kernel(XcorrParams p) {
             }
         }
     if (p.stamps && lane == 0) p.stamps[((size_t)blockIdx.x * 4 + wave) * 8 + 5] = __builtin_amdgcn_s_memrealtime();
-}
-
-// ---------------------------------------------------------------------------------------
-// EXPERIMENT (timing only, results wrong): two accumulators per tile so that two work-groups fit
-// per CU (<= 256 registers per wave, 72 KB LDS).  Measures what 2 waves/SIMD would buy.
-// ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void xcorr_occ2_experiment_kernel(XcorrParams p) {
-    constexpr int KT_STAGE = XC_KT;
-    constexpr int SLOT_BYTES = KT_STAGE * KT_BYTES;
-    constexpr int STAGE_BYTES = XC_NSLOT * SLOT_BYTES;
-    constexpr int NLOAD = 2 * KT_STAGE;
-    constexpr int RING = 3;
-    __shared__ __attribute__((aligned(16))) uint8_t lds[RING * STAGE_BYTES];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int c, wg;
-    {
-        const int b = blockIdx.x;
-        if ((p.nchan & 7) == 0) { const int xcd = b & 7, slot = b >> 3; c = xcd + 8 * (slot / p.nwg); wg = slot % p.nwg; }
-        else { c = b / p.nwg; wg = b % p.nwg; }
-    }
-    const WgDesc* dp = p.descs + wg;
-    const int a_slot = dp->wave_a[wave], b_slot = dp->wave_b[wave];
-    const bool active = a_slot != 0xFF;
-    const int blk_a = active ? dp->slot_blk[a_slot] : 0, blk_b = active ? dp->slot_blk[b_slot] : 0;
-    const uint8_t* gsrc = p.stash + ((size_t)c * p.nblk64 + dp->slot_blk[wave]) * (size_t)p.cap_kt * KT_BYTES + lane * 16;
-    const int nstage = p.nkt / KT_STAGE;
-    auto issue = [&](int s, int buf) {
-        const uint8_t* g = gsrc + (size_t)(s < nstage ? s : nstage - 1) * SLOT_BYTES;
-        uint8_t* l = lds + buf * STAGE_BYTES + wave * SLOT_BYTES;
-#pragma unroll
-        for (int n = 0; n < NLOAD; n++)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + n * FRAG_BYTES),
-                                             (__attribute__((address_space(3))) void*)(l + n * FRAG_BYTES), 16, 0, 0);
-    };
-    v16i accR[2][2], accI[2][2];
-#pragma unroll
-    for (int m = 0; m < 2; m++)
-#pragma unroll
-        for (int n = 0; n < 2; n++) { accR[m][n] = (v16i)(0); accI[m][n] = (v16i)(0); }
-    const int a_off = (active ? a_slot : 0) * SLOT_BYTES + lane * 16;
-    const int b_off = (active ? b_slot : 0) * SLOT_BYTES + lane * 16;
-    issue(0, 0);
-    issue(1, 1);
-    int buf = 0;
-    for (int s = 0; s < nstage; s++) {
-        wait_vmcnt<NLOAD>();
-        __builtin_amdgcn_s_barrier();
-        issue(s + 2, buf >= 1 ? buf - 1 : RING - 1);
-        const uint8_t* base = lds + buf * STAGE_BYTES;
-#pragma unroll
-        for (int k = 0; k < KT_STAGE; k++) {
-            RawFrags r;
-            r.a[0] = *reinterpret_cast<const v4i*>(base + a_off + k * KT_BYTES);
-            r.a[1] = *reinterpret_cast<const v4i*>(base + a_off + k * KT_BYTES + FRAG_BYTES);
-            r.b[0] = *reinterpret_cast<const v4i*>(base + b_off + k * KT_BYTES);
-            r.b[1] = *reinterpret_cast<const v4i*>(base + b_off + k * KT_BYTES + FRAG_BYTES);
-            const v4i M = (v4i)(0xF0F0F0F0), K8 = (v4i)(0x08080808);
-            v4i ar[2], ai[2], an[2], br[2], bi[2];
-#pragma unroll
-            for (int m = 0; m < 2; m++) {   // same op count as the odd-integer encoding would need
-                ar[m] = (r.a[m] & M) | K8; ai[m] = ((r.a[m] << 4) & M) | K8; an[m] = ar[m] ^ M;
-                br[m] = (r.b[m] & M) | K8; bi[m] = ((r.b[m] << 4) & M) | K8;
-            }
-#pragma unroll
-            for (int m = 0; m < 2; m++)
-#pragma unroll
-                for (int n = 0; n < 2; n++) {
-                    accR[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ar[m], br[n], accR[m][n], 0, 0, 0);
-                    accI[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ai[m], br[n], accI[m][n], 0, 0, 0);
-                    accR[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ai[m], bi[n], accR[m][n], 0, 0, 0);
-                    accI[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(an[m], bi[n], accI[m][n], 0, 0, 0);
-                }
-        }
-        buf = (buf + 1 == RING) ? 0 : buf + 1;
-    }
-    wait_vmcnt<0>();
-    if (!active) return;
-    // same store pattern / byte count as the real epilogue (values meaningless)
-    const int qs = (int)(((int64_t)(p.nstand / 2 + 1) * p.nstand) / 4);
-    int32_t* out_r = p.out + (int64_t)c * p.per_chan;
-    int32_t* out_i = out_r + p.matlen;
-    const int odd = lane & 1, cpar = (lane >> 1) & 1, quad = 2 * cpar + odd;
-#pragma unroll
-    for (int m = 0; m < 2; m++)
-#pragma unroll
-        for (int n = 0; n < 2; n++) {
-            const int ibase = blk_a * 64 + m * 32, jbase = blk_b * 64 + n * 32;
-            const int Ch = (jbase >> 2) + ((lane & 31) >> 2), C = 2 * Ch + cpar;
-            const int wcol = (quad * qs + Ch) * 4;
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int Rh = (ibase >> 2) + 2 * u + (lane >> 5), R = 2 * Rh + odd;
-                int vr[4], vi[4];
-#pragma unroll
-                for (int v = 0; v < 4; v++) { vr[v] = accR[m][n][4 * u + v] >> 8; vi[v] = accI[m][n][4 * u + v] >> 8; }
-                const int g0 = dpp_xor1(odd ? vr[0] : vr[2]), g1 = dpp_xor1(odd ? vr[1] : vr[3]);
-                const int h0 = dpp_xor1(odd ? vi[0] : vi[2]), h1 = dpp_xor1(odd ? vi[1] : vi[3]);
-                const int4 cr = odd ? make_int4(g0, vr[2], g1, vr[3]) : make_int4(vr[0], g0, vr[1], g1);
-                const int4 ci = odd ? make_int4(h0, vi[2], h1, vi[3]) : make_int4(vi[0], h0, vi[1], h1);
-                const int w = wcol + ((Rh * (Rh + 1)) >> 1) * 4;
-                if (Rh >= Ch && R < p.nstand && C < p.nstand) {
-                    *reinterpret_cast<int4*>(out_r + w) = cr;
-                    *reinterpret_cast<int4*>(out_i + w) = ci;
-                }
-            }
-        }
 }
 
 // ---------------------------------------------------------------------------------------

@@ -153,3 +153,30 @@ def test_integrated_mode(gpu):
     exp = orc.beamform_integrate(orc.beamform(vin, w, ntime, nchan, ninput, nbeam), ntime // nblk)
     assert np.all(np.isclose(got, exp, rtol=1e-5, atol=1e-5 * np.abs(exp).max()))
     gpu.ffi.call("xengBeamformDestroy")
+
+
+def test_versioned_weights_are_resplit_only_on_change(gpu):
+    """xengBeamformRunVersioned: same (pointer, version) reuses the bf16-split weights; a new version
+    (or version 0) re-splits, so results always follow the current weights."""
+    ntime, nchan, ninput, nbeam = 128, 2, 64, 32
+    rng = np.random.default_rng(9)
+    vin = rng.integers(0, 256, (ntime, nchan, ninput), dtype=np.uint8)
+    w1, w2 = block_weights(nchan, nbeam, ninput, seed=1), block_weights(nchan, nbeam, ninput, seed=2)
+    gpu.ffi.call("xengBeamformInitialize", 0, ninput, nchan, ntime, nbeam, 0)
+    di = gpu.ffi.DeviceBuffer(vin.size).upload(vin)
+    dw = gpu.ffi.DeviceBuffer(w1.nbytes).upload(w1)
+    do = gpu.ffi.DeviceBuffer(nchan * nbeam * ntime * 8)
+
+    def run(version):
+        gpu.ffi.call("xengBeamformRunVersioned", di.ptr, do.ptr, dw.ptr, version)
+        gpu.ffi.call("xengBeamformSync")
+        return do.download(np.complex64).reshape(nchan, nbeam, ntime)
+    e1 = orc.beamform(vin, w1, ntime, nchan, ninput, nbeam)
+    e2 = orc.beamform(vin, w2, ntime, nchan, ninput, nbeam)
+    check_beams(run(7), e1)
+    dw.upload(w2)
+    check_beams(run(7), e1)          # caller said "unchanged": the prepared copy of w1 is still in use
+    check_beams(run(8), e2)          # new version: re-split
+    dw.upload(w1)
+    check_beams(run(0), e1)          # version 0: always re-split (the reference call shape)
+    gpu.ffi.call("xengBeamformDestroy")

@@ -217,3 +217,42 @@ def test_config2_full_size(gpu):
     # every product is (-8-8j)*conj(-8-8j) = 128: all words 128*ntime (re) / 0 (im), incl. the unaddressed ones
     assert np.all(g88[:matlen] == 128 * ntime) and np.all(g88[matlen:] == 0)
     x.close()
+
+
+def test_streaming_lagged_sync_two_outputs(gpu):
+    """The streaming call pattern of bench.py: integration n+1 is enqueued (into the other output
+    span) before the caller waits for dump n with xengXgpuSyncLag(1).  Every dumped span must equal
+    the oracle, i.e. the double-buffered staging areas / three streams keep their ordering."""
+    nstand, nchan, ntime, ngulp, nint = 80, 8, 64, 3, 7
+    x = gpu.Xgpu(nstand, nchan, ntime, max_gulps=ngulp)
+    outs = [x.out, gpu.ffi.DeviceBuffer(x.out.nbytes)]
+    vin = gpu.synth_voltages(ntime * ngulp * nint, nchan, nstand, "full", seed=77).reshape(nint, ngulp, -1)
+    din = gpu.ffi.DeviceBuffer(vin.size).upload(vin)
+    results = {}
+    for n in range(nint):
+        for g in range(ngulp):
+            gpu.ffi.call("xengXgpuKernelAsync", din.ptr + (n * ngulp + g) * x.gulp_bytes, outs[n & 1].ptr, int(g == ngulp - 1))
+        gpu.ffi.call("xengXgpuSyncLag", 1)
+        if n >= 1:
+            results[n - 1] = outs[(n - 1) & 1].download(np.int32)     # complete although dump n is still running
+    gpu.ffi.call("xengXgpuSyncLag", 0)
+    results[nint - 1] = outs[(nint - 1) & 1].download(np.int32)
+    for n in range(nint):
+        assert np.array_equal(results[n], oracle_run(vin[n], nstand, nchan, ntime)), n
+    with pytest.raises(gpu.ffi.XengError):
+        gpu.ffi.call("xengXgpuSyncLag", 4)
+    x.close()
+    outs[1].free()
+
+
+def test_reset_drops_partial_integration(gpu):
+    nstand, nchan, ntime = 32, 8, 32
+    x = gpu.Xgpu(nstand, nchan, ntime, max_gulps=1)        # depth 1: the first gulp is flushed into `out`
+    v = gpu.synth_voltages(ntime * 3, nchan, nstand, "full", seed=5)
+    x.inbuf = gpu.ffi.DeviceBuffer(v.size).upload(v)
+    gpu.ffi.call("xengXgpuKernel", x.inbuf.ptr, x.out.ptr, 0)
+    gpu.ffi.call("xengXgpuReset")                           # abandon it
+    gpu.ffi.call("xengXgpuKernel", x.inbuf.ptr + x.gulp_bytes, x.out.ptr, 0)
+    gpu.ffi.call("xengXgpuKernel", x.inbuf.ptr + 2 * x.gulp_bytes, x.out.ptr, 1)
+    assert np.array_equal(x.out.download(np.int32), oracle_run(v[ntime:], nstand, nchan, ntime))
+    x.close()
