@@ -91,6 +91,8 @@ struct XgpuContext {
     int gpu = 0;
     XgpuConfig cfg;
     int ninput = 0, nblk64 = 0, gkt = 0, cap_kt = 0, cap_gulps = 0, kt_stage = 1;
+    bool fp6 = false;          // XENG_MFMA=fp6: E3M2 codes + block-scaled FP6 MFMA (exact), see xcorr_kernels.h
+    int ghk = 0;               // fp6: 32-sample half-tiles per gulp; cap_kt then counts 64-sample K steps
     int64_t per_chan = 0, matlen = 0;
     // Two staging areas and two streams: corner turns (HBM-bound) of integration n+1 run on `stream`
     // while the MFMA contraction (power-bound) of integration n runs on `stream_mm`.
@@ -178,7 +180,14 @@ static int flush_locked(void* out, bool dump) {
                   "xgpu: output buffer changed inside one integration (partial sums live in %p, got %p)",
                   x.acc_out, out);
     int nkt = x.nfilled * x.gkt;
-    const int rem = nkt % x.kt_stage;
+    if (x.fp6) {
+        const int nhk = x.nfilled * x.ghk;
+        if (nhk & 1)   // the last 64-sample K step is half filled: its second half must hold the value 0
+            hipLaunchKernelGGL(fp6_zero_half_kernel, dim3(x.cfg.nchan * x.nblk64), dim3(64), 0, x.stream,
+                               x.stash[x.cur], x.nblk64, x.cap_kt, nhk >> 1);
+        nkt = (nhk + 1) >> 1;
+    }
+    const int rem = x.fp6 ? 0 : nkt % x.kt_stage;
     if (rem) {  // zero-fill the K padding of every (channel, block) row of the stash
         const int padk = x.kt_stage - rem;
         XENG_HIP(hipMemset2DAsync(x.stash[x.cur] + (size_t)nkt * KT_BYTES, (size_t)x.cap_kt * KT_BYTES, 0,
@@ -200,7 +209,8 @@ static int flush_locked(void* out, bool dump) {
     if (x.mm_used[x.cur ^ 1] && (x.acc_started || x.last_out[x.cur ^ 1] == out))
         XENG_HIP(hipStreamWaitEvent(smm, x.ev_mm[x.cur ^ 1], 0));
     int slot = x.timer.begin(smm, 1);
-    launch_xcorr(p, smm);
+    if (x.fp6) hipLaunchKernelGGL(xcorr_fp6_kernel, dim3(p.nchan * p.nwg), dim3(256), 0, smm, p);
+    else launch_xcorr(p, smm);
     x.timer.end(smm, slot);
     XENG_HIP(hipGetLastError());
     XENG_HIP(hipEventRecord(x.ev_mm[x.cur], smm));
@@ -230,7 +240,12 @@ static int kernel_locked(const void* in_dev, void* out_dev, int doDump, bool syn
     int slot = x.timer.begin(x.stream, 0);
     const size_t lds_bytes = (((size_t)32 * x.ninput + 1023) & ~(size_t)1023) + (size_t)x.nblk64 * KT_BYTES;
     static const int ct_mode = getenv("XENG_CT_MODE") ? atoi(getenv("XENG_CT_MODE")) : 2;   // 0 register-only, 1 LDS full tile, 2 LDS half tiles
-    if (x.ninput % 16 == 0 && lds_bytes <= 64 * 1024 && ct_mode == 1) {
+    if (x.fp6) {
+        const size_t l6 = (((size_t)32 * x.ninput + 1023) & ~(size_t)1023) + (size_t)x.nblk64 * 2 * F6_FRAG;
+        hipLaunchKernelGGL(corner_turn_fp6_kernel, dim3(x.cfg.nchan, x.ghk), dim3(192), l6, x.stream,
+                           (const uint8_t*)in_dev, stash, x.cfg.ntime_gulp, x.cfg.nchan, x.ninput, x.nblk64,
+                           x.cap_kt, x.nfilled * x.ghk);
+    } else if (x.ninput % 16 == 0 && lds_bytes <= 64 * 1024 && ct_mode == 1) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(corner_turn_lds_kernel<0>), dim3(x.cfg.nchan, x.gkt), dim3(256), lds_bytes, x.stream,
                            (const uint8_t*)in_dev, stash, x.cfg.ntime_gulp, x.cfg.nchan, x.ninput, x.nblk64,
                            x.cap_kt, x.nfilled * x.gkt);
@@ -306,6 +321,16 @@ int xengXgpuInitialize(int gpu) {
     x.per_chan = (int64_t)(x.cfg.nstand / 2 + 1) * (x.cfg.nstand / 4) * x.cfg.npol * x.cfg.npol * 4;
     x.matlen = x.per_chan * x.cfg.nchan;
     x.stash_bytes = (size_t)x.cfg.nchan * x.nblk64 * x.cap_kt * KT_BYTES;
+    {
+        const char* m = getenv("XENG_MFMA");
+        const size_t l6 = (((size_t)32 * x.ninput + 1023) & ~(size_t)1023) + (size_t)x.nblk64 * 2 * F6_FRAG;
+        x.fp6 = m && !strcmp(m, "fp6") && x.ninput % 16 == 0 && l6 <= 64 * 1024;
+        if (x.fp6) {
+            x.ghk = (x.cfg.ntime_gulp + 31) / 32;
+            x.cap_kt = (cap * x.ghk + 1) / 2;                       // 64-sample K steps
+            x.stash_bytes = (size_t)x.cfg.nchan * x.nblk64 * x.cap_kt * F6_KT_BYTES;
+        }
+    }
     for (int b = 0; b < 2; b++) {
         XENG_HIP(hipMalloc((void**)&x.stash[b], x.stash_bytes));
         XENG_HIP(hipMemset(x.stash[b], 0, x.stash_bytes));

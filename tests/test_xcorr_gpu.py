@@ -256,3 +256,24 @@ def test_reset_drops_partial_integration(gpu):
     gpu.ffi.call("xengXgpuKernel", x.inbuf.ptr + 2 * x.gulp_bytes, x.out.ptr, 1)
     assert np.array_equal(x.out.download(np.int32), oracle_run(v[ntime:], nstand, nchan, ntime))
     x.close()
+
+
+@pytest.mark.parametrize("nstand,nchan,ntime,ngulp,kind", [
+    (32, 8, 32, 3, "full"),          # odd number of 32-sample half-tiles: the last 64-sample K step is half zero
+    (80, 8, 480, 2, "full"),         # the reference gulp length (7.5 K steps per gulp), 3 input blocks
+    (96, 3, 100, 2, "88"),           # ragged gulp, every nibble -8 (code 0b111000): largest magnitudes
+    (176, 2, 64, 1, "full"),
+])
+def test_fp6_route_is_bit_exact(gpu, nstand, nchan, ntime, ngulp, kind):
+    """Opt-in XENG_MFMA=fp6 route: E3M2 codes + block-scaled FP6 MFMA with fp32 accumulation.  Integers
+    -8..7 and their products/sums (< 2^24) are exact, so the visibilities must equal the oracle bit for bit."""
+    os.environ["XENG_MFMA"] = "fp6"
+    try:
+        x = gpu.Xgpu(nstand, nchan, ntime)
+        vin = gpu.synth_voltages(ntime * ngulp, nchan, nstand, kind, seed=nstand)
+        exp = oracle_run(vin, nstand, nchan, ntime)
+        assert np.array_equal(x.run(vin), exp)
+        assert np.array_equal(x.run(vin, use_async=True), exp)
+        x.close()
+    finally:
+        del os.environ["XENG_MFMA"]
