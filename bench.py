@@ -170,7 +170,7 @@ def main():
     # outside the timed region: PCIe-inclusive regime (SURVEY 8d "two reporting regimes", ii): gulps start in
     # pinned host memory, are copied H2D (xengMemcpy, the Copy block's copy_array) and then correlated
     pcie = None
-    if args.h2d and rank == 0:
+    if args.h2d and rank == 0 and world == 1:
         nh = 2 * gulps_per_step
         hostbuf = ffi.DeviceBuffer(nh * gulp_bytes, ffi.SPACE_CUDA_HOST)
         hostbuf.as_host_array(np.uint8)[:] = np.random.RandomState(1).randint(0, 255, size=nh * gulp_bytes, dtype=np.uint8)
@@ -192,7 +192,7 @@ def main():
     # outside the timed region: BASELINE config 4 -- Beamform (32 beams, 96 chan, 960 samples, fp32 weights)
     # + BeamformSumBeams (16 dual-pol power beams, ntime_sum 24) on the same GPU
     beam = None
-    if args.beamform and rank == 0:
+    if args.beamform and rank == 0 and world == 1:
         ffi.call("xengXgpuSync")
         NT_B, NB, NS = 960, 32, 24
         ffi.call("xengBeamformInitialize", gpu, NINPUT, NCHAN, NT_B, NB, 0)

@@ -91,6 +91,7 @@ struct XgpuContext {
     int gpu = 0;
     XgpuConfig cfg;
     int ninput = 0, nblk64 = 0, gkt = 0, cap_kt = 0, cap_gulps = 0, kt_stage = 1;
+    int ct_pitch = 0;          // LDS row pitch of the transposing corner turn (0: register-only fallback)
     bool fp6 = false;          // XENG_MFMA=fp6: E3M2 codes + block-scaled FP6 MFMA (exact), see xcorr_kernels.h
     int ghk = 0;               // fp6: 32-sample half-tiles per gulp; cap_kt then counts 64-sample K steps
     int64_t per_chan = 0, matlen = 0;
@@ -238,23 +239,16 @@ static int kernel_locked(const void* in_dev, void* out_dev, int doDump, bool syn
         XENG_HIP(hipStreamWaitEvent(x.stream, x.ev_mm[x.cur], 0));
     uint8_t* const stash = x.stash[x.cur];
     int slot = x.timer.begin(x.stream, 0);
-    const size_t lds_bytes = (((size_t)32 * x.ninput + 1023) & ~(size_t)1023) + (size_t)x.nblk64 * KT_BYTES;
-    static const int ct_mode = getenv("XENG_CT_MODE") ? atoi(getenv("XENG_CT_MODE")) : 2;   // 0 register-only, 1 LDS full tile, 2 LDS half tiles
     if (x.fp6) {
         const size_t l6 = (((size_t)32 * x.ninput + 1023) & ~(size_t)1023) + (size_t)x.nblk64 * 2 * F6_FRAG;
         hipLaunchKernelGGL(corner_turn_fp6_kernel, dim3(x.cfg.nchan, x.ghk), dim3(192), l6, x.stream,
                            (const uint8_t*)in_dev, stash, x.cfg.ntime_gulp, x.cfg.nchan, x.ninput, x.nblk64,
                            x.cap_kt, x.nfilled * x.ghk);
-    } else if (x.ninput % 16 == 0 && lds_bytes <= 64 * 1024 && ct_mode == 1) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(corner_turn_lds_kernel<0>), dim3(x.cfg.nchan, x.gkt), dim3(256), lds_bytes, x.stream,
+    } else if (x.ct_pitch > 0) {
+        const size_t l8 = (((size_t)16 * x.ct_pitch + 1023) & ~(size_t)1023);
+        hipLaunchKernelGGL(corner_turn_tr8_kernel, dim3(x.cfg.nchan, x.gkt, 2), dim3(256), l8, x.stream,
                            (const uint8_t*)in_dev, stash, x.cfg.ntime_gulp, x.cfg.nchan, x.ninput, x.nblk64,
-                           x.cap_kt, x.nfilled * x.gkt);
-    } else if (x.ninput % 16 == 0 && lds_bytes <= 64 * 1024 && ct_mode == 2) {
-        const size_t half_bytes = (((size_t)16 * x.ninput + 1023) & ~(size_t)1023) + (size_t)x.nblk64 * KT_BYTES / 2;
-        const int thr = std::min(256, ((x.nblk64 * 16 + 63) / 64) * 64);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(corner_turn_lds_kernel<1>), dim3(x.cfg.nchan, x.gkt, 2), dim3(thr), half_bytes, x.stream,
-                           (const uint8_t*)in_dev, stash, x.cfg.ntime_gulp, x.cfg.nchan, x.ninput, x.nblk64,
-                           x.cap_kt, x.nfilled * x.gkt);
+                           x.cap_kt, x.nfilled * x.gkt, x.ct_pitch);
     } else {
         const int ct_items = 2 * x.nblk64 * 16;                   // (input quad, k-half) work items per (K-tile, channel)
         const int ct_threads = std::min(1024, ((ct_items + 63) / 64) * 64);
@@ -321,6 +315,12 @@ int xengXgpuInitialize(int gpu) {
     x.per_chan = (int64_t)(x.cfg.nstand / 2 + 1) * (x.cfg.nstand / 4) * x.cfg.npol * x.cfg.npol * 4;
     x.matlen = x.per_chan * x.cfg.nchan;
     x.stash_bytes = (size_t)x.cfg.nchan * x.nblk64 * x.cap_kt * KT_BYTES;
+    if (x.ninput % 16 == 0) {
+        // LDS row pitch: >= ninput, a multiple of 16 bytes, and 8 mod 64 dwords (conflict-free transposing reads)
+        int pitch = x.ninput;
+        while (((pitch / 4) & 63) != 8) pitch += 16;
+        if ((size_t)16 * pitch + 1024 <= 64 * 1024) x.ct_pitch = pitch;
+    }
     {
         const char* m = getenv("XENG_MFMA");
         const size_t l6 = (((size_t)32 * x.ninput + 1023) & ~(size_t)1023) + (size_t)x.nblk64 * 2 * F6_FRAG;

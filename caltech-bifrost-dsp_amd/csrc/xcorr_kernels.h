@@ -37,6 +37,7 @@ namespace xeng {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
+typedef int v2i __attribute__((ext_vector_type(2)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int FRAG_BYTES = 1024;          // one 32-input x 32-sample fragment
@@ -70,6 +71,7 @@ __device__ __forceinline__ void transpose4x4_bytes(uint32_t a, uint32_t b, uint3
     o3 = __builtin_amdgcn_perm(u1, t1, 0x07060302u);
 }
 
+// Register-only fallback (input counts that are not a multiple of 16).
 // grid (gkt, nchan), one thread per work item (threads = 32*nblk64 rounded up to a wave, set by the
 // launcher) so every load of the tile is in flight at once.  Each work item is (input quad q, k-half h): it reads
 // 16 samples x 4 inputs as 16 coalesced dwords (a wave covers 256 contiguous bytes of one
@@ -107,82 +109,63 @@ __global__ __launch_bounds__(1024) void corner_turn_kernel(const uint8_t* __rest
     }
 }
 
-// LDS-staged corner turn (used when ninput is a multiple of 16, e.g. 704): grid (gkt, nchan), 256 threads.
-//   phase 1  the raw tile (32 samples x ninput bytes) is copied HBM -> LDS by LDS-DMA, 16 B per lane; the
-//            LDS image is the tile's rows back to back, so each 1 KiB wave-instruction lands linearly
-//            while its per-lane source addresses walk the [t][c] rows of the input;
-//   phase 2  each thread transposes 16 samples x 4 inputs (16 conflict-free ds_read_b32, 32 v_perm_b32)
-//            and writes its four 16-byte fragment entries into an LDS image of the output;
-//   phase 3  the output image (2 KiB per 64-input block) is streamed out with fully contiguous
-//            1 KiB-per-wave stores.
-// HALF = 0: one block per (K tile, channel), 32 samples.  HALF = 1: one block per (K tile, channel,
-// k-half), 16 samples -- half the LDS per block, so twice the blocks overlap their phases per CU.
-template <int HALF>
-__global__ __launch_bounds__(256) void corner_turn_lds_kernel(const uint8_t* __restrict__ in,
+// Corner turn on the hardware byte-transposing LDS read (default for input counts that are a multiple
+// of 16).  ds_read_b64_tr_b8 (profiles/microbench/tr8_probe.hip): in every 16-lane group, lane 2q+p supplies
+// the address of row q, columns 8p..8p+7 of an 8x16 byte block and lane i receives column i of the 8 rows.
+// With rows = samples and columns = inputs, two such reads give a lane the 16 samples of one input:
+// exactly one 16-byte fragment entry, which it stores straight to HBM (lanes of a wave cover two contiguous
+// 512-byte runs).  No permutes, no output image in LDS.
+//   grid (channel, K tile, k-half), 256 threads.  LDS: 16 rows at a pitch that is 8 mod 64 dwords, so the
+//   transposing reads are bank-conflict-free; the rows arrive by LDS-DMA (the LDS image is linear per 1 KiB
+//   piece; columns past ninput inside the pitch are padding).
+__global__ __launch_bounds__(256) void corner_turn_tr8_kernel(const uint8_t* __restrict__ in,
                                                               uint8_t* __restrict__ stash, int ntime,
                                                               int nchan, int ninput, int nblk64,
-                                                              int cap_kt, int kt_off) {
+                                                              int cap_kt, int kt_off, int pitch) {
     extern __shared__ __attribute__((aligned(16))) uint8_t ct_lds[];
-    constexpr int NROW = HALF ? 16 : 32;
-    // channel is the fastest grid index: blocks resident together read adjacent segments of the same [t] rows
-    const int c = blockIdx.x, kt = blockIdx.y, hz = HALF ? blockIdx.z : 0;
+    const int c = blockIdx.x, kt = blockIdx.y, hz = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwave = blockDim.x >> 6;
-    const int in_bytes = NROW * ninput;                          // raw tile
-    const int out_bytes = nblk64 * KT_BYTES / (HALF ? 2 : 1);    // fragment image (or its k-half)
-    uint8_t* lin = ct_lds;
-    uint8_t* lout = ct_lds + ((in_bytes + 1023) & ~1023);
     const size_t row_stride = (size_t)nchan * ninput;
     const uint8_t* src_c = in + (size_t)c * ninput;
     const int t_base = kt * 32 + 16 * hz;
-    const int t_valid = max(0, min(NROW, ntime - t_base));       // samples of this tile that exist
+    const int t_valid = max(0, min(16, ntime - t_base));
 
-    // phase 1: pieces of 1 KiB; lane L of piece n covers tile bytes n*1024 + 16L .. +15 = (t, i..i+15)
-    const int npiece = (in_bytes + 1023) >> 10;
+    // phase 1: LDS byte o = row * pitch + col
+    const int npiece = (16 * pitch + 1023) >> 10;
     for (int n = wave; n < npiece; n += nwave) {
         const int off = n * 1024 + lane * 16;
-        int t = off / ninput, i = off - t * ninput;
-        if (t >= t_valid) { t = 0; i = 0; }           // past the tile / past ntime: any valid address (masked below)
+        int t = off / pitch, i = off - t * pitch;
+        if (t >= t_valid || i + 16 > ninput) { t = 0; i = 0; }     // padding / missing rows: any valid address
         const uint8_t* g = src_c + (size_t)(t_valid > 0 ? t_base + t : 0) * row_stride + i;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(lin + n * 1024), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(ct_lds + n * 1024), 16, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // phase 2
-    const int nq = nblk64 * 16;
-    const int nitem = HALF ? nq : 2 * nq;
-    for (int item = tid; item < nitem; item += blockDim.x) {
-        const int h = HALF ? hz : item / nq, q = HALF ? item : item - h * nq;
-        const int i0 = q * 4;
-        uint32_t v[16];
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const int t = (HALF ? 0 : 16 * h) + j;
-            v[j] = (i0 < ninput && t < t_valid) ? *reinterpret_cast<const uint32_t*>(lin + t * ninput + i0) : 0u;
-        }
-        uint32_t o[4][4];
-#pragma unroll
-        for (int g = 0; g < 4; g++)
-            transpose4x4_bytes(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3], o[0][g], o[1][g],
-                               o[2][g], o[3][g]);
-        // full image: (i0>>5)*1024 + h*512 + (i0&31)*16 ; half image: (i0>>5)*512 + (i0&31)*16
-        uint8_t* dst = HALF ? lout + (i0 >> 5) * 512 + (i0 & 31) * 16
-                            : lout + (i0 >> 5) * FRAG_BYTES + h * 512 + (i0 & 31) * 16;
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            *reinterpret_cast<uint4*>(dst + 16 * j) = make_uint4(o[j][0], o[j][1], o[j][2], o[j][3]);
-    }
-    __syncthreads();
-
-    // phase 3: 1 KiB LDS pieces -> HBM (contiguous 1 KiB, or two contiguous 512 B runs for HALF)
-    const int nout = out_bytes >> 10;
-    for (int n = wave; n < nout; n += nwave) {
-        const uint4 val = *reinterpret_cast<const uint4*>(lout + n * 1024 + lane * 16);
-        const int f = HALF ? 2 * n + (lane >> 5) : n;            // 32-input fragment index = ib*2 + sub
-        const int within = HALF ? hz * 512 + (lane & 31) * 16 : lane * 16;
-        uint8_t* dst = stash + (((size_t)c * nblk64 + (f >> 1)) * cap_kt + (kt_off + kt)) * KT_BYTES + (f & 1) * FRAG_BYTES + within;
+    // byte masks for rows that do not exist (t >= t_valid): wave-uniform
+    const int v0 = min(t_valid, 8), v1 = max(t_valid - 8, 0);
+    const unsigned long long m0 = v0 >= 8 ? ~0ull : ((1ull << (8 * v0)) - 1), m1 = v1 >= 8 ? ~0ull : ((1ull << (8 * v1)) - 1);
+    const int grp = lane >> 4, w = lane & 15;
+    const int rd_off = (w >> 1) * pitch + (w & 1) * 8 + grp * 16;   // row q = w/2, columns 8*(w&1).. of this group's 16
+    const int nstep = nblk64;                                        // 64 inputs per wave step
+    for (int st = wave; st < nstep; st += nwave) {
+        const int col0 = st * 64;
+        // all 64 lanes execute the transposing reads (the instruction needs EXEC = all ones); columns past
+        // ninput read padding, zeroed below
+        v2i lo = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) v2i*)(ct_lds + rd_off + col0));
+        v2i hi = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) v2i*)(ct_lds + rd_off + col0 + 8 * pitch));
+        const int I = col0 + lane;                                   // this lane's input: column 16*grp + (lane&15)
+        const bool live = I < ninput;
+        uint4 val;
+        val.x = live ? ((uint32_t)lo.x & (uint32_t)m0) : 0u;
+        val.y = live ? ((uint32_t)lo.y & (uint32_t)(m0 >> 32)) : 0u;
+        val.z = live ? ((uint32_t)hi.x & (uint32_t)m1) : 0u;
+        val.w = live ? ((uint32_t)hi.y & (uint32_t)(m1 >> 32)) : 0u;
+        // fragment entry (ib = st, sub = lane>>5, k-half hz, r = lane&31)
+        uint8_t* dst = stash + ((((size_t)c * nblk64 + st) * cap_kt + (kt_off + kt)) * 2 + (lane >> 5)) * FRAG_BYTES +
+                       (hz * 32 + (lane & 31)) * 16;
         *reinterpret_cast<uint4*>(dst) = val;
     }
 }
@@ -464,7 +447,6 @@ __global__ __launch_bounds__(256, 1) void xcorr_mfma_kernel(XcorrParams p) {
 //   [lane*16], dwords 4-5 at [1024 + lane*8]  (ds_read_b128 + ds_read_b64, both conflict-free).
 // =======================================================================================
 typedef int v8i __attribute__((ext_vector_type(8)));
-typedef int v2i __attribute__((ext_vector_type(2)));
 constexpr int F6_FRAG = 1536;
 constexpr int F6_KT_BYTES = 4 * F6_FRAG;     // (sub, plane) x 1536 per 64-input block per 64 samples
 
