@@ -92,6 +92,12 @@ struct XgpuContext {
     XgpuConfig cfg;
     int ninput = 0, nblk64 = 0, gkt = 0, cap_kt = 0, cap_gulps = 0, kt_stage = 1;
     int ct_pitch = 0;          // LDS row pitch of the transposing corner turn (0: register-only fallback)
+    // raw: no corner-turn pass.  The contraction kernel reads time-major gulps in place and transposes in
+    // LDS (xcorr_mfma_kernel<.., RAW>): asynchronous calls hand over the caller's buffer itself, synchronous
+    // calls a raw copy of it in the staging area.
+    bool raw = false;
+    size_t gulp_bytes = 0;
+    const uint8_t* gulp_ptr[XC_MAX_GULPS] = {};
     bool fp6 = false;          // XENG_MFMA=fp6: E3M2 codes + block-scaled FP6 MFMA (exact), see xcorr_kernels.h
     int ghk = 0;               // fp6: 32-sample half-tiles per gulp; cap_kt then counts 64-sample K steps
     int64_t per_chan = 0, matlen = 0;
@@ -152,9 +158,13 @@ static int destroy_locked() {
 
 template <int ABL>
 static void launch_abl(const XcorrParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_mfma_kernel<ABL>), dim3(p.nchan * p.nwg), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_mfma_kernel<ABL, false>), dim3(p.nchan * p.nwg), dim3(256), 0, s, p);
 }
-static void launch_xcorr(const XcorrParams& p, hipStream_t s) {
+static void launch_xcorr(const XcorrParams& p, hipStream_t s, bool raw) {
+    if (raw) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_mfma_kernel<0, true>), dim3(p.nchan * p.nwg), dim3(256), 0, s, p);
+        return;
+    }
 #ifdef XENG_DIAGNOSTICS
     // timing-only ablations of the K loop (results are wrong): build with -DXENG_DIAGNOSTICS, select with
     // XENG_ABLATE = 1 (no LDS-DMA) | 2 (no unpack) | 4 (no LDS reads) | 8 (no barrier); see profiles/r01/README.md
@@ -188,7 +198,7 @@ static int flush_locked(void* out, bool dump) {
                                x.stash[x.cur], x.nblk64, x.cap_kt, nhk >> 1);
         nkt = (nhk + 1) >> 1;
     }
-    const int rem = x.fp6 ? 0 : nkt % x.kt_stage;
+    const int rem = (x.fp6 || x.raw) ? 0 : nkt % x.kt_stage;
     if (rem) {  // zero-fill the K padding of every (channel, block) row of the stash
         const int padk = x.kt_stage - rem;
         XENG_HIP(hipMemset2DAsync(x.stash[x.cur] + (size_t)nkt * KT_BYTES, (size_t)x.cap_kt * KT_BYTES, 0,
@@ -201,6 +211,9 @@ static int flush_locked(void* out, bool dump) {
     p.nstand = x.cfg.nstand; p.per_chan = x.per_chan; p.matlen = x.matlen;
     p.accumulate = x.acc_started ? 1 : 0;
     p.stamps = x.stamps;
+    p.spg = x.raw ? x.cfg.ntime_gulp / (XC_KT * 32) : 0;
+    p.ninput = x.ninput;
+    for (int g = 0; g < XC_MAX_GULPS; g++) p.gulps[g] = g < x.nfilled ? x.gulp_ptr[g] : nullptr;
     // the contraction starts when this area's corner turns are done and runs beside the next area's
     hipStream_t smm = x.stream_mm2[x.cur];
     XENG_HIP(hipEventRecord(x.ev_ct, x.stream));
@@ -211,7 +224,7 @@ static int flush_locked(void* out, bool dump) {
         XENG_HIP(hipStreamWaitEvent(smm, x.ev_mm[x.cur ^ 1], 0));
     int slot = x.timer.begin(smm, 1);
     if (x.fp6) hipLaunchKernelGGL(xcorr_fp6_kernel, dim3(p.nchan * p.nwg), dim3(256), 0, smm, p);
-    else launch_xcorr(p, smm);
+    else launch_xcorr(p, smm, x.raw);
     x.timer.end(smm, slot);
     XENG_HIP(hipGetLastError());
     XENG_HIP(hipEventRecord(x.ev_mm[x.cur], smm));
@@ -232,24 +245,36 @@ static int kernel_locked(const void* in_dev, void* out_dev, int doDump, bool syn
     XgpuContext& x = g_ctx;
     if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized (call xengXgpuInitialize)");
     if (!in_dev || !out_dev) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "xgpu: null buffer");
-    if (((uintptr_t)out_dev & 15) || ((uintptr_t)in_dev & 3))
-        XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "xgpu: out must be 16-byte and in 4-byte aligned");
+    if (((uintptr_t)out_dev & 15) || ((uintptr_t)in_dev & (x.raw ? 15 : 3)))
+        XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "xgpu: out must be 16-byte and in %d-byte aligned", x.raw ? 16 : 4);
     XENG_HIP(hipSetDevice(x.gpu));
     if (x.nfilled == 0 && x.mm_used[x.cur])   // this staging area may still be read by an earlier contraction
         XENG_HIP(hipStreamWaitEvent(x.stream, x.ev_mm[x.cur], 0));
     uint8_t* const stash = x.stash[x.cur];
-    int slot = x.timer.begin(x.stream, 0);
-    if (x.fp6) {
+    int slot = -1;
+    if (x.raw) {
+        if (sync) {   // the caller may recycle in_dev on return: keep a raw copy
+            uint8_t* copy = stash + (size_t)x.nfilled * x.gulp_bytes;
+            slot = x.timer.begin(x.stream, 0);
+            XENG_HIP(hipMemcpyAsync(copy, in_dev, x.gulp_bytes, hipMemcpyDeviceToDevice, x.stream));
+            x.gulp_ptr[x.nfilled] = copy;
+        } else {
+            x.gulp_ptr[x.nfilled] = (const uint8_t*)in_dev;
+        }
+    } else if (x.fp6) {
+        slot = x.timer.begin(x.stream, 0);
         const size_t l6 = (((size_t)32 * x.ninput + 1023) & ~(size_t)1023) + (size_t)x.nblk64 * 2 * F6_FRAG;
         hipLaunchKernelGGL(corner_turn_fp6_kernel, dim3(x.cfg.nchan, x.ghk), dim3(192), l6, x.stream,
                            (const uint8_t*)in_dev, stash, x.cfg.ntime_gulp, x.cfg.nchan, x.ninput, x.nblk64,
                            x.cap_kt, x.nfilled * x.ghk);
     } else if (x.ct_pitch > 0) {
+        slot = x.timer.begin(x.stream, 0);
         const size_t l8 = (((size_t)16 * x.ct_pitch + 1023) & ~(size_t)1023);
         hipLaunchKernelGGL(corner_turn_tr8_kernel, dim3(x.cfg.nchan, x.gkt, 2), dim3(256), l8, x.stream,
                            (const uint8_t*)in_dev, stash, x.cfg.ntime_gulp, x.cfg.nchan, x.ninput, x.nblk64,
                            x.cap_kt, x.nfilled * x.gkt, x.ct_pitch);
     } else {
+        slot = x.timer.begin(x.stream, 0);
         const int ct_items = 2 * x.nblk64 * 16;                   // (input quad, k-half) work items per (K-tile, channel)
         const int ct_threads = std::min(1024, ((ct_items + 63) / 64) * 64);
         hipLaunchKernelGGL(corner_turn_kernel, dim3(x.gkt, x.cfg.nchan), dim3(ct_threads), 0, x.stream,
@@ -310,6 +335,16 @@ int xengXgpuInitialize(int gpu) {
     // the X-engine flushes early when full).  K per launch must stay <= 65535 samples (int32 bound).
     int cap = x.cfg.max_gulps > 0 ? x.cfg.max_gulps : std::max(1, 4800 / (x.gkt * 32));
     cap = std::min(cap, std::max(1, 65535 / (x.gkt * 32)));
+    {
+        // default: fused corner turn whenever the shape allows it (whole 16-byte input chunks, gulps made
+        // of whole 96-sample stages); XENG_RAW=0 keeps the two-pass path
+        const char* r = getenv("XENG_RAW");
+        const char* m = getenv("XENG_MFMA");
+        x.gulp_bytes = (size_t)x.cfg.ntime_gulp * x.cfg.nchan * x.ninput;
+        x.raw = !(m && !strcmp(m, "fp6")) && !(r && !strcmp(r, "0")) && x.ninput % 16 == 0 &&
+                x.cfg.ntime_gulp % (XC_KT * 32) == 0 && x.gulp_bytes + (size_t)16 * x.cfg.nchan * x.ninput < (1ull << 32);
+        if (x.raw) cap = std::min(cap, XC_MAX_GULPS);   // gulp pointers travel in the kernel arguments
+    }
     x.cap_gulps = cap;
     x.cap_kt = ((cap * x.gkt + x.kt_stage - 1) / x.kt_stage) * x.kt_stage;
     x.per_chan = (int64_t)(x.cfg.nstand / 2 + 1) * (x.cfg.nstand / 4) * x.cfg.npol * x.cfg.npol * 4;
@@ -331,6 +366,7 @@ int xengXgpuInitialize(int gpu) {
             x.stash_bytes = (size_t)x.cfg.nchan * x.nblk64 * x.cap_kt * F6_KT_BYTES;
         }
     }
+    if (x.raw) x.stash_bytes = (size_t)cap * x.gulp_bytes;   // raw copies of synchronously handed gulps
     for (int b = 0; b < 2; b++) {
         XENG_HIP(hipMalloc((void**)&x.stash[b], x.stash_bytes));
         XENG_HIP(hipMemset(x.stash[b], 0, x.stash_bytes));
@@ -519,6 +555,15 @@ int xengXgpuGetInfo(int* nstand, int* npol, int* nchan, int* ntime_gulp, int64_t
     if (ntime_gulp) *ntime_gulp = x.cfg.ntime_gulp;
     if (matlen) *matlen = x.matlen;
     if (max_gulps) *max_gulps = x.cap_gulps;
+    return XENG_STATUS_SUCCESS;
+}
+
+int xengXgpuGetPath(int* fused_corner_turn, int* fp6) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    XgpuContext& x = g_ctx;
+    if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized");
+    if (fused_corner_turn) *fused_corner_turn = x.raw ? 1 : 0;
+    if (fp6) *fp6 = x.fp6 ? 1 : 0;
     return XENG_STATUS_SUCCESS;
 }
 

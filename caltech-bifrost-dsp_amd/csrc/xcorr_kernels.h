@@ -184,6 +184,7 @@ __device__ __forceinline__ int dpp_xor1(int x) {
 
 __device__ __forceinline__ int64_t tri64(int64_t i, int64_t j) { return (i * (i + 1)) / 2 + j; }
 
+constexpr int XC_MAX_GULPS = 16;
 struct XcorrParams {
     const uint8_t* stash;
     int32_t* out;
@@ -192,6 +193,10 @@ struct XcorrParams {
     int64_t per_chan, matlen;
     int accumulate;
     unsigned long long* stamps;   // diagnostic only (null in production): per wave {d_memtime, d_memrealtime, loop cycles}
+    // RAW variant: the gulps themselves (time-major, uint8[ntime][nchan][ninput]), read in place
+    const uint8_t* gulps[XC_MAX_GULPS];
+    int spg;                      // 96-sample stages per gulp
+    int ninput;
 };
 
 struct Frags {   // the 8 unpacked int8 operand fragments of one 64x64 wave tile and one K-tile
@@ -219,7 +224,19 @@ constexpr int XC_RING = 4;    // LDS ring depth (stages)
 
 // ABL: timing-only ablation bits (results are wrong unless ABL == 0): 1 no LDS-DMA in the loop,
 // 2 no nibble unpack, 4 no LDS reads in the loop, 8 no barrier/vmcnt wait in the loop.
-template <int ABL>
+//
+// RAW = false: operands come from the fragment-major staging area written by the corner turn.
+// RAW = true : the corner turn is fused into the LDS staging.  The kernel reads the gulps where they lie
+//   (time-major rows of ninput bytes per channel): per stage and 64-input block the LDS-DMA brings 96 rows
+//   x 64 bytes (six 1 KiB pieces of 16 rows x four 16-byte chunks), and the operand fragments come out of
+//   LDS through ds_read_b64_tr_b8, the byte-transposing read (profiles/microbench/tr8_probe.hip): 16-lane
+//   group (h, rg) of a wave reads the 8x16 byte block rows 16h+8hh.., inputs 32 sub + 16 rg.. and lane r
+//   receives 8 consecutive samples of input r -- two reads make the 16 bytes of an MFMA operand register
+//   quad.  (Which samples sit in which byte does not matter: A and B use the same map.)  The 64-byte row
+//   pitch would put rows q and q+4 on the same banks, so chunk j of row t is stored at chunk position
+//   j ^ 2*((t>>2)&1): applied to the per-lane DMA source address (the LDS side of the DMA is linear) and
+//   to the read address; the 32 lanes of a read phase then cover 32 distinct even banks.
+template <int ABL, bool RAW>
 __global__ __launch_bounds__(256, 1) void xcorr_mfma_kernel(XcorrParams p) {
     constexpr int KT_STAGE = XC_KT;
     constexpr int SLOT_BYTES = KT_STAGE * KT_BYTES;
@@ -255,16 +272,48 @@ __global__ __launch_bounds__(256, 1) void xcorr_mfma_kernel(XcorrParams p) {
     const uint8_t* gsrc =
         p.stash + ((size_t)c * p.nblk64 + dp->slot_blk[wave]) * (size_t)p.cap_kt * KT_BYTES + lane * 16;
     const int nstage = p.nkt / KT_STAGE;
+    // RAW: slots are staged in pairs (0,1) and (2,3): the LDS image of a pair and stage is [96 rows][128 B]
+    // (slot parity = 64-byte half), chunk position = chunk ^ 2*((row>>1)&3).  Wave w brings rows
+    // 48*(w&1).. of pair w>>1: a piece is 8 rows x 128 B, lane = 8*row + chunk position.  The tiling
+    // makes most pairs adjacent blocks (2k, 2k+1), whose two halves then form whole 128-byte lines:
+    // half as many L2 requests as 64-byte row segments.
+    // (columns past ninput in the last block: any valid bytes of the row; their products are never stored)
+    const uint32_t row_stride = (uint32_t)p.nchan * (uint32_t)p.ninput;
+    const int raw_chunk = (lane & 7) ^ (((lane >> 4) & 3) << 1);          // source chunk 0..7 of the 128-byte pair row
+    const uint32_t raw_col = (uint32_t)dp->slot_blk[(wave & 2) + (raw_chunk >> 2)] * 64u + (uint32_t)(raw_chunk & 3) * 16u;
+    const uint32_t raw_lane_off = (uint32_t)(lane >> 3) * row_stride + (raw_col + 16u <= (uint32_t)p.ninput ? raw_col : 0u);
 
-    // one 1 KiB LDS-DMA piece n (0..NLOAD-1) of stage s into ring buffer s % XC_RING.  Stages past
-    // the end re-read the last real stage (never consumed): the issue stays unconditional, so every
-    // stage costs exactly NLOAD pieces on the vmcnt counter and the loop body is one scheduling region.
+    // RAW: scalar base address of the stage being issued, advanced once per stage (no divisions in the loop);
+    // it stays on the last real stage once K is exhausted
+    const uint8_t* raw_stage = nullptr;
+    int raw_g = 0, raw_sl = 0, raw_issued = 0;
+    auto raw_next_stage = [&]() {
+        raw_stage = p.gulps[raw_g] + ((size_t)(raw_sl * (KT_STAGE * 32)) * p.nchan + c) * (size_t)p.ninput;
+        if (++raw_issued < nstage) {
+            if (++raw_sl == p.spg) { raw_sl = 0; raw_g++; }
+        }
+    };
     auto issue_piece = [&](int s, int n) {
         const int ssrc = s < nstage ? s : nstage - 1;
-        const uint8_t* g = gsrc + (size_t)ssrc * SLOT_BYTES + n * FRAG_BYTES;
+        const uint8_t* g;
+        if (RAW) {
+            g = raw_stage + (size_t)(48 * (wave & 1) + 8 * n) * row_stride + raw_lane_off;   // scalar base + 32-bit lane offset
+        } else {
+            g = gsrc + (size_t)ssrc * SLOT_BYTES + n * FRAG_BYTES;
+        }
         uint8_t* l = lds + (s & (XC_RING - 1)) * STAGE_BYTES + wave * SLOT_BYTES + n * FRAG_BYTES;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+        if (RAW) {
+            // issued from asm: hipcc cannot prove that the transposing reads below do not alias a pending
+            // builtin LDS-DMA and would put `s_waitcnt vmcnt(0)` in front of every one of them; the
+            // counted vmcnt + barrier at the end of each stage is the real ordering
+            unsigned keep;
+            const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(const __attribute__((address_space(3))) void*)l);
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(g), "s"(la) : "memory");
+        } else {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+        }
     };
 
     v16i accR[2][2], accP[2][2], accQ[2][2];
@@ -280,17 +329,36 @@ __global__ __launch_bounds__(256, 1) void xcorr_mfma_kernel(XcorrParams p) {
     // Idle waves (a_slot == 0xFF) run the same loop on slot 0 and skip the epilogue: keeping the
     // MFMA chain unconditional keeps the 192 accumulator registers in place (a wave-uniform
     // branch around it makes hipcc shuttle them AGPR<->VGPR every stage).
-    const int a_off = (active ? a_slot : 0) * SLOT_BYTES + lane * 16;
-    const int b_off = (active ? b_slot : 0) * SLOT_BYTES + lane * 16;
+    // RAW: lane 16*grp + 2q + pp addresses row 16*(grp>>1) + q (+8 for the second read), chunk position
+    // (4*slot parity + 2*sub + (grp&1)) ^ 2*((q>>1)&3), bytes 8pp..8pp+7: slot parity flips address bit 6,
+    // sub = 1 flips bit 5.  Per 32-lane phase the 32 addresses fall on 32 distinct even banks.
+    const int tr_off = ((lane >> 5) * 16 + ((lane & 15) >> 1)) * 128 +
+                       (((lane >> 4) & 1) ^ (((lane >> 2) & 3) << 1)) * 16 + (lane & 1) * 8;
+    const int sa = active ? a_slot : 0, sb = active ? b_slot : 0;
+    const int a_off = RAW ? (sa >> 1) * (2 * SLOT_BYTES) + (tr_off ^ ((sa & 1) * 64)) : sa * SLOT_BYTES + lane * 16;
+    const int b_off = RAW ? (sb >> 1) * (2 * SLOT_BYTES) + (tr_off ^ ((sb & 1) * 64)) : sb * SLOT_BYTES + lane * 16;
 
     // fragments of K-tile j (0..KT_STAGE-1) of stage s
     auto load_raw = [&](int s, int j) {
-        const uint8_t* base = lds + (s & (XC_RING - 1)) * STAGE_BYTES + j * KT_BYTES;
+        const uint8_t* base = lds + (s & (XC_RING - 1)) * STAGE_BYTES + j * (RAW ? 2 * KT_BYTES : KT_BYTES);
         RawFrags r;
-        r.a[0] = *reinterpret_cast<const v4i*>(base + a_off);
-        r.a[1] = *reinterpret_cast<const v4i*>(base + a_off + FRAG_BYTES);
-        r.b[0] = *reinterpret_cast<const v4i*>(base + b_off);
-        r.b[1] = *reinterpret_cast<const v4i*>(base + b_off + FRAG_BYTES);
+        if (RAW) {
+            auto tr = [&](int off) {
+                return __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) v2i*)(base + off));
+            };
+#pragma unroll
+            for (int sub = 0; sub < 2; sub++) {
+                const v2i a0 = tr(a_off ^ (sub * 32)), a1 = tr((a_off ^ (sub * 32)) + 1024);
+                const v2i b0 = tr(b_off ^ (sub * 32)), b1 = tr((b_off ^ (sub * 32)) + 1024);
+                r.a[sub] = (v4i){a0.x, a0.y, a1.x, a1.y};
+                r.b[sub] = (v4i){b0.x, b0.y, b1.x, b1.y};
+            }
+        } else {
+            r.a[0] = *reinterpret_cast<const v4i*>(base + a_off);
+            r.a[1] = *reinterpret_cast<const v4i*>(base + a_off + FRAG_BYTES);
+            r.b[0] = *reinterpret_cast<const v4i*>(base + b_off);
+            r.b[1] = *reinterpret_cast<const v4i*>(base + b_off + FRAG_BYTES);
+        }
         return r;
     };
 
@@ -317,9 +385,11 @@ __global__ __launch_bounds__(256, 1) void xcorr_mfma_kernel(XcorrParams p) {
     // are now visible to all waves (the LDS reads two K-tiles ahead cross into the next stage), and
     // everybody is done reading stage s, whose buffer the DMA of stage s+4 overwrites.
 #pragma unroll
-    for (int st = 0; st < 3; st++)
+    for (int st = 0; st < 3; st++) {
+        if (RAW) raw_next_stage();
 #pragma unroll
         for (int n = 0; n < NLOAD; n++) issue_piece(st, n);
+    }
     wait_vmcnt<NLOAD>();
     __builtin_amdgcn_s_barrier();
 
@@ -331,6 +401,7 @@ __global__ __launch_bounds__(256, 1) void xcorr_mfma_kernel(XcorrParams p) {
         r_start = __builtin_amdgcn_s_memrealtime();
     }
     for (int s = 0; s < nstage; s++) {
+        if (RAW) raw_next_stage();
 #pragma unroll
         for (int j = 0; j < KT_STAGE; j++) {
             if (!(ABL & 1)) {
@@ -355,7 +426,7 @@ __global__ __launch_bounds__(256, 1) void xcorr_mfma_kernel(XcorrParams p) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // MFMA
                 __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                   // VALU
                 if (i == 1 || i == 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read (LDS-DMA)
-                if (i >= 8 && i < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+                if (RAW ? (i >= 8) : (i >= 8 && i < 12)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
             }
         }
         if (!(ABL & 8)) {

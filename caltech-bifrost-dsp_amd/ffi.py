@@ -45,6 +45,7 @@ SYMBOLS = {
     "xengXgpuCorrelate": [_vp, _vp, _i], "xengXgpuGetOrder": [_vp, _vp, _vp],
     "xengXgpuSubSelect": [_vp, _vp, _vp, _vp, _i, _i], "xengXgpuReorder": [_vp, _vp, _vp, _vp],
     "xengXgpuGetInfo": [_pi, _pi, _pi, _pi, ctypes.POINTER(ctypes.c_int64), _pi],
+    "xengXgpuGetPath": [_pi, _pi],
     "xengXgpuSetProfiling": [_i], "xengXgpuGetTimes": [ctypes.POINTER(ctypes.c_double), _pi],
     "xengMapAssignI32": [_vp, _vp, _sz], "xengMapAddI32": [_vp, _vp, _sz], "xengMapSync": [],
     "xengBeamformInitialize": [_i, _i, _i, _i, _i, _i], "xengBeamformDestroy": [],

@@ -102,8 +102,11 @@ int xengXgpuDestroy(void);
  * consumed and, if doDump, the output is complete. */
 int xengXgpuKernel(const void *in_dev, void *out_dev, int doDump);
 
-/* Same, but enqueue only: the caller must keep in_dev valid and call xengXgpuSync before reading
- * out_dev or recycling in_dev.  (No reference counterpart; used to pipeline gulps of one integration.) */
+/* Same, but enqueue only: the caller must keep in_dev valid AND UNCHANGED until the dump that consumes
+ * it has completed (xengXgpuSync, or xengXgpuSyncLag covering that dump) before reading out_dev or
+ * recycling in_dev.  On the default path the contraction kernel reads the gulps in place at dump time
+ * (corner turn fused into its LDS staging): no copy of the gulp is made, in_dev must be 16-byte
+ * aligned.  (No reference counterpart; this is how a ring-resident pipeline streams gulps.) */
 int xengXgpuKernelAsync(const void *in_dev, void *out_dev, int doDump);
 int xengXgpuSync(void);
 /* Wait until all but the last `lag` (0..3) dumps are complete -- lag 1 lets a streaming caller enqueue
@@ -136,6 +139,11 @@ int xengXgpuReorder(const void *in_host, void *out_host, const int32_t *antpol_t
 
 /* sizes of the current context */
 int xengXgpuGetInfo(int *nstand, int *npol, int *nchan, int *ntime_gulp, int64_t *matlen, int *max_gulps);
+
+/* which contraction path the current context runs: fused_corner_turn = 1 when gulps are read in place
+ * (ninput % 16 == 0, ntime_gulp % 96 == 0, not disabled with XENG_RAW=0), else the two-pass path
+ * (corner turn into a fragment-major staging area); fp6 = 1 for the opt-in XENG_MFMA=fp6 experiment. */
+int xengXgpuGetPath(int *fused_corner_turn, int *fp6);
 
 /* profiling: HIP events around each kernel on the context's stream.  GetTimes returns and clears
  * the totals (ms) and launch counts since the last call: [0]=corner-turn, [1]=MFMA X-engine. */

@@ -53,6 +53,12 @@ class Xgpu:
             ffi.call("xengXgpuSync")
         return self.out.download(np.int32)
 
+    def path(self):
+        """(fused_corner_turn, fp6) of the live context."""
+        a, b = ctypes.c_int(), ctypes.c_int()
+        ffi.call("xengXgpuGetPath", ctypes.byref(a), ctypes.byref(b))
+        return a.value, b.value
+
     def close(self):
         ffi.call("xengXgpuDestroy")
         self.out.free()

@@ -32,6 +32,7 @@ def test_corner_turn_layout(gpu):
     samples kt*32+16h+[0,16) of input ib*64+sub*32+r (as a set: the order inside a fragment is free)."""
     nstand, nchan, ntime = 48, 3, 80      # 96 inputs -> 2 blocks (second half padded); 80 = 2.5 K tiles
     x = gpu.Xgpu(nstand, nchan, ntime, max_gulps=2)
+    assert x.path() == (0, 0)             # 80 samples per gulp: not whole 96-sample stages -> two-pass path
     vin = gpu.synth_voltages(ntime, nchan, nstand, "full", seed=3)
     x.inbuf = gpu.ffi.DeviceBuffer(vin.size).upload(vin)
     gpu.ffi.call("xengXgpuKernelAsync", x.inbuf.ptr, x.out.ptr, 0)
@@ -137,6 +138,62 @@ def test_parity_vs_oracle(gpu, nstand, nchan, ntime, ngulp, kind):
     x.close()
 
 
+@pytest.mark.parametrize("nstand,nchan,ntime,ngulp,kind", [
+    (32, 8, 96, 3, "full"),          # one full 64-input block
+    (40, 3, 96, 2, "full"),          # 80 inputs: last block has one live 16-byte chunk (clamped source columns)
+    (64, 5, 192, 2, "random"),       # 2 blocks, 2 stages per gulp, nchan not a multiple of 8
+    (96, 3, 96, 4, "88"),            # 3 blocks, every nibble -8
+    (160, 2, 288, 2, "full"),        # 5 blocks (odd)
+    (224, 1, 96, 1, "full"),         # 7 blocks, a single stage: the pipeline prologue covers all of K
+    (80, 8, 480, 2, "full"),         # the reference gulp length; 2.5 blocks
+])
+def test_parity_fused_corner_turn(gpu, nstand, nchan, ntime, ngulp, kind):
+    """Default path when gulps are whole 96-sample stages: the contraction kernel reads the time-major
+    gulps in place (async) or a raw copy (sync) and transposes in LDS.  Same words as the oracle, and as
+    the two-pass path (XENG_RAW=0) on the same input."""
+    vin = gpu.synth_voltages(ntime * ngulp, nchan, nstand, kind, seed=nstand + ntime)
+    exp = oracle_run(vin, nstand, nchan, ntime)
+    x = gpu.Xgpu(nstand, nchan, ntime)
+    assert x.path() == (1, 0)
+    assert np.array_equal(x.run(vin), exp)                     # synchronous drop-in calls
+    assert np.array_equal(x.run(vin, use_async=True), exp)     # in place
+    x.close()
+    os.environ["XENG_RAW"] = "0"
+    try:
+        x = gpu.Xgpu(nstand, nchan, ntime)
+        assert x.path() == (0, 0)
+        assert np.array_equal(x.run(vin, use_async=True), exp)
+        x.close()
+    finally:
+        del os.environ["XENG_RAW"]
+
+
+def test_fused_mixed_sync_async_and_early_flush(gpu):
+    """One integration fed by both call flavours, longer than the staging depth: the first flush (3 gulps)
+    and the dump (2 gulps) accumulate into the same span; sync gulps are copied, async ones read in place."""
+    nstand, nchan, ntime, ngulp = 64, 8, 96, 5
+    x = gpu.Xgpu(nstand, nchan, ntime, max_gulps=3)
+    assert x.path() == (1, 0)
+    vin = gpu.synth_voltages(ntime * ngulp, nchan, nstand, "full", seed=11)
+    x.inbuf = gpu.ffi.DeviceBuffer(vin.size).upload(vin)
+    scratch = gpu.ffi.DeviceBuffer(x.gulp_bytes)
+    for g in range(ngulp):
+        src = x.inbuf.ptr + g * x.gulp_bytes
+        if g % 2 == 0:
+            gpu.ffi.call("xengXgpuKernelAsync", src, x.out.ptr, int(g == ngulp - 1))
+        else:
+            # sync: the caller's buffer is recycled right after the call returns
+            gpu.ffi.call("xengMemcpy", scratch.ptr, src, x.gulp_bytes)
+            gpu.ffi.call("xengXgpuKernel", scratch.ptr, x.out.ptr, 0)
+            gpu.ffi.call("xengMemset", scratch.ptr, 0xEE, x.gulp_bytes)
+    gpu.ffi.call("xengXgpuSync")
+    assert np.array_equal(x.out.download(np.int32), oracle_run(vin, nstand, nchan, ntime))
+    with pytest.raises(gpu.ffi.XengError):                      # in-place reads are 16-byte loads
+        gpu.ffi.call("xengXgpuKernelAsync", x.inbuf.ptr + 4, x.out.ptr, 0)
+    x.close()
+    scratch.free()
+
+
 def test_mid_integration_flush_accumulates(gpu):
     """Staging depth 2 with 5 gulps: the library flushes early (overwrite), later flushes
     read-modify-write the caller's buffer; the dumped result is still the 5-gulp sum, and the
@@ -202,10 +259,20 @@ def test_config2_full_size(gpu):
     """BASELINE config 2: 704 inputs, 96 channels, 5 gulps of 480 (acc_len 2400), bit-exact vs the
     C oracle on every word of both planes -- random bytes (the golden generator), then all-0x88."""
     nstand, nchan, ntime, ngulp = 352, 96, 480, 5
-    x = gpu.Xgpu(nstand, nchan, ntime)
     vin = gpu.synth_voltages(ntime * ngulp, nchan, nstand, "random")
-    got = x.run(vin)
     exp = oracle_run(vin, nstand, nchan, ntime)
+    os.environ["XENG_RAW"] = "0"                # the two-pass path (corner turn + fragment-major staging)
+    try:
+        x = gpu.Xgpu(nstand, nchan, ntime)
+        assert x.path() == (0, 0)
+        assert np.array_equal(x.run(vin), exp)
+        x.close()
+    finally:
+        del os.environ["XENG_RAW"]
+    x = gpu.Xgpu(nstand, nchan, ntime)          # default: gulps read in place, corner turn fused
+    assert x.path() == (1, 0)
+    assert np.array_equal(x.run(vin, use_async=True), exp)
+    got = x.run(vin)
     assert np.array_equal(got, exp)
     # size-independent properties at full size: autos are real and positive, planes have the xGPU length
     matlen = 96 * 249216                       # SURVEY 8: per_chan = 249216 words per plane per channel
@@ -219,12 +286,14 @@ def test_config2_full_size(gpu):
     x.close()
 
 
-def test_streaming_lagged_sync_two_outputs(gpu):
+@pytest.mark.parametrize("ntime,fused", [(64, 0), (96, 1)])
+def test_streaming_lagged_sync_two_outputs(gpu, ntime, fused):
     """The streaming call pattern of bench.py: integration n+1 is enqueued (into the other output
     span) before the caller waits for dump n with xengXgpuSyncLag(1).  Every dumped span must equal
     the oracle, i.e. the double-buffered staging areas / three streams keep their ordering."""
-    nstand, nchan, ntime, ngulp, nint = 80, 8, 64, 3, 7
+    nstand, nchan, ngulp, nint = 80, 8, 3, 7
     x = gpu.Xgpu(nstand, nchan, ntime, max_gulps=ngulp)
+    assert x.path() == (fused, 0)
     outs = [x.out, gpu.ffi.DeviceBuffer(x.out.nbytes)]
     vin = gpu.synth_voltages(ntime * ngulp * nint, nchan, nstand, "full", seed=77).reshape(nint, ngulp, -1)
     din = gpu.ffi.DeviceBuffer(vin.size).upload(vin)
