@@ -453,16 +453,28 @@ __global__ __launch_bounds__(256, 1) void xcorr_mfma_kernel(XcorrParams p) {
     // the cell of station 2Rh+1; the two words each is missing (the other polC) come from its partner
     // lane by DPP (quad_perm [1,0,3,2]):
     //   even: {v0, odd.v0, v1, odd.v1}     odd: {even.v2, v2, even.v3, v3}
+    //
+    // A lane quad 4k..4k+3 then holds the four quadrants of column station pair k, i.e. four cells that lie
+    // a quarter of the matrix apart, while the cells of one quadrant and eight consecutive column pairs are
+    // contiguous (8 x 16 B = one 128-byte run).  Each 16-byte store of a lane would be its own request to
+    // L2; so the cells are first moved across lanes (ds_bpermute: lane 8q+k takes the cell of lane 4k+q in
+    // its 32-lane half) and every 8 adjacent lanes write one contiguous run.
     const int qs = (int)(((int64_t)(p.nstand / 2 + 1) * p.nstand) / 4);
     int32_t* out_r = p.out + (int64_t)c * p.per_chan;
     int32_t* out_i = out_r + p.matlen;
     const int odd = lane & 1;
-    const int cpar = (lane >> 1) & 1;          // C & 1 of this lane's column station
-    const int quad = 2 * cpar + odd;           // quadrant of the cell this lane stores
     auto cell = [&](int v0, int v1, int v2, int v3) {
         const int g0 = dpp_xor1(odd ? v0 : v2), g1 = dpp_xor1(odd ? v1 : v3);
         return odd ? make_int4(g0, v2, g1, v3) : make_int4(v0, g0, v1, g1);
     };
+    const int pull = ((lane & 32) | (4 * (lane & 7) + ((lane >> 3) & 3))) * 4;   // byte address of the source lane
+    auto regroup = [&](int4 v) {
+        return make_int4(__builtin_amdgcn_ds_bpermute(pull, v.x), __builtin_amdgcn_ds_bpermute(pull, v.y),
+                         __builtin_amdgcn_ds_bpermute(pull, v.z), __builtin_amdgcn_ds_bpermute(pull, v.w));
+    };
+    // identity of the cell this lane stores after the regrouping
+    const int quad = (lane >> 3) & 3;          // 2*(C&1) + (R&1)
+    const int cpar = quad >> 1, rpar = quad & 1;
     // interior tiles (strictly below the block diagonal, no padded inputs) need no per-cell mask
     const bool interior = __builtin_amdgcn_readfirstlane((int)(blk_a > blk_b && blk_a * 64 + 64 <= 2 * p.nstand)) != 0;
     const bool accumulate = p.accumulate != 0;
@@ -472,21 +484,21 @@ __global__ __launch_bounds__(256, 1) void xcorr_mfma_kernel(XcorrParams p) {
         for (int n = 0; n < 2; n++) {
             if (m == 0 && n == 1 && skip01) continue;      // never stored (and not computed) on diagonal tiles
             const int ibase = blk_a * 64 + m * 32, jbase = blk_b * 64 + n * 32;
-            const int Ch = (jbase >> 2) + ((lane & 31) >> 2);
+            const int Ch = (jbase >> 2) + (lane & 7);
             const int C = 2 * Ch + cpar;
             const int wcol = (quad * qs + Ch) * 4;
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int Rh = (ibase >> 2) + 2 * u + (lane >> 5);
-                const int R = 2 * Rh + odd;
+                const int R = 2 * Rh + rpar;
                 int vr[4], vi[4];
 #pragma unroll
                 for (int v = 0; v < 4; v++) {
                     vr[v] = accR[m][n][4 * u + v] >> 8;
                     vi[v] = (accP[m][n][4 * u + v] - accQ[m][n][4 * u + v]) >> 8;
                 }
-                int4 cr = cell(vr[0], vr[1], vr[2], vr[3]);
-                int4 ci = cell(vi[0], vi[1], vi[2], vi[3]);
+                int4 cr = regroup(cell(vr[0], vr[1], vr[2], vr[3]));
+                int4 ci = regroup(cell(vi[0], vi[1], vi[2], vi[3]));
                 const int w = wcol + ((Rh * (Rh + 1)) >> 1) * 4;
                 int4* pr = reinterpret_cast<int4*>(out_r + w);
                 int4* pi = reinterpret_cast<int4*>(out_i + w);
