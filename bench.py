@@ -59,9 +59,13 @@ def cpu_baseline(budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    # steady state of the streaming pipeline is reached after ~100 integrations (clock ramp, launch overlap
+    # pattern): the defaults time 1000 integrations (0.22 s) after 200 untimed ones
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--ring-gulps", type=int, default=10, help="device-resident replay ring depth (gulps)")
+    ap.add_argument("--lag", type=int, default=1, choices=[1, 2, 3],
+                    help="streaming depth: after enqueueing integration n wait for dump n-lag (lag+1 output spans)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d", dest="h2d", action="store_false", help="skip the PCIe-inclusive measurement")
     ap.add_argument("--no-beamform", dest="beamform", action="store_false", help="skip the config-4 beamformer leg")
@@ -105,7 +109,8 @@ def main():
         else:
             blk = np.full(gulp_bytes, 0 if args.data == "zeros" else 0x88, dtype=np.uint8)
         ring.upload(blk, offset=g * gulp_bytes)
-    outs = [ffi.DeviceBuffer(2 * matlen * 4) for _ in range(2)]     # output spans alternate, as ring spans do
+    nout = args.lag + 1
+    outs = [ffi.DeviceBuffer(2 * matlen * 4) for _ in range(max(2, nout))]     # output spans rotate, as ring spans do
     kern = "xengXgpuKernel" if args.sync_per_call else "xengXgpuKernelAsync"
     L = ffi.lib()
     kfn = getattr(L, kern)
@@ -114,14 +119,14 @@ def main():
     elif args.sync_per_integration:
         call_mode = "enqueue gulps, sync per integration"
     else:
-        call_mode = "streaming: enqueue integration n+1, then wait for dump n (xengXgpuSyncLag(1))"
+        call_mode = "streaming: enqueue integration n, then wait for dump n-%d (xengXgpuSyncLag(%d)), %d output spans" % (args.lag, args.lag, nout)
 
     gi = [0]
     si = [0]
     units_per_step_c = ACC_LEN * NCHAN
 
     def step():
-        out = outs[si[0] & 1]
+        out = outs[si[0] % nout]
         si[0] += 1
         for g in range(gulps_per_step):
             rc = kfn(ring.ptr + (gi[0] % args.ring_gulps) * gulp_bytes, out.ptr, int(g == gulps_per_step - 1))
@@ -131,7 +136,7 @@ def main():
         if args.sync_per_call:
             return
         # the span of dump n-1 (or n) is complete before it would be committed downstream
-        rc = L.xengXgpuSync() if args.sync_per_integration else L.xengXgpuSyncLag(1)
+        rc = L.xengXgpuSync() if args.sync_per_integration else L.xengXgpuSyncLag(args.lag)
         if rc:
             ffi.check("xengXgpuSync", rc)
 

@@ -90,6 +90,7 @@ struct XgpuContext {
     bool live = false;
     int gpu = 0;
     XgpuConfig cfg;
+    int ncu = 256;
     int ninput = 0, nblk64 = 0, gkt = 0, cap_kt = 0, cap_gulps = 0, kt_stage = 1;
     int ct_pitch = 0;          // LDS row pitch of the transposing corner turn (0: register-only fallback)
     // raw: no corner-turn pass.  The contraction kernel reads time-major gulps in place and transposes in
@@ -109,13 +110,20 @@ struct XgpuContext {
     WgDesc* descs_dev = nullptr;
     int nwg = 0;
     hipStream_t stream = nullptr;              // corner turns (+ H2D of the host-buffer variant)
-    hipStream_t stream_mm2[2] = {nullptr, nullptr};   // MFMA contraction of staging area b: alternating
-                                               // streams let the tail of one launch fill with the next
+    // MFMA contractions rotate over nmm streams: consecutive launches are independent (unless they touch the
+    // same output span), so the tail of one fills with the next.  Two is the measured optimum (three or
+    // four streams: -5 %, HIP maps them onto the same few hardware queues as the other streams).
+    static constexpr int NMM = 4;
+    hipStream_t stream_mm2[NMM] = {};
+    int nmm = 2;
+    unsigned long long nlaunch = 0;
     hipStream_t stream_mm = nullptr;           // = stream_mm2[0] (sub-selection, D2H)
-    void* last_out[2] = {nullptr, nullptr};    // output buffer of the last contraction on each stream
+    void* last_out[NMM] = {};                  // output buffer of the last contraction on each stream
+    hipEvent_t ev_last[NMM] = {};              // ... and its completion
+    bool mm_used[NMM] = {};
     hipEvent_t ev_ct = nullptr;                // staged gulps of the area about to be contracted are complete
     hipEvent_t ev_mm[2] = {nullptr, nullptr};  // the contraction reading staging area b is complete
-    bool mm_used[2] = {false, false};
+    bool area_used[2] = {false, false};
     hipEvent_t ev_dump[4] = {nullptr, nullptr, nullptr, nullptr};   // completion of the last dumps
     unsigned long long ndump = 0;
     // integration state
@@ -138,8 +146,10 @@ static int destroy_locked() {
     if (!x.live) return XENG_STATUS_SUCCESS;
     (void)hipSetDevice(x.gpu);
     if (x.stream) (void)hipStreamSynchronize(x.stream);
-    for (int b = 0; b < 2; b++)
+    for (int b = 0; b < XgpuContext::NMM; b++) {
         if (x.stream_mm2[b]) (void)hipStreamSynchronize(x.stream_mm2[b]);
+        if (x.ev_last[b]) (void)hipEventDestroy(x.ev_last[b]);
+    }
     for (int b = 0; b < 2; b++) {
         if (x.stash[b]) (void)hipFree(x.stash[b]);
         if (x.ev_mm[b]) (void)hipEventDestroy(x.ev_mm[b]);
@@ -158,11 +168,30 @@ static int destroy_locked() {
 
 template <int ABL>
 static void launch_abl(const XcorrParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_mfma_kernel<ABL, false>), dim3(p.nchan * p.nwg), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_mfma_kernel<ABL>), dim3(p.nchan * p.nwg), dim3(256), 0, s, p);
 }
-static void launch_xcorr(const XcorrParams& p, hipStream_t s, bool raw) {
+// persistent grid of the fused kernel: one work-group per CU, a multiple of 8 when channels are dealt per XCD
+static int fused_grid(int nchan, int nwg, int ncu) {
+    const int nitems = nchan * nwg;
+    if ((nchan & 7) == 0 && ncu >= 8) return 8 * std::min(ncu / 8, (nchan / 8) * nwg);
+    return std::min(ncu, nitems);
+}
+static void launch_xcorr(const XcorrParams& p, hipStream_t s, bool raw, int ncu) {
     if (raw) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_mfma_kernel<0, true>), dim3(p.nchan * p.nwg), dim3(256), 0, s, p);
+        const dim3 grid(fused_grid(p.nchan, p.nwg, ncu));
+#ifdef XENG_DIAGNOSTICS
+        static const int fabl = getenv("XENG_ABLATE") ? atoi(getenv("XENG_ABLATE")) : 0;
+        switch (fabl) {
+            case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<1>), grid, dim3(256), 0, s, p); return;
+            case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<2>), grid, dim3(256), 0, s, p); return;
+            case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<4>), grid, dim3(256), 0, s, p); return;
+            case 8: hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<8>), grid, dim3(256), 0, s, p); return;
+            case 9: hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<9>), grid, dim3(256), 0, s, p); return;
+            case 15: hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<15>), grid, dim3(256), 0, s, p); return;
+            default: break;
+        }
+#endif
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<0>), grid, dim3(256), 0, s, p);
         return;
     }
 #ifdef XENG_DIAGNOSTICS
@@ -215,21 +244,24 @@ static int flush_locked(void* out, bool dump) {
     p.ninput = x.ninput;
     for (int g = 0; g < XC_MAX_GULPS; g++) p.gulps[g] = g < x.nfilled ? x.gulp_ptr[g] : nullptr;
     // the contraction starts when this area's corner turns are done and runs beside the next area's
-    hipStream_t smm = x.stream_mm2[x.cur];
+    const int si = (int)(x.nlaunch++ % x.nmm);
+    hipStream_t smm = x.stream_mm2[si];
     XENG_HIP(hipEventRecord(x.ev_ct, x.stream));
     XENG_HIP(hipStreamWaitEvent(smm, x.ev_ct, 0));
     // contractions that touch the same output (partial sums of one integration, or a caller that
     // reuses one buffer for consecutive integrations) stay ordered; independent ones may overlap
-    if (x.mm_used[x.cur ^ 1] && (x.acc_started || x.last_out[x.cur ^ 1] == out))
-        XENG_HIP(hipStreamWaitEvent(smm, x.ev_mm[x.cur ^ 1], 0));
+    for (int t = 0; t < x.nmm; t++)
+        if (t != si && x.mm_used[t] && x.last_out[t] == out) XENG_HIP(hipStreamWaitEvent(smm, x.ev_last[t], 0));
     int slot = x.timer.begin(smm, 1);
     if (x.fp6) hipLaunchKernelGGL(xcorr_fp6_kernel, dim3(p.nchan * p.nwg), dim3(256), 0, smm, p);
-    else launch_xcorr(p, smm, x.raw);
+    else launch_xcorr(p, smm, x.raw, x.ncu);
     x.timer.end(smm, slot);
     XENG_HIP(hipGetLastError());
     XENG_HIP(hipEventRecord(x.ev_mm[x.cur], smm));
-    x.mm_used[x.cur] = true;
-    x.last_out[x.cur] = out;
+    XENG_HIP(hipEventRecord(x.ev_last[si], smm));
+    x.area_used[x.cur] = true;
+    x.mm_used[si] = true;
+    x.last_out[si] = out;
     if (dump) {
         XENG_HIP(hipEventRecord(x.ev_dump[x.ndump & 3], smm));
         x.ndump++;
@@ -248,7 +280,7 @@ static int kernel_locked(const void* in_dev, void* out_dev, int doDump, bool syn
     if (((uintptr_t)out_dev & 15) || ((uintptr_t)in_dev & (x.raw ? 15 : 3)))
         XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "xgpu: out must be 16-byte and in %d-byte aligned", x.raw ? 16 : 4);
     XENG_HIP(hipSetDevice(x.gpu));
-    if (x.nfilled == 0 && x.mm_used[x.cur])   // this staging area may still be read by an earlier contraction
+    if (x.nfilled == 0 && x.area_used[x.cur])   // this staging area may still be read by an earlier contraction
         XENG_HIP(hipStreamWaitEvent(x.stream, x.ev_mm[x.cur], 0));
     uint8_t* const stash = x.stash[x.cur];
     int slot = -1;
@@ -294,8 +326,7 @@ static int kernel_locked(const void* in_dev, void* out_dev, int doDump, bool syn
         // input consumed = its corner turn is done; on a dump the output must be complete too
         XENG_HIP(hipStreamSynchronize(x.stream));
         if (doDump) {
-            XENG_HIP(hipStreamSynchronize(x.stream_mm2[0]));
-            XENG_HIP(hipStreamSynchronize(x.stream_mm2[1]));
+            for (int t = 0; t < x.nmm; t++) XENG_HIP(hipStreamSynchronize(x.stream_mm2[t]));
             x.timer.drain();
         }
     }
@@ -327,6 +358,13 @@ int xengXgpuInitialize(int gpu) {
     x.cfg = g_cfg;
     x.gpu = gpu < 0 ? 0 : gpu;
     XENG_HIP(hipSetDevice(x.gpu));
+    {
+        int ncu = 0;
+        XENG_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, x.gpu));
+        const char* e = getenv("XENG_GRID");          // experiment: persistent grid size
+        x.ncu = e ? atoi(e) : ncu;
+        if (x.ncu < 1) x.ncu = 1;
+    }
     x.ninput = x.cfg.nstand * x.cfg.npol;
     x.nblk64 = (x.ninput + 63) / 64;
     x.gkt = (x.cfg.ntime_gulp + 31) / 32;
@@ -380,11 +418,12 @@ int xengXgpuInitialize(int gpu) {
     XENG_HIP(hipMemcpy(x.descs_dev, descs.data(), descs.size() * sizeof(WgDesc), hipMemcpyHostToDevice));
     int rc = get_stream(STREAM_XGPU, &x.stream);
     if (rc) return rc;
-    rc = get_stream(STREAM_XGPU_MM, &x.stream_mm2[0]);
-    if (rc) return rc;
-    rc = get_stream(STREAM_XGPU_MM2, &x.stream_mm2[1]);
-    if (rc) return rc;
-    if (getenv("XENG_ONE_MM_STREAM")) x.stream_mm2[1] = x.stream_mm2[0];   // experiment: no tail overlap
+    for (int t = 0; t < XgpuContext::NMM; t++) {
+        rc = get_stream((StreamId)(STREAM_XGPU_MM + t), &x.stream_mm2[t]);
+        if (rc) return rc;
+        XENG_HIP(hipEventCreateWithFlags(&x.ev_last[t], hipEventDisableTiming));
+    }
+    if (const char* e = getenv("XENG_MM_STREAMS")) x.nmm = std::max(1, std::min(XgpuContext::NMM, atoi(e)));   // experiment
     x.stream_mm = x.stream_mm2[0];
     if (getenv("XENG_DBG_STAMPS")) {
         XENG_HIP(hipMalloc((void**)&x.stamps, (size_t)x.cfg.nchan * x.nwg * 4 * 8 * sizeof(unsigned long long)));
@@ -415,8 +454,7 @@ int xengXgpuSync(void) {
     if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized");
     XENG_HIP(hipSetDevice(x.gpu));
     XENG_HIP(hipStreamSynchronize(x.stream));
-    XENG_HIP(hipStreamSynchronize(x.stream_mm2[0]));
-    XENG_HIP(hipStreamSynchronize(x.stream_mm2[1]));
+    for (int t = 0; t < x.nmm; t++) XENG_HIP(hipStreamSynchronize(x.stream_mm2[t]));
     x.timer.drain();
     return XENG_STATUS_SUCCESS;
 }
@@ -439,8 +477,7 @@ int xengXgpuReset(void) {
     if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized");
     XENG_HIP(hipSetDevice(x.gpu));
     XENG_HIP(hipStreamSynchronize(x.stream));
-    XENG_HIP(hipStreamSynchronize(x.stream_mm2[0]));
-    XENG_HIP(hipStreamSynchronize(x.stream_mm2[1]));
+    for (int t = 0; t < x.nmm; t++) XENG_HIP(hipStreamSynchronize(x.stream_mm2[t]));
     x.timer.drain();
     x.nfilled = 0;
     x.acc_started = false;
@@ -463,8 +500,7 @@ int xengXgpuCorrelate(const void* in_host, void* out_host, int doDump) {
     if (rc) return rc;
     if (doDump) {
         XENG_HIP(hipMemcpyAsync(out_host, x.out_dev, out_bytes, hipMemcpyDeviceToHost, x.stream_mm));
-        XENG_HIP(hipStreamSynchronize(x.stream_mm2[0]));
-    XENG_HIP(hipStreamSynchronize(x.stream_mm2[1]));
+        for (int t = 0; t < x.nmm; t++) XENG_HIP(hipStreamSynchronize(x.stream_mm2[t]));
     }
     return XENG_STATUS_SUCCESS;
 }
@@ -516,8 +552,7 @@ int xengXgpuSubSelect(const void* in_dev, void* out_dev, const int32_t* vismap_d
                        (const int32_t*)in_dev, (int32_t*)out_dev, vismap_dev, conj_dev, nvis, nchan_sum,
                        x.per_chan, x.matlen);
     XENG_HIP(hipGetLastError());
-    XENG_HIP(hipStreamSynchronize(x.stream_mm2[0]));
-    XENG_HIP(hipStreamSynchronize(x.stream_mm2[1]));
+    for (int t = 0; t < x.nmm; t++) XENG_HIP(hipStreamSynchronize(x.stream_mm2[t]));
     return XENG_STATUS_SUCCESS;
 }
 
@@ -578,8 +613,7 @@ int xengXgpuGetTimes(double ms[2], int count[2]) {
     XgpuContext& x = g_ctx;
     if (x.live && x.stream) {
         XENG_HIP(hipStreamSynchronize(x.stream));
-        XENG_HIP(hipStreamSynchronize(x.stream_mm2[0]));
-    XENG_HIP(hipStreamSynchronize(x.stream_mm2[1]));
+        for (int t = 0; t < x.nmm; t++) XENG_HIP(hipStreamSynchronize(x.stream_mm2[t]));
         x.timer.drain();
     }
     for (int k = 0; k < 2; k++) {
@@ -598,8 +632,7 @@ int xengXgpuDebugReadStamps(unsigned long long* host, size_t nwords, int* nwaves
     if (!x.live || !x.stamps) XENG_FAIL(XENG_STATUS_INVALID_STATE, "stamps not enabled");
     const size_t n = (size_t)x.cfg.nchan * x.nwg * 4 * 8;
     if (nwaves) *nwaves = x.cfg.nchan * x.nwg * 4;
-    XENG_HIP(hipStreamSynchronize(x.stream_mm2[0]));
-    XENG_HIP(hipStreamSynchronize(x.stream_mm2[1]));
+    for (int t = 0; t < x.nmm; t++) XENG_HIP(hipStreamSynchronize(x.stream_mm2[t]));
     if (host) XENG_HIP(hipMemcpy(host, x.stamps, std::min(nwords, n) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return XENG_STATUS_SUCCESS;
 }

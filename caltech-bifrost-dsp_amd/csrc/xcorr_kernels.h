@@ -220,245 +220,27 @@ __device__ __forceinline__ Frags unpack_frags(const RawFrags& r) {
 }
 
 constexpr int XC_KT = 3;      // K-tiles (32 samples each) per LDS stage
-constexpr int XC_RING = 4;    // LDS ring depth (stages)
+constexpr int XC_RING = 4;    // LDS ring depth (stages), two-pass kernel
+#ifndef XF_DEPTH
+#define XF_DEPTH 5            // fused kernel: stages of LDS-DMA in flight ahead of the MFMAs (ring = XF_DEPTH+1 stages of 24 KiB)
+#endif
 
-// ABL: timing-only ablation bits (results are wrong unless ABL == 0): 1 no LDS-DMA in the loop,
-// 2 no nibble unpack, 4 no LDS reads in the loop, 8 no barrier/vmcnt wait in the loop.
+// ---- epilogue shared by both contraction kernels: D[i][j] = sum x_i conj(x_j), lane = column j,
+// register = row i.  MFMA C/D map (32x32): col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+// Registers 4u..4u+3 of a lane are (station 2Rh, pol 0/1), (station 2Rh+1, pol 0/1) of one column
+// (station C, pol = lane&1).  The even lane of a pair assembles the cell of station 2Rh, the odd lane
+// the cell of station 2Rh+1; the two words each is missing (the other polC) come from its partner
+// lane by DPP (quad_perm [1,0,3,2]):
+//   even: {v0, odd.v0, v1, odd.v1}     odd: {even.v2, v2, even.v3, v3}
 //
-// RAW = false: operands come from the fragment-major staging area written by the corner turn.
-// RAW = true : the corner turn is fused into the LDS staging.  The kernel reads the gulps where they lie
-//   (time-major rows of ninput bytes per channel): per stage and 64-input block the LDS-DMA brings 96 rows
-//   x 64 bytes (six 1 KiB pieces of 16 rows x four 16-byte chunks), and the operand fragments come out of
-//   LDS through ds_read_b64_tr_b8, the byte-transposing read (profiles/microbench/tr8_probe.hip): 16-lane
-//   group (h, rg) of a wave reads the 8x16 byte block rows 16h+8hh.., inputs 32 sub + 16 rg.. and lane r
-//   receives 8 consecutive samples of input r -- two reads make the 16 bytes of an MFMA operand register
-//   quad.  (Which samples sit in which byte does not matter: A and B use the same map.)  The 64-byte row
-//   pitch would put rows q and q+4 on the same banks, so chunk j of row t is stored at chunk position
-//   j ^ 2*((t>>2)&1): applied to the per-lane DMA source address (the LDS side of the DMA is linear) and
-//   to the read address; the 32 lanes of a read phase then cover 32 distinct even banks.
-template <int ABL, bool RAW>
-__global__ __launch_bounds__(256, 1) void xcorr_mfma_kernel(XcorrParams p) {
-    constexpr int KT_STAGE = XC_KT;
-    constexpr int SLOT_BYTES = KT_STAGE * KT_BYTES;
-    constexpr int STAGE_BYTES = XC_NSLOT * SLOT_BYTES;
-    constexpr int NLOAD = 2 * KT_STAGE;  // 1 KiB LDS-DMA pieces per wave per stage
-    __shared__ __attribute__((aligned(16))) uint8_t lds[XC_RING * STAGE_BYTES];
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned long long r_entry = p.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
-
-    // block -> (channel, work-group).  Blocks b and b+8 share an XCD (round-robin dispatch),
-    // so give each XCD whole channels: all tiles of a channel then stream the same stash
-    // rows through one L2.  Placement only affects speed.
-    int c, wg;
-    {
-        const int b = blockIdx.x;
-        if ((p.nchan & 7) == 0) {
-            const int xcd = b & 7, slot = b >> 3;
-            c = xcd + 8 * (slot / p.nwg);
-            wg = slot % p.nwg;
-        } else {
-            c = b / p.nwg;
-            wg = b % p.nwg;
-        }
-    }
-    const WgDesc* dp = p.descs + wg;   // indexed in memory: no runtime-indexed register arrays
-    const int a_slot = dp->wave_a[wave], b_slot = dp->wave_b[wave];
-    const bool active = a_slot != 0xFF;
-    const int blk_a = active ? dp->slot_blk[a_slot] : 0, blk_b = active ? dp->slot_blk[b_slot] : 0;
-
-    // this wave stages 64-input block slot_blk[wave]: KT_STAGE*2 KiB contiguous per stage
-    const uint8_t* gsrc =
-        p.stash + ((size_t)c * p.nblk64 + dp->slot_blk[wave]) * (size_t)p.cap_kt * KT_BYTES + lane * 16;
-    const int nstage = p.nkt / KT_STAGE;
-    // RAW: slots are staged in pairs (0,1) and (2,3): the LDS image of a pair and stage is [96 rows][128 B]
-    // (slot parity = 64-byte half), chunk position = chunk ^ 2*((row>>1)&3).  Wave w brings rows
-    // 48*(w&1).. of pair w>>1: a piece is 8 rows x 128 B, lane = 8*row + chunk position.  The tiling
-    // makes most pairs adjacent blocks (2k, 2k+1), whose two halves then form whole 128-byte lines:
-    // half as many L2 requests as 64-byte row segments.
-    // (columns past ninput in the last block: any valid bytes of the row; their products are never stored)
-    const uint32_t row_stride = (uint32_t)p.nchan * (uint32_t)p.ninput;
-    const int raw_chunk = (lane & 7) ^ (((lane >> 4) & 3) << 1);          // source chunk 0..7 of the 128-byte pair row
-    const uint32_t raw_col = (uint32_t)dp->slot_blk[(wave & 2) + (raw_chunk >> 2)] * 64u + (uint32_t)(raw_chunk & 3) * 16u;
-    const uint32_t raw_lane_off = (uint32_t)(lane >> 3) * row_stride + (raw_col + 16u <= (uint32_t)p.ninput ? raw_col : 0u);
-
-    // RAW: scalar base address of the stage being issued, advanced once per stage (no divisions in the loop);
-    // it stays on the last real stage once K is exhausted
-    const uint8_t* raw_stage = nullptr;
-    int raw_g = 0, raw_sl = 0, raw_issued = 0;
-    auto raw_next_stage = [&]() {
-        raw_stage = p.gulps[raw_g] + ((size_t)(raw_sl * (KT_STAGE * 32)) * p.nchan + c) * (size_t)p.ninput;
-        if (++raw_issued < nstage) {
-            if (++raw_sl == p.spg) { raw_sl = 0; raw_g++; }
-        }
-    };
-    auto issue_piece = [&](int s, int n) {
-        const int ssrc = s < nstage ? s : nstage - 1;
-        const uint8_t* g;
-        if (RAW) {
-            g = raw_stage + (size_t)(48 * (wave & 1) + 8 * n) * row_stride + raw_lane_off;   // scalar base + 32-bit lane offset
-        } else {
-            g = gsrc + (size_t)ssrc * SLOT_BYTES + n * FRAG_BYTES;
-        }
-        uint8_t* l = lds + (s & (XC_RING - 1)) * STAGE_BYTES + wave * SLOT_BYTES + n * FRAG_BYTES;
-        if (RAW) {
-            // issued from asm: hipcc cannot prove that the transposing reads below do not alias a pending
-            // builtin LDS-DMA and would put `s_waitcnt vmcnt(0)` in front of every one of them; the
-            // counted vmcnt + barrier at the end of each stage is the real ordering
-            unsigned keep;
-            const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(const __attribute__((address_space(3))) void*)l);
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(g), "s"(la) : "memory");
-        } else {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-        }
-    };
-
-    v16i accR[2][2], accP[2][2], accQ[2][2];
-#pragma unroll
-    for (int m = 0; m < 2; m++)
-#pragma unroll
-        for (int n = 0; n < 2; n++) {
-            accR[m][n] = (v16i)(0);
-            accP[m][n] = (v16i)(0);
-            accQ[m][n] = (v16i)(0);
-        }
-
-    // Idle waves (a_slot == 0xFF) run the same loop on slot 0 and skip the epilogue: keeping the
-    // MFMA chain unconditional keeps the 192 accumulator registers in place (a wave-uniform
-    // branch around it makes hipcc shuttle them AGPR<->VGPR every stage).
-    // RAW: lane 16*grp + 2q + pp addresses row 16*(grp>>1) + q (+8 for the second read), chunk position
-    // (4*slot parity + 2*sub + (grp&1)) ^ 2*((q>>1)&3), bytes 8pp..8pp+7: slot parity flips address bit 6,
-    // sub = 1 flips bit 5.  Per 32-lane phase the 32 addresses fall on 32 distinct even banks.
-    const int tr_off = ((lane >> 5) * 16 + ((lane & 15) >> 1)) * 128 +
-                       (((lane >> 4) & 1) ^ (((lane >> 2) & 3) << 1)) * 16 + (lane & 1) * 8;
-    const int sa = active ? a_slot : 0, sb = active ? b_slot : 0;
-    const int a_off = RAW ? (sa >> 1) * (2 * SLOT_BYTES) + (tr_off ^ ((sa & 1) * 64)) : sa * SLOT_BYTES + lane * 16;
-    const int b_off = RAW ? (sb >> 1) * (2 * SLOT_BYTES) + (tr_off ^ ((sb & 1) * 64)) : sb * SLOT_BYTES + lane * 16;
-
-    // fragments of K-tile j (0..KT_STAGE-1) of stage s
-    auto load_raw = [&](int s, int j) {
-        const uint8_t* base = lds + (s & (XC_RING - 1)) * STAGE_BYTES + j * (RAW ? 2 * KT_BYTES : KT_BYTES);
-        RawFrags r;
-        if (RAW) {
-            auto tr = [&](int off) {
-                return __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) v2i*)(base + off));
-            };
-#pragma unroll
-            for (int sub = 0; sub < 2; sub++) {
-                const v2i a0 = tr(a_off ^ (sub * 32)), a1 = tr((a_off ^ (sub * 32)) + 1024);
-                const v2i b0 = tr(b_off ^ (sub * 32)), b1 = tr((b_off ^ (sub * 32)) + 1024);
-                r.a[sub] = (v4i){a0.x, a0.y, a1.x, a1.y};
-                r.b[sub] = (v4i){b0.x, b0.y, b1.x, b1.y};
-            }
-        } else {
-            r.a[0] = *reinterpret_cast<const v4i*>(base + a_off);
-            r.a[1] = *reinterpret_cast<const v4i*>(base + a_off + FRAG_BYTES);
-            r.b[0] = *reinterpret_cast<const v4i*>(base + b_off);
-            r.b[1] = *reinterpret_cast<const v4i*>(base + b_off + FRAG_BYTES);
-        }
-        return r;
-    };
-
-    // Diagonal wave tiles (row block == column block) never store the upper-right 32x32 MFMA tile
-    // (rows 0-31 x columns 32-63: Rh < Ch): skip its 4 MFMAs (wave-uniform branch; idle waves too).
-    const bool skip01 = __builtin_amdgcn_readfirstlane((int)(!active || blk_a == blk_b)) != 0;
-    auto mfma_tile = [&](const Frags& u) {
-#pragma unroll
-        for (int m = 0; m < 2; m++)
-#pragma unroll
-            for (int n = 0; n < 2; n++) {
-                if (m == 0 && n == 1 && skip01) continue;
-                accR[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(u.ar[m], u.br[n], accR[m][n], 0, 0, 0);
-                accP[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(u.ai[m], u.br[n], accP[m][n], 0, 0, 0);
-                accQ[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(u.ar[m], u.bi[n], accQ[m][n], 0, 0, 0);
-                accR[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(u.ai[m], u.bi[n], accR[m][n], 0, 0, 0);
-            }
-    };
-
-    // ---- software pipeline over K-tiles g = s*KT_STAGE + j ------------------------------------
-    //   MFMA(g)  ||  unpack(g+1)  ||  LDS read(g+2)  ||  LDS-DMA of stage s+3
-    // 4-deep LDS ring.  At the end of stage s every wave waits until its own pieces of stage s+2
-    // have landed (counted vmcnt: stage s+3 stays in flight), then one barrier: stages s+1 and s+2
-    // are now visible to all waves (the LDS reads two K-tiles ahead cross into the next stage), and
-    // everybody is done reading stage s, whose buffer the DMA of stage s+4 overwrites.
-#pragma unroll
-    for (int st = 0; st < 3; st++) {
-        if (RAW) raw_next_stage();
-#pragma unroll
-        for (int n = 0; n < NLOAD; n++) issue_piece(st, n);
-    }
-    wait_vmcnt<NLOAD>();
-    __builtin_amdgcn_s_barrier();
-
-    Frags cur = unpack_frags(load_raw(0, 0));
-    RawFrags raw = load_raw(0, 1);
-    unsigned long long t_start = 0, r_start = 0;
-    if (p.stamps) {   // diagnostic build path: shader clock vs 100 MHz reference (MI355X_MICROARCH, DVFS item 6)
-        t_start = __builtin_amdgcn_s_memtime();
-        r_start = __builtin_amdgcn_s_memrealtime();
-    }
-    for (int s = 0; s < nstage; s++) {
-        if (RAW) raw_next_stage();
-#pragma unroll
-        for (int j = 0; j < KT_STAGE; j++) {
-            if (!(ABL & 1)) {
-                issue_piece(s + 3, 2 * j);
-                issue_piece(s + 3, 2 * j + 1);
-            }
-            mfma_tile(cur);
-            if (ABL & 2) {
-#pragma unroll
-                for (int m = 0; m < 2; m++) { cur.ar[m] = raw.a[m]; cur.ai[m] = raw.a[m]; cur.br[m] = raw.b[m]; cur.bi[m] = raw.b[m]; }
-            } else {
-                cur = unpack_frags(raw);
-            }
-            // K-tile g+2: same stage for j < KT_STAGE-2, else the next stage (already visible; past the
-            // end of K the read lands in a valid ring buffer and is never used)
-            if (!(ABL & 4)) raw = (j + 2 < KT_STAGE) ? load_raw(s, j + 2) : load_raw(s + 1, j + 2 - KT_STAGE);
-            else { asm volatile("" : "+v"(raw.a[0]), "+v"(raw.a[1]), "+v"(raw.b[0]), "+v"(raw.b[1])); }
-            // pin the interleave: 1 MFMA : 3 VALU (the 48 mask/shift ops of the next K-tile hide under
-            // the 16 MFMAs of this one), the two DMA pieces early, the four LDS reads in the second half
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                   // VALU
-                if (i == 1 || i == 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read (LDS-DMA)
-                if (RAW ? (i >= 8) : (i >= 8 && i < 12)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-            }
-        }
-        if (!(ABL & 8)) {
-            if (!(ABL & 1)) wait_vmcnt<NLOAD>();
-            __builtin_amdgcn_s_barrier();
-        }
-    }
-    wait_vmcnt<0>();   // no LDS-DMA may still be in flight when the wave ends
-    if (p.stamps) {
-        // wait for the last MFMA to retire before stamping (read one accumulator element)
-        asm volatile("" :: "v"(accR[1][1][15]), "v"(accQ[1][1][15]), "v"(accP[1][1][15]));
-        const unsigned long long t_end = __builtin_amdgcn_s_memtime(), r_end = __builtin_amdgcn_s_memrealtime();
-        if (lane == 0) {
-            unsigned long long* o = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
-            o[0] = t_end - t_start; o[1] = r_end - r_start; o[2] = r_start; o[3] = r_end; o[4] = r_entry;
-        }
-    }
-    if (!active) return;
-
-    // ---- epilogue: D[i][j] = sum x_i conj(x_j), lane = column j, register = row i.
-    // MFMA C/D map (32x32): col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-    // Registers 4u..4u+3 of a lane are (station 2Rh, pol 0/1), (station 2Rh+1, pol 0/1) of one column
-    // (station C, pol = lane&1).  The even lane of a pair stores the cell of station 2Rh, the odd lane
-    // the cell of station 2Rh+1; the two words each is missing (the other polC) come from its partner
-    // lane by DPP (quad_perm [1,0,3,2]):
-    //   even: {v0, odd.v0, v1, odd.v1}     odd: {even.v2, v2, even.v3, v3}
-    //
-    // A lane quad 4k..4k+3 then holds the four quadrants of column station pair k, i.e. four cells that lie
-    // a quarter of the matrix apart, while the cells of one quadrant and eight consecutive column pairs are
-    // contiguous (8 x 16 B = one 128-byte run).  Each 16-byte store of a lane would be its own request to
-    // L2; so the cells are first moved across lanes (ds_bpermute: lane 8q+k takes the cell of lane 4k+q in
-    // its 32-lane half) and every 8 adjacent lanes write one contiguous run.
+// A lane quad 4k..4k+3 then holds the four quadrants of column station pair k, i.e. four cells that lie
+// a quarter of the matrix apart, while the cells of one quadrant and eight consecutive column pairs are
+// contiguous (8 x 16 B = one 128-byte run).  Each 16-byte store of a lane would be its own request to
+// L2; so the cells are first moved across lanes (ds_bpermute: lane 8q+k takes the cell of lane 4k+q in
+// its 32-lane half) and every 8 adjacent lanes write one contiguous run.
+__device__ __forceinline__ void xcorr_store_tile(const XcorrParams& p, int c, int blk_a, int blk_b, bool skip01, int lane,
+                                                 const v16i (&accR)[2][2], const v16i (&accP)[2][2],
+                                                 const v16i (&accQ)[2][2]) {
     const int qs = (int)(((int64_t)(p.nstand / 2 + 1) * p.nstand) / 4);
     int32_t* out_r = p.out + (int64_t)c * p.per_chan;
     int32_t* out_i = out_r + p.matlen;
@@ -513,7 +295,398 @@ __global__ __launch_bounds__(256, 1) void xcorr_mfma_kernel(XcorrParams p) {
                 }
             }
         }
-    if (p.stamps && lane == 0) p.stamps[((size_t)blockIdx.x * 4 + wave) * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+}
+
+// the 16 (12 on diagonal tiles) int8 MFMAs of one K-tile: R += ar*br + ai*bi, P += ai*br, Q += ar*bi
+__device__ __forceinline__ void xcorr_mfma_tile(const Frags& u, bool skip01, v16i (&accR)[2][2], v16i (&accP)[2][2],
+                                                v16i (&accQ)[2][2]) {
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+            if (m == 0 && n == 1 && skip01) continue;
+            accR[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(u.ar[m], u.br[n], accR[m][n], 0, 0, 0);
+            accP[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(u.ai[m], u.br[n], accP[m][n], 0, 0, 0);
+            accQ[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(u.ar[m], u.bi[n], accQ[m][n], 0, 0, 0);
+            accR[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(u.ai[m], u.bi[n], accR[m][n], 0, 0, 0);
+        }
+}
+
+// =======================================================================================
+// Two-pass path, pass 2: operands come from the fragment-major staging area written by the corner turn.
+// One work-group per (channel, tile group).
+// ABL: timing-only ablation bits (results are wrong unless ABL == 0): 1 no LDS-DMA in the loop,
+// 2 no nibble unpack, 4 no LDS reads in the loop, 8 no barrier/vmcnt wait in the loop.
+// =======================================================================================
+template <int ABL>
+__global__ __launch_bounds__(256, 1) void xcorr_mfma_kernel(XcorrParams p) {
+    constexpr int KT_STAGE = XC_KT;
+    constexpr int SLOT_BYTES = KT_STAGE * KT_BYTES;
+    constexpr int STAGE_BYTES = XC_NSLOT * SLOT_BYTES;
+    constexpr int NLOAD = 2 * KT_STAGE;  // 1 KiB LDS-DMA pieces per wave per stage
+    __shared__ __attribute__((aligned(16))) uint8_t lds[XC_RING * STAGE_BYTES];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned long long r_entry = p.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
+
+    // block -> (channel, work-group).  Blocks b and b+8 share an XCD (round-robin dispatch),
+    // so give each XCD whole channels: all tiles of a channel then stream the same stash
+    // rows through one L2.  Placement only affects speed.
+    int c, wg;
+    {
+        const int b = blockIdx.x;
+        if ((p.nchan & 7) == 0) {
+            const int xcd = b & 7, slot = b >> 3;
+            c = xcd + 8 * (slot / p.nwg);
+            wg = slot % p.nwg;
+        } else {
+            c = b / p.nwg;
+            wg = b % p.nwg;
+        }
+    }
+    const WgDesc* dp = p.descs + wg;   // indexed in memory: no runtime-indexed register arrays
+    const int a_slot = dp->wave_a[wave], b_slot = dp->wave_b[wave];
+    const bool active = a_slot != 0xFF;
+    const int blk_a = active ? dp->slot_blk[a_slot] : 0, blk_b = active ? dp->slot_blk[b_slot] : 0;
+
+    // this wave stages 64-input block slot_blk[wave]: KT_STAGE*2 KiB contiguous per stage
+    const uint8_t* gsrc =
+        p.stash + ((size_t)c * p.nblk64 + dp->slot_blk[wave]) * (size_t)p.cap_kt * KT_BYTES + lane * 16;
+    const int nstage = p.nkt / KT_STAGE;
+
+    // one 1 KiB LDS-DMA piece n (0..NLOAD-1) of stage s into ring buffer s % XC_RING.  Stages past
+    // the end re-read the last real stage (never consumed): the issue stays unconditional, so every
+    // stage costs exactly NLOAD pieces on the vmcnt counter and the loop body is one scheduling region.
+    auto issue_piece = [&](int s, int n) {
+        const int ssrc = s < nstage ? s : nstage - 1;
+        const uint8_t* g = gsrc + (size_t)ssrc * SLOT_BYTES + n * FRAG_BYTES;
+        uint8_t* l = lds + (s & (XC_RING - 1)) * STAGE_BYTES + wave * SLOT_BYTES + n * FRAG_BYTES;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+    };
+
+    v16i accR[2][2], accP[2][2], accQ[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+            accR[m][n] = (v16i)(0);
+            accP[m][n] = (v16i)(0);
+            accQ[m][n] = (v16i)(0);
+        }
+
+    // Idle waves (a_slot == 0xFF) run the same loop on slot 0 and skip the epilogue: keeping the
+    // MFMA chain unconditional keeps the 192 accumulator registers in place (a wave-uniform
+    // branch around it makes hipcc shuttle them AGPR<->VGPR every stage).
+    const int a_off = (active ? a_slot : 0) * SLOT_BYTES + lane * 16;
+    const int b_off = (active ? b_slot : 0) * SLOT_BYTES + lane * 16;
+
+    // fragments of K-tile j (0..KT_STAGE-1) of stage s
+    auto load_raw = [&](int s, int j) {
+        const uint8_t* base = lds + (s & (XC_RING - 1)) * STAGE_BYTES + j * KT_BYTES;
+        RawFrags r;
+        r.a[0] = *reinterpret_cast<const v4i*>(base + a_off);
+        r.a[1] = *reinterpret_cast<const v4i*>(base + a_off + FRAG_BYTES);
+        r.b[0] = *reinterpret_cast<const v4i*>(base + b_off);
+        r.b[1] = *reinterpret_cast<const v4i*>(base + b_off + FRAG_BYTES);
+        return r;
+    };
+
+    // Diagonal wave tiles (row block == column block) never store the upper-right 32x32 MFMA tile
+    // (rows 0-31 x columns 32-63: Rh < Ch): skip its 4 MFMAs (wave-uniform branch; idle waves too).
+    const bool skip01 = __builtin_amdgcn_readfirstlane((int)(!active || blk_a == blk_b)) != 0;
+
+    // ---- software pipeline over K-tiles g = s*KT_STAGE + j ------------------------------------
+    //   MFMA(g)  ||  unpack(g+1)  ||  LDS read(g+2)  ||  LDS-DMA of stage s+3
+    // 4-deep LDS ring.  At the end of stage s every wave waits until its own pieces of stage s+2
+    // have landed (counted vmcnt: stage s+3 stays in flight), then one barrier: stages s+1 and s+2
+    // are now visible to all waves (the LDS reads two K-tiles ahead cross into the next stage), and
+    // everybody is done reading stage s, whose buffer the DMA of stage s+4 overwrites.
+#pragma unroll
+    for (int st = 0; st < 3; st++)
+#pragma unroll
+        for (int n = 0; n < NLOAD; n++) issue_piece(st, n);
+    wait_vmcnt<NLOAD>();
+    __builtin_amdgcn_s_barrier();
+
+    Frags cur = unpack_frags(load_raw(0, 0));
+    RawFrags raw = load_raw(0, 1);
+    unsigned long long t_start = 0, r_start = 0;
+    if (p.stamps) {   // diagnostic build path: shader clock vs 100 MHz reference (MI355X_MICROARCH, DVFS item 6)
+        t_start = __builtin_amdgcn_s_memtime();
+        r_start = __builtin_amdgcn_s_memrealtime();
+    }
+    for (int s = 0; s < nstage; s++) {
+#pragma unroll
+        for (int j = 0; j < KT_STAGE; j++) {
+            if (!(ABL & 1)) {
+                issue_piece(s + 3, 2 * j);
+                issue_piece(s + 3, 2 * j + 1);
+            }
+            xcorr_mfma_tile(cur, skip01, accR, accP, accQ);
+            if (ABL & 2) {
+#pragma unroll
+                for (int m = 0; m < 2; m++) { cur.ar[m] = raw.a[m]; cur.ai[m] = raw.a[m]; cur.br[m] = raw.b[m]; cur.bi[m] = raw.b[m]; }
+            } else {
+                cur = unpack_frags(raw);
+            }
+            // K-tile g+2: same stage for j < KT_STAGE-2, else the next stage (already visible; past the
+            // end of K the read lands in a valid ring buffer and is never used)
+            if (!(ABL & 4)) raw = (j + 2 < KT_STAGE) ? load_raw(s, j + 2) : load_raw(s + 1, j + 2 - KT_STAGE);
+            else { asm volatile("" : "+v"(raw.a[0]), "+v"(raw.a[1]), "+v"(raw.b[0]), "+v"(raw.b[1])); }
+            // pin the interleave: 1 MFMA : 3 VALU (the 48 mask/shift ops of the next K-tile hide under
+            // the 16 MFMAs of this one), the two DMA pieces early, the four LDS reads in the second half
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                   // VALU
+                if (i == 1 || i == 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read (LDS-DMA)
+                if (i >= 8 && i < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+            }
+        }
+        if (!(ABL & 8)) {
+            if (!(ABL & 1)) wait_vmcnt<NLOAD>();
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    wait_vmcnt<0>();   // no LDS-DMA may still be in flight when the wave ends
+    if (p.stamps) {
+        // wait for the last MFMA to retire before stamping (read one accumulator element)
+        asm volatile("" :: "v"(accR[1][1][15]), "v"(accQ[1][1][15]), "v"(accP[1][1][15]));
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime(), r_end = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+            unsigned long long* o = p.stamps + ((size_t)(c * p.nwg + wg) * 4 + wave) * 8;
+            o[0] = t_end - t_start; o[1] = r_end - r_start; o[2] = r_start; o[3] = r_end; o[4] = r_entry;
+        }
+    }
+    if (!active) return;
+    xcorr_store_tile(p, c, blk_a, blk_b, skip01, lane, accR, accP, accQ);
+    if (p.stamps && lane == 0) p.stamps[((size_t)(c * p.nwg + wg) * 4 + wave) * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+}
+
+// =======================================================================================
+// Default path: corner turn fused into the LDS staging, persistent work-groups.
+//
+// The kernel reads the gulps where they lie (time-major rows of ninput bytes per channel).  Per stage
+// (96 samples) and pair of 64-input blocks the LDS-DMA brings 96 rows x 128 B; the operand fragments come
+// out of LDS through ds_read_b64_tr_b8, the byte-transposing read (profiles/microbench/tr8_probe.hip):
+// 16-lane group (h, rg) of a wave reads the 8x16 byte block rows 16h+8hh.., inputs 32 sub + 16 rg.., and
+// lane r receives 8 consecutive samples of input r -- two reads make the 16 bytes of an MFMA operand
+// register quad.  (Which samples sit in which byte does not matter: A and B use the same map.)
+//
+// LDS image: slots are staged in pairs (0,1) and (2,3); the image of a pair and stage is
+// [96 rows][128 B] (slot parity = 64-byte half) with chunk position = chunk ^ 2*((row>>1)&3): the swizzle
+// is applied to the per-lane DMA source address (the LDS side of the DMA is linear) and to the read
+// address, so that the 32 lanes of a read phase fall on 32 distinct even banks.  Wave w brings rows
+// 48*(w&1).. of pair w>>1; a piece is 8 rows x 128 B, lane = 8*row + chunk position.  The tiling makes
+// most pairs adjacent blocks (2k, 2k+1), whose halves then form whole 128-byte lines (half as many L2
+// requests as 64-byte row segments).
+//
+// Persistence: the grid is one work-group per CU; each walks a list of (channel, tile group) items
+// (whole channels per XCD, as above).  The LDS-DMA stream runs ahead of the MFMA stream by three stages
+// ACROSS items: while an item's last K-tiles are contracted and its tiles are stored, the first stages of
+// the next item are already landing, so the fill of the pipeline (and the dispatch of a new work-group)
+// is paid once per CU instead of once per item.
+// =======================================================================================
+// ABL: timing-only ablation bits as for xcorr_mfma_kernel (diagnostic builds; results are wrong unless 0).
+template <int ABL>
+__global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
+    constexpr int KT_STAGE = XC_KT;
+    constexpr int SLOT_BYTES = KT_STAGE * KT_BYTES;
+    constexpr int STAGE_BYTES = XC_NSLOT * SLOT_BYTES;
+    constexpr int NLOAD = 2 * KT_STAGE;  // 1 KiB LDS-DMA pieces per wave per stage
+    constexpr int DEPTH = XF_DEPTH;          // the LDS-DMA of stage S+DEPTH is issued while stage S is contracted
+    constexpr int RING = DEPTH + 1;          // LDS ring (stages)
+    __shared__ __attribute__((aligned(16))) uint8_t lds[RING * STAGE_BYTES];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nstage = p.nkt / KT_STAGE;
+    const uint32_t row_stride = (uint32_t)p.nchan * (uint32_t)p.ninput;
+    // tile-group table through the constant address space: wave-uniform reads become scalar loads (a vector
+    // load would make the compiler wait for vmcnt(0), i.e. for the whole LDS-DMA stream, at every item switch)
+    // (16-byte descriptors read as aligned dwords: slot_blk | wave_a | wave_b)
+    typedef const __attribute__((address_space(4))) uint32_t* DescPtr;
+    const DescPtr descs = (DescPtr)(uintptr_t)p.descs;
+    static_assert(sizeof(WgDesc) == 16, "descriptor layout");
+
+    // item k of this work-group -> (channel, tile group); false past the end of the list
+    const bool xcd_map = (p.nchan & 7) == 0 && (gridDim.x & 7) == 0;
+    auto item = [&](int k, int& c, int& wg) {
+        int idx, n;
+        if (xcd_map) {
+            idx = (int)(blockIdx.x >> 3) + k * (int)(gridDim.x >> 3);   // index among this XCD's items
+            n = (p.nchan >> 3) * p.nwg;
+        } else {
+            idx = (int)blockIdx.x + k * (int)gridDim.x;
+            n = p.nchan * p.nwg;
+        }
+        if (idx >= n) return false;
+        const int q = idx / p.nwg;
+        wg = idx - q * p.nwg;
+        c = xcd_map ? (int)(blockIdx.x & 7) + 8 * q : q;
+        return true;
+    };
+
+    // ---- issue side: the stage stream (item, gulp, stage in gulp) three stages ahead of the MFMAs ----
+    int is_k = 0, is_c = 0, is_wg = 0, is_g = 0, is_sl = 0, is_issued = 0;
+    uint32_t is_lane_off = 0;
+    const uint8_t* is_stage = nullptr;
+    auto is_setup = [&]() {
+        // (columns past ninput in the last block: any valid bytes of the row; their products are never stored)
+        const uint32_t slots = descs[is_wg * 4];                          // slot_blk[0..3]
+        const int chunk = (lane & 7) ^ (((lane >> 4) & 3) << 1);          // source chunk 0..7 of the 128-byte pair row
+        const int blk0 = (slots >> (8 * (wave & 2))) & 0xFF, blk1 = (slots >> (8 * (wave & 2) + 8)) & 0xFF;
+        const uint32_t col = (uint32_t)((chunk >> 2) ? blk1 : blk0) * 64u + (uint32_t)(chunk & 3) * 16u;
+        is_lane_off = (uint32_t)(lane >> 3) * row_stride + (col + 16u <= (uint32_t)p.ninput ? col : 0u);
+        is_g = is_sl = is_issued = 0;
+    };
+    auto next_stage = [&]() {
+        if (is_issued == nstage) {           // this item is fully issued: go on with the next one, if any
+            int c2, wg2;
+            if (!item(is_k + 1, c2, wg2)) return;   // past the end: keep re-reading the last stage (never consumed)
+            is_k++; is_c = c2; is_wg = wg2;
+            is_setup();
+        }
+        is_stage = p.gulps[is_g] + ((size_t)(is_sl * (KT_STAGE * 32)) * p.nchan + is_c) * (size_t)p.ninput;
+        is_issued++;
+        if (++is_sl == p.spg) { is_sl = 0; is_g++; }
+    };
+    // one 1 KiB piece (8 rows x 128 B) of the stage last returned by next_stage() into ring buffer S % XC_RING.
+    // Issued from asm: hipcc cannot prove that the transposing reads do not alias a pending builtin LDS-DMA
+    // and would put `s_waitcnt vmcnt(0)` in front of every one of them; the counted vmcnt + barrier at the
+    // end of each stage is the real ordering.
+    // M0 (the LDS base of the transfer) is written without saving it: nothing else in this kernel uses M0
+    // (no builtin LDS-DMA, no s_movrel/sendmsg; hipcc rejects "m0" as a clobber, so the ISA was checked).
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(const __attribute__((address_space(3))) void*)lds);
+    auto issue_piece = [&](int ring_slot, int n) {
+        const uint8_t* sb = is_stage + (size_t)(48 * (wave & 1) + 8 * n) * row_stride;    // scalar base; lane part is 32-bit
+        const uint32_t la = lds_base + ring_slot * STAGE_BYTES + wave * SLOT_BYTES + n * FRAG_BYTES;
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     :: "v"(is_lane_off), "s"(sb), "s"(la) : "memory");
+    };
+
+    // read side: lane 16*grp + 2q + pp addresses row 16*(grp>>1) + q (+8 for the second read), chunk position
+    // (4*slot parity + 2*sub + (grp&1)) ^ 2*((q>>1)&3), bytes 8pp..8pp+7: slot parity flips address bit 6,
+    // sub = 1 flips bit 5
+    const int tr_off = ((lane >> 5) * 16 + ((lane & 15) >> 1)) * 128 +
+                       (((lane >> 4) & 1) ^ (((lane >> 2) & 3) << 1)) * 16 + (lane & 1) * 8;
+
+    int c, wg;
+    if (!item(0, c, wg)) return;             // (the host never launches more work-groups than items)
+    is_c = c; is_wg = wg;
+    is_setup();
+#pragma unroll
+    for (int st = 0; st < DEPTH; st++) {
+        next_stage();
+#pragma unroll
+        for (int n = 0; n < NLOAD; n++) issue_piece(st, n);
+    }
+    wait_vmcnt<(DEPTH - 2) * NLOAD>();       // stages 0 and 1 have landed
+    __builtin_amdgcn_s_barrier();
+
+    // ring slots of the stage being contracted (rs), the next one (rs1) and the one being filled (rf):
+    // the stage counter is continuous across items
+    int rs = 0, rs1 = 1, rf = DEPTH;
+    auto bump = [&](int& r) { r = (r + 1 == RING) ? 0 : r + 1; };
+    for (int k = 0; item(k, c, wg); k++) {
+        const unsigned long long r_entry = p.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
+        const uint32_t slots = descs[wg * 4], wa4 = descs[wg * 4 + 1], wb4 = descs[wg * 4 + 2];
+        const int a_slot = (wa4 >> (8 * wave)) & 0xFF, b_slot = (wb4 >> (8 * wave)) & 0xFF;
+        // Idle waves (a_slot == 0xFF) run the same loop on slot 0 and skip the stores: keeping the MFMA chain
+        // unconditional keeps the 192 accumulator registers in place
+        const bool active = a_slot != 0xFF;
+        const int sa = active ? a_slot : 0, sb = active ? b_slot : 0;
+        const int blk_a = (slots >> (8 * sa)) & 0xFF, blk_b = (slots >> (8 * sb)) & 0xFF;
+        const int a_off = (sa >> 1) * (2 * SLOT_BYTES) + (tr_off ^ ((sa & 1) * 64));
+        const int b_off = (sb >> 1) * (2 * SLOT_BYTES) + (tr_off ^ ((sb & 1) * 64));
+        // Diagonal wave tiles never store the upper-right 32x32 MFMA tile: skip its 4 MFMAs
+        const bool skip01 = __builtin_amdgcn_readfirstlane((int)(!active || blk_a == blk_b)) != 0;
+
+        auto load_raw = [&](int ring_slot, int j) {     // fragments of K-tile j (0..KT_STAGE-1) of a landed stage
+            const uint8_t* base = lds + ring_slot * STAGE_BYTES + j * (2 * KT_BYTES);
+            auto tr = [&](int off) {
+                return __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) v2i*)(base + off));
+            };
+            RawFrags r;
+#pragma unroll
+            for (int sub = 0; sub < 2; sub++) {
+                const v2i a0 = tr(a_off ^ (sub * 32)), a1 = tr((a_off ^ (sub * 32)) + 1024);
+                const v2i b0 = tr(b_off ^ (sub * 32)), b1 = tr((b_off ^ (sub * 32)) + 1024);
+                r.a[sub] = (v4i){a0.x, a0.y, a1.x, a1.y};
+                r.b[sub] = (v4i){b0.x, b0.y, b1.x, b1.y};
+            }
+            return r;
+        };
+
+        v16i accR[2][2], accP[2][2], accQ[2][2];
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int n = 0; n < 2; n++) {
+                accR[m][n] = (v16i)(0);
+                accP[m][n] = (v16i)(0);
+                accQ[m][n] = (v16i)(0);
+            }
+
+        // ---- software pipeline over K-tiles: MFMA(g) || unpack(g+1) || LDS read(g+2) || LDS-DMA of stage S+DEPTH.
+        // At the end of stage S every wave waits until its own pieces of stage S+2 have landed (counted
+        // vmcnt: the younger stages stay in flight), then one barrier: stages S+1 and S+2 are visible to all
+        // waves and everybody is done reading stage S, whose buffer the DMA of stage S+DEPTH+1 overwrites.
+        Frags cur = unpack_frags(load_raw(rs, 0));
+        RawFrags raw = load_raw(rs, 1);
+        unsigned long long t_start = 0, r_start = 0;
+        if (p.stamps) {   // diagnostic: shader clock vs 100 MHz reference (MI355X_MICROARCH, DVFS item 6)
+            t_start = __builtin_amdgcn_s_memtime();
+            r_start = __builtin_amdgcn_s_memrealtime();
+        }
+        for (int s = 0; s < nstage; s++) {
+            next_stage();
+#pragma unroll
+            for (int j = 0; j < KT_STAGE; j++) {
+                if (!(ABL & 1)) {
+                    issue_piece(rf, 2 * j);
+                    issue_piece(rf, 2 * j + 1);
+                }
+                xcorr_mfma_tile(cur, skip01, accR, accP, accQ);
+                if (ABL & 2) {
+#pragma unroll
+                    for (int m = 0; m < 2; m++) { cur.ar[m] = raw.a[m]; cur.ai[m] = raw.a[m]; cur.br[m] = raw.b[m]; cur.bi[m] = raw.b[m]; }
+                } else {
+                    cur = unpack_frags(raw);
+                }
+                // K-tile g+2: same stage for j < KT_STAGE-2, else the next stage (already visible; at the end
+                // of an item the read lands in a valid ring buffer and is not used)
+                if (!(ABL & 4)) raw = (j + 2 < KT_STAGE) ? load_raw(rs, j + 2) : load_raw(rs1, j + 2 - KT_STAGE);
+                else { asm volatile("" : "+v"(raw.a[0]), "+v"(raw.a[1]), "+v"(raw.b[0]), "+v"(raw.b[1])); }
+                // pin the interleave: 1 MFMA : 3 VALU (the 48 mask/shift ops of the next K-tile hide under the
+                // 16 MFMAs of this one), the eight transposing LDS reads in the second half
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                   // VALU
+                    if (i >= 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // DS read
+                }
+            }
+            if (!(ABL & 8)) {
+                if (!(ABL & 1)) wait_vmcnt<(DEPTH - 2) * NLOAD>();
+                __builtin_amdgcn_s_barrier();
+            }
+            bump(rs); bump(rs1); bump(rf);
+        }
+        if (p.stamps) {
+            asm volatile("" :: "v"(accR[1][1][15]), "v"(accQ[1][1][15]), "v"(accP[1][1][15]));
+            const unsigned long long t_end = __builtin_amdgcn_s_memtime(), r_end = __builtin_amdgcn_s_memrealtime();
+            if (lane == 0) {
+                unsigned long long* o = p.stamps + ((size_t)(c * p.nwg + wg) * 4 + wave) * 8;
+                o[0] = t_end - t_start; o[1] = r_end - r_start; o[2] = r_start; o[3] = r_end; o[4] = r_entry;
+            }
+        }
+        if (active) xcorr_store_tile(p, c, blk_a, blk_b, skip01, lane, accR, accP, accQ);
+        if (p.stamps && lane == 0) p.stamps[((size_t)(c * p.nwg + wg) * 4 + wave) * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+    }
+    wait_vmcnt<0>();   // no LDS-DMA may still be in flight when the wave ends
 }
 
 // =======================================================================================

@@ -43,5 +43,14 @@ epi = (st[ok, 5] - st[ok, 3]) / 100.0
 tot = (st[ok, 5] - st[ok, 4]) / 100.0
 print("per wave us: prologue median %.2f p90 %.2f | loop %.2f | epilogue median %.2f p90 %.2f | total %.2f" % (
     np.median(pro), np.percentile(pro, 90), np.median(st[ok, 1]) / 100.0, np.median(epi), np.percentile(epi, 90), np.median(tot)))
+# per work item (channel, tile group) = 4 consecutive stamp rows: first wave entry -> last wave exit
+it = st.reshape(-1, 4, 8)
+it_start = it[:, :, 4].min(axis=1)
+it_end = it[:, :, 5].max(axis=1)
+dur = (it_end - it_start) / 100.0
+print("per item us (entry of first wave -> exit of last): median %.2f mean %.2f p10 %.2f p90 %.2f max %.2f; sum/256 CUs = %.1f us" % (
+    np.median(dur), dur.mean(), np.percentile(dur, 10), np.percentile(dur, 90), dur.max(), dur.sum() / 256))
+skew = (it[:, :, 4].max(axis=1) - it_start) / 100.0
+print("entry skew between the waves of an item us: median %.2f p90 %.2f" % (np.median(skew), np.percentile(skew, 90)))
 kspan = (st[ok, 5].max() - st[ok, 4].min()) / 100.0
 print("kernel entry->exit span %.1f us; wave-resident fraction %.3f" % (kspan, tot.sum() / (1024 * kspan)))
