@@ -291,10 +291,13 @@ def main():
     ct_bytes = 2 * gulp_bytes
     # HBM traffic of the dominant kernel from the committed PMC passes (profiles/pmc_run.sh:
     # FETCH_SIZE x2 for the gfx950 wide-load under-count + WRITE_SIZE, per launch); null if absent
+    fused, fp6 = ctypes.c_int(), ctypes.c_int()
+    ffi.call("xengXgpuGetPath", ctypes.byref(fused), ctypes.byref(fp6))
+    kname = "xcorr_fused_kernel" if fused.value else ("xcorr_fp6_kernel" if fp6.value else "xcorr_mfma_kernel")
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as fh:
-            traffic = json.load(fh).get("xcorr_mfma_kernel_bytes_per_launch")
+            traffic = json.load(fh).get(kname + "_bytes_per_launch")
     except (OSError, ValueError):
         pass
     res = {
@@ -311,18 +314,28 @@ def main():
         "cmac_per_s": cmacs,
         "mfma_peak_frac_end_to_end": round(8 * cmacs / (PEAK_INT8_OPS * world), 4),
         "design_rate_x": round(gbps / world / 12.94, 1),
-        "roofline": {"kernel": "xcorr_mfma_kernel", "bound": "mfma", "achieved": round(achieved, 1),
+        "roofline": {"kernel": kname, "bound": "mfma", "achieved": round(achieved, 1),
                      "peak": round(PEAK_INT8_OPS / 1e12, 1), "unit": "TFLOP/s",
                      "frac": round(achieved / (PEAK_INT8_OPS / 1e12), 4), "traffic": traffic,
                      "algorithmic_bytes_per_launch": units_per_step * NINPUT + 2 * matlen * 4,
+                     "launch_concurrency": round(mm_ms / (el / args.steps * 1e3), 2) if el > 0 else None,
+                     "frac_concurrency_corrected": round(8 * cmacs / (PEAK_INT8_OPS * world), 4),
                      "note": "int8 TOP/s; algorithmic ops = 8*704*705/2 per (sample,chan) x %d units per launch; "
-                             "avg launch %.1f us over %d launches (HIP events on the X-engine stream)"
+                             "avg launch %.1f us over %d launches (HIP events on the X-engine streams).  In the "
+                             "streaming call mode consecutive launches share the GPU (launch_concurrency = avg launch "
+                             "/ step time), so a launch lasts longer than a step: per-GPU rate / peak is "
+                             "mfma_peak_frac_end_to_end"
                              % (units_per_step, mm_ms * 1e3, cn[1])},
-        "corner_turn": {"bound": "hbm", "avg_us": round(ct_ms * 1e3, 2), "launches": int(cn[0]),
-                        "achieved_GBs": round(ct_bytes / (ct_ms * 1e-3) / 1e9, 1) if ct_ms > 0 else 0.0,
-                        "peak_GBs": HBM_PEAK_GBS, "bytes_per_launch": ct_bytes},
         "device": info,
     }
+    if cn[0] > 0:
+        res["corner_turn"] = {"bound": "hbm", "avg_us": round(ct_ms * 1e3, 2), "launches": int(cn[0]),
+                              "achieved_GBs": round(ct_bytes / (ct_ms * 1e-3) / 1e9, 1) if ct_ms > 0 else 0.0,
+                              "peak_GBs": HBM_PEAK_GBS, "bytes_per_launch": ct_bytes,
+                              "note": "two-pass path: corner turn, or raw gulp copy of the synchronous calls"}
+    else:
+        res["corner_turn"] = {"fused": True, "note": "no separate pass: gulps are read in place and transposed in "
+                                                     "the contraction kernel's LDS staging (ds_read_b64_tr_b8)"}
     if pcie is not None:
         res["pcie_inclusive"] = pcie
     if beam is not None:
@@ -331,12 +344,12 @@ def main():
         iso_mm = iso_tm[1] / iso_cn[1]
         iso_ach = ops_per_launch / (iso_mm * 1e-3) / 1e12
         res["roofline_isolated_launches"] = {
-            "kernel": "xcorr_mfma_kernel", "avg_us": round(iso_mm * 1e3, 1), "achieved": round(iso_ach, 1),
+            "kernel": kname, "avg_us": round(iso_mm * 1e3, 1), "achieved": round(iso_ach, 1),
             "frac": round(iso_ach / (PEAK_INT8_OPS / 1e12), 4), "launches": int(iso_cn[1]),
             "corner_turn_avg_us": round(iso_tm[0] / max(iso_cn[0], 1) * 1e3, 2),
-            "note": "same kernels, one integration at a time (outside the timed region): in the timed streaming "
-                    "region consecutive MFMA launches overlap each other and the corner turns, which lengthens "
-                    "each launch but shortens the step"}
+            "note": "same kernel, one integration at a time (outside the timed region): in the timed streaming "
+                    "region consecutive launches overlap (the next one takes over CUs as work-groups of the "
+                    "previous one run out of items), which lengthens each launch but shortens the step"}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
