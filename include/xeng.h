@@ -84,9 +84,9 @@ int xengStreamSynchronize(void);                               /* all library st
  * bfXgpuSubSelect / bfXgpuReorder. */
 
 /* Sizes the next xengXgpuInitialize will use (xGPU compile-time NSTATION/NFREQUENCY/NTIME,
- * install_xgpu.sh:5; block args corr_block.py:221-231).  max_gulps_per_flush bounds the
- * device staging area (gulps are corner-turned into HBM and contracted in one launch at
- * dump time); 0 picks a default.  Defaults before any call: 352, 2, 96, 480. */
+ * install_xgpu.sh:5; block args corr_block.py:221-231).  max_gulps_per_flush bounds how many
+ * gulps are held back (kept in HBM and contracted in one launch at dump time; more gulps than
+ * that are flushed early and accumulated in out_dev); 0 picks a default.  Defaults before any call: 352, 2, 96, 480. */
 int xengXgpuConfigure(int nstand, int npol, int nchan, int ntime_gulp, int max_gulps_per_flush);
 
 /* corr_block.py:251-256, xgpu_test.py:76.  Creates (or re-creates) the process-global context on `gpu`. */
@@ -110,8 +110,8 @@ int xengXgpuKernel(const void *in_dev, void *out_dev, int doDump);
 int xengXgpuKernelAsync(const void *in_dev, void *out_dev, int doDump);
 int xengXgpuSync(void);
 /* Wait until all but the last `lag` (0..3) dumps are complete -- lag 1 lets a streaming caller enqueue
- * integration n+1 (into a different out_dev) before it waits for integration n, so the corner turns of
- * n+1 overlap the contraction of n on the GPU.  lag 0 waits for the latest dump. */
+ * integration n+1 (into a different out_dev) before it waits for integration n, so the contraction of
+ * n+1 fills the CUs that the contraction of n vacates.  lag 0 waits for the latest dump. */
 int xengXgpuSyncLag(int lag);
 
 /* Drop the gulps staged and the partial sums accumulated since the last dump (an integration that
@@ -146,7 +146,8 @@ int xengXgpuGetInfo(int *nstand, int *npol, int *nchan, int *ntime_gulp, int64_t
 int xengXgpuGetPath(int *fused_corner_turn, int *fp6);
 
 /* profiling: HIP events around each kernel on the context's stream.  GetTimes returns and clears
- * the totals (ms) and launch counts since the last call: [0]=corner-turn, [1]=MFMA X-engine. */
+ * the totals (ms) and launch counts since the last call: [0]=corner turn (two-pass path) or raw
+ * gulp copy (synchronous calls on the fused path), [1]=MFMA contraction. */
 int xengXgpuSetProfiling(int enable);
 int xengXgpuGetTimes(double ms[2], int count[2]);
 
