@@ -194,6 +194,34 @@ def main():
                 "h2d_GBs": round(gulp_bytes * gulps_per_step * nint / el2 / 1e9, 1),
                 "note": "pinned host -> H2D -> X-engine, %d integrations; link-bound (PCIe Gen5 x16)" % nint}
         hostbuf.free()
+    # outside the timed region: the slow-visibility output step (SURVEY 8f rows 2+4): device reorder of one
+    # integration into per-baseline packet payloads (CorrOutputFull), HBM-bound
+    pktz = None
+    if args.beamform and rank == 0 and world == 1:
+        ffi.call("xengXgpuSync")
+        a2i = np.arange(NINPUT, dtype=np.int32)
+        nst = NINPUT // 2
+        blm = np.zeros(nst * nst * 4, dtype=np.int32)
+        cjm = np.zeros_like(blm)
+        ffi.call("xengXgpuGetOrder", a2i.ctypes.data, blm.ctypes.data, cjm.ctypes.data)
+        dbl, dcj = ffi.DeviceBuffer(blm.nbytes).upload(blm), ffi.DeviceBuffer(cjm.nbytes).upload(cjm)
+        nbl = nst * (nst + 1) // 2
+        dpay = ffi.DeviceBuffer(nbl * 4 * NCHAN * 8)
+        for _ in range(3):
+            ffi.call("xengXgpuPacketize", outs[0].ptr, dpay.ptr, dbl.ptr, dcj.ptr, 1)
+        t1 = time.perf_counter()
+        nrep = 20
+        for _ in range(nrep):
+            ffi.call("xengXgpuPacketize", outs[0].ptr, dpay.ptr, dbl.ptr, dcj.ptr, 1)
+        pk_ms = (time.perf_counter() - t1) / nrep * 1e3
+        pk_bytes = nbl * 4 * NCHAN * 8 * 2          # read every addressed word once, write every payload word once
+        pktz = {"kernel": "packetize_kernel", "avg_us": round(pk_ms * 1e3, 1), "payload_bytes": nbl * 4 * NCHAN * 8,
+                "roofline": {"bound": "hbm", "achieved": round(pk_bytes / (pk_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": round(pk_bytes / (pk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                "note": "xGPU-order int32 planes -> %d COR payloads [chan][pol][pol][2] in sending order; wall time of the "
+                        "synchronous call (includes launch + stream sync)" % nbl}
+        for b in (dbl, dcj, dpay):
+            b.free()
     # outside the timed region: BASELINE config 4 -- Beamform (32 beams, 96 chan, 960 samples, fp32 weights)
     # + BeamformSumBeams (16 dual-pol power beams, ntime_sum 24) on the same GPU
     beam = None
@@ -340,6 +368,8 @@ def main():
         res["pcie_inclusive"] = pcie
     if beam is not None:
         res["beamform"] = beam
+    if pktz is not None:
+        res["corr_output_packetize"] = pktz
     if iso_cn[1] > 0:
         iso_mm = iso_tm[1] / iso_cn[1]
         iso_ach = ops_per_launch / (iso_mm * 1e-3) / 1e12

@@ -45,6 +45,10 @@ class HipBackend:
     def bfXgpuSubSelect(self, in_arr, out_arr, vismap, conj, nchan_sum, unused=0):
         return self._lib.bfXgpuSubSelect(in_arr, out_arr, vismap, conj, int(nchan_sum), int(unused))
 
+    def xgpu_packetize(self, in_arr, out_arr, antpol_to_bl, is_conj, fmt):
+        """Device reorder + per-baseline payloads of CorrOutputFull (corr_output_full_block.py:669, 461-467, 512-519)."""
+        return self._lib.xengXgpuPacketize(in_arr.ptr, out_arr.ptr, antpol_to_bl.ptr, is_conj.ptr, int(fmt))
+
     def xgpu_reset(self):
         """Drop staged gulps / partial sums of an aborted integration (no reference counterpart)."""
         return self._lib.xengXgpuReset()

@@ -556,6 +556,30 @@ int xengXgpuSubSelect(const void* in_dev, void* out_dev, const int32_t* vismap_d
     return XENG_STATUS_SUCCESS;
 }
 
+int xengXgpuPacketize(const void* in_dev, void* out_dev, const int32_t* antpol_to_bl_dev, const int32_t* is_conj_dev,
+                      int fmt) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    XgpuContext& x = g_ctx;
+    if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized");
+    if (!in_dev || !out_dev || !antpol_to_bl_dev || !is_conj_dev) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Packetize: null buffer");
+    if (fmt != 0 && fmt != 1) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Packetize: fmt must be 0 ([pol][pol][chan][2]) or 1 ([chan][pol][pol][2])");
+    if ((uintptr_t)out_dev & 7) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Packetize: out must be 8-byte aligned");
+    // LDS row pitch (int2 units): >= nchan and 1 mod 32, i.e. 2 mod 64 dwords: the 64 rows of phase A fall on distinct banks
+    int pitch = x.cfg.nchan;
+    while ((pitch & 31) != 1) pitch++;
+    const size_t lds = (size_t)64 * pitch * sizeof(int2);
+    if (lds > 160 * 1024) XENG_FAIL(XENG_STATUS_UNSUPPORTED, "Packetize: nchan=%d needs %zu B of LDS", x.cfg.nchan, lds);
+    XENG_HIP(hipSetDevice(x.gpu));
+    if (lds > 64 * 1024)
+        XENG_HIP(hipFuncSetAttribute((const void*)packetize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(packetize_kernel, dim3(x.cfg.nstand, (x.cfg.nstand + 15) / 16), dim3(256), lds, x.stream_mm,
+                       (const int32_t*)in_dev, (int2*)out_dev, antpol_to_bl_dev, is_conj_dev, x.cfg.nstand, x.cfg.nchan,
+                       x.per_chan, x.matlen, pitch, fmt);
+    XENG_HIP(hipGetLastError());
+    XENG_HIP(hipStreamSynchronize(x.stream_mm));
+    return XENG_STATUS_SUCCESS;
+}
+
 int xengXgpuReorder(const void* in_host, void* out_host, const int32_t* bl, const int32_t* conj) {
     XgpuConfig cfg;
     {

@@ -997,4 +997,54 @@ __global__ void subselect_kernel(const int32_t* __restrict__ xg, int32_t* __rest
     reinterpret_cast<int2*>(out)[(int64_t)co * nvis + v] = res;
 }
 
+// ---------------------------------------------------------------------------------------
+// Full-correlation packet payloads on the device (CorrOutputFull: bfXgpuReorder on the host,
+// corr_output_full_block.py:669, then one payload per dual-pol baseline s0 <= s1,
+// :461-467 `reordered_data[s0, s1].tobytes()` = int32[npol][npol][nchan][2] (fmt 0) or, for the COR
+// format, :512-519 int32[nchan][npol][npol][2] (fmt 1)).  Payload k = baseline (s0, s1) in sending order
+// (s0 ascending, s1 from s0): k = s0*nstand - s0(s0-1)/2 + (s1 - s0).
+//
+// HBM-bound gather + transpose through LDS, driven by the GetOrder maps (any antpol_to_input).
+// grid (s1, tile of 16 stands s0), 256 threads.  A tile is 64 rows = (s0 parity, 8 stands, p0, p1):
+// with the identity input map the 32 rows of one parity are one 128-byte run of xGPU cells, so a wave reads
+// two full lines per plane and channel.  Phase A: rows x channels -> LDS (int2 re|im, conjugated per map);
+// phase B: every baseline's payload (4*nchan int2, contiguous) is written out in order.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void packetize_kernel(const int32_t* __restrict__ xg, int2* __restrict__ out,
+                                                        const int32_t* __restrict__ antpol_to_bl,
+                                                        const int32_t* __restrict__ is_conj, int nstand, int nchan,
+                                                        int64_t per_chan, int64_t matlen, int pitch, int fmt) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t pk_lds[];
+    int2* tile = reinterpret_cast<int2*>(pk_lds);       // [64 rows][pitch] int2
+    const int s1 = blockIdx.x, s0base = blockIdx.y * 16;
+    if (s0base > s1) return;
+    const int t = threadIdx.x;
+    {
+        const int row = t & 63, cg = t >> 6;
+        const int s0 = s0base + 2 * ((row >> 2) & 7) + (row >> 5), pp = row & 3;
+        if (s0 <= s1 && s0 < nstand) {
+            const size_t m = ((size_t)s0 * nstand + s1) * 4 + pp;
+            const int64_t w = antpol_to_bl[m];
+            const bool cj = is_conj[m] != 0;
+            for (int c = cg; c < nchan; c += 4) {
+                const int64_t o = (int64_t)c * per_chan + w;
+                const int re = xg[o], im = xg[matlen + o];
+                tile[row * pitch + c] = make_int2(re, cj ? -im : im);
+            }
+        }
+    }
+    __syncthreads();
+    const int per_bl = 4 * nchan;                        // int2 elements per payload
+    for (int i = t; i < 16 * per_bl; i += 256) {
+        const int b = i / per_bl, e = i - b * per_bl;    // b = 2*k + parity: s0 = s0base + b
+        const int s0 = s0base + b;
+        if (s0 > s1 || s0 >= nstand) continue;
+        const int pp = fmt ? (e & 3) : e / nchan;
+        const int c = fmt ? (e >> 2) : e - pp * nchan;
+        const int row = ((b & 1) << 5) | ((b >> 1) << 2) | pp;
+        const int64_t k = (int64_t)s0 * nstand - ((int64_t)s0 * (s0 - 1)) / 2 + (s1 - s0);
+        out[k * per_bl + e] = tile[row * pitch + c];
+    }
+}
+
 }  // namespace xeng

@@ -134,6 +134,14 @@ int xengXgpuGetOrder(const int32_t *antpol_to_input, int32_t *antpol_to_bl, int3
 int xengXgpuSubSelect(const void *in_dev, void *out_dev, const int32_t *vismap_dev,
                       const int32_t *conj_dev, int nvis, int nchan_sum);
 
+/* corr_output_full_block.py:669 + :461-467 / :512-519 done on the device: planar xGPU buffer -> the packet
+ * payloads CorrOutputFull sends, one per dual-pol baseline s0 <= s1 in sending order
+ * (k = s0*nstand - s0(s0-1)/2 + s1 - s0): out_dev int32[nstand(nstand+1)/2][npol][npol][nchan][2] (fmt 0,
+ * send_packets_py) or [..][nchan][npol][npol][2] (fmt 1, COR).  Maps: device copies of the GetOrder
+ * arrays.  The caller must have synchronised the contraction that produced in_dev.  Synchronous. */
+int xengXgpuPacketize(const void *in_dev, void *out_dev, const int32_t *antpol_to_bl_dev,
+                      const int32_t *is_conj_dev, int fmt);
+
 /* corr_output_full_block.py:669.  Host: planar xGPU buffer -> int32[nstand][nstand][npol][npol][nchan][2]. */
 int xengXgpuReorder(const void *in_host, void *out_host, const int32_t *antpol_to_bl, const int32_t *is_conj);
 

@@ -154,6 +154,27 @@ def xgpu_reorder(planar, bl, cj, nchan):
     return out
 
 
+def corr_packet_payloads(reordered, use_cor_fmt):
+    """Payloads of the full-correlation packets in sending order, int32[nbl][4*nchan*2].
+    use_cor_fmt=False: corr_output_full_block.py:461-467 (`reordered_data[s0, s1].tobytes()` for s0, s1 >= s0,
+    i.e. [p0][p1][chan][2]); True: :512-519 (`reordered_data[i, i:]` transposed [0,3,1,2,4] -> [chan][p0][p1][2])."""
+    nstand = reordered.shape[0]
+    out = []
+    for s0 in range(nstand):
+        sdata = reordered[s0, s0:]                      # [s1 - s0][p0][p1][chan][2]
+        if use_cor_fmt:
+            sdata = sdata.transpose(0, 3, 1, 2, 4)
+        out.append(np.ascontiguousarray(sdata).reshape(sdata.shape[0], -1))
+    return np.concatenate(out)
+
+
+def corr_packet_header_py(sync_time, spectra_id, bw_hz, sfreq, acc_len, nchan, chan0, npol, s0, s1):
+    """corr_output_full_block.py:443-452, 463 (`>QQ2d4I` + `>2I`): 56 bytes, big-endian
+    (docs/source/outputs.rst:33-46)."""
+    import struct
+    return struct.pack(">QQ2d4I", sync_time, spectra_id, bw_hz, sfreq, acc_len, nchan, chan0, npol) + struct.pack(">2I", s0, s1)
+
+
 def xgpu_subselect(planar, vismap, conj, nchan, nchan_sum, nstand, npol=2):
     planar = np.ascontiguousarray(planar, dtype=np.int32)
     vismap = np.ascontiguousarray(vismap, dtype=np.int32)

@@ -93,9 +93,13 @@ int main(int argc, char** argv) {
     srand(1);
     for (auto& v : h) v = zero ? 0 : (int)((unsigned)rand() * 2654435761u ^ (unsigned)rand());
     if (argc > 1 && atoi(argv[1]) == 2) for (auto& v : h) v &= 0xF0F0F0F0;   // like the x16-scaled nibbles
+    if (argc > 1 && atoi(argv[1]) == 3)                                        // sign-extended 4-bit values per byte
+        for (auto& v : h) { unsigned o = 0; for (int k = 0; k < 4; k++) { int b = (signed char)((v >> (8 * k)) & 0xF0) >> 4; o |= (unsigned)(b & 0xFF) << (8 * k); } v = (int)o; }
+    if (argc > 1 && atoi(argv[1]) == 4) for (auto& v : h) v &= 0x0F0F0F0F;   // unsigned 4-bit values per byte
+    if (argc > 1 && atoi(argv[1]) == 5) for (auto& v : h) v &= 0x07070707;   // unsigned 3-bit values per byte
     hipMalloc(&seed, h.size() * 4); hipMemcpy(seed, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     hipMalloc(&out, 256 * 256 * 4); hipMalloc(&st, 256 * 4 * 16);
-    printf("operands: %s\n", zero ? "zeros" : (argc > 1 && atoi(argv[1]) == 2 ? "random high nibbles (x16-scaled 4-bit)" : "random bits"));
+    printf("operands: class %s (0 random bits, 1 zeros, 2 x16-scaled 4-bit, 3 sign-extended 4-bit, 4 unsigned 4-bit, 5 unsigned 3-bit)\n", argc > 1 ? argv[1] : "0");
     run<0>("i8  32x32x32", 2.0 * 32 * 32 * 32, seed, out, st, 0);
     run<1>("i8  16x16x64", 2.0 * 16 * 16 * 64, seed, out, st, 0);
     run<2>("bf6(e3m2) 32x32x64 scaled", 2.0 * 32 * 32 * 64, seed, out, st, 0);

@@ -74,6 +74,14 @@ class OracleBackend:
         _np(cj, np.int32, ocj.size)[...] = ocj.ravel()
         return 0
 
+    def xgpu_packetize(self, in_arr, out_arr, antpol_to_bl, is_conj, fmt):
+        c = self.cfg
+        bl = antpol_to_bl.numpy().reshape(c["nstand"], c["nstand"], c["npol"], c["npol"])
+        cj = is_conj.numpy().reshape(bl.shape)
+        reordered = orc.xgpu_reorder(in_arr.numpy().reshape(-1), bl, cj, c["nchan"])
+        out_arr.numpy().reshape(-1)[...] = orc.corr_packet_payloads(reordered, bool(fmt)).ravel()
+        return 0
+
     def bfXgpuSubSelect(self, in_arr, out_arr, vismap, conj, nchan_sum, unused=0):
         c = self.cfg
         matlen = orc.per_chan(c["nstand"]) * c["nchan"]

@@ -328,3 +328,57 @@ def test_corr_then_subsel_chain(golden_dir):
     # wrong-length selection lists are rejected (condition len == nvis_out)
     sub.process_command_strings(cmd(2, baselines=sel[:-1]))
     assert sub.stats['last_cmd_response'] == COMMAND_INVALID
+
+
+@pytest.mark.parametrize("use_cor_fmt", [False, True])
+def test_corr_then_output_full_packets(golden_dir, tmp_path, use_cor_fmt):
+    """Corr -> CorrOutputFull on CPU rings with the reference's golden visibilities as `checkfile`
+    (corr_output_full_block.py:550-603: every component of every baseline must match) and a packet sink:
+    one packet per dual-pol baseline s0 <= s1 in sending order, 56-byte `>QQ2d4I2I` header + [p0][p1][chan][2]
+    payload (:443-463), or the 32-byte COR header + [chan][p0][p1][2] payload (:213-226, 512-519)."""
+    import struct
+    from caltech_bifrost_dsp_amd.blocks import CorrOutputFull
+    _, vin = load_dat(os.path.join(golden_dir, "in_8t_4c_16s_2p_deadbeef.dat"))
+    meta, corr = load_dat(os.path.join(golden_dir, "corr_8t_4a_4c_16s_2p_deadbeef.dat"))
+    T, C, S, P = vin.shape
+    acc_len = meta["acc_len"]
+    check = tmp_path / "golden_raw.bin"                      # raw complex128 [t][chan][s0][s1][p0][p1], as :419-434 reads it
+    check.write_bytes(np.ascontiguousarray(corr).tobytes())
+    r0, r1 = Ring("gpu-input"), Ring("corr-output")
+    be = OracleBackend()
+    hdr = source_header(C, S, P, seq0=0, sync_time=1600000000, sfreq=4.0e7)
+    cblk = Corr(LOG, r0, r1, ntime_gulp=2, nchan=C, npol=P, nstand=S, acc_len=acc_len, autostartat=0,
+                ant_to_input=hdr['ant_to_input'], backend=be)
+    pkts = []
+    oblk = CorrOutputFull(LOG, r1, nchan=C, npol=P, nstand=S, checkfile=str(check), checkfile_acc_len=acc_len,
+                          antpol_to_bl=cblk.antpol_to_bl.numpy(), bl_is_conj=cblk.bl_is_conj.numpy(),
+                          use_cor_fmt=use_cor_fmt, nchan_sum=1, pipeline_idx=3, npipeline=2, backend=be,
+                          sink=pkts.append)
+    run_blocks([cblk, oblk], Source(r0, [(hdr, vin, 2 * C * S * P)]), [])
+    nint, nbl = T // acc_len, S * (S + 1) // 2
+    assert oblk.check_results == [(nbl * 8, 0)] * nint           # the reference's own golden check, all good
+    assert len(pkts) == nint * nbl
+    hlen = 32 if use_cor_fmt else 56
+    k = 0
+    for it in range(nint):
+        for s0 in range(S):
+            for s1 in range(s0, S):
+                pkt = pkts[k]
+                k += 1
+                assert len(pkt) == hlen + 4 * C * 2 * 4
+                pay = np.frombuffer(pkt[hlen:], dtype=np.int32)
+                g = corr[it, :, s0, s1]                              # [chan][p0][p1] complex
+                if use_cor_fmt:
+                    sync, w1, secs, f0, gain, tt, navg, si, sj = struct.unpack(">IIIhhqihh", pkt[:32])
+                    spp = int(C * hdr['fs_hz'] / hdr['bw_hz'])
+                    assert sync == 0x5CDEC0DE and w1 >> 24 == 2 and (w1 & 0xFFFFFF) == (1 << 16) | (2 << 8) | 1
+                    assert (f0, gain, tt, navg, si, sj) == (0, 0, it * acc_len * spp, acc_len * spp, s0 + 1, s1 + 1)
+                    pay = pay.reshape(C, P, P, 2)
+                    assert np.array_equal(pay[..., 0], g.real) and np.array_equal(pay[..., 1], g.imag)
+                else:
+                    f = struct.unpack(">QQ2d4I2I", pkt[:56])
+                    assert f == (1600000000, it * acc_len, hdr['bw_hz'], 4.0e7, acc_len, C, 0, P, s0, s1)
+                    pay = pay.reshape(P, P, C, 2)
+                    assert np.array_equal(pay[..., 0], np.moveaxis(g.real, 0, -1))
+                    assert np.array_equal(pay[..., 1], np.moveaxis(g.imag, 0, -1))
+    assert oblk.stats['curr_sample'] == (nint - 1) * acc_len and 'output_gbps' in oblk.stats

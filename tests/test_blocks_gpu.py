@@ -91,3 +91,40 @@ def test_ingest_copy_corr_subsel_chain():
         planar = orc.xgpu_correlate(vin[k * acc:(k + 1) * acc], S, C)
         exp = orc.xgpu_subselect(planar, vismap, conj, C, nsum, S)
         assert np.array_equal(sp.view(np.int32).reshape(exp.shape), exp)
+
+
+@pytest.mark.parametrize("host_ring", [False, True])
+def test_corr_corracc_output_full_chain(tmp_path, host_ring):
+    """The slow-visibility side: Corr -> CorrAcc -> CorrOutputFull with the device
+    packetiser (xengXgpuPacketize).  CorrAcc publishes into a cuda_host ring as in lwa352-pipeline.py:154
+    (the block then stages the span on the device) or into a cuda ring (read in place).  The block's golden
+    check (corr_output_full_block.py:550-603) runs against visibilities computed independently in numpy."""
+    from caltech_bifrost_dsp_amd.blocks import CorrOutputFull
+    C, S, g, acc, lacc = 8, 20, 32, 64, 128
+    rng = np.random.default_rng(9)
+    vin = rng.integers(0, 256, (2 * lacc, C, S, 2), dtype=np.uint8)
+    # golden [t][chan][s0][s1][p0][p1] = sum x[s0,p0] conj(x[s1,p1])  (make_golden_inputs.py:156-158)
+    re, im = orc.decode(vin)
+    x = (re + 1j * im).reshape(2, lacc, C, S * 2)
+    gold = np.einsum('ktci,ktcj->kcij', x, np.conj(x)).reshape(2, C, S, 2, S, 2).transpose(0, 1, 2, 4, 3, 5)
+    check = tmp_path / "golden_raw.bin"
+    check.write_bytes(np.ascontiguousarray(gold.astype(np.complex128)).tobytes())
+    r0, r1 = Ring("gpu-input", space="cuda"), Ring("corr-output", space="cuda")
+    r2 = Ring("corr-slow-output", space="cuda_host" if host_ring else "cuda")
+    hdr = source_header(C, S, 2, seq0=0, sync_time=7)
+    corr = Corr(LOG, r0, r1, ntime_gulp=g, nchan=C, npol=2, nstand=S, acc_len=acc, autostartat=0, gpu=0,
+                ant_to_input=hdr['ant_to_input'])
+    cacc = CorrAcc(LOG, r1, r2, nchan=C, npol=2, nstand=S, acc_len=lacc, autostartat=0, gpu=0)
+    pkts = []
+    out = CorrOutputFull(LOG, r2, nchan=C, npol=2, nstand=S, checkfile=str(check), checkfile_acc_len=lacc,
+                         antpol_to_bl=corr.antpol_to_bl.numpy(), bl_is_conj=corr.bl_is_conj.numpy(),
+                         use_cor_fmt=False, gpu=0, sink=pkts.append)
+    run_blocks([corr, cacc, out], Source(r0, [(hdr, vin, g * C * S * 2)], wait_readers=1), [])
+    nbl = S * (S + 1) // 2
+    assert out.check_results == [(nbl * 8, 0)] * 2
+    assert len(pkts) == 2 * nbl and all(len(p) == 56 + 4 * C * 8 for p in pkts)
+    # spot-check one packet's payload against the golden matrix
+    k = nbl + (3 * S - (3 * 2) // 2 + (11 - 3))              # second integration, baseline (3, 11): s0*S - s0(s0-1)/2 + s1 - s0
+    pay = np.frombuffer(pkts[k][56:], dtype=np.int32).reshape(2, 2, C, 2)
+    assert np.array_equal(pay[..., 0], np.moveaxis(gold[1, :, 3, 11].real, 0, -1))
+    assert np.array_equal(pay[..., 1], np.moveaxis(gold[1, :, 3, 11].imag, 0, -1))

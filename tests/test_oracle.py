@@ -180,3 +180,24 @@ def test_beamform_matches_reference_functions(golden_dir, tag):
     assert np.all(np.isclose(op, power, rtol=1e-5, atol=1e-4))
     for b in range(nbeam // 2):
         assert np.array_equal(orc.beamform_integrate_single(beams, int(z["ntime_sum"]), b), op[b])
+
+
+def test_packet_payloads_follow_the_sending_order():
+    """corr_output_full_block.py:461-467 / :512-519 on a reordered matrix whose entries encode their own index."""
+    nstand, nchan = 6, 5
+    r = np.zeros((nstand, nstand, 2, 2, nchan, 2), dtype=np.int32)
+    idx = np.indices(r.shape)
+    r[...] = idx[0] * 100000 + idx[1] * 10000 + idx[2] * 1000 + idx[3] * 100 + idx[4] * 10 + idx[5]
+    py = orc.corr_packet_payloads(r, False)
+    cor = orc.corr_packet_payloads(r, True)
+    nbl = nstand * (nstand + 1) // 2
+    assert py.shape == cor.shape == (nbl, 4 * nchan * 2)
+    k = 0
+    for s0 in range(nstand):
+        for s1 in range(s0, nstand):
+            assert py[k].tobytes() == r[s0, s1].tobytes()                       # send_packets_py payload
+            assert np.array_equal(cor[k].reshape(nchan, 2, 2, 2), r[s0, s1].transpose(2, 0, 1, 3))
+            k += 1
+    h = orc.corr_packet_header_py(1600000000, 2400, 2.3e6, 5.0e7, 2400, nchan, 96, 2, 3, 5)
+    assert len(h) == 56                                                           # docs/source/outputs.rst:29
+    assert h[:8] == (1600000000).to_bytes(8, "big") and h[-8:] == (3).to_bytes(4, "big") + (5).to_bytes(4, "big")

@@ -346,3 +346,33 @@ def test_fp6_route_is_bit_exact(gpu, nstand, nchan, ntime, ngulp, kind):
         x.close()
     finally:
         del os.environ["XENG_MFMA"]
+
+
+@pytest.mark.parametrize("nstand,nchan,permute", [(16, 4, False), (48, 7, True), (36, 96, False)])
+def test_packetize_matches_reorder_then_slice(gpu, nstand, nchan, permute):
+    """xengXgpuPacketize (device) == bfXgpuReorder followed by the per-baseline slicing of
+    CorrOutputFull.send_packets_py / send_packets_bf, for the identity and a scrambled antpol_to_input map."""
+    ntime = 32
+    vin = gpu.synth_voltages(ntime, nchan, nstand, "full", seed=nstand)
+    planar = orc.xgpu_correlate(vin, nstand, nchan)
+    a2i = np.arange(nstand * 2, dtype=np.int32).reshape(nstand, 2)
+    if permute:
+        a2i = np.random.RandomState(4).permutation(nstand * 2).astype(np.int32).reshape(nstand, 2)
+    bl, cj = orc.xgpu_get_order(a2i)
+    reordered = orc.xgpu_reorder(planar, bl, cj, nchan)
+    x = gpu.Xgpu(nstand, nchan, ntime)
+    din = gpu.ffi.DeviceBuffer(planar.nbytes).upload(planar)
+    dbl = gpu.ffi.DeviceBuffer(bl.nbytes).upload(np.ascontiguousarray(bl))
+    dcj = gpu.ffi.DeviceBuffer(cj.nbytes).upload(np.ascontiguousarray(cj))
+    nbl = nstand * (nstand + 1) // 2
+    dout = gpu.ffi.DeviceBuffer(nbl * 4 * nchan * 8)
+    for fmt in (0, 1):
+        gpu.ffi.call("xengMemset", dout.ptr, 0x5A, dout.nbytes)
+        gpu.ffi.call("xengXgpuPacketize", din.ptr, dout.ptr, dbl.ptr, dcj.ptr, fmt)
+        got = dout.download(np.int32).reshape(nbl, -1)
+        assert np.array_equal(got, orc.corr_packet_payloads(reordered, bool(fmt))), fmt
+    with pytest.raises(gpu.ffi.XengError):
+        gpu.ffi.call("xengXgpuPacketize", din.ptr, dout.ptr, dbl.ptr, dcj.ptr, 2)
+    x.close()
+    for b in (din, dbl, dcj, dout):
+        b.free()
