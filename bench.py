@@ -222,6 +222,41 @@ def main():
                         "synchronous call (includes launch + stream sync)" % nbl}
         for b in (dbl, dcj, dpay):
             b.free()
+    # outside the timed region: the ingest step: one config-2 gulp worth of SNAP2 packets
+    # (5280 packets of 32 + 6144 bytes, device-resident) scattered into the gulp layout
+    ingest = None
+    if args.beamform and rank == 0 and world == 1:
+        import struct
+        nspp, ncb = 32, 1                                     # stands per packet, channel blocks
+        npb = (NINPUT // 2) // nspp
+        stride = 32 + NCHAN * nspp * 2
+        npk = NTIME_GULP * ncb * npb
+        slab = np.zeros((npk, stride), dtype=np.uint8)
+        k = 0
+        for t in range(NTIME_GULP):
+            for pb in range(npb):
+                slab[k, :32] = np.frombuffer(struct.pack(">QLHHHHLLL", t, 0, nspp * 2, NINPUT, NCHAN, NCHAN, 0, 0, pb * nspp * 2), dtype=np.uint8)
+                k += 1
+        slab[:, 32:] = np.random.RandomState(5).randint(0, 255, size=(npk, stride - 32), dtype=np.uint8)
+        dslab = ffi.DeviceBuffer(slab.nbytes).upload(slab)
+        dgulp = ffi.DeviceBuffer(gulp_bytes)
+        placed = ctypes.c_int()
+        for _ in range(3):
+            ffi.call("xengSnap2Unpack", dslab.ptr, npk, stride, dgulp.ptr, 0, NTIME_GULP, 0, NCHAN, NINPUT, 1, ctypes.byref(placed), None)
+        assert placed.value == npk
+        t1 = time.perf_counter()
+        nrep = 20
+        for _ in range(nrep):
+            ffi.call("xengSnap2Unpack", dslab.ptr, npk, stride, dgulp.ptr, 0, NTIME_GULP, 0, NCHAN, NINPUT, 1, None, None)
+        in_ms = (time.perf_counter() - t1) / nrep * 1e3
+        in_bytes = slab.nbytes + 2 * gulp_bytes              # packets read, gulp zero-filled and written
+        ingest = {"kernel": "snap2_unpack_kernel", "avg_us": round(in_ms * 1e3, 1), "packets": npk, "packet_bytes": stride,
+                  "ingest_gbps": round(8 * gulp_bytes / (in_ms * 1e-3) / 1e9, 1),
+                  "roofline": {"bound": "hbm", "achieved": round(in_bytes / (in_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": round(in_bytes / (in_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                  "note": "wall time of the synchronous call: memset of the gulp + scatter kernel + counter read-back"}
+        dslab.free()
+        dgulp.free()
     # outside the timed region: BASELINE config 4 -- Beamform (32 beams, 96 chan, 960 samples, fp32 weights)
     # + BeamformSumBeams (16 dual-pol power beams, ntime_sum 24) on the same GPU
     beam = None
@@ -370,6 +405,8 @@ def main():
         res["beamform"] = beam
     if pktz is not None:
         res["corr_output_packetize"] = pktz
+    if ingest is not None:
+        res["ingest_unpack"] = ingest
     if iso_cn[1] > 0:
         iso_mm = iso_tm[1] / iso_cn[1]
         iso_ach = ops_per_launch / (iso_mm * 1e-3) / 1e12

@@ -53,6 +53,15 @@ class HipBackend:
         """Drop staged gulps / partial sums of an aborted integration (no reference counterpart)."""
         return self._lib.xengXgpuReset()
 
+    # ---- ingest: SNAP2 packets -> gulp (the scatter bifrost's UDP capture does on the CPU; capture_block.py:296-305)
+    def snap2_unpack(self, packets, npkt, pkt_stride, out, seq0, ntime, chan0, nchan_tot, npol_tot, clear=True):
+        """Returns (status, packets placed, packets dropped)."""
+        import ctypes
+        placed, dropped = ctypes.c_int(), ctypes.c_int()
+        rc = self._lib.xengSnap2Unpack(packets.ptr, int(npkt), int(pkt_stride), out.ptr, int(seq0), int(ntime), int(chan0),
+                                       int(nchan_tot), int(npol_tot), int(bool(clear)), ctypes.byref(placed), ctypes.byref(dropped))
+        return rc, placed.value, dropped.value
+
     # ---- CorrAcc (corr_acc_block.py:304,306: BFMap "a = b" / "a += b")
     def map_assign_i32(self, a, b):
         return self._lib.xengMapAssignI32(a.ptr, b.ptr, a.nbytes // 4)

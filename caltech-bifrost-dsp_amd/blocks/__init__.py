@@ -7,6 +7,7 @@ from .beamform_sum_beams_block import BeamformSumBeams
 from .copy_block import Copy
 from .corr_subsel_block import CorrSubsel
 from .corr_output_full_block import CorrOutputFull
+from .snap2_ingest_block import Snap2Ingest
 
-__all__ = ["Block", "Corr", "CorrAcc", "Beamform", "BeamformSumBeams", "Copy", "CorrSubsel", "CorrOutputFull", "regtile_index", "tri_index",
+__all__ = ["Block", "Corr", "CorrAcc", "Beamform", "BeamformSumBeams", "Copy", "CorrSubsel", "CorrOutputFull", "Snap2Ingest", "regtile_index", "tri_index",
            "COMMAND_OK", "COMMAND_NOT_RECOGNIZED", "COMMAND_WRONG_TYPE", "COMMAND_INVALID"]

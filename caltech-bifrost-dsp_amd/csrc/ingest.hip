@@ -1,0 +1,113 @@
+// Ingest: scatter SNAP2 F-engine packets into the time-major gulp layout the X-engine and the beamformer
+// read (uint8[ntime][nchan][nstand*npol], pol fastest; corr_block.py:115-116).
+//
+// In the reference the scatter happens on the CPU inside bifrost's UDP capture (an absent submodule;
+// capture_block.py:296-305 only configures it) and the assembled gulp then crosses PCIe in the Copy block.
+// Here the receive slab (packets as they arrived, headers included: 32 B per ~6 KB) crosses PCIe and the
+// scatter is a device kernel, so the host touches no payload byte.
+//
+// Packet (test_tx_vectors.py:38-48,103-108; test_tx_mt.c:39-49), header big-endian `>QLHHHHLLL`:
+//   u64 seq | u32 sync_time (magic) | u16 npol | u16 npol_tot | u16 nchan | u16 nchan_tot |
+//   u32 chan_block_id | u32 chan0 | u32 pol0 ; payload u8[nchan][npol] (4+4 bit, npol = stands*2 in the packet)
+// Destination of payload row c: gulp[seq - seq0][chan0 - chan0_pipeline + c][pol0 .. pol0 + npol).
+#include "xeng_common.h"
+
+namespace xeng {
+
+__device__ __forceinline__ uint32_t be32(const uint8_t* p) {
+    return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+}
+__device__ __forceinline__ uint32_t be16(const uint8_t* p) { return ((uint32_t)p[0] << 8) | p[1]; }
+
+// Work-groups of 256 threads walk the packets (grid-stride); the header is fetched with two 16-byte loads
+// (all lanes, same address) and byte-swapped in registers; payload rows move as 16-byte pieces when the
+// geometry is 16-byte aligned (the deployed 64-byte rows are), else byte by byte.
+__global__ __launch_bounds__(256) void snap2_unpack_kernel(const uint8_t* __restrict__ pkts, int npkt, size_t stride,
+                                                           uint8_t* __restrict__ out, unsigned long long seq0, int ntime,
+                                                           int chan0_pipe, int nchan_tot, int npol_tot, int payload_max,
+                                                           int* __restrict__ counters) {
+    const bool aligned = (((uintptr_t)pkts | (uintptr_t)out | stride) & 15) == 0;
+    int nplaced = 0, ndropped = 0;
+    for (int p = blockIdx.x; p < npkt; p += gridDim.x) {
+        const uint8_t* h = pkts + (size_t)p * stride;
+        unsigned long long seq;
+        int npol, nchan;
+        long long chan0, pol0;
+        if (aligned) {
+            const uint4 h0 = *reinterpret_cast<const uint4*>(h), h1 = *reinterpret_cast<const uint4*>(h + 16);
+            seq = ((unsigned long long)__builtin_bswap32(h0.x) << 32) | __builtin_bswap32(h0.y);
+            npol = (int)(__builtin_bswap32(h0.w) >> 16);                  // bytes 12-13
+            nchan = (int)(__builtin_bswap32(h1.x) >> 16);                 // bytes 16-17
+            chan0 = (long long)__builtin_bswap32(h1.z) - chan0_pipe;      // bytes 24-27
+            pol0 = __builtin_bswap32(h1.w);                               // bytes 28-31
+        } else {
+            seq = ((unsigned long long)be32(h) << 32) | be32(h + 4);
+            npol = (int)be16(h + 12);
+            nchan = (int)be16(h + 16);
+            chan0 = (long long)be32(h + 24) - chan0_pipe;
+            pol0 = be32(h + 28);
+        }
+        // work-group-uniform validation: window, geometry, payload size
+        const bool ok = seq >= seq0 && seq - seq0 < (unsigned long long)ntime && npol > 0 && nchan > 0 && chan0 >= 0 &&
+                        chan0 + nchan <= nchan_tot && pol0 + npol <= npol_tot && (long long)nchan * npol <= payload_max;
+        if (!ok) {
+            ndropped++;
+            continue;
+        }
+        nplaced++;
+        const uint8_t* src = h + 32;
+        uint8_t* dst = out + (((size_t)(seq - seq0) * nchan_tot + (size_t)chan0) * npol_tot + (size_t)pol0);
+        if (aligned && ((npol | npol_tot | (int)pol0) & 15) == 0) {
+            const int per_row = npol >> 4;                       // 16-byte pieces per channel row
+            for (int i = threadIdx.x; i < nchan * per_row; i += 256) {
+                const int c = i / per_row, j = i - c * per_row;
+                *reinterpret_cast<uint4*>(dst + (size_t)c * npol_tot + j * 16) =
+                    *reinterpret_cast<const uint4*>(src + (size_t)c * npol + j * 16);
+            }
+        } else {
+            for (int i = threadIdx.x; i < nchan * npol; i += 256) {
+                const int c = i / npol, j = i - c * npol;
+                dst[(size_t)c * npol_tot + j] = src[i];
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (nplaced) atomicAdd(&counters[0], nplaced);
+        if (ndropped) atomicAdd(&counters[1], ndropped);
+    }
+}
+
+static int* g_counters[16] = {};
+
+}  // namespace xeng
+
+using namespace xeng;
+
+extern "C" int xengSnap2Unpack(const void* packets_dev, int npkt, size_t pkt_stride, void* out_dev, uint64_t seq0, int ntime,
+                               int chan0_pipeline, int nchan_tot, int npol_tot, int clear, int* nplaced, int* ndropped) {
+    if (!packets_dev || !out_dev) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Snap2Unpack: null buffer");
+    if (npkt < 0 || ntime <= 0 || nchan_tot <= 0 || npol_tot <= 0 || pkt_stride < 33)
+        XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Snap2Unpack: npkt=%d ntime=%d nchan_tot=%d npol_tot=%d stride=%zu", npkt, ntime,
+                  nchan_tot, npol_tot, pkt_stride);
+    int dev = 0;
+    XENG_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "device %d out of range", dev);
+    hipStream_t s;
+    int rc = get_stream(STREAM_COPY, &s);
+    if (rc) return rc;
+    if (!g_counters[dev]) XENG_HIP(hipMalloc((void**)&g_counters[dev], 2 * sizeof(int)));
+    XENG_HIP(hipMemsetAsync(g_counters[dev], 0, 2 * sizeof(int), s));
+    if (clear) XENG_HIP(hipMemsetAsync(out_dev, 0, (size_t)ntime * nchan_tot * npol_tot, s));   // missing packets = blanked samples
+    if (npkt > 0) {
+        hipLaunchKernelGGL(snap2_unpack_kernel, dim3(npkt < 4096 ? npkt : 4096), dim3(256), 0, s, (const uint8_t*)packets_dev, npkt, pkt_stride,
+                           (uint8_t*)out_dev, (unsigned long long)seq0, ntime, chan0_pipeline, nchan_tot, npol_tot,
+                           (int)(pkt_stride - 32), g_counters[dev]);
+        XENG_HIP(hipGetLastError());
+    }
+    int host[2] = {0, 0};
+    XENG_HIP(hipMemcpyAsync(host, g_counters[dev], sizeof(host), hipMemcpyDeviceToHost, s));
+    XENG_HIP(hipStreamSynchronize(s));
+    if (nplaced) *nplaced = host[0];
+    if (ndropped) *ndropped = host[1];
+    return XENG_STATUS_SUCCESS;
+}

@@ -47,6 +47,7 @@ SYMBOLS = {
     "xengXgpuGetInfo": [_pi, _pi, _pi, _pi, ctypes.POINTER(ctypes.c_int64), _pi],
     "xengXgpuGetPath": [_pi, _pi],
     "xengXgpuPacketize": [_vp, _vp, _vp, _vp, _i],
+    "xengSnap2Unpack": [_vp, _i, ctypes.c_size_t, _vp, ctypes.c_uint64, _i, _i, _i, _i, _i, _pi, _pi],
     "xengXgpuSetProfiling": [_i], "xengXgpuGetTimes": [ctypes.POINTER(ctypes.c_double), _pi],
     "xengMapAssignI32": [_vp, _vp, _sz], "xengMapAddI32": [_vp, _vp, _sz], "xengMapSync": [],
     "xengBeamformInitialize": [_i, _i, _i, _i, _i, _i], "xengBeamformDestroy": [],

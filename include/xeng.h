@@ -159,6 +159,19 @@ int xengXgpuGetPath(int *fused_corner_turn, int *fp6);
 int xengXgpuSetProfiling(int enable);
 int xengXgpuGetTimes(double ms[2], int count[2]);
 
+/* ---------------------------------------------------------------- Ingest (SNAP2 F-engine packets)
+ * Scatter received packets into a gulp on the device.  In the reference this scatter happens on the CPU inside
+ * bifrost's UDP capture, which capture_block.py:296-305 only configures; the packet format is pinned by the
+ * reference's transmitters (test_tx_vectors.py:38-48,103-108; test_tx_mt.c:39-49): 32-byte big-endian header
+ * `>QLHHHHLLL` = seq, sync_time, npol, npol_tot, nchan, nchan_tot, chan_block_id, chan0, pol0, then
+ * u8[nchan][npol] 4+4-bit samples.  packets_dev: npkt packets, pkt_stride bytes apart (any order, duplicates
+ * allowed).  out_dev: u8[ntime][nchan_tot][npol_tot]; row c of a packet lands at
+ * [seq - seq0][chan0 - chan0_pipeline + c][pol0 ..].  Packets outside the window [seq0, seq0+ntime) or outside
+ * the gulp geometry are dropped and counted.  clear != 0 zero-fills the gulp first, so samples of missing
+ * packets read as 0 (blanked).  Synchronous; the counters may be NULL. */
+int xengSnap2Unpack(const void *packets_dev, int npkt, size_t pkt_stride, void *out_dev, uint64_t seq0, int ntime,
+                    int chan0_pipeline, int nchan_tot, int npol_tot, int clear, int *nplaced, int *ndropped);
+
 /* ---------------------------------------------------------------- CorrAcc
  * replaces bifrost.map "a = b" / "a += b" on int32 (corr_acc_block.py:304,306).  Device pointers;
  * enqueued on the library's map stream; xengStreamSynchronize() (corr_acc_block.py:317) completes it. */

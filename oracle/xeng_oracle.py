@@ -175,6 +175,50 @@ def corr_packet_header_py(sync_time, spectra_id, bw_hz, sfreq, acc_len, nchan, c
     return struct.pack(">QQ2d4I", sync_time, spectra_id, bw_hz, sfreq, acc_len, nchan, chan0, npol) + struct.pack(">2I", s0, s1)
 
 
+SNAP2_HDR = ">QLHHHHLLL"     # test_tx_vectors.py:103-108, test_tx_mt.c:39-49 (32 bytes)
+
+
+def snap2_packets(data, seq0=0, sync_time=0, nchan_blocks=2, nstand_per_pkt=32, chan0_pipeline=0):
+    """The packet stream the reference's SNAP2 emulator sends for data u8[ntime][nchan][nstand][npol]
+    (test_tx_vectors.py:79-112): per sequence number, per channel block, per block of `nstand_per_pkt` stands,
+    one packet = header `>QLHHHHLLL` + payload [nchan_per_pkt][nstand_per_pkt][npol].  Returns a list of bytes
+    in sending order.  (The emulator numbers channels from 0; chan0_pipeline offsets them as a pipeline that
+    does not start at channel 0 sees them.)"""
+    import struct
+    ntime, nchan, nstand, npol = data.shape
+    assert nchan % nchan_blocks == 0 and nstand % nstand_per_pkt == 0
+    nchan_per_pkt = nchan // nchan_blocks
+    npol_blocks = nstand // nstand_per_pkt
+    pkts = []
+    for t in range(ntime):
+        for cb in range(nchan_blocks):
+            for pb in range(npol_blocks):
+                hdr = struct.pack(SNAP2_HDR, seq0 + t, sync_time, npol * nstand_per_pkt, nstand * npol,
+                                  nchan_per_pkt, nchan, cb, chan0_pipeline + cb * nchan_per_pkt, pb * nstand_per_pkt * npol)
+                pay = data[t, cb * nchan_per_pkt:(cb + 1) * nchan_per_pkt, pb * nstand_per_pkt:(pb + 1) * nstand_per_pkt, :]
+                pkts.append(hdr + np.ascontiguousarray(pay).tobytes())
+    return pkts
+
+
+def snap2_unpack(pkts, seq0, ntime, chan0_pipeline, nchan_tot, npol_tot):
+    """Inverse: scatter packets (any order) into u8[ntime][nchan_tot][npol_tot]; returns (gulp, nplaced, ndropped).
+    Row c of a packet goes to [seq - seq0][chan0 - chan0_pipeline + c][pol0 : pol0 + npol]; packets outside the
+    window / geometry are dropped; samples no packet covers stay 0."""
+    import struct
+    out = np.zeros((ntime, nchan_tot, npol_tot), dtype=np.uint8)
+    placed = dropped = 0
+    for p in pkts:
+        seq, _, npol, _, nchan, _, _, chan0, pol0 = struct.unpack(SNAP2_HDR, p[:32])
+        t, c0 = seq - seq0, chan0 - chan0_pipeline
+        if not (0 <= t < ntime and npol > 0 and nchan > 0 and c0 >= 0 and c0 + nchan <= nchan_tot
+                and pol0 + npol <= npol_tot and nchan * npol <= len(p) - 32):
+            dropped += 1
+            continue
+        out[t, c0:c0 + nchan, pol0:pol0 + npol] = np.frombuffer(p[32:32 + nchan * npol], dtype=np.uint8).reshape(nchan, npol)
+        placed += 1
+    return out, placed, dropped
+
+
 def xgpu_subselect(planar, vismap, conj, nchan, nchan_sum, nstand, npol=2):
     planar = np.ascontiguousarray(planar, dtype=np.int32)
     vismap = np.ascontiguousarray(vismap, dtype=np.int32)

@@ -92,6 +92,17 @@ class OracleBackend:
         _np(out_arr, np.int32, out.size)[...] = out.ravel()
         return 0
 
+    def snap2_unpack(self, packets, npkt, pkt_stride, out, seq0, ntime, chan0, nchan_tot, npol_tot, clear=True):
+        raw = packets.numpy().reshape(-1).view(np.uint8)
+        pkts = [raw[i * pkt_stride:(i + 1) * pkt_stride].tobytes() for i in range(npkt)]
+        gulp, placed, dropped = orc.snap2_unpack(pkts, seq0, ntime, chan0, nchan_tot, npol_tot)
+        o = out.numpy().reshape(-1).view(np.uint8)
+        if clear:
+            o[...] = gulp.ravel()
+        else:
+            o[...] = np.where(gulp.ravel() != 0, gulp.ravel(), o)
+        return 0, placed, dropped
+
     # CorrAcc
     def map_assign_i32(self, a, b):
         orc.map_i32(a.numpy().reshape(-1), b.numpy().reshape(-1), add=False)

@@ -382,3 +382,63 @@ def test_corr_then_output_full_packets(golden_dir, tmp_path, use_cor_fmt):
                     assert np.array_equal(pay[..., 0], np.moveaxis(g.real, 0, -1))
                     assert np.array_equal(pay[..., 1], np.moveaxis(g.imag, 0, -1))
     assert oblk.stats['curr_sample'] == (nint - 1) * acc_len and 'output_gbps' in oblk.stats
+
+
+def test_snap2_ingest_then_corr(golden_dir):
+    """Packets of the reference's SNAP2 emulator (test_tx_vectors.py:79-112) -> Snap2Ingest -> Corr on CPU rings:
+    the gulps are restored exactly, the sequence header is the one capture_block.py:264-282 builds, and the
+    visibilities equal the golden file; a lost packet blanks its samples and is reported."""
+    from caltech_bifrost_dsp_amd.blocks import Snap2Ingest
+    _, vin = load_dat(os.path.join(golden_dir, "in_8t_4c_16s_2p_deadbeef.dat"))
+    meta, corr = load_dat(os.path.join(golden_dir, "corr_8t_4a_4c_16s_2p_deadbeef.dat"))
+    T, C, S, P = vin.shape
+    g = 2                                                              # sequence numbers per gulp
+    be = OracleBackend()
+    seq0, chan0 = 4000, 96
+    pk = orc.snap2_packets(vin, seq0=seq0, sync_time=1234, nchan_blocks=2, nstand_per_pkt=8, chan0_pipeline=chan0)
+    per_win = len(pk) // (T // g)
+    rng = np.random.default_rng(8)
+    slabs = []
+    for w in range(T // g):                                           # arrival order inside a window is arbitrary
+        win = pk[w * per_win:(w + 1) * per_win]
+        slabs.append(b"".join(win[i] for i in rng.permutation(per_win)))
+    r_pk, r_in, r_vis = Ring("packets"), Ring("gpu-input"), Ring("corr-output")
+    ing = Snap2Ingest(LOG, r_pk, r_in, ntime_gulp=g, nchan=C, nstand=S, npol=P, nchan_per_pkt=C // 2, nstand_per_pkt=8,
+                      backend=be)
+    assert ing.npkt_per_gulp == per_win and ing.pkt_stride == len(pk[0])
+    hdr_src = source_header(C, S, P, seq0=seq0, chan0=chan0)
+    cblk = Corr(LOG, r_in, r_vis, ntime_gulp=g, nchan=C, npol=P, nstand=S, acc_len=meta["acc_len"], autostartat=seq0,
+                ant_to_input=hdr_src['ant_to_input'], backend=be)
+    raw_sink, vis_sink = Sink(r_in, ing.ogulp_size), Sink(r_vis, cblk.ogulp_size)
+    run_blocks([ing, cblk], Source(r_pk, [({'seq0': seq0, 'chan0': chan0, 'sync_time': 1234}, b"".join(slabs), ing.igulp_size)]),
+               [raw_sink, vis_sink])
+    (h, tag, spans), = raw_sink.sequences
+    assert (h['seq0'], h['chan0'], h['nchan'], h['nstand'], h['npol'], h['sync_time'], h['nbit'], h['complex']) == \
+           (seq0, chan0, C, S, P, 1234, 4, True)
+    assert h['sfreq'] == chan0 * 23925.78125 and h['bw_hz'] == C * 23925.78125 and tag == 1
+    assert np.array_equal(np.concatenate(spans).reshape(vin.shape), vin)
+    assert ing.stats['packets_placed'] == len(pk) and ing.stats['packets_dropped'] == 0 and ing.stats['missing_frac'] == 0.0
+    # Corr's seq0-relative start: the visibilities equal the golden ones
+    (vh, _, vspans), = vis_sink.sequences
+    bl, cj = cblk.antpol_to_bl.numpy(), cblk.bl_is_conj.numpy()
+    ro = orc.xgpu_reorder(vspans[0].view(np.int32), bl, cj, C)
+    gold = corr[0]
+    assert np.array_equal(ro[1, 5, :, :, :, 0], np.moveaxis(gold[:, 1, 5].real, 0, -1))
+    assert np.array_equal(ro[1, 5, :, :, :, 1], np.moveaxis(gold[:, 1, 5].imag, 0, -1))
+
+    # a window with one packet lost (slot left zero) and a stray packet of another window in its place
+    r_pk2, r_in2 = Ring("packets"), Ring("gpu-input")
+    ing2 = Snap2Ingest(LOG, r_pk2, r_in2, ntime_gulp=g, nchan=C, nstand=S, npol=P, nchan_per_pkt=C // 2, nstand_per_pkt=8,
+                       backend=be)
+    win = list(pk[:per_win])
+    win[3] = pk[per_win]                                               # belongs to the next window -> dropped
+    sink2 = Sink(r_in2, ing2.ogulp_size)
+    run_blocks([ing2], Source(r_pk2, [({'seq0': seq0, 'chan0': chan0}, b"".join(win), ing2.igulp_size)]), [sink2])
+    got = sink2.sequences[0][2][0].reshape(g, C, S * P)
+    exp = vin[:g].reshape(g, C, S * P).copy()
+    import struct
+    seq, _, npol, _, nchan, _, _, c0, p0 = struct.unpack(orc.SNAP2_HDR, pk[3][:32])
+    exp[seq - seq0, c0 - chan0:c0 - chan0 + nchan, p0:p0 + npol] = 0
+    assert np.array_equal(got, exp)
+    assert ing2.stats['packets_placed'] == per_win - 1 and ing2.stats['packets_dropped'] == 1
+    assert abs(ing2.stats['missing_frac'] - 1.0 / per_win) < 1e-12

@@ -1,0 +1,99 @@
+"""Ingest on the GPU: xengSnap2Unpack against the oracle's restatement of the reference SNAP2 emulator
+(test_tx_vectors.py:79-112), and Snap2Ingest -> Corr on device rings."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import caltech_bifrost_dsp_amd  # noqa: E402,F401
+from caltech_bifrost_dsp_amd import ffi  # noqa: E402
+from caltech_bifrost_dsp_amd.blocks import Corr, Snap2Ingest  # noqa: E402
+from caltech_bifrost_dsp_amd.ring import Ring  # noqa: E402
+from oracle import xeng_oracle as orc  # noqa: E402
+from tests.pipeline_util import LOG, Sink, Source, run_blocks, source_header  # noqa: E402
+
+
+def _unpack(slab, npkt, stride, seq0, ntime, chan0, nchan, ninput, clear=1, out=None):
+    dpk = ffi.DeviceBuffer(max(len(slab), 1)).upload(np.frombuffer(slab, dtype=np.uint8))
+    dout = out if out is not None else ffi.DeviceBuffer(ntime * nchan * ninput)
+    placed, dropped = ctypes.c_int(), ctypes.c_int()
+    ffi.call("xengSnap2Unpack", dpk.ptr, npkt, stride, dout.ptr, seq0, ntime, chan0, nchan, ninput, clear,
+             ctypes.byref(placed), ctypes.byref(dropped))
+    got = dout.download(np.uint8).reshape(ntime, nchan, ninput)
+    dpk.free()
+    if out is None:
+        dout.free()
+    return got, placed.value, dropped.value
+
+
+@pytest.mark.parametrize("T,C,S,nchan_blocks,nstand_per_pkt", [
+    (6, 8, 64, 2, 32),        # the deployed packet shape: 32 stands x 2 pol = 64 bytes per channel row (16-byte path)
+    (5, 6, 12, 3, 3),         # 6-byte rows: byte path
+    (480, 96, 352, 1, 32),    # config 2: one gulp, 5280 packets of 6176 bytes
+])
+def test_unpack_matches_oracle(T, C, S, nchan_blocks, nstand_per_pkt):
+    rng = np.random.default_rng(T + S)
+    vin = rng.integers(0, 256, (T, C, S, 2), dtype=np.uint8)
+    seq0, chan0 = 10 ** 12 + 5, 1000                                   # sequence numbers beyond 32 bits
+    pk = orc.snap2_packets(vin, seq0=seq0, sync_time=9, nchan_blocks=nchan_blocks, nstand_per_pkt=nstand_per_pkt,
+                           chan0_pipeline=chan0)
+    stride = len(pk[0])
+    order = rng.permutation(len(pk))
+    got, placed, dropped = _unpack(b"".join(pk[i] for i in order), len(pk), stride, seq0, T, chan0, C, S * 2)
+    assert placed == len(pk) and dropped == 0
+    assert np.array_equal(got.reshape(vin.shape), vin)
+
+
+def test_unpack_drops_and_blanks():
+    T, C, S = 8, 8, 64
+    rng = np.random.default_rng(1)
+    vin = rng.integers(1, 256, (T, C, S, 2), dtype=np.uint8)
+    seq0, chan0 = 777, 96
+    pk = orc.snap2_packets(vin, seq0=seq0, nchan_blocks=2, nstand_per_pkt=32, chan0_pipeline=chan0)
+    stride = len(pk[0])
+    stray = [orc.snap2_packets(vin[:1], seq0=seq0 + T, nchan_blocks=2, chan0_pipeline=chan0)[0],      # next window
+             orc.snap2_packets(vin[:1], seq0=seq0 - 1, nchan_blocks=2, chan0_pipeline=chan0)[0],      # previous window
+             orc.snap2_packets(vin[:1], seq0=seq0, nchan_blocks=2, chan0_pipeline=chan0 + C)[0],      # other channels
+             bytes(stride)]                                                                             # empty slot
+    lost = {2, 17}
+    mixed = [p for i, p in enumerate(pk) if i not in lost] + stray + [pk[4]]                           # + a duplicate
+    mixed = [mixed[i] for i in rng.permutation(len(mixed))]
+    exp, eplaced, edropped = orc.snap2_unpack(mixed, seq0, T, chan0, C, S * 2)
+    got, placed, dropped = _unpack(b"".join(mixed), len(mixed), stride, seq0, T, chan0, C, S * 2)
+    assert (placed, dropped) == (eplaced, edropped) == (len(pk) - 2 + 1, 4)
+    assert np.array_equal(got, exp)
+    assert (got == 0).sum() == 2 * (C // 2) * 64                      # exactly the two lost packets' samples
+    # clear=0 leaves what is already in the gulp (a second slab of the same window completes it)
+    dout = ffi.DeviceBuffer(T * C * S * 2)
+    _unpack(b"".join(mixed), len(mixed), stride, seq0, T, chan0, C, S * 2, clear=1, out=dout)
+    late = [pk[i] for i in sorted(lost)]
+    got2, placed2, _ = _unpack(b"".join(late), 2, stride, seq0, T, chan0, C, S * 2, clear=0, out=dout)
+    assert placed2 == 2 and np.array_equal(got2.reshape(vin.shape), vin)
+    dout.free()
+    with pytest.raises(ffi.XengError):
+        ffi.call("xengSnap2Unpack", None, 1, stride, None, 0, T, 0, C, S * 2, 1, None, None)
+
+
+def test_ingest_corr_on_device_rings():
+    """pinned packet slabs -> Snap2Ingest (H2D of raw packets + device scatter) -> gpu-input (cuda) -> Corr."""
+    T, C, S, g, acc = 128, 8, 64, 32, 64
+    rng = np.random.default_rng(12)
+    vin = rng.integers(0, 256, (T, C, S, 2), dtype=np.uint8)
+    seq0, chan0 = 6400, 192
+    pk = orc.snap2_packets(vin, seq0=seq0, sync_time=5, nchan_blocks=2, nstand_per_pkt=32, chan0_pipeline=chan0)
+    per_win = len(pk) // (T // g)
+    slabs = b"".join(b"".join(pk[w * per_win + i] for i in rng.permutation(per_win)) for w in range(T // g))
+    r_pk, r_in, r_vis = Ring("packets", space="cuda_host"), Ring("gpu-input", space="cuda"), Ring("corr-output", space="cuda")
+    ing = Snap2Ingest(LOG, r_pk, r_in, ntime_gulp=g, nchan=C, nstand=S, npol=2, nchan_per_pkt=C // 2, nstand_per_pkt=32, gpu=0)
+    hdr = source_header(C, S, 2)
+    corr = Corr(LOG, r_in, r_vis, ntime_gulp=g, nchan=C, npol=2, nstand=S, acc_len=acc, autostartat=seq0, gpu=0,
+                ant_to_input=hdr['ant_to_input'])
+    sink = Sink(r_vis, corr.ogulp_size)
+    run_blocks([ing, corr], Source(r_pk, [({'seq0': seq0, 'chan0': chan0, 'sync_time': 5}, slabs, ing.igulp_size)]), [sink])
+    (h, _, spans), = sink.sequences
+    assert h['seq0'] == seq0 and h['chan0'] == chan0 and len(spans) == T // acc
+    for k, sp in enumerate(spans):
+        assert np.array_equal(sp.view(np.int32), orc.xgpu_correlate(vin[k * acc:(k + 1) * acc], S, C))
+    assert ing.stats['packets_placed'] == len(pk) and ing.stats['missing_frac'] == 0.0

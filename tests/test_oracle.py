@@ -201,3 +201,34 @@ def test_packet_payloads_follow_the_sending_order():
     h = orc.corr_packet_header_py(1600000000, 2400, 2.3e6, 5.0e7, 2400, nchan, 96, 2, 3, 5)
     assert len(h) == 56                                                           # docs/source/outputs.rst:29
     assert h[:8] == (1600000000).to_bytes(8, "big") and h[-8:] == (3).to_bytes(4, "big") + (5).to_bytes(4, "big")
+
+
+def test_snap2_packets_follow_the_reference_emulator_and_round_trip(golden_dir):
+    """test_tx_vectors.py:79-112 on the reference's own golden input file: packet count, header fields, payload
+    slices; unpack(packets) restores the array; lost / late / foreign packets are dropped and leave zeros."""
+    import struct
+    with open(os.path.join(golden_dir, "in_8t_4c_16s_2p_deadbeef.dat"), "rb") as fh:
+        meta = json.loads(fh.readline().decode())
+        vin = np.frombuffer(fh.read(), dtype=np.uint8).reshape(meta["shape"])
+    T, C, S, P = vin.shape
+    pk = orc.snap2_packets(vin, seq0=1000, sync_time=77, nchan_blocks=2, nstand_per_pkt=8, chan0_pipeline=192)
+    assert len(pk) == T * 2 * (S // 8) and all(len(p) == 32 + (C // 2) * 8 * P for p in pk)
+    # third packet of sequence 1001: channel block 0, stands 16.. (third block of 8) -- there are only 2: so block (1, 0)
+    h = struct.unpack(orc.SNAP2_HDR, pk[2 * (S // 8) + 2][:32])
+    assert h == (1001, 77, 8 * P, S * P, C // 2, C, 1, 192 + C // 2, 0)
+    assert pk[2 * (S // 8) + 2][32:] == vin[1, C // 2:, 0:8, :].tobytes()
+    out, placed, dropped = orc.snap2_unpack(pk, 1000, T, 192, C, S * P)
+    assert placed == len(pk) and dropped == 0 and np.array_equal(out.reshape(vin.shape), vin)
+    # shuffled, one packet lost, one duplicated, one from the next window, one for another pipeline's channels
+    rng = np.random.default_rng(3)
+    lost = 5
+    extra = [pk[7], orc.snap2_packets(vin[:1], seq0=1000 + T, nstand_per_pkt=8, chan0_pipeline=192)[0],
+             orc.snap2_packets(vin[:1], seq0=1000, nstand_per_pkt=8, chan0_pipeline=192 + C)[0]]
+    mixed = [p for i, p in enumerate(pk) if i != lost] + extra
+    mixed = [mixed[i] for i in rng.permutation(len(mixed))]
+    out2, placed2, dropped2 = orc.snap2_unpack(mixed, 1000, T, 192, C, S * P)
+    assert placed2 == len(pk) and dropped2 == 2
+    exp = vin.copy().reshape(T, C, S * P)
+    seq, _, npol, _, nchan, _, _, chan0, pol0 = struct.unpack(orc.SNAP2_HDR, pk[lost][:32])
+    exp[seq - 1000, chan0 - 192:chan0 - 192 + nchan, pol0:pol0 + npol] = 0
+    assert np.array_equal(out2, exp)
