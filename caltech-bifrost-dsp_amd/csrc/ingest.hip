@@ -59,10 +59,23 @@ __global__ __launch_bounds__(256) void snap2_unpack_kernel(const uint8_t* __rest
         uint8_t* dst = out + (((size_t)(seq - seq0) * nchan_tot + (size_t)chan0) * npol_tot + (size_t)pol0);
         if (aligned && ((npol | npol_tot | (int)pol0) & 15) == 0) {
             const int per_row = npol >> 4;                       // 16-byte pieces per channel row
-            for (int i = threadIdx.x; i < nchan * per_row; i += 256) {
-                const int c = i / per_row, j = i - c * per_row;
-                *reinterpret_cast<uint4*>(dst + (size_t)c * npol_tot + j * 16) =
-                    *reinterpret_cast<const uint4*>(src + (size_t)c * npol + j * 16);
+            const int n = nchan * per_row;
+            // batches of four pieces per thread: four loads in flight before the first store
+            for (int i0 = threadIdx.x; i0 < n; i0 += 4 * 256) {
+                uint4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int i = i0 + u * 256;
+                    if (i < n) v[u] = *reinterpret_cast<const uint4*>(src + (size_t)i * 16);   // rows are contiguous in the packet
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int i = i0 + u * 256;
+                    if (i < n) {
+                        const int c = i / per_row, j = i - c * per_row;
+                        *reinterpret_cast<uint4*>(dst + (size_t)c * npol_tot + j * 16) = v[u];
+                    }
+                }
             }
         } else {
             for (int i = threadIdx.x; i < nchan * npol; i += 256) {
