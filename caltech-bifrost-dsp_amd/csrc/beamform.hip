@@ -50,7 +50,7 @@ static int run_locked(const void* in, float* out, const void* w, long long versi
     }
     // split the fp32 weights into three bf16 terms unless this exact (pointer, version) is already prepared
     if (!(version != 0 && version == x.w_version && w == x.w_cached)) {
-        hipLaunchKernelGGL(beam_weights_prep_kernel, dim3(x.nchunk, x.nbtile, x.nchan), dim3(256), 0, x.stream,
+        hipLaunchKernelGGL(beam_weights_prep_kernel, dim3((x.ninput + 63) / 64, x.nbtile, x.nchan), dim3(256), 0, x.stream,
                            (const float*)w, x.wprep, x.nchan, x.nbeam, x.ninput, x.nchunk, x.nbtile);
         XENG_HIP(hipGetLastError());
         x.w_cached = w;
@@ -58,7 +58,7 @@ static int run_locked(const void* in, float* out, const void* w, long long versi
     }
     dim3 grid(((x.ntime + BF3_NT - 1) / BF3_NT) * x.nchan * x.nbtile);
     int slot = x.timer.begin(x.stream, 0);
-    hipLaunchKernelGGL(beamform_bf16x3_kernel, grid, dim3(BF3_NT * 2), 0, x.stream, (const uint8_t*)in, x.wprep, out,
+    hipLaunchKernelGGL(beamform_bf16x3_kernel, grid, dim3(64 * BF3_NW), 0, x.stream, (const uint8_t*)in, x.wprep, out,
                        x.ntime, x.nchan, x.ninput, x.nbeam, x.nchunk, x.nbtile);
     x.timer.end(x.stream, slot);
     XENG_HIP(hipGetLastError());
@@ -97,7 +97,7 @@ int xengBeamformInitialize(int gpu, int ninput, int nchan, int ntime, int nbeam,
     XENG_HIP(hipSetDevice(x.gpu));
     x.ninput = ninput; x.nchan = nchan; x.ntime = ntime; x.nbeam = nbeam; x.ntime_blocks = ntime_blocks;
     if (ntime_blocks > 0) XENG_HIP(hipMalloc((void**)&x.scratch, (size_t)nchan * nbeam * ntime * 8));
-    x.nchunk = (ninput + BF_KC - 1) / BF_KC;
+    x.nchunk = (ninput + BF3_KC - 1) / BF3_KC;
     x.nbtile = (nbeam + 31) / 32;
     x.wprep_bytes = (size_t)nchan * x.nbtile * x.nchunk * BF3_WCHUNK;
     XENG_HIP(hipMalloc((void**)&x.wprep, x.wprep_bytes));

@@ -139,27 +139,37 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, uint32_t lds_byte_ad
 __device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
     return (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)p;
 }
-constexpr int BF3_ROW = 144;                         // 64 bf16 + 16 B pad
-constexpr int BF3_WCHUNK = 3 * 2 * 32 * BF3_ROW;      // 27648 B of weights per 64-input chunk
-constexpr int BF3_NT = 128;                           // samples per work-group: 4 waves x 32, one per SIMD
-constexpr int BF3_XCHUNK = BF3_NT * BF_KC;            // 12288 B of packed voltages per chunk
-constexpr int BF3_STAGE = BF3_WCHUNK + BF3_XCHUNK;
+constexpr int BF3_KC = 32;                           // inputs per LDS chunk
+constexpr int BF3_ROW = BF3_KC * 2;                  // 64 B of bf16 per (term, re|im, beam) row, no padding:
+                                                     //   16-byte piece p of row j sits at position p ^ ((j>>2)&3)
+constexpr int BF3_WCHUNK = 3 * 2 * 32 * BF3_ROW;      // 12288 B of weights per chunk
+#ifndef BF3_NW
+#define BF3_NW 4                                      // waves per work-group (measured: 4 -> 52.5 us, 8 -> 58.4 (384 work-groups
+#endif                                                //  leave half the CUs with one), 6 -> 64.6 (waves land unevenly on the SIMDs))
+constexpr int BF3_NT = 32 * BF3_NW;                   // samples per work-group: one 32-sample MFMA column tile per wave
+constexpr int BF3_XCHUNK = BF3_NT * BF3_KC;           // packed voltages per chunk (1 KiB per wave)
+constexpr int BF3_STAGE = BF3_WCHUNK + BF3_XCHUNK;    // 16 KiB for 4 waves
+constexpr int BF3_WSLOTS = (12 + BF3_NW - 1) / BF3_NW;  // weight pieces issued per wave and chunk (12 pieces in all)
+constexpr int BF3_RING = 3;                           // stages: the LDS-DMA runs two chunks ahead of the MFMAs
 
 __device__ __forceinline__ uint32_t f32_to_bf16_rne(float f) {
     const uint32_t u = __float_as_uint(f);
     return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;   // weights are finite
 }
 
-// grid (nchunk, nbtile, nchan), 256 threads: thread = (beam tid/8, 8 inputs (tid%8)*8)
+// grid (ceil(ninput/64), nbtile, nchan), 256 threads: thread = (beam tid/8, 8 inputs (tid%8)*8) of a 64-input
+// span = two chunks.  Layout Wp[c][beam tile][chunk][term][re|im][32 beams][32 inputs] bf16.
 __global__ __launch_bounds__(256) void beam_weights_prep_kernel(const float* __restrict__ w, uint8_t* __restrict__ wp,
                                                                 int nchan, int nbeam, int ninput, int nchunk, int nbtile) {
-    const int ch = blockIdx.x, bt = blockIdx.y, c = blockIdx.z;
+    const int sp = blockIdx.x, bt = blockIdx.y, c = blockIdx.z;
     const int beam = threadIdx.x >> 3, k0 = (threadIdx.x & 7) * 8;
     const int b = bt * 32 + beam;
+    const int ch = 2 * sp + (k0 >> 5);                 // chunk of this thread's 8 inputs
+    if (ch >= nchunk) return;
     uint32_t t[3][2][4];   // [term][re|im][4 dwords = 8 bf16]
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        const int i = ch * BF_KC + k0 + j;
+        const int i = sp * 64 + k0 + j;
         float re = 0.f, im = 0.f;
         if (b < nbeam && i < ninput) {
             const float2 v = *reinterpret_cast<const float2*>(w + (((size_t)c * nbeam + b) * ninput + i) * 2);
@@ -178,13 +188,13 @@ __global__ __launch_bounds__(256) void beam_weights_prep_kernel(const float* __r
         }
     }
     uint8_t* base = wp + (((size_t)c * nbtile + bt) * nchunk + ch) * BF3_WCHUNK;
+    const int pos = ((k0 & 31) >> 3) ^ ((beam >> 2) & 3);  // swizzled 16-byte piece of the row
 #pragma unroll
     for (int term = 0; term < 3; term++)
 #pragma unroll
         for (int comp = 0; comp < 2; comp++)
-            *reinterpret_cast<uint4*>(base + ((term * 2 + comp) * 32 + beam) * BF3_ROW + k0 * 2) =
+            *reinterpret_cast<uint4*>(base + ((term * 2 + comp) * 32 + beam) * BF3_ROW + pos * 16) =
                 make_uint4(t[term][comp][0], t[term][comp][1], t[term][comp][2], t[term][comp][3]);
-    // the 16-byte pad of each row is never read
 }
 
 __device__ __forceinline__ v8bf as_v8bf(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
@@ -193,18 +203,20 @@ __device__ __forceinline__ v8bf as_v8bf(uint32_t a, uint32_t b, uint32_t c, uint
     return __builtin_bit_cast(v8bf, v);
 }
 
-// grid nchan * nbtile * ceil(ntime/128) (1-D), 256 threads; wave w owns samples t0 + 32w .. +31.
-// One LDS stage (36 KB) per work-group: four work-groups per CU interleave, so one group's LDS-DMA
-// latency and barriers hide under the MFMAs of the other three (4 waves per SIMD, all SIMDs equal).
-__global__ __launch_bounds__(256, 4) void beamform_bf16x3_kernel(const uint8_t* __restrict__ in,
+// grid nchan * nbtile * ceil(ntime/BF3_NT) (1-D), 64*BF3_NW threads; wave w owns samples t0 + 32w .. +31.
+// Config 4 is a single round of 768 work-groups (3 per CU), each a chain of 22 chunk steps: the kernel is
+// bound by how well the staging latency hides, not by MFMA throughput.  So the LDS-DMA runs two chunks
+// ahead on a ring of three 16 KiB stages (counted vmcnt, one barrier per chunk), and three work-groups per
+// CU (48 KiB each) interleave on every SIMD.
+__global__ __launch_bounds__(64 * BF3_NW, BF3_NW == 8 ? 2 : 3) void beamform_bf16x3_kernel(const uint8_t* __restrict__ in,
                                                                  const uint8_t* __restrict__ wp,
                                                                  float* __restrict__ out, int ntime, int nchan,
                                                                  int ninput, int nbeam, int nchunk, int nbtile) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[BF3_STAGE];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[BF3_RING * BF3_STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // 1-D grid of nchan*nbtile*nttile blocks.  Blocks b and b+8 share an XCD: give each XCD whole channels
-    // so the work-groups of a channel read its 304 KB of split weights through one L2 (speed only).
+    // so the work-groups of a channel read its split weights through one L2 (speed only).
     const int nttile = (ntime + BF3_NT - 1) / BF3_NT, per_c = nbtile * nttile;
     int c, rem;
     if ((nchan & 7) == 0) { const int b = blockIdx.x, slot = b >> 3; c = (b & 7) + 8 * (slot / per_c); rem = slot % per_c; }
@@ -212,35 +224,42 @@ __global__ __launch_bounds__(256, 4) void beamform_bf16x3_kernel(const uint8_t* 
     const int bt = rem / nttile, t0 = (rem % nttile) * BF3_NT;
     const int h = lane >> 5, j = lane & 31;
     const uint8_t* wsrc = wp + (((size_t)c * nbtile + bt) * nchunk) * BF3_WCHUNK + lane * 16;
-    // X piece n (1 KiB) of a chunk = samples 16n..16n+15, 64 B each; this lane: row 16n + lane/4, bytes (lane%4)*16
     const size_t row_stride = (size_t)nchan * ninput;
-    constexpr int NWP = BF3_WCHUNK / 1024;            // 27 weight pieces per chunk
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
+    // X piece `wave` of a chunk = samples 32*wave .. +31, 32 B each; this lane: row 32*wave + lane/2, 16-byte half
+    // (lane&1) ^ ((row>>3)&1): the swizzle (applied on the source side, the LDS side of the DMA is lane-linear)
+    // makes the 8-byte fragment reads below bank-conflict-free.  Rows past ntime: any valid row (never stored).
+    int xt = t0 + wave * 32 + (lane >> 1);
+    if (xt >= ntime) xt = ntime - 1;
+    const uint8_t* xsrc = in + (size_t)xt * row_stride + (size_t)c * ninput;
+    const int xhalf = ((lane & 1) ^ ((lane >> 4) & 1)) * 16;
+    // every stage costs exactly BF3_WSLOTS + 1 pieces per wave on the vmcnt counter (chunks past the end re-read
+    // the last one; weight slots past the 12th piece re-copy an earlier piece onto itself)
     auto issue = [&](int ch, int buf) {
+        const int cs = ch < nchunk ? ch : nchunk - 1;
         const uint32_t l = lds0 + buf * BF3_STAGE;
-        for (int n = wave; n < NWP; n += BF3_NT / 32)
-            lds_dma16(wsrc + (size_t)ch * BF3_WCHUNK + n * 1024, l + n * 1024);
-        for (int n = wave; n < BF3_NT / 16; n += BF3_NT / 32) {
-            int t = t0 + n * 16 + (lane >> 2);
-            int i = ch * BF_KC + (lane & 3) * 16;
-            if (t >= ntime) t = ntime - 1;             // rows past the end: any valid row (never stored)
-            if (i + 16 > ninput) i = 0;                // columns past the end meet zero weights
-            const uint8_t* g = in + (size_t)t * row_stride + (size_t)c * ninput + i;
-            lds_dma16(g, l + BF3_WCHUNK + n * 1024);
+#pragma unroll
+        for (int n = 0; n < BF3_WSLOTS; n++) {
+            const int pc = (wave + BF3_NW * n) % 12;
+            lds_dma16(wsrc + (size_t)cs * BF3_WCHUNK + pc * 1024, l + pc * 1024);
         }
+        int i = cs * BF3_KC + xhalf;
+        if (i + 16 > ninput) i = 0;                    // columns past the end meet zero weights
+        lds_dma16(xsrc + i, l + BF3_WCHUNK + wave * 1024);
     };
     v16f acc_r = (v16f)(0.f), acc_i = (v16f)(0.f);
+    issue(0, 0);
+    issue(1, 1);
+    int buf = 0, nbuf = 2;
     for (int ch = 0; ch < nchunk; ch++) {
-        const int buf = 0;
-        if (ch > 0) __builtin_amdgcn_s_barrier();      // everybody is done reading chunk ch-1
-        issue(ch, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                  // chunk ch landed for all waves
-        const uint8_t* lw = lds + buf * BF3_STAGE + j * BF3_ROW + h * 16;
-        const uint8_t* lx = lds + buf * BF3_STAGE + BF3_WCHUNK + (wave * 32 + j) * BF_KC + h * 8;
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(BF3_WSLOTS + 1) : "memory");   // this wave's pieces of chunk ch have landed (ch+1 in flight)
+        __builtin_amdgcn_s_barrier();                  // ... for all waves; and everybody is done reading chunk ch-1,
+        issue(ch + 2, nbuf);                           // whose buffer the DMA of chunk ch+2 now overwrites
+        const uint8_t* lw = lds + buf * BF3_STAGE + j * BF3_ROW;
+        const uint8_t* lx = lds + buf * BF3_STAGE + BF3_WCHUNK + (wave * 32 + j) * BF3_KC + h * 8;
 #pragma unroll
-        for (int s = 0; s < 4; s++) {                  // 16 inputs per step: this lane-half takes 8 of them
-            const uint2 xb = *reinterpret_cast<const uint2*>(lx + s * 16);
+        for (int s = 0; s < 2; s++) {                  // 16 inputs per step: this lane-half takes 8 of them
+            const uint2 xb = *reinterpret_cast<const uint2*>(lx + ((s ^ ((j >> 3) & 1)) * 16));
             uint32_t xr[4], xi[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {              // bytes 2q, 2q+1 -> one dword of two bf16
@@ -258,10 +277,11 @@ __global__ __launch_bounds__(256, 4) void beamform_bf16x3_kernel(const uint8_t* 
             const v8bf Xr = as_v8bf(xr[0], xr[1], xr[2], xr[3]);
             const v8bf Xi = as_v8bf(xi[0], xi[1], xi[2], xi[3]);
             const v8bf nXi = as_v8bf(xi[0] ^ 0x80008000u, xi[1] ^ 0x80008000u, xi[2] ^ 0x80008000u, xi[3] ^ 0x80008000u);
+            const int wpos = ((2 * s + h) ^ ((j >> 2) & 3)) * 16;
 #pragma unroll
             for (int term = 2; term >= 0; term--) {    // smallest term first
-                const uint4 a = *reinterpret_cast<const uint4*>(lw + ((term * 2 + 0) * 32) * BF3_ROW + s * 32);
-                const uint4 b = *reinterpret_cast<const uint4*>(lw + ((term * 2 + 1) * 32) * BF3_ROW + s * 32);
+                const uint4 a = *reinterpret_cast<const uint4*>(lw + ((term * 2 + 0) * 32) * BF3_ROW + wpos);
+                const uint4 b = *reinterpret_cast<const uint4*>(lw + ((term * 2 + 1) * 32) * BF3_ROW + wpos);
                 const v8bf Wr = as_v8bf(a.x, a.y, a.z, a.w), Wi = as_v8bf(b.x, b.y, b.z, b.w);
                 acc_r = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr, Xr, acc_r, 0, 0, 0);
                 acc_i = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr, Xi, acc_i, 0, 0, 0);
@@ -269,7 +289,10 @@ __global__ __launch_bounds__(256, 4) void beamform_bf16x3_kernel(const uint8_t* 
                 acc_i = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wi, Xr, acc_i, 0, 0, 0);
             }
         }
+        buf = buf + 1 == BF3_RING ? 0 : buf + 1;
+        nbuf = nbuf + 1 == BF3_RING ? 0 : nbuf + 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may be in flight when the wave ends
     // C/D map: col (sample) = lane&31, row (beam) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     const int t = t0 + wave * 32 + j;
     if (t < ntime) {
