@@ -84,10 +84,10 @@ __global__ __launch_bounds__(256) void snap2_unpack_kernel(const uint8_t* __rest
             }
         }
     }
-    if (threadIdx.x == 0) {
-        if (nplaced) atomicAdd(&counters[0], nplaced);
-        if (ndropped) atomicAdd(&counters[1], ndropped);
-    }
+    // only drops are counted on the device (rare): thousands of work-groups adding to one counter serialise in L2
+    // (4096 same-address atomics cost ~40 us); placed = npkt - dropped on the host
+    (void)nplaced;
+    if (threadIdx.x == 0 && ndropped) atomicAdd(&counters[1], ndropped);
 }
 
 static int* g_counters[16] = {};
@@ -120,7 +120,7 @@ extern "C" int xengSnap2Unpack(const void* packets_dev, int npkt, size_t pkt_str
     int host[2] = {0, 0};
     XENG_HIP(hipMemcpyAsync(host, g_counters[dev], sizeof(host), hipMemcpyDeviceToHost, s));
     XENG_HIP(hipStreamSynchronize(s));
-    if (nplaced) *nplaced = host[0];
+    if (nplaced) *nplaced = npkt - host[1];
     if (ndropped) *ndropped = host[1];
     return XENG_STATUS_SUCCESS;
 }
