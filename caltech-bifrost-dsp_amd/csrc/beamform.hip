@@ -6,6 +6,8 @@
 #include <mutex>
 
 #include "beamform_kernels.h"
+#include <algorithm>
+
 #include "xeng_common.h"
 
 namespace xeng {
@@ -69,7 +71,8 @@ static int integrate_locked(const void* in, void* out, int ntime_sum, int pair0,
     BeamContext& x = g_b;
     if (ntime_sum <= 0 || x.ntime % ntime_sum) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Integrate: ntime %d not a multiple of ntime_sum %d", x.ntime, ntime_sum);
     if (x.nbeam % 2) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Integrate: nbeam %d must be even (X/Y pairs)", x.nbeam);
-    dim3 grid((x.nchan + 3) / 4, npair);
+    const int nblk = x.ntime / ntime_sum;
+    dim3 grid((x.nchan + 3) / 4, npair, std::max(1, std::min(8, (nblk + 7) / 8)));
     int slot = x.timer.begin(x.stream, 1);
     hipLaunchKernelGGL(beam_integrate_kernel, grid, dim3(256), 0, x.stream, (const float2*)in, (float4*)out, x.nchan,
                        x.nbeam, x.ntime, ntime_sum, pair0, npair);

@@ -320,7 +320,9 @@ __global__ __launch_bounds__(256) void beam_integrate_kernel(const float2* __res
     const float2* x = in + ((size_t)c * nbeam + 2 * (pair0 + bp)) * ntime;
     const float2* y = x + ntime;
     const int sub = lane & 7, grp = lane >> 3;  // 8 groups of 8 lanes
-    for (int tb = grp; tb < nblk; tb += 8) {
+    // gridDim.z slices the time blocks (8 per slice when the grid is large enough): the kernel is a short
+    // latency chain, so more resident waves beat longer loops
+    for (int tb = blockIdx.z * 8 + grp; tb < nblk; tb += 8 * gridDim.z) {
         float xx = 0.f, yy = 0.f, xyr = 0.f, xyi = 0.f;
         for (int t = sub; t < ntime_sum; t += 8) {
             const float2 a = x[(size_t)tb * ntime_sum + t], b = y[(size_t)tb * ntime_sum + t];
