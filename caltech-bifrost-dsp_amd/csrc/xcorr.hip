@@ -4,6 +4,7 @@
 //  corr_output_full_block.py:669; verification/xgpu_test.py:76-89).
 #include <algorithm>
 #include <cstdlib>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -82,6 +83,64 @@ static std::vector<WgDesc> build_wg_descs(int nblk64) {
     return out;
 }
 
+// --------------------------------------------------------------------------------------
+// Work lists of the persistent fused kernel (WorkEntry[grid][maxi], xcorr_kernels.h).
+// Work-groups b with the same b & 7 sit on one XCD and share that XCD's items (channels = xcd mod 8), dealt
+// round-robin so that concurrent work-groups contract neighbouring tile groups of the same channels.  With
+// n items for W work-groups every work-group gets n / W whole items and the first n % W one more
+// (704 inputs x 96 channels on 256 CUs: 204 items per XCD for 32 work-groups = 7 items for 12 of them, 6 for
+// 20; the next launch's work-groups take over the CUs of the latter).  Opt-in (XENG_SPLITK=1): the left-over
+// items are cut along K into W slices in all, one per work-group, with an ordered read-modify-write hand-over
+// between the slices of an item -- balanced, but not faster (see xengXgpuInitialize).
+// --------------------------------------------------------------------------------------
+struct WorkList {
+    std::vector<WorkEntry> entries;
+    int maxi = 0, nchains = 0;
+    uint32_t* dev = nullptr;
+};
+
+static WorkList build_work(int grid, int nchan, int nwg, int nstage, bool splitk) {
+    WorkList wl;
+    const bool xcd_map = (nchan & 7) == 0 && (grid & 7) == 0;
+    const int ngroup = xcd_map ? 8 : 1;
+    const int W = grid / ngroup;
+    const int n = xcd_map ? (nchan / 8) * nwg : nchan * nwg;
+    const int f = n / W, r = n % W;
+    wl.maxi = f + (r ? 1 : 0);
+    wl.entries.assign((size_t)grid * wl.maxi, WorkEntry{0, 0, 0, 0});
+    // (only per-XCD lists are split: the slices of an item exchange partial sums through one XCD's L2)
+    const bool split = splitk && xcd_map && r > 0 && nstage >= (W + r - 1) / r;
+    wl.nchains = split ? ngroup * r : 0;
+    auto put = [&](int b, int k, int x, int idx, int stage0, int nst, int slice, int nslices, int chain) {
+        const int q = idx / nwg, wg = idx - q * nwg;
+        const int c = xcd_map ? x + 8 * q : q;
+        WorkEntry& e = wl.entries[(size_t)b * wl.maxi + k];
+        e.c_wg = (uint32_t)c | ((uint32_t)wg << 16);
+        e.stages = (uint32_t)stage0 | ((uint32_t)nst << 16);
+        e.slice = (uint32_t)slice | ((uint32_t)nslices << 8) | (1u << 16);
+        e.chain = (uint32_t)chain;
+    };
+    for (int x = 0; x < ngroup; x++) {
+        auto block_of = [&](int j) { return xcd_map ? j * 8 + x : j; };
+        for (int j = 0; j < W; j++)
+            for (int k = 0; k < f; k++) put(block_of(j), k, x, j + k * W, 0, nstage, 0, 1, 0);
+        if (!r) continue;
+        if (!split) {
+            for (int i = 0; i < r; i++) put(block_of(i), f, x, f * W + i, 0, nstage, 0, 1, 0);
+            continue;
+        }
+        int j = 0;
+        for (int i = 0; i < r; i++) {
+            const int ns = W / r + (i < W % r ? 1 : 0);
+            for (int sl = 0; sl < ns; sl++, j++) {
+                const int s0 = (int)((int64_t)sl * nstage / ns), s1 = (int)((int64_t)(sl + 1) * nstage / ns);
+                put(block_of(j), f, x, f * W + i, s0, s1 - s0, sl, ns, x * r + i);
+            }
+        }
+    }
+    return wl;
+}
+
 struct XgpuConfig {
     int nstand = 352, npol = 2, nchan = 96, ntime_gulp = 480, max_gulps = 0;
 };
@@ -97,6 +156,11 @@ struct XgpuContext {
     // LDS (xcorr_mfma_kernel<.., RAW>): asynchronous calls hand over the caller's buffer itself, synchronous
     // calls a raw copy of it in the staging area.
     bool raw = false;
+    bool splitk = false;                       // XENG_SPLITK=1: cut the left-over items along K (experiment, see Initialize)
+    std::map<int, WorkList> work;              // per number of stages of a flush
+    uint32_t* flags = nullptr;                 // [NMM][flags_per_stream] slice-ordering flags of split items
+    int flags_per_stream = 0;
+    uint32_t epoch = 0;
     size_t gulp_bytes = 0;
     const uint8_t* gulp_ptr[XC_MAX_GULPS] = {};
     bool fp6 = false;          // XENG_MFMA=fp6: E3M2 codes + block-scaled FP6 MFMA (exact), see xcorr_kernels.h
@@ -158,6 +222,9 @@ static int destroy_locked() {
     for (int k = 0; k < 4; k++)
         if (x.ev_dump[k]) (void)hipEventDestroy(x.ev_dump[k]);
     if (x.descs_dev) (void)hipFree(x.descs_dev);
+    for (auto& kv : x.work)
+        if (kv.second.dev) (void)hipFree(kv.second.dev);
+    if (x.flags) (void)hipFree(x.flags);
     if (x.in_dev) (void)hipFree(x.in_dev);
     if (x.stamps) (void)hipFree(x.stamps);
     if (x.out_dev) (void)hipFree(x.out_dev);
@@ -242,10 +309,26 @@ static int flush_locked(void* out, bool dump) {
     p.stamps = x.stamps;
     p.spg = x.raw ? x.cfg.ntime_gulp / (XC_KT * 32) : 0;
     p.ninput = x.ninput;
+    p.work = nullptr; p.maxi = 0; p.flags = nullptr; p.epoch = 0;
+    if (x.raw) {
+        const int nstage = nkt / XC_KT;
+        auto itw = x.work.find(nstage);
+        if (itw == x.work.end()) {
+            WorkList wl = build_work(fused_grid(x.cfg.nchan, x.nwg, x.ncu), x.cfg.nchan, x.nwg, nstage, x.splitk);
+            if (wl.nchains > x.flags_per_stream) XENG_FAIL(XENG_STATUS_DEVICE_ERROR, "xgpu: %d slice chains exceed the flag array", wl.nchains);
+            XENG_HIP(hipMalloc((void**)&wl.dev, wl.entries.size() * sizeof(WorkEntry)));
+            XENG_HIP(hipMemcpy(wl.dev, wl.entries.data(), wl.entries.size() * sizeof(WorkEntry), hipMemcpyHostToDevice));
+            itw = x.work.emplace(nstage, std::move(wl)).first;
+        }
+        p.work = itw->second.dev;
+        p.maxi = itw->second.maxi;
+    }
     for (int g = 0; g < XC_MAX_GULPS; g++) p.gulps[g] = g < x.nfilled ? x.gulp_ptr[g] : nullptr;
     // the contraction starts when this area's corner turns are done and runs beside the next area's
     const int si = (int)(x.nlaunch++ % x.nmm);
     hipStream_t smm = x.stream_mm2[si];
+    p.flags = x.flags ? x.flags + (size_t)si * x.flags_per_stream : nullptr;   // launches on one stream are ordered
+    p.epoch = ++x.epoch;
     XENG_HIP(hipEventRecord(x.ev_ct, x.stream));
     XENG_HIP(hipStreamWaitEvent(smm, x.ev_ct, 0));
     // contractions that touch the same output (partial sums of one integration, or a caller that
@@ -405,6 +488,7 @@ int xengXgpuInitialize(int gpu) {
         }
     }
     if (x.raw) x.stash_bytes = (size_t)cap * x.gulp_bytes;   // raw copies of synchronously handed gulps
+
     for (int b = 0; b < 2; b++) {
         XENG_HIP(hipMalloc((void**)&x.stash[b], x.stash_bytes));
         XENG_HIP(hipMemset(x.stash[b], 0, x.stash_bytes));
@@ -414,6 +498,16 @@ int xengXgpuInitialize(int gpu) {
     for (int k = 0; k < 4; k++) XENG_HIP(hipEventCreateWithFlags(&x.ev_dump[k], hipEventDisableTiming));
     std::vector<WgDesc> descs = build_wg_descs(x.nblk64);
     x.nwg = (int)descs.size();
+    if (x.raw) {
+        // opt-in: measured 233-236 us per launch alone (whole items: 230-236) and 0.235 ms per streaming step
+        // (whole items: 0.219): the extra read-modify-write epilogues and the ordered hand-over between slices
+        // cost what the balanced tail saves, and overlapping launches already fill the tail
+        const char* e = getenv("XENG_SPLITK");
+        x.splitk = e && !strcmp(e, "1");
+        x.flags_per_stream = fused_grid(x.cfg.nchan, x.nwg, x.ncu);   // split items < work-groups
+        XENG_HIP(hipMalloc((void**)&x.flags, (size_t)XgpuContext::NMM * x.flags_per_stream * sizeof(uint32_t)));
+        XENG_HIP(hipMemset(x.flags, 0, (size_t)XgpuContext::NMM * x.flags_per_stream * sizeof(uint32_t)));
+    }
     XENG_HIP(hipMalloc((void**)&x.descs_dev, descs.size() * sizeof(WgDesc)));
     XENG_HIP(hipMemcpy(x.descs_dev, descs.data(), descs.size() * sizeof(WgDesc), hipMemcpyHostToDevice));
     int rc = get_stream(STREAM_XGPU, &x.stream);

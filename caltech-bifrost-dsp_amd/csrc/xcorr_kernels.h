@@ -197,6 +197,23 @@ struct XcorrParams {
     const uint8_t* gulps[XC_MAX_GULPS];
     int spg;                      // 96-sample stages per gulp
     int ninput;
+    // fused kernel: per work-group list of work entries (WorkEntry[gridDim.x][maxi]) and the flags that order the
+    // K slices of a split item (one per split item; value = epoch*16 + slices stored so far)
+    const uint32_t* work;
+    int maxi;
+    uint32_t* flags;
+    uint32_t epoch;
+};
+
+// One entry of a work-group's list: a (channel, tile group) item, or one K slice of it.  Whole items cover all
+// stages; the items left over after dealing whole items evenly are cut along K into slices, one per work-group,
+// so that every work-group of a launch contracts (almost) the same number of stages.  Slice j > 0 adds to what
+// slice j-1 stored: it waits for flags[chain] >= epoch*16 + j before its read-modify-write.
+struct WorkEntry {
+    uint32_t c_wg;        // channel | tile group << 16
+    uint32_t stages;      // first stage | number of stages << 16
+    uint32_t slice;       // slice index | slices of the item << 8 | valid << 16
+    uint32_t chain;       // flag index of a split item
 };
 
 struct Frags {   // the 8 unpacked int8 operand fragments of one 64x64 wave tile and one K-tile
@@ -222,7 +239,7 @@ __device__ __forceinline__ Frags unpack_frags(const RawFrags& r) {
 constexpr int XC_KT = 3;      // K-tiles (32 samples each) per LDS stage
 constexpr int XC_RING = 4;    // LDS ring depth (stages), two-pass kernel
 #ifndef XF_DEPTH
-#define XF_DEPTH 5            // fused kernel: stages of LDS-DMA in flight ahead of the MFMAs (ring = XF_DEPTH+1 stages of 24 KiB)
+#define XF_DEPTH 3            // fused kernel: stages of LDS-DMA in flight ahead of the MFMAs (ring = XF_DEPTH+1 stages of 24 KiB; 3, 4, 5 measure the same)
 #endif
 
 // ---- epilogue shared by both contraction kernels: D[i][j] = sum x_i conj(x_j), lane = column j,
@@ -240,7 +257,7 @@ constexpr int XC_RING = 4;    // LDS ring depth (stages), two-pass kernel
 // its 32-lane half) and every 8 adjacent lanes write one contiguous run.
 __device__ __forceinline__ void xcorr_store_tile(const XcorrParams& p, int c, int blk_a, int blk_b, bool skip01, int lane,
                                                  const v16i (&accR)[2][2], const v16i (&accP)[2][2],
-                                                 const v16i (&accQ)[2][2]) {
+                                                 const v16i (&accQ)[2][2], bool add_to_stored = false) {
     const int qs = (int)(((int64_t)(p.nstand / 2 + 1) * p.nstand) / 4);
     int32_t* out_r = p.out + (int64_t)c * p.per_chan;
     int32_t* out_i = out_r + p.matlen;
@@ -259,7 +276,7 @@ __device__ __forceinline__ void xcorr_store_tile(const XcorrParams& p, int c, in
     const int cpar = quad >> 1, rpar = quad & 1;
     // interior tiles (strictly below the block diagonal, no padded inputs) need no per-cell mask
     const bool interior = __builtin_amdgcn_readfirstlane((int)(blk_a > blk_b && blk_a * 64 + 64 <= 2 * p.nstand)) != 0;
-    const bool accumulate = p.accumulate != 0;
+    const bool accumulate = p.accumulate != 0 || add_to_stored;
 #pragma unroll
     for (int m = 0; m < 2; m++)
 #pragma unroll
@@ -502,7 +519,6 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nstage = p.nkt / KT_STAGE;
     const uint32_t row_stride = (uint32_t)p.nchan * (uint32_t)p.ninput;
     // tile-group table through the constant address space: wave-uniform reads become scalar loads (a vector
     // load would make the compiler wait for vmcnt(0), i.e. for the whole LDS-DMA stream, at every item switch)
@@ -511,43 +527,42 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
     const DescPtr descs = (DescPtr)(uintptr_t)p.descs;
     static_assert(sizeof(WgDesc) == 16, "descriptor layout");
 
-    // item k of this work-group -> (channel, tile group); false past the end of the list
-    const bool xcd_map = (p.nchan & 7) == 0 && (gridDim.x & 7) == 0;
-    auto item = [&](int k, int& c, int& wg) {
-        int idx, n;
-        if (xcd_map) {
-            idx = (int)(blockIdx.x >> 3) + k * (int)(gridDim.x >> 3);   // index among this XCD's items
-            n = (p.nchan >> 3) * p.nwg;
-        } else {
-            idx = (int)blockIdx.x + k * (int)gridDim.x;
-            n = p.nchan * p.nwg;
-        }
-        if (idx >= n) return false;
-        const int q = idx / p.nwg;
-        wg = idx - q * p.nwg;
-        c = xcd_map ? (int)(blockIdx.x & 7) + 8 * q : q;
+    // entry k of this work-group's list; false past the end
+    const DescPtr work = (DescPtr)(uintptr_t)p.work + (size_t)blockIdx.x * p.maxi * 4;
+    struct Item { int c, wg, stage0, nst, slice, nslices, chain; };
+    auto item = [&](int k, Item& it) {
+        if (k >= p.maxi) return false;
+        const uint32_t w0 = work[k * 4], w1 = work[k * 4 + 1], w2 = work[k * 4 + 2];
+        if (!(w2 >> 16)) return false;
+        it.c = (int)(w0 & 0xFFFF); it.wg = (int)(w0 >> 16);
+        it.stage0 = (int)(w1 & 0xFFFF); it.nst = (int)(w1 >> 16);
+        it.slice = (int)(w2 & 0xFF); it.nslices = (int)((w2 >> 8) & 0xFF);
+        it.chain = (int)work[k * 4 + 3];
         return true;
     };
 
-    // ---- issue side: the stage stream (item, gulp, stage in gulp) three stages ahead of the MFMAs ----
-    int is_k = 0, is_c = 0, is_wg = 0, is_g = 0, is_sl = 0, is_issued = 0;
+    // ---- issue side: the stage stream (item, gulp, stage in gulp) DEPTH stages ahead of the MFMAs ----
+    int is_k = 0, is_c = 0, is_wg = 0, is_g = 0, is_sl = 0, is_issued = 0, is_nst = 0;
     uint32_t is_lane_off = 0;
     const uint8_t* is_stage = nullptr;
-    auto is_setup = [&]() {
+    auto is_setup = [&](const Item& it) {
+        is_c = it.c; is_wg = it.wg; is_nst = it.nst;
         // (columns past ninput in the last block: any valid bytes of the row; their products are never stored)
         const uint32_t slots = descs[is_wg * 4];                          // slot_blk[0..3]
         const int chunk = (lane & 7) ^ (((lane >> 4) & 3) << 1);          // source chunk 0..7 of the 128-byte pair row
         const int blk0 = (slots >> (8 * (wave & 2))) & 0xFF, blk1 = (slots >> (8 * (wave & 2) + 8)) & 0xFF;
         const uint32_t col = (uint32_t)((chunk >> 2) ? blk1 : blk0) * 64u + (uint32_t)(chunk & 3) * 16u;
         is_lane_off = (uint32_t)(lane >> 3) * row_stride + (col + 16u <= (uint32_t)p.ninput ? col : 0u);
-        is_g = is_sl = is_issued = 0;
+        is_g = it.stage0 / p.spg;
+        is_sl = it.stage0 - is_g * p.spg;
+        is_issued = 0;
     };
     auto next_stage = [&]() {
-        if (is_issued == nstage) {           // this item is fully issued: go on with the next one, if any
-            int c2, wg2;
-            if (!item(is_k + 1, c2, wg2)) return;   // past the end: keep re-reading the last stage (never consumed)
-            is_k++; is_c = c2; is_wg = wg2;
-            is_setup();
+        if (is_issued == is_nst) {           // this entry is fully issued: go on with the next one, if any
+            Item nx;
+            if (!item(is_k + 1, nx)) return;   // past the end: keep re-reading the last stage (never consumed)
+            is_k++;
+            is_setup(nx);
         }
         is_stage = p.gulps[is_g] + ((size_t)(is_sl * (KT_STAGE * 32)) * p.nchan + is_c) * (size_t)p.ninput;
         is_issued++;
@@ -573,10 +588,9 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
     const int tr_off = ((lane >> 5) * 16 + ((lane & 15) >> 1)) * 128 +
                        (((lane >> 4) & 1) ^ (((lane >> 2) & 3) << 1)) * 16 + (lane & 1) * 8;
 
-    int c, wg;
-    if (!item(0, c, wg)) return;             // (the host never launches more work-groups than items)
-    is_c = c; is_wg = wg;
-    is_setup();
+    Item it;
+    if (!item(0, it)) return;                // (the host never launches work-groups without work)
+    is_setup(it);
 #pragma unroll
     for (int st = 0; st < DEPTH; st++) {
         next_stage();
@@ -590,7 +604,8 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
     // the stage counter is continuous across items
     int rs = 0, rs1 = 1, rf = DEPTH;
     auto bump = [&](int& r) { r = (r + 1 == RING) ? 0 : r + 1; };
-    for (int k = 0; item(k, c, wg); k++) {
+    for (int k = 0; item(k, it); k++) {
+        const int c = it.c, wg = it.wg;
         const unsigned long long r_entry = p.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
         const uint32_t slots = descs[wg * 4], wa4 = descs[wg * 4 + 1], wb4 = descs[wg * 4 + 2];
         const int a_slot = (wa4 >> (8 * wave)) & 0xFF, b_slot = (wb4 >> (8 * wave)) & 0xFF;
@@ -641,7 +656,7 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
             t_start = __builtin_amdgcn_s_memtime();
             r_start = __builtin_amdgcn_s_memrealtime();
         }
-        for (int s = 0; s < nstage; s++) {
+        for (int s = 0; s < it.nst; s++) {
             next_stage();
 #pragma unroll
             for (int j = 0; j < KT_STAGE; j++) {
@@ -683,7 +698,27 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
                 o[0] = t_end - t_start; o[1] = r_end - r_start; o[2] = r_start; o[3] = r_end; o[4] = r_entry;
             }
         }
-        if (active) xcorr_store_tile(p, c, blk_a, blk_b, skip01, lane, accR, accP, accQ);
+        if (it.slice > 0) {
+            // K slice j adds to what slices 0..j-1 stored: wait for them.  All slices of an item run on one XCD
+            // (the host only splits per-XCD item lists), so the data is exchanged through that XCD's L2: no
+            // agent-scope fence (an L2 write-back / invalidate costs tens of microseconds here).  The flag is read
+            // at agent scope (bypasses the L1); the lines read by the read-modify-write below cannot be in this
+            // CU's L1: nothing in this launch has touched them, and the L1 is invalidated between launches.
+            const uint32_t target = p.epoch * 16u + (uint32_t)it.slice;
+            while (__hip_atomic_load(p.flags + it.chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
+                __builtin_amdgcn_s_sleep(4);
+            asm volatile("" ::: "memory");
+        }
+        if (active) xcorr_store_tile(p, c, blk_a, blk_b, skip01, lane, accR, accP, accQ, it.slice > 0);
+        if (it.slice + 1 < it.nslices) {
+            // publish: every wave's stores have been acknowledged by the L2 (vmcnt counts stores too), then one
+            // lane bumps the flag
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (threadIdx.x == 0)
+                __hip_atomic_store(p.flags + it.chain, p.epoch * 16u + (uint32_t)it.slice + 1u, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (p.stamps && lane == 0) p.stamps[((size_t)(c * p.nwg + wg) * 4 + wave) * 8 + 5] = __builtin_amdgcn_s_memrealtime();
     }
     wait_vmcnt<0>();   // no LDS-DMA may still be in flight when the wave ends

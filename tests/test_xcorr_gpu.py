@@ -376,3 +376,20 @@ def test_packetize_matches_reorder_then_slice(gpu, nstand, nchan, permute):
     x.close()
     for b in (din, dbl, dcj, dout):
         b.free()
+
+
+def test_split_k_work_lists_are_bit_exact(gpu):
+    """XENG_SPLITK=1 (experiment): the items left over after dealing whole items to the persistent work-groups
+    are cut along K and handed from slice to slice in order (read-modify-write through one XCD's L2).  Same words."""
+    nstand, nchan, ntime, ngulp = 352, 96, 480, 2          # 1632 items for 256 work-groups: 12 split items per XCD
+    vin = gpu.synth_voltages(ntime * ngulp, nchan, nstand, "random", seed=31)
+    exp = oracle_run(vin, nstand, nchan, ntime)
+    os.environ["XENG_SPLITK"] = "1"
+    try:
+        x = gpu.Xgpu(nstand, nchan, ntime)
+        assert x.path() == (1, 0)
+        for _ in range(3):                                  # the hand-over flags count epochs: repeat launches
+            assert np.array_equal(x.run(vin, use_async=True), exp)
+        x.close()
+    finally:
+        del os.environ["XENG_SPLITK"]
