@@ -39,6 +39,14 @@ class HipBackend:
     def bfXgpuKernel(self, in_arr, out_arr, do_dump):
         return self._lib.bfXgpuKernel(in_arr, out_arr, int(do_dump))
 
+    def bfXgpuKernelAsync(self, in_arr, out_arr, do_dump):
+        """Enqueue only: the gulp is read in place at dump time, so the caller keeps it alive and unchanged until
+        xgpu_sync() (include/xeng.h: xengXgpuKernelAsync).  No reference counterpart."""
+        return self._lib.xengXgpuKernelAsync(in_arr.contents.data, out_arr.contents.data, int(do_dump))
+
+    def xgpu_sync(self):
+        return self._lib.xengXgpuSync()
+
     def bfXgpuGetOrder(self, antpol_to_input, antpol_to_bl, is_conj):
         return self._lib.bfXgpuGetOrder(antpol_to_input, antpol_to_bl, is_conj)
 

@@ -132,6 +132,14 @@ class Corr(Block):
             self.update_pending = True
             oseq = ospan = None
             acquire_time = reserve_time = 0
+            # In-place mode: when the input ring keeps a span's memory alive for as long as the span is referenced
+            # (the in-repo Ring does; a bifrost ring is circular and does not), the gulps of an integration are only
+            # registered (`bfXgpuKernelAsync`) and the contraction kernel reads them where they lie at dump time --
+            # no copy of the voltages at all.  Otherwise the reference's synchronous call is used and libxeng keeps
+            # a raw copy of every gulp until the dump.
+            in_place = (getattr(self.iring, 'span_memory_outlives_release', False)
+                        and hasattr(self._bf, 'bfXgpuKernelAsync') and hasattr(self._bf, 'xgpu_sync'))
+            self._held = []
             for iseq in self.iring.read(guarantee=self.guarantee):
                 self.log.info('CORR >> new input sequence!')
                 process_time = 0
@@ -199,7 +207,14 @@ class Corr(Block):
                         continue
                     if self.test:
                         test_out += self._test(ispan.data, ihdr['nchan'], ihdr['nstand'], ihdr['npol'])
-                    rv = self._bf.bfXgpuKernel(ispan.data.as_BFarray(), ospan.data.as_BFarray(), int(now == gate.last))
+                    if in_place:
+                        self._held.append(ispan.data)      # keeps the gulp's memory alive until the dump has run
+                        rv = self._bf.bfXgpuKernelAsync(ispan.data.as_BFarray(), ospan.data.as_BFarray(), int(now == gate.last))
+                        if rv == self._bf.BF_STATUS_SUCCESS and now == gate.last:
+                            rv = self._bf.xgpu_sync()      # the output span is complete before it is committed
+                            self._held = []
+                    else:
+                        rv = self._bf.bfXgpuKernel(ispan.data.as_BFarray(), ospan.data.as_BFarray(), int(now == gate.last))
                     if rv != self._bf.BF_STATUS_SUCCESS:
                         raise RuntimeError("xgpuKernel returned %d: %s" % (rv, self._bf.last_error()))
                     curr_time = time.time()
@@ -227,4 +242,5 @@ class Corr(Block):
     def _abort_integration(self):
         reset = getattr(self._bf, 'xgpu_reset', None)
         if reset is not None:
-            reset()
+            reset()                                 # synchronises: nothing reads the held gulps afterwards
+        self._held = []

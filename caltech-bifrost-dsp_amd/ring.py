@@ -172,6 +172,11 @@ class _Writer:
 
 
 class Ring:
+    # Every committed span is its own allocation, kept alive by reference counting: a reader that keeps
+    # `ispan.data` may go on reading it after the ring has recycled the span (a bifrost ring is one circular
+    # buffer and cannot promise that).  Corr uses this to let the X-engine read gulps in place.
+    span_memory_outlives_release = True
+
     def __init__(self, name="", space="system", core=None):
         self.name, self.space = name, space
         self._cond = threading.Condition()

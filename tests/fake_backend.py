@@ -60,6 +60,13 @@ class OracleBackend:
             self.acc = None
         return 0
 
+    def bfXgpuKernelAsync(self, in_arr, out_arr, do_dump):
+        self.async_calls = getattr(self, "async_calls", 0) + 1
+        return self.bfXgpuKernel(in_arr, out_arr, do_dump)
+
+    def xgpu_sync(self):
+        return 0
+
     def xgpu_reset(self):
         self.acc = None
         self.resets += 1

@@ -128,3 +128,31 @@ def test_corr_corracc_output_full_chain(tmp_path, host_ring):
     pay = np.frombuffer(pkts[k][56:], dtype=np.int32).reshape(2, 2, C, 2)
     assert np.array_equal(pay[..., 0], np.moveaxis(gold[1, :, 3, 11].real, 0, -1))
     assert np.array_equal(pay[..., 1], np.moveaxis(gold[1, :, 3, 11].imag, 0, -1))
+
+
+def test_corr_reads_gulps_in_place_from_the_in_repo_ring():
+    """Corr on the in-repo ring (span memory stays alive while referenced): gulps are handed to the X-engine
+    with the enqueue-only call and read in place by the fused kernel -- no raw copy, no corner turn -- and the
+    visibilities are the oracle's.  A sequence that ends mid-integration drops the partial sums."""
+    import ctypes
+    from caltech_bifrost_dsp_amd import ffi
+    C, S, g, acc = 8, 32, 96, 288
+    rng = np.random.default_rng(17)
+    vin = rng.integers(0, 256, (2 * acc + g, C, S, 2), dtype=np.uint8)   # two integrations + one stray gulp
+    r0, r1 = Ring("gpu-input", space="cuda"), Ring("corr-output", space="cuda")
+    corr = Corr(LOG, r0, r1, ntime_gulp=g, nchan=C, npol=2, nstand=S, acc_len=acc, autostartat=0, gpu=0)
+    fused, fp6 = ctypes.c_int(), ctypes.c_int()
+    ffi.call("xengXgpuGetPath", ctypes.byref(fused), ctypes.byref(fp6))
+    assert fused.value == 1
+    ffi.call("xengXgpuSetProfiling", 1)
+    tm, cn = (ctypes.c_double * 2)(), (ctypes.c_int * 2)()
+    ffi.call("xengXgpuGetTimes", tm, cn)                                  # clear
+    sink = Sink(r1, corr.ogulp_size)
+    run_blocks([corr], Source(r0, [(source_header(C, S, 2), vin, g * C * S * 2)], wait_readers=1), [sink])
+    ffi.call("xengXgpuGetTimes", tm, cn)
+    ffi.call("xengXgpuSetProfiling", 0)
+    assert cn[0] == 0 and cn[1] == 2                                      # no copies / corner turns; two contractions
+    (h, _, spans), = sink.sequences
+    assert len(spans) == 2
+    for k, sp in enumerate(spans):
+        assert np.array_equal(sp.view(np.int32), orc.xgpu_correlate(vin[k * acc:(k + 1) * acc], S, C))
