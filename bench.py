@@ -254,7 +254,7 @@ def main():
                   "ingest_gbps": round(8 * gulp_bytes / (in_ms * 1e-3) / 1e9, 1),
                   "roofline": {"bound": "hbm", "achieved": round(in_bytes / (in_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": round(in_bytes / (in_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-                  "note": "wall time of the synchronous call: memset of the gulp + scatter kernel + counter read-back"}
+                  "note": "wall time of the synchronous call: memset of the gulp + scatter kernel (24 us on the device, profiles/r01/v4_kernel_stats_all_legs.csv) + counter read-back"}
         dslab.free()
         dgulp.free()
     # outside the timed region: BASELINE config 4 -- Beamform (32 beams, 96 chan, 960 samples, fp32 weights)
@@ -333,7 +333,7 @@ def main():
         beam["full_xengine_concurrent"] = {
             "ingest_gbps": round(8 * NINPUT * units_per_step_c * nfull / elf / 1e9, 1),
             "ms_per_integration": round(elf / nfull * 1e3, 4),
-            "note": "config 5 on one GPU: per 2400-sample integration 5 corner turns + 1 MFMA contraction (X-engine streams), "
+            "note": "config 5 on one GPU: per 2400-sample integration 5 gulps registered in place + 1 fused MFMA contraction (X-engine streams), "
                     "2.5 beamformer gulps + power sums (beam stream), 1 CorrAcc int32 map over 191 MB (map stream)"}
         ffi.call("xengBeamformDestroy")
     if dist is not None:
