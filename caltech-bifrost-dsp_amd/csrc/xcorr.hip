@@ -368,7 +368,8 @@ static int kernel_locked(const void* in_dev, void* out_dev, int doDump, bool syn
     uint8_t* const stash = x.stash[x.cur];
     int slot = -1;
     if (x.raw) {
-        if (sync) {   // the caller may recycle in_dev on return: keep a raw copy
+        if (sync && !doDump) {   // the caller may recycle in_dev on return: keep a raw copy (a synchronous dump
+                                 // waits for the contraction before it returns, so its own gulp is read in place)
             uint8_t* copy = stash + (size_t)x.nfilled * x.gulp_bytes;
             slot = x.timer.begin(x.stream, 0);
             XENG_HIP(hipMemcpyAsync(copy, in_dev, x.gulp_bytes, hipMemcpyDeviceToDevice, x.stream));
