@@ -146,6 +146,7 @@ def test_parity_vs_oracle(gpu, nstand, nchan, ntime, ngulp, kind):
     (160, 2, 288, 2, "full"),        # 5 blocks (odd)
     (224, 1, 96, 1, "full"),         # 7 blocks, a single stage: the pipeline prologue covers all of K
     (80, 8, 480, 2, "full"),         # the reference gulp length; 2.5 blocks
+    (512, 8, 96, 1, "random"),       # 1024 inputs = 16 blocks: 136 wave tiles in 34 tile groups, more work-groups than CUs
 ])
 def test_parity_fused_corner_turn(gpu, nstand, nchan, ntime, ngulp, kind):
     """Default path when gulps are whole 96-sample stages: the contraction kernel reads the time-major
