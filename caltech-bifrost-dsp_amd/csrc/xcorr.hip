@@ -152,9 +152,9 @@ struct XgpuContext {
     int ncu = 256;
     int ninput = 0, nblk64 = 0, gkt = 0, cap_kt = 0, cap_gulps = 0, kt_stage = 1;
     int ct_pitch = 0;          // LDS row pitch of the transposing corner turn (0: register-only fallback)
-    // raw: no corner-turn pass.  The contraction kernel reads time-major gulps in place and transposes in
-    // LDS (xcorr_mfma_kernel<.., RAW>): asynchronous calls hand over the caller's buffer itself, synchronous
-    // calls a raw copy of it in the staging area.
+    // raw: no corner-turn pass.  The contraction kernel (xcorr_fused_kernel) reads time-major gulps in place and
+    // transposes in LDS: asynchronous calls hand over the caller's buffer itself, synchronous calls a raw copy
+    // of it in the staging area (except the dump call, which waits for the contraction anyway).
     bool raw = false;
     bool splitk = false;                       // XENG_SPLITK=1: cut the left-over items along K (experiment, see Initialize)
     std::map<int, WorkList> work;              // per number of stages of a flush
@@ -166,14 +166,14 @@ struct XgpuContext {
     bool fp6 = false;          // XENG_MFMA=fp6: E3M2 codes + block-scaled FP6 MFMA (exact), see xcorr_kernels.h
     int ghk = 0;               // fp6: 32-sample half-tiles per gulp; cap_kt then counts 64-sample K steps
     int64_t per_chan = 0, matlen = 0;
-    // Two staging areas and two streams: corner turns (HBM-bound) of integration n+1 run on `stream`
-    // while the MFMA contraction (power-bound) of integration n runs on `stream_mm`.
+    // Two staging areas (raw gulp copies of the synchronous calls, or corner-turned fragments on the two-pass
+    // path): filled on `stream` while the contraction of the previous flush reads the other one.
     uint8_t* stash[2] = {nullptr, nullptr};
     size_t stash_bytes = 0;
     int cur = 0;                               // staging area being filled
     WgDesc* descs_dev = nullptr;
     int nwg = 0;
-    hipStream_t stream = nullptr;              // corner turns (+ H2D of the host-buffer variant)
+    hipStream_t stream = nullptr;              // raw copies / corner turns (+ H2D of the host-buffer variant)
     // MFMA contractions rotate over nmm streams: consecutive launches are independent (unless they touch the
     // same output span), so the tail of one fills with the next.  Two is the measured optimum (three or
     // four streams: -5 %, HIP maps them onto the same few hardware queues as the other streams).

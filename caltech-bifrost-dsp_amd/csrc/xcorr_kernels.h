@@ -2,11 +2,17 @@
 //
 // What they replace: the xGPU CUDA X-engine + its DEVSWIZZLE input swizzle that the
 // reference reaches through _bf.bfXgpuKernel (corr_block.py:445; xGPU itself is an
-// empty submodule in the reference tree).  Nothing here is derived from xGPU code:
-// the design is a two-stage HBM-resident pipeline built for CDNA4.
+// empty submodule in the reference tree).  Nothing here is derived from xGPU code.
 //
-//  stage 1  corner_turn_kernel      (HBM-bound, one launch per gulp)
-//     in   uint8[t][c][i]  4+4 bit   (corr_block.py:115-116)
+// Gulps stay in HBM and all gulps of an integration (K = n_gulps * ntime) are contracted in ONE launch, so
+// the 191 MB int32 accumulator is written once per integration instead of being read-modify-written every
+// 480 samples.  Two paths:
+//
+//  default   xcorr_fused_kernel     (int8 MFMA; persistent work-groups, corner turn fused into the LDS staging)
+//     in   the gulps themselves, uint8[t][c][i] 4+4 bit (corr_block.py:115-116), read where they lie:
+//          LDS-DMA of 96-sample x 128-byte tiles, operand fragments through ds_read_b64_tr_b8.
+//
+//  two-pass  corner_turn_tr8_kernel / corner_turn_kernel   (HBM-bound, one launch per gulp)
 //     out  stash[c][ib][kt][sub][lane][16 B]   "MFMA-fragment-major":
 //          ib  = 64-input block, kt = 32-sample K tile, sub = 32-input half,
 //          lane = h*32 + r holds the 16 samples t = kt*32 + 16h + (0..15) of input
@@ -14,20 +20,17 @@
 //          1 KiB and is byte-for-byte the A (or B) register image of
 //          v_mfma_i32_32x32x32_i8, so the contraction kernel moves it HBM -> LDS with
 //          linear global_load_lds_dwordx4 and LDS -> VGPR with conflict-free ds_read_b128.
+//            xcorr_mfma_kernel      (int8 MFMA, one work-group per (channel, tile group))
+//          (also: xcorr_fp6_kernel + corner_turn_fp6_kernel, the opt-in FP6 experiment)
 //
-//  stage 2  xcorr_mfma_kernel       (int8 MFMA-bound, one launch per dump/flush)
-//     contracts all staged gulps (K = n_gulps * ntime) in one pass, so the 191 MB
-//     int32 accumulator is written once per integration instead of being
-//     read-modify-written every 480 samples.
+// Common to the contraction kernels:
 //     Nibbles are sign-extended "for free": (x & 0xF0F0F0F0) is 16*re as int8,
 //     ((x<<4) & 0xF0F0F0F0) is 16*im; all products are exact multiples of 256 and
 //     the epilogue shifts them back (>> 8).  No negated operand is needed: the
 //     imaginary part is kept as two accumulators P = sum ai*br, Q = sum ar*bi and
 //     subtracted in the epilogue (-(-8) does not fit int8 after the x16 scaling).
 //     Bound: |acc| <= 2*128*128*K < 2^31  =>  K <= 65535 samples per launch.
-//     Epilogue writes the xGPU register-tile order (corr_block.py:27-58) directly:
-//     a lane pair exchanges two registers by DPP so every lane stores whole
-//     16-byte cells [polR][polC].
+//     The epilogue (xcorr_store_tile) writes the xGPU register-tile order (corr_block.py:27-58) directly.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
