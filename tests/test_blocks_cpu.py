@@ -442,3 +442,54 @@ def test_snap2_ingest_then_corr(golden_dir):
     assert np.array_equal(got, exp)
     assert ing2.stats['packets_placed'] == per_win - 1 and ing2.stats['packets_dropped'] == 1
     assert abs(ing2.stats['missing_frac'] - 1.0 / per_win) < 1e-12
+
+
+def test_beamform_sum_beams_output_packets():
+    """Beamform -> BeamformSumBeams -> BeamformOutput: one 18-byte-header packet per (dual-pol beam, integrated
+    time sample), header fields and the seq step of beamform_output_block.py:303-309, payload f32[nchan][4]
+    = [XX, YY, re XY, im XY] (the oracle's power sums), destinations per beam modulo the list length."""
+    import struct
+    from caltech_bifrost_dsp_amd.blocks import BeamformOutput
+    nchan, nstand, nbeam, g, ntime_sum = 3, 6, 4, 8, 4
+    ninput = nstand * 2
+    rng = np.random.default_rng(5)
+    vin = rng.integers(0, 256, (2 * g, nchan, ninput), dtype=np.uint8)
+    sfreq, chan_bw = 50e6, 23925.78125
+    r0, r1, r2 = Ring("gpu-input"), Ring("bf-output"), Ring("bf-pow-output")
+    be = OracleBackend()
+    bf = Beamform(LOG, r0, r1, nchan=nchan, nbeam=nbeam, ninput=ninput, ntime_gulp=g, backend=be)
+    sb = BeamformSumBeams(LOG, r1, r2, nchan=nchan, ntime_gulp=g, ntime_sum=ntime_sum, backend=be)
+    pk = []
+    out = BeamformOutput(LOG, r2, ntime_gulp=g // ntime_sum, pipeline_idx=3, nchan=nchan, nbeam=nbeam // 2,
+                         sink=lambda b, p: pk.append((b, p)))
+    cmds, cal, delays, amps = _beam_cmds(nchan, nbeam, ninput, rng)
+    hdr = source_header(nchan, nstand, 2, seq0=960, chan0=nchan * 2, sfreq=sfreq, chan_bw=chan_bw)
+    hdr['system_nchan'] = nchan * 8
+    bf.freqs = sfreq + chan_bw * np.arange(nchan)
+    bf.process_command_strings(cmds)
+    run_blocks([bf, sb, out], Source(r0, [(hdr, vin, g * nchan * ninput)], wait_readers=1), [])
+    nblk = g // ntime_sum
+    assert len(pk) == 2 * (nbeam // 2) * nblk
+    k = 0
+    for span in range(2):
+        beams = orc.beamform(vin[span * g:(span + 1) * g], bf.gains_cpu, g, nchan, ninput, nbeam)
+        power = orc.beamform_integrate(beams, ntime_sum)                  # [nbeam/2][nblk][nchan][4]
+        for b in range(nbeam // 2):
+            for t in range(nblk):
+                beam, p = pk[k]
+                k += 1
+                assert beam == b and len(p) == 18 + nchan * 16
+                server, bb, tuning, nc, nb, nserver = struct.unpack(">6B", p[:6])
+                navg, chan0 = struct.unpack(">2H", p[6:10])
+                seq, = struct.unpack(">Q", p[10:18])
+                assert (server, bb, tuning, nc, nb, nserver, navg, chan0) == (2, b, 1, nchan, nbeam // 2, 8, ntime_sum, nchan * 2)
+                # spans advance by acc_len * ntime_gulp samples (:378); inside a span seq steps by ntime_gulp * navg (:309)
+                assert seq == 960 + span * ntime_sum * nblk + t * nblk * ntime_sum
+                assert np.array_equal(np.frombuffer(p[18:], dtype=np.float32).reshape(nchan, 4), power[b, t])
+    assert out.stats['last_end_sample'] == 960 + ntime_sum * nblk
+    # destinations: beam i -> dest_ip[i % len]
+    out.process_command_strings(cmd(1, dest_ip=['0.0.0.0', '127.0.0.1'], dest_port=[10000, 10001]))
+    out._update_destinations()
+    assert out.beam_ips == ['0.0.0.0', '127.0.0.1'] and out.beam_ports == [10000, 10001]
+    assert out.socks[0] is None and out.socks[1] is not None
+    out.socks[1].close()
