@@ -9,6 +9,7 @@ from .corr_subsel_block import CorrSubsel
 from .corr_output_full_block import CorrOutputFull
 from .snap2_ingest_block import Snap2Ingest
 from .beamform_output_block import BeamformOutput
+from .corr_output_part_block import CorrOutputPart
 
-__all__ = ["Block", "Corr", "CorrAcc", "Beamform", "BeamformSumBeams", "Copy", "CorrSubsel", "CorrOutputFull", "Snap2Ingest", "BeamformOutput", "regtile_index", "tri_index",
+__all__ = ["Block", "Corr", "CorrAcc", "Beamform", "BeamformSumBeams", "Copy", "CorrSubsel", "CorrOutputFull", "Snap2Ingest", "BeamformOutput", "CorrOutputPart", "regtile_index", "tri_index",
            "COMMAND_OK", "COMMAND_NOT_RECOGNIZED", "COMMAND_WRONG_TYPE", "COMMAND_INVALID"]

@@ -493,3 +493,51 @@ def test_beamform_sum_beams_output_packets():
     assert out.beam_ips == ['0.0.0.0', '127.0.0.1'] and out.beam_ports == [10000, 10001]
     assert out.socks[0] is None and out.socks[1] is not None
     out.socks[1].close()
+
+
+def test_corr_subsel_then_output_part_packets(golden_dir):
+    """Corr -> CorrSubsel -> CorrOutputPart: packets of `nvis_per_packet` visibilities, big-endian header
+    `>QQ2d4I` + baselines + data[nvis][nchan][2] (corr_output_part_block.py:346-364), values = the golden
+    x[s0,p0]*conj(x[s1,p1]) summed over nchan_sum channels."""
+    import struct
+    from caltech_bifrost_dsp_amd.blocks import CorrOutputPart, CorrSubsel
+    z = np.load(os.path.join(golden_dir, "golden_64t_32a_8c_32s_2p_deadbeef.npz"))
+    vin, gre, gim = z["vin"], z["corr_re"], z["corr_im"]
+    T, C, S, P = vin.shape
+    nvis, nsum, npp = 12, 4, 4
+    r0, r1, r2 = Ring("gpu-input"), Ring("corr-output"), Ring("corr-fast-output")
+    be = OracleBackend()
+    hdr = source_header(C, S, P, seq0=0, sync_time=99, sfreq=3.0e7)
+    corr = Corr(LOG, r0, r1, ntime_gulp=16, nchan=C, npol=P, nstand=S, acc_len=32, autostartat=0,
+                ant_to_input=hdr['ant_to_input'], backend=be)
+    sub = CorrSubsel(LOG, r1, r2, nchan=C, npol=P, nstand=S, nchan_sum=nsum, backend=be, nvis_out=nvis,
+                     antpol_to_bl=corr.antpol_to_bl.numpy(), bl_is_conj=corr.bl_is_conj.numpy())
+    rng = np.random.default_rng(2)
+    sel = [[[int(a), int(b)], [int(c), int(d)]] for a, b, c, d in
+           zip(rng.integers(0, S, nvis), rng.integers(0, 2, nvis), rng.integers(0, S, nvis), rng.integers(0, 2, nvis))]
+    sub.process_command_strings(cmd(1, baselines=sel))
+    pk = []
+    out = CorrOutputPart(LOG, r2, nvis_per_packet=npp, nchan_sum=nsum, sink=pk.append)
+    run_blocks([corr, sub, out], Source(r0, [(hdr, vin, 16 * C * S * P)]), [])
+    nco = C // nsum
+    assert len(pk) == 2 * (nvis // npp)
+    k = 0
+    for it in range(2):
+        for vn in range(nvis // npp):
+            p = pk[k]
+            k += 1
+            hlen = 56 - 8 + 8 + 16 * npp                       # `>QQ2d4I` is 48 bytes; then 4 int32 per visibility
+            f = struct.unpack(">QQ2d4I", p[:48])
+            chan_width = hdr['bw_hz'] / C
+            assert f[:2] == (99, it * 32) and f[2] == hdr['bw_hz'] and f[4:] == (32, npp, nco, 0)
+            assert abs(f[3] - (3.0e7 + (nsum - 1) * chan_width) / nsum) < 1e-6            # corr_subsel_block.py header
+            bl = np.frombuffer(p[48:48 + 16 * npp], dtype='>i4').reshape(npp, 2, 2)
+            assert bl.tolist() == sel[vn * npp:(vn + 1) * npp]
+            data = np.frombuffer(p[48 + 16 * npp:], dtype='>i4').reshape(npp, nco, 2)
+            assert len(p) == hlen - 8 + npp * nco * 8
+            for v in range(npp):
+                (s0, p0), (s1, p1) = sel[vn * npp + v]
+                assert np.array_equal(data[v, :, 0], gre[it][:, s0, s1, p0, p1].reshape(nco, nsum).sum(1))
+                assert np.array_equal(data[v, :, 1], gim[it][:, s0, s1, p0, p1].reshape(nco, nsum).sum(1))
+    with pytest.raises(NotImplementedError):
+        CorrOutputPart(LOG, r2, use_cor_fmt=True)
