@@ -1044,8 +1044,8 @@ __global__ void subselect_kernel(const int32_t* __restrict__ xg, int32_t* __rest
 //
 // HBM-bound gather + transpose through LDS, driven by the GetOrder maps (any antpol_to_input).
 // grid (s1, tile of 16 stands s0), 256 threads.  A tile is 64 rows = (s0 parity, 8 stands, p0, p1):
-// with the identity input map the 32 rows of one parity are one 128-byte run of xGPU cells, so a wave reads
-// two full lines per plane and channel.  Phase A: rows x channels -> LDS (int2 re|im, conjugated per map);
+// with the identity input map the 32 rows of one parity are one 128-byte run of xGPU cells (16-byte loads of
+// whole cells: a wave reads two full lines per plane and channel group).  Phase A: rows x channels -> LDS (int2 re|im, conjugated per map);
 // phase B: every baseline's payload (4*nchan int2, contiguous) is written out in order.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void packetize_kernel(const int32_t* __restrict__ xg, int2* __restrict__ out,
@@ -1058,16 +1058,43 @@ __global__ __launch_bounds__(256) void packetize_kernel(const int32_t* __restric
     if (s0base > s1) return;
     const int t = threadIdx.x;
     {
-        const int row = t & 63, cg = t >> 6;
-        const int s0 = s0base + 2 * ((row >> 2) & 7) + (row >> 5), pp = row & 3;
+        // thread = (baseline slot bs of the tile's 16, channel group cg of 16).  bs = parity*8 + k: the 8 baselines
+        // of one parity are neighbouring xGPU cells.  When the four map entries of a baseline lie in one aligned
+        // 4-word cell (any input map that keeps a stand's two polarisations together) the cell is fetched with one
+        // 16-byte load per plane and channel; otherwise word by word.
+        const int bs = t & 15, cg = t >> 4;
+        const int s0 = s0base + 2 * (bs & 7) + (bs >> 3);
         if (s0 <= s1 && s0 < nstand) {
-            const size_t m = ((size_t)s0 * nstand + s1) * 4 + pp;
-            const int64_t w = antpol_to_bl[m];
-            const bool cj = is_conj[m] != 0;
-            for (int c = cg; c < nchan; c += 4) {
-                const int64_t o = (int64_t)c * per_chan + w;
-                const int re = xg[o], im = xg[matlen + o];
-                tile[row * pitch + c] = make_int2(re, cj ? -im : im);
+            const size_t m = ((size_t)s0 * nstand + s1) * 4;
+            const int4 w4 = *reinterpret_cast<const int4*>(antpol_to_bl + m);
+            const int4 c4 = *reinterpret_cast<const int4*>(is_conj + m);
+            const int wv[4] = {w4.x, w4.y, w4.z, w4.w};
+            const bool cj[4] = {c4.x != 0, c4.y != 0, c4.z != 0, c4.w != 0};
+            const int cell = wv[0] & ~3;
+            const bool one_cell = (wv[1] & ~3) == cell && (wv[2] & ~3) == cell && (wv[3] & ~3) == cell;
+            const int rbase = ((bs >> 3) << 5) | ((bs & 7) << 2);
+            for (int c = cg; c < nchan; c += 16) {
+                const int64_t o = (int64_t)c * per_chan;
+                int re[4], im[4];
+                if (one_cell) {
+                    const int4 r4 = *reinterpret_cast<const int4*>(xg + o + cell);
+                    const int4 i4 = *reinterpret_cast<const int4*>(xg + matlen + o + cell);
+                    const int rr[4] = {r4.x, r4.y, r4.z, r4.w}, ii[4] = {i4.x, i4.y, i4.z, i4.w};
+#pragma unroll
+                    for (int pp = 0; pp < 4; pp++) {
+                        const int k = wv[pp] & 3;
+                        re[pp] = k == 0 ? rr[0] : k == 1 ? rr[1] : k == 2 ? rr[2] : rr[3];
+                        im[pp] = k == 0 ? ii[0] : k == 1 ? ii[1] : k == 2 ? ii[2] : ii[3];
+                    }
+                } else {
+#pragma unroll
+                    for (int pp = 0; pp < 4; pp++) {
+                        re[pp] = xg[o + wv[pp]];
+                        im[pp] = xg[matlen + o + wv[pp]];
+                    }
+                }
+#pragma unroll
+                for (int pp = 0; pp < 4; pp++) tile[(rbase | pp) * pitch + c] = make_int2(re[pp], cj[pp] ? -im[pp] : im[pp]);
             }
         }
     }
