@@ -295,11 +295,18 @@ def main():
                 "ingest_gbps": round(8 * NT_B * NCHAN * NINPUT / (elb / nb_it) / 1e9, 1),
                 "run_us": round(run_us, 1), "integrate_us": round(btm[1] / max(bcn[1], 1) * 1e3, 1),
                 "algorithmic_tflops": round(flop / run_us / 1e6, 1),
-                "roofline": {"kernel": "beamform_bf16x3_kernel", "bound": "mfma", "unit": "TFLOP/s",
-                             "achieved": round(3 * flop / run_us / 1e6, 1), "peak": 2500.0,
-                             "frac": round(3 * flop / run_us / 1e6 / 2500.0, 4),
-                             "note": "bf16 MFMA flops issued = 3 x 8 x nbeam x ninput per (sample, chan) (three bf16 terms "
-                                     "per fp32 weight); algorithmic fp32 flops are 1/3 of that"}}
+                "roofline": ({"kernel": "beamform_bf16x3_kernel", "bound": "mfma", "unit": "TFLOP/s",
+                              "achieved": round(3 * flop / run_us / 1e6, 1), "peak": 2500.0,
+                              "frac": round(3 * flop / run_us / 1e6 / 2500.0, 4),
+                              "note": "bf16 MFMA flops issued = 3 x 8 x nbeam x ninput per (sample, chan) (three bf16 terms "
+                                      "per fp32 weight); algorithmic fp32 flops are 1/3 of that"}
+                             if os.environ.get("XENG_BEAM") == "bf16x3" else
+                             {"kernel": "beamform_i8x3_kernel", "bound": "mfma", "unit": "TFLOP/s",
+                              "achieved": round(3 * flop / run_us / 1e6, 1), "peak": round(PEAK_INT8_OPS / 1e12, 1),
+                              "frac": round(3 * flop / run_us / 1e6 / (PEAK_INT8_OPS / 1e12), 4),
+                              "note": "int8 MFMA ops issued = 3 x 8 x nbeam x ninput per (sample, chan) (three base-255 "
+                                      "digits per fp32 weight); algorithmic fp32 flops are 1/3 of that (algorithmic_tflops, "
+                                      "against the 157 TFLOP/s fp32 MFMA peak the survey names)"})}
         # ---- BASELINE config 5 (one GPU's share): Corr + CorrAcc + Beamform + SumBeams concurrently, each on
         # its own HIP stream, all fed from the same device-resident gulps
         ffi.call("xengXgpuSync")

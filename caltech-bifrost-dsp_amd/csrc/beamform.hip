@@ -21,7 +21,12 @@ struct BeamContext {
     int nchunk = 0, nbtile = 0;
     const void* w_cached = nullptr;   // weights the prepared copy was made from ...
     long long w_version = 0;          // ... and their caller-supplied version (0 = never reuse)
-    bool use_f32 = false;             // XENG_BEAM_F32=1: the fp32-MFMA kernel
+    bool use_f32 = false;             // XENG_BEAM_F32=1 / XENG_BEAM=f32: the fp32-MFMA kernel
+    bool use_i8 = false;              // default: fixed-point digits on the int8 MFMA (XENG_BEAM=bf16x3: the bf16 split)
+    uint8_t* wq = nullptr;            // int8x3 digit planes
+    float* wscale = nullptr;          // ... and their per-(channel, beam) scale
+    float* wmax = nullptr;            // row maxima (between the two prep passes)
+    int nchunk_i8 = 0;
     hipStream_t stream = nullptr;
     EventTimer timer;
 };
@@ -34,6 +39,9 @@ static int beam_destroy_locked() {
     if (g_b.stream) (void)hipStreamSynchronize(g_b.stream);
     if (g_b.scratch) (void)hipFree(g_b.scratch);
     if (g_b.wprep) (void)hipFree(g_b.wprep);
+    if (g_b.wq) (void)hipFree(g_b.wq);
+    if (g_b.wscale) (void)hipFree(g_b.wscale);
+    if (g_b.wmax) (void)hipFree(g_b.wmax);
     g_b.timer.destroy();
     g_b = BeamContext();
     return XENG_STATUS_SUCCESS;
@@ -46,6 +54,24 @@ static int run_locked(const void* in, float* out, const void* w, long long versi
         int slot = x.timer.begin(x.stream, 0);
         hipLaunchKernelGGL(beamform_f32_kernel, grid, dim3(256), 0, x.stream, (const uint8_t*)in, (const float*)w, out,
                            x.ntime, x.nchan, x.ninput, x.nbeam);
+        x.timer.end(x.stream, slot);
+        XENG_HIP(hipGetLastError());
+        return XENG_STATUS_SUCCESS;
+    }
+    if (x.use_i8) {
+        if (!(version != 0 && version == x.w_version && w == x.w_cached)) {
+            hipLaunchKernelGGL(beam_weights_rowmax_kernel, dim3(4 * x.nbtile, x.nchan), dim3(256), 0, x.stream,
+                               (const float*)w, x.wscale, x.wmax, x.nchan, x.nbeam, x.ninput, x.nbtile);
+            hipLaunchKernelGGL(beam_weights_prep_i8_kernel, dim3(x.nchunk_i8, x.nbtile, x.nchan), dim3(256), 0, x.stream,
+                               (const float*)w, x.wq, x.wmax, x.nchan, x.nbeam, x.ninput, x.nchunk_i8, x.nbtile);
+            XENG_HIP(hipGetLastError());
+            x.w_cached = w;
+            x.w_version = version;
+        }
+        dim3 grid(((x.ntime + BI_NT - 1) / BI_NT) * x.nchan * x.nbtile);
+        int slot = x.timer.begin(x.stream, 0);
+        hipLaunchKernelGGL(beamform_i8x3_kernel, grid, dim3(256), 0, x.stream, (const uint8_t*)in, x.wq, x.wscale, out,
+                           x.ntime, x.nchan, x.ninput, x.nbeam, x.nchunk_i8, x.nbtile);
         x.timer.end(x.stream, slot);
         XENG_HIP(hipGetLastError());
         return XENG_STATUS_SUCCESS;
@@ -106,7 +132,17 @@ int xengBeamformInitialize(int gpu, int ninput, int nchan, int ntime, int nbeam,
     XENG_HIP(hipMalloc((void**)&x.wprep, x.wprep_bytes));
     XENG_HIP(hipMemset(x.wprep, 0, x.wprep_bytes));
     // the bf16x3 kernel moves the packed voltages by 16-byte LDS-DMA columns: inputs must be a multiple of 16
-    x.use_f32 = getenv("XENG_BEAM_F32") != nullptr || (ninput % 16) != 0;
+    const char* mode = getenv("XENG_BEAM");
+    x.use_f32 = getenv("XENG_BEAM_F32") != nullptr || (mode && !strcmp(mode, "f32")) || (ninput % 16) != 0;
+    x.use_i8 = !x.use_f32 && !(mode && !strcmp(mode, "bf16x3"));     // default; XENG_BEAM=bf16x3 | f32 select the others
+    if (x.use_i8) {
+        x.nchunk_i8 = (ninput + BI_KC - 1) / BI_KC;
+        const size_t qb = (size_t)nchan * x.nbtile * x.nchunk_i8 * BI_WCHUNK;
+        XENG_HIP(hipMalloc((void**)&x.wq, qb));
+        XENG_HIP(hipMemset(x.wq, 0, qb));
+        XENG_HIP(hipMalloc((void**)&x.wscale, (size_t)nchan * x.nbtile * 32 * sizeof(float)));
+        XENG_HIP(hipMalloc((void**)&x.wmax, (size_t)nchan * x.nbtile * 32 * sizeof(float)));
+    }
     int rc = get_stream(STREAM_BEAM, &x.stream);
     if (rc) return rc;
     x.live = true;

@@ -306,6 +306,189 @@ __global__ __launch_bounds__(64 * BF3_NW, BF3_NW == 8 ? 2 : 3) void beamform_bf1
     }
 }
 
+// =======================================================================================
+// int8 x 3 beamformer: fixed-point weights on the int8 MFMA (twice the bf16 rate, half the weight bytes).
+//
+// Every fp32 weight component is quantised per (channel, beam) row to q = round(w / wmax * QMAX),
+// QMAX = 127*(255^2 + 255 + 1), and written as three balanced base-255 digits d1, d2, d3 in [-127, 127]
+// (q = d1*255^2 + d2*255 + d3; the representation is symmetric, so -q is the negated digits).  The voltages
+// enter as 16*re / 16*im (the mask trick of the X-engine: no conversion at all).  All products and the int32
+// sums over the inputs are exact; per digit plane
+//     Tre = sum (dr * 16xr - di * 16xi),   Tim = sum (dr * 16xi + di * 16xr)          (|T| <= 2*127*128*ninput)
+// and the epilogue combines   out = (wmax / QMAX / 16) * (255^2 * T1 + 255 * T2 + T3)   in fp32.
+// Quantisation step = wmax * 1.2e-7 (an fp32 ulp of the row's largest weight): the output error is
+// <= 4e-6 * wmax/wrms of the output RMS in the worst (fully coherent) case and ~1e-7 for ordinary data, inside
+// the 1e-5 bar; measured in tests/test_beamform_gpu.py.
+//
+// Layout Wq[c][beam tile][32-input chunk][digit][Wr | Wi | -Wi][lane = 32h + beam][16 B]: the A-operand image of
+// v_mfma_i32_32x32x32_i8 (lane holds inputs 16h..16h+15 of its beam), 9 KiB per chunk; scale[c][beam].
+// Kernel structure as beamform_bf16x3_kernel: ring of three stages (9 KiB of digits + 4 KiB of voltages), LDS-DMA
+// two chunks ahead, one barrier per chunk, three work-groups per CU.
+// =======================================================================================
+constexpr int BI_KC = 32;                          // inputs per chunk = K of one int8 MFMA
+constexpr int BI_WCHUNK = 3 * 3 * 1024;             // digits x {Wr, Wi, -Wi} x 1 KiB operand image
+constexpr int BI_NT = 128;                          // samples per work-group (4 waves x 32)
+constexpr int BI_XCHUNK = BI_NT * BI_KC;            // 4 KiB of packed voltages per chunk
+constexpr int BI_STAGE = BI_WCHUNK + BI_XCHUNK;     // 13 KiB
+constexpr int BI_RING = 3;
+constexpr int BI_QMAX = 127 * (255 * 255 + 255 + 1);
+
+// pass 1, grid (4 * nbtile, nchan), 256 threads = (beam tid/32 of the block's 8, lane32 tid%32): row maxima ->
+// scale[c][beam] (with the 1/16 of the voltage scaling folded in) and wmax[c][beam] for pass 2
+__global__ __launch_bounds__(256) void beam_weights_rowmax_kernel(const float* __restrict__ w, float* __restrict__ scale,
+                                                                  float* __restrict__ wmax, int nchan, int nbeam,
+                                                                  int ninput, int nbtile) {
+    const int c = blockIdx.y;
+    const int beam = blockIdx.x * 8 + (threadIdx.x >> 5), l32 = threadIdx.x & 31;   // beam index within the padded tiles
+    float m = 0.f;
+    if (beam < nbeam) {
+        const float* wrow = w + ((size_t)c * nbeam + beam) * ninput * 2;
+        for (int i = l32; i < ninput; i += 32) {
+            const float2 v = *reinterpret_cast<const float2*>(wrow + 2 * i);
+            m = fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y)));
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (l32 == 0) {
+        scale[(size_t)c * nbtile * 32 + beam] = m > 0.f ? m / (float)BI_QMAX / 16.f : 0.f;
+        wmax[(size_t)c * nbtile * 32 + beam] = m;
+    }
+}
+
+// pass 2, grid (nchunk, nbtile, nchan), 256 threads = (beam tid/8, 4 inputs (tid%8)*4 of the chunk)
+__global__ __launch_bounds__(256) void beam_weights_prep_i8_kernel(const float* __restrict__ w, uint8_t* __restrict__ wq,
+                                                                   const float* __restrict__ wmax, int nchan, int nbeam,
+                                                                   int ninput, int nchunk, int nbtile) {
+    const int ch = blockIdx.x, bt = blockIdx.y, c = blockIdx.z;
+    const int beam = threadIdx.x >> 3, l8 = threadIdx.x & 7;
+    const int b = bt * 32 + beam;
+    const float* wrow = w + ((size_t)c * nbeam + (b < nbeam ? b : 0)) * ninput * 2;
+    const float m = wmax[(size_t)(c * nbtile + bt) * 32 + beam];
+    const float inv = m > 0.f ? (float)BI_QMAX / m : 0.f;
+    auto digits = [](int q, int (&d)[3]) {      // balanced base 255, most significant first
+#pragma unroll
+        for (int k = 2; k >= 0; k--) {
+            int r = q % 255;                     // C remainder: sign of q
+            if (r > 127) r -= 255;
+            if (r < -127) r += 255;
+            d[k] = r;
+            q = (q - r) / 255;
+        }
+    };
+    const int h = l8 >> 2, byte0 = (l8 & 3) * 4, lane = 32 * h + beam;
+    uint32_t pk[3][3] = {};                      // [digit][Wr | Wi | -Wi] 4 packed int8
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int i = ch * BI_KC + l8 * 4 + j;
+        int qr = 0, qi = 0;
+        if (b < nbeam && i < ninput) {
+            const float2 v = *reinterpret_cast<const float2*>(wrow + 2 * i);
+            // (the row maximum itself may round to QMAX + 1, whose leading digit would be 128: clamp)
+            qr = max(-BI_QMAX, min(BI_QMAX, (int)rintf(v.x * inv)));
+            qi = max(-BI_QMAX, min(BI_QMAX, (int)rintf(v.y * inv)));
+        }
+        int dr[3], di[3];
+        digits(qr, dr);
+        digits(qi, di);
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            pk[t][0] |= (uint32_t)(dr[t] & 0xFF) << (8 * j);
+            pk[t][1] |= (uint32_t)(di[t] & 0xFF) << (8 * j);
+            pk[t][2] |= (uint32_t)((-di[t]) & 0xFF) << (8 * j);
+        }
+    }
+    uint8_t* base = wq + (((size_t)c * nbtile + bt) * nchunk + ch) * BI_WCHUNK + lane * 16 + byte0;
+#pragma unroll
+    for (int t = 0; t < 3; t++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) *reinterpret_cast<uint32_t*>(base + (t * 3 + k) * 1024) = pk[t][k];
+}
+
+__global__ __launch_bounds__(256, 3) void beamform_i8x3_kernel(const uint8_t* __restrict__ in,
+                                                               const uint8_t* __restrict__ wq,
+                                                               const float* __restrict__ scale,
+                                                               float* __restrict__ out, int ntime, int nchan,
+                                                               int ninput, int nbeam, int nchunk, int nbtile) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[BI_RING * BI_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nttile = (ntime + BI_NT - 1) / BI_NT, per_c = nbtile * nttile;
+    int c, rem;
+    if ((nchan & 7) == 0) { const int b = blockIdx.x, slot = b >> 3; c = (b & 7) + 8 * (slot / per_c); rem = slot % per_c; }
+    else { c = blockIdx.x / per_c; rem = blockIdx.x % per_c; }
+    const int bt = rem / nttile, t0 = (rem % nttile) * BI_NT;
+    const int h = lane >> 5, j = lane & 31;
+    const uint8_t* wsrc = wq + (((size_t)c * nbtile + bt) * nchunk) * BI_WCHUNK + lane * 16;
+    const size_t row_stride = (size_t)nchan * ninput;
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
+    // X piece `wave` of a chunk = samples 32*wave .. +31, 32 B each; lane: row 32*wave + lane/2, 16-byte half lane&1
+    // (32-byte rows: the 16-byte operand reads of 8 consecutive samples fall on distinct banks as they are)
+    int xt = t0 + wave * 32 + (lane >> 1);
+    if (xt >= ntime) xt = ntime - 1;
+    const uint8_t* xsrc = in + (size_t)xt * row_stride + (size_t)c * ninput;
+    const int xhalf = (lane & 1) * 16;
+    // every stage costs exactly 4 pieces per wave on the vmcnt counter (chunks past the end re-read the last one;
+    // digit slots past the 9th piece re-copy an earlier piece onto itself)
+    auto issue = [&](int ch, int buf) {
+        const int cs = ch < nchunk ? ch : nchunk - 1;
+        const uint32_t l = lds0 + buf * BI_STAGE;
+#pragma unroll
+        for (int n = 0; n < 3; n++) {
+            const int pc = (wave + 4 * n) % 9;
+            lds_dma16(wsrc + (size_t)cs * BI_WCHUNK + pc * 1024, l + pc * 1024);
+        }
+        int i = cs * BI_KC + xhalf;
+        if (i + 16 > ninput) i = 0;                    // columns past the end meet zero digits
+        lds_dma16(xsrc + i, l + BI_WCHUNK + wave * 1024);
+    };
+    typedef int v4i_ __attribute__((ext_vector_type(4)));
+    typedef int v16i_ __attribute__((ext_vector_type(16)));
+    v16i_ acc_re[3], acc_im[3];
+#pragma unroll
+    for (int t = 0; t < 3; t++) { acc_re[t] = (v16i_)(0); acc_im[t] = (v16i_)(0); }
+    issue(0, 0);
+    issue(1, 1);
+    int buf = 0, nbuf = 2;
+    for (int ch = 0; ch < nchunk; ch++) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // this wave's pieces of chunk ch have landed (ch+1 in flight)
+        __builtin_amdgcn_s_barrier();                  // ... for all waves; and everybody is done reading chunk ch-1,
+        issue(ch + 2, nbuf);                           // whose buffer the DMA of chunk ch+2 now overwrites
+        const uint8_t* lw = lds + buf * BI_STAGE + lane * 16;
+        const v4i_ xraw = *reinterpret_cast<const v4i_*>(lds + buf * BI_STAGE + BI_WCHUNK + (wave * 32 + j) * BI_KC + h * 16);
+        const v4i_ M = (v4i_)(0xF0F0F0F0);
+        const v4i_ Xr = xraw & M, Xi = (xraw << 4) & M;    // 16*re, 16*im (hi nibble real, lo nibble imag; beamformer_test.py:69-73)
+#pragma unroll
+        for (int t = 2; t >= 0; t--) {
+            const v4i_ Wr = *reinterpret_cast<const v4i_*>(lw + (t * 3 + 0) * 1024);
+            const v4i_ Wi = *reinterpret_cast<const v4i_*>(lw + (t * 3 + 1) * 1024);
+            const v4i_ nWi = *reinterpret_cast<const v4i_*>(lw + (t * 3 + 2) * 1024);
+            acc_re[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(Wr, Xr, acc_re[t], 0, 0, 0);
+            acc_im[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(Wr, Xi, acc_im[t], 0, 0, 0);
+            acc_re[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(nWi, Xi, acc_re[t], 0, 0, 0);
+            acc_im[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(Wi, Xr, acc_im[t], 0, 0, 0);
+        }
+        buf = buf + 1 == BI_RING ? 0 : buf + 1;
+        nbuf = nbuf + 1 == BI_RING ? 0 : nbuf + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may be in flight when the wave ends
+    // C/D map: col (sample) = lane&31, row (beam) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const int t = t0 + wave * 32 + j;
+    if (t < ntime) {
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            const int brow = (g & 3) + 8 * (g >> 2) + 4 * h;
+            const int b = bt * 32 + brow;
+            if (b < nbeam) {
+                const float s = scale[(size_t)(c * nbtile + bt) * 32 + brow];
+                const float re = s * (((float)acc_re[0][g] * 65025.f + (float)acc_re[1][g] * 255.f) + (float)acc_re[2][g]);
+                const float im = s * (((float)acc_im[0][g] * 65025.f + (float)acc_im[1][g] * 255.f) + (float)acc_im[2][g]);
+                *reinterpret_cast<float2*>(out + (((size_t)c * nbeam + b) * ntime + t) * 2) = make_float2(re, im);
+            }
+        }
+    }
+}
+
 // beam power sums (beamformer_sum_test.py:64-77, cublas_beamform.cu:46-79).
 // in cf32[nchan][nbeam][ntime] -> out f32[npair][ntime/ntime_sum][nchan][4]; one wave per
 // (channel, beam pair): lanes stride the time blocks, 8-lane groups sweep one block's samples

@@ -180,3 +180,37 @@ def test_versioned_weights_are_resplit_only_on_change(gpu):
     dw.upload(w1)
     check_beams(run(0), e1)          # version 0: always re-split (the reference call shape)
     gpu.ffi.call("xengBeamformDestroy")
+
+
+@pytest.mark.parametrize("ntime,nchan,ninput,nbeam,kind", [
+    (32, 2, 64, 32, "block"),
+    (100, 3, 48, 5, "block"),          # ragged: time not /32, inputs not /32, beams not /32
+    (960, 4, 704, 32, "block"),        # config 4 shapes at 4 channels
+    (130, 1, 704, 34, "block"),        # more than one beam tile
+    (96, 2, 704, 8, "dynamic"),        # 60 dB of dynamic range inside a beam's weights, some inputs flagged (zero)
+    (64, 1, 704, 4, "coherent"),       # every sample -8-8j and weights of one phase: quantisation errors add coherently
+])
+@pytest.mark.parametrize("mode", ["int8x3", "bf16x3", "f32"])
+def test_beamform_kernel_routes(gpu, ntime, nchan, ninput, nbeam, kind, mode):
+    """The three Run kernels against the float64 oracle at the same 1e-5-of-RMS bar: int8x3 (default: weights as
+    three balanced base-255 int8 digits per (channel, beam) row on the int8 MFMA, exact integer sums, fp32
+    recombination), bf16x3 (exact three-term bf16 split, fp32 accumulation) and f32 (fp32 MFMA chain)."""
+    rng = np.random.default_rng(ntime + ninput + nbeam)
+    vin = rng.integers(0, 256, (ntime, nchan, ninput), dtype=np.uint8)
+    w = block_weights(nchan, nbeam, ninput)
+    if kind == "dynamic":
+        w = (w * (10.0 ** rng.uniform(-3, 0, (nchan, nbeam, ninput)))).astype(np.complex64)
+        w[:, :, rng.integers(0, ninput, 40)] = 0
+    if kind == "coherent":
+        vin[...] = 0x88
+        w = (np.abs(w) * np.exp(1j * 0.7)).astype(np.complex64)
+    os.environ["XENG_BEAM"] = mode
+    try:
+        got, _ = run_beamform(gpu, vin, w, ntime, nchan, ninput, nbeam)
+        err = check_beams(got, orc.beamform(vin, w, ntime, nchan, ninput, nbeam))
+        got2, _ = run_beamform(gpu, vin, (2 * w).astype(np.complex64), ntime, nchan, ninput, nbeam)
+        assert np.array_equal(got2, 2 * got)            # power-of-two scaling is exact in all three
+        print("%s %s max err / rms = %.2e" % (mode, kind, err))
+    finally:
+        del os.environ["XENG_BEAM"]
+        gpu.ffi.call("xengBeamformDestroy")
