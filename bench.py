@@ -254,7 +254,7 @@ def main():
                   "ingest_gbps": round(8 * gulp_bytes / (in_ms * 1e-3) / 1e9, 1),
                   "roofline": {"bound": "hbm", "achieved": round(in_bytes / (in_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": round(in_bytes / (in_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-                  "note": "wall time of the synchronous call: memset of the gulp + scatter kernel (24 us on the device, profiles/r01/v4_kernel_stats_all_legs.csv) + counter read-back"}
+                  "note": "wall time of the synchronous call: memset of the gulp + scatter kernel (24 us on the device, profiles/r01/v5_kernel_stats_all_legs.csv) + counter read-back"}
         dslab.free()
         dgulp.free()
     # outside the timed region: BASELINE config 4 -- Beamform (32 beams, 96 chan, 960 samples, fp32 weights)
