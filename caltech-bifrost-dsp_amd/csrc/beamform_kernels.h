@@ -330,7 +330,10 @@ constexpr int BI_WCHUNK = 3 * 3 * 1024;             // digits x {Wr, Wi, -Wi} x 
 constexpr int BI_NT = 128;                          // samples per work-group (4 waves x 32)
 constexpr int BI_XCHUNK = BI_NT * BI_KC;            // 4 KiB of packed voltages per chunk
 constexpr int BI_STAGE = BI_WCHUNK + BI_XCHUNK;     // 13 KiB
-constexpr int BI_RING = 3;
+#ifndef BI_RING_STAGES
+#define BI_RING_STAGES 3
+#endif
+constexpr int BI_RING = BI_RING_STAGES;
 constexpr int BI_QMAX = 127 * (255 * 255 + 255 + 1);
 
 // pass 1, grid (4 * nbtile, nchan), 256 threads = (beam tid/32 of the block's 8, lane32 tid%32): row maxima ->
@@ -447,13 +450,14 @@ __global__ __launch_bounds__(256, 3) void beamform_i8x3_kernel(const uint8_t* __
     v16i_ acc_re[3], acc_im[3];
 #pragma unroll
     for (int t = 0; t < 3; t++) { acc_re[t] = (v16i_)(0); acc_im[t] = (v16i_)(0); }
-    issue(0, 0);
-    issue(1, 1);
-    int buf = 0, nbuf = 2;
+#pragma unroll
+    for (int k = 0; k < BI_RING - 1; k++) issue(k, k);
+    int buf = 0, nbuf = BI_RING - 1;
     for (int ch = 0; ch < nchunk; ch++) {
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // this wave's pieces of chunk ch have landed (ch+1 in flight)
+        // this wave's pieces of chunk ch have landed (the BI_RING-2 younger chunks stay in flight)
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (BI_RING - 2)) : "memory");
         __builtin_amdgcn_s_barrier();                  // ... for all waves; and everybody is done reading chunk ch-1,
-        issue(ch + 2, nbuf);                           // whose buffer the DMA of chunk ch+2 now overwrites
+        issue(ch + BI_RING - 1, nbuf);                 // whose buffer the DMA of chunk ch+BI_RING-1 now overwrites
         const uint8_t* lw = lds + buf * BI_STAGE + lane * 16;
         const v4i_ xraw = *reinterpret_cast<const v4i_*>(lds + buf * BI_STAGE + BI_WCHUNK + (wave * 32 + j) * BI_KC + h * 16);
         const v4i_ M = (v4i_)(0xF0F0F0F0);
