@@ -26,6 +26,7 @@ struct BeamContext {
     uint8_t* wq = nullptr;            // int8x3 digit planes
     float* wscale = nullptr;          // ... and their per-(channel, beam) scale
     float* wmax = nullptr;            // row maxima (between the two prep passes)
+    unsigned long long* stamps = nullptr;   // diagnostic (XENG_BEAM_STAMPS=1): per wave {entry, first chunk, loop end, exit}
     int nchunk_i8 = 0;
     hipStream_t stream = nullptr;
     EventTimer timer;
@@ -42,6 +43,7 @@ static int beam_destroy_locked() {
     if (g_b.wq) (void)hipFree(g_b.wq);
     if (g_b.wscale) (void)hipFree(g_b.wscale);
     if (g_b.wmax) (void)hipFree(g_b.wmax);
+    if (g_b.stamps) (void)hipFree(g_b.stamps);
     g_b.timer.destroy();
     g_b = BeamContext();
     return XENG_STATUS_SUCCESS;
@@ -62,8 +64,8 @@ static int run_locked(const void* in, float* out, const void* w, long long versi
         if (!(version != 0 && version == x.w_version && w == x.w_cached)) {
             hipLaunchKernelGGL(beam_weights_rowmax_kernel, dim3(4 * x.nbtile, x.nchan), dim3(256), 0, x.stream,
                                (const float*)w, x.wscale, x.wmax, x.nchan, x.nbeam, x.ninput, x.nbtile);
-            hipLaunchKernelGGL(beam_weights_prep_i8_kernel, dim3(x.nchunk_i8, x.nbtile, x.nchan), dim3(256), 0, x.stream,
-                               (const float*)w, x.wq, x.wmax, x.nchan, x.nbeam, x.ninput, x.nchunk_i8, x.nbtile);
+            hipLaunchKernelGGL(beam_weights_prep_i8_kernel, dim3(x.nchunk_i8 * BI_KS, x.nbtile, x.nchan), dim3(256), 0, x.stream,
+                               (const float*)w, x.wq, x.wmax, x.nchan, x.nbeam, x.ninput, x.nchunk_i8 * BI_KS, x.nbtile);
             XENG_HIP(hipGetLastError());
             x.w_cached = w;
             x.w_version = version;
@@ -71,7 +73,7 @@ static int run_locked(const void* in, float* out, const void* w, long long versi
         dim3 grid(((x.ntime + BI_NT - 1) / BI_NT) * x.nchan * x.nbtile);
         int slot = x.timer.begin(x.stream, 0);
         hipLaunchKernelGGL(beamform_i8x3_kernel, grid, dim3(256), 0, x.stream, (const uint8_t*)in, x.wq, x.wscale, out,
-                           x.ntime, x.nchan, x.ninput, x.nbeam, x.nchunk_i8, x.nbtile);
+                           x.ntime, x.nchan, x.ninput, x.nbeam, x.nchunk_i8, x.nbtile, x.stamps);
         x.timer.end(x.stream, slot);
         XENG_HIP(hipGetLastError());
         return XENG_STATUS_SUCCESS;
@@ -142,10 +144,25 @@ int xengBeamformInitialize(int gpu, int ninput, int nchan, int ntime, int nbeam,
         XENG_HIP(hipMemset(x.wq, 0, qb));
         XENG_HIP(hipMalloc((void**)&x.wscale, (size_t)nchan * x.nbtile * 32 * sizeof(float)));
         XENG_HIP(hipMalloc((void**)&x.wmax, (size_t)nchan * x.nbtile * 32 * sizeof(float)));
+        if (getenv("XENG_BEAM_STAMPS")) {
+            const size_t nw = (size_t)((ntime + BI_NT - 1) / BI_NT) * nchan * x.nbtile * 4 * 4;
+            XENG_HIP(hipMalloc((void**)&x.stamps, nw * sizeof(unsigned long long)));
+            XENG_HIP(hipMemset(x.stamps, 0, nw * sizeof(unsigned long long)));
+        }
     }
     int rc = get_stream(STREAM_BEAM, &x.stream);
     if (rc) return rc;
     x.live = true;
+    return XENG_STATUS_SUCCESS;
+}
+
+// diagnostic hook: per-wave clock stamps of the last int8x3 launch (needs XENG_BEAM_STAMPS=1 at Initialize)
+int xengBeamformDebugReadStamps(unsigned long long* host, size_t nwords) {
+    std::lock_guard<std::mutex> lk(g_bmu);
+    BeamContext& x = g_b;
+    if (!x.live || !x.stamps) XENG_FAIL(XENG_STATUS_INVALID_STATE, "beam stamps not enabled");
+    XENG_HIP(hipStreamSynchronize(x.stream));
+    XENG_HIP(hipMemcpy(host, x.stamps, nwords * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return XENG_STATUS_SUCCESS;
 }
 

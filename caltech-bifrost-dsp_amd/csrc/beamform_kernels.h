@@ -325,13 +325,17 @@ __global__ __launch_bounds__(64 * BF3_NW, BF3_NW == 8 ? 2 : 3) void beamform_bf1
 // Kernel structure as beamform_bf16x3_kernel: ring of three stages (9 KiB of digits + 4 KiB of voltages), LDS-DMA
 // two chunks ahead, one barrier per chunk, three work-groups per CU.
 // =======================================================================================
-constexpr int BI_KC = 32;                          // inputs per chunk = K of one int8 MFMA
-constexpr int BI_WCHUNK = 3 * 3 * 1024;             // digits x {Wr, Wi, -Wi} x 1 KiB operand image
+constexpr int BI_KS = 2;                            // int8 MFMA K steps (32 inputs each) per chunk
+constexpr int BI_KC = 32 * BI_KS;                   // inputs per chunk
+constexpr int BI_WSTEP = 3 * 3 * 1024;              // per K step: digits x {Wr, Wi, -Wi} x 1 KiB operand image
+constexpr int BI_WCHUNK = BI_KS * BI_WSTEP;         // 18 KiB
 constexpr int BI_NT = 128;                          // samples per work-group (4 waves x 32)
-constexpr int BI_XCHUNK = BI_NT * BI_KC;            // 4 KiB of packed voltages per chunk
-constexpr int BI_STAGE = BI_WCHUNK + BI_XCHUNK;     // 13 KiB
+constexpr int BI_XCHUNK = BI_NT * BI_KC;            // 8 KiB of packed voltages per chunk
+constexpr int BI_STAGE = BI_WCHUNK + BI_XCHUNK;     // 26 KiB
+constexpr int BI_WSLOTS = (BI_KS * 9 + 3) / 4;      // weight pieces issued per wave and chunk
+constexpr int BI_XSLOTS = BI_XCHUNK / 1024 / 4;     // voltage pieces issued per wave and chunk
 #ifndef BI_RING_STAGES
-#define BI_RING_STAGES 3
+#define BI_RING_STAGES 2
 #endif
 constexpr int BI_RING = BI_RING_STAGES;
 constexpr int BI_QMAX = 127 * (255 * 255 + 255 + 1);
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(256) void beam_weights_rowmax_kernel(const float* _
 __global__ __launch_bounds__(256) void beam_weights_prep_i8_kernel(const float* __restrict__ w, uint8_t* __restrict__ wq,
                                                                    const float* __restrict__ wmax, int nchan, int nbeam,
                                                                    int ninput, int nchunk, int nbtile) {
-    const int ch = blockIdx.x, bt = blockIdx.y, c = blockIdx.z;
+    const int ch = blockIdx.x, bt = blockIdx.y, c = blockIdx.z;      // ch: 32-input K step (nchunk = number of steps, padded to whole chunks)
     const int beam = threadIdx.x >> 3, l8 = threadIdx.x & 7;
     const int b = bt * 32 + beam;
     const float* wrow = w + ((size_t)c * nbeam + (b < nbeam ? b : 0)) * ninput * 2;
@@ -383,7 +387,7 @@ __global__ __launch_bounds__(256) void beam_weights_prep_i8_kernel(const float* 
     uint32_t pk[3][3] = {};                      // [digit][Wr | Wi | -Wi] 4 packed int8
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const int i = ch * BI_KC + l8 * 4 + j;
+        const int i = ch * 32 + l8 * 4 + j;
         int qr = 0, qi = 0;
         if (b < nbeam && i < ninput) {
             const float2 v = *reinterpret_cast<const float2*>(wrow + 2 * i);
@@ -401,7 +405,7 @@ __global__ __launch_bounds__(256) void beam_weights_prep_i8_kernel(const float* 
             pk[t][2] |= (uint32_t)((-di[t]) & 0xFF) << (8 * j);
         }
     }
-    uint8_t* base = wq + (((size_t)c * nbtile + bt) * nchunk + ch) * BI_WCHUNK + lane * 16 + byte0;
+    uint8_t* base = wq + (((size_t)c * nbtile + bt) * nchunk + ch) * BI_WSTEP + lane * 16 + byte0;
 #pragma unroll
     for (int t = 0; t < 3; t++)
 #pragma unroll
@@ -412,8 +416,10 @@ __global__ __launch_bounds__(256, 3) void beamform_i8x3_kernel(const uint8_t* __
                                                                const uint8_t* __restrict__ wq,
                                                                const float* __restrict__ scale,
                                                                float* __restrict__ out, int ntime, int nchan,
-                                                               int ninput, int nbeam, int nchunk, int nbtile) {
+                                                               int ninput, int nbeam, int nchunk, int nbtile,
+                                                               unsigned long long* __restrict__ stamps) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[BI_RING * BI_STAGE];
+    const unsigned long long r0 = stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;   // diagnostic (XENG_BEAM_STAMPS=1)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nttile = (ntime + BI_NT - 1) / BI_NT, per_c = nbtile * nttile;
@@ -425,26 +431,38 @@ __global__ __launch_bounds__(256, 3) void beamform_i8x3_kernel(const uint8_t* __
     const uint8_t* wsrc = wq + (((size_t)c * nbtile + bt) * nchunk) * BI_WCHUNK + lane * 16;
     const size_t row_stride = (size_t)nchan * ninput;
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
-    // X piece `wave` of a chunk = samples 32*wave .. +31, 32 B each; lane: row 32*wave + lane/2, 16-byte half lane&1
-    // (32-byte rows: the 16-byte operand reads of 8 consecutive samples fall on distinct banks as they are)
-    int xt = t0 + wave * 32 + (lane >> 1);
-    if (xt >= ntime) xt = ntime - 1;
-    const uint8_t* xsrc = in + (size_t)xt * row_stride + (size_t)c * ninput;
-    const int xhalf = (lane & 1) * 16;
-    // every stage costs exactly 4 pieces per wave on the vmcnt counter (chunks past the end re-read the last one;
-    // digit slots past the 9th piece re-copy an earlier piece onto itself)
+    // X pieces 2*wave, 2*wave+1 of a chunk = samples 32*wave .. +31, 64 B each (16 rows per 1 KiB piece); lane: row
+    // lane/4 of the piece, 16-byte position lane&3 holding source piece (lane&3) ^ ((row>>2)&1): the swizzle (on the
+    // source side; the LDS side of the DMA is lane-linear) makes the 16-byte operand reads conflict-free at 64-byte pitch
+    const uint8_t* xsrc[BI_XSLOTS];
+#pragma unroll
+    for (int n = 0; n < BI_XSLOTS; n++) {
+        int xt = t0 + wave * 32 + n * 16 + (lane >> 2);
+        if (xt >= ntime) xt = ntime - 1;
+        xsrc[n] = in + (size_t)xt * row_stride + (size_t)c * ninput;
+    }
+    const int xpiece = ((lane & 3) ^ ((lane >> 4) & 1)) * 16;
+    // every stage costs exactly BI_WSLOTS + BI_XSLOTS pieces per wave on the vmcnt counter (chunks past the end
+    // re-read the last one; digit slots past the last piece re-copy an earlier piece onto itself)
     auto issue = [&](int ch, int buf) {
         const int cs = ch < nchunk ? ch : nchunk - 1;
         const uint32_t l = lds0 + buf * BI_STAGE;
 #pragma unroll
-        for (int n = 0; n < 3; n++) {
-            const int pc = (wave + 4 * n) % 9;
+        for (int n = 0; n < BI_WSLOTS; n++) {
+            const int pc = (wave + 4 * n) % (BI_KS * 9);
             lds_dma16(wsrc + (size_t)cs * BI_WCHUNK + pc * 1024, l + pc * 1024);
         }
-        int i = cs * BI_KC + xhalf;
-        if (i + 16 > ninput) i = 0;                    // columns past the end meet zero digits
-        lds_dma16(xsrc + i, l + BI_WCHUNK + wave * 1024);
+#pragma unroll
+        for (int n = 0; n < BI_XSLOTS; n++) {
+            int i = cs * BI_KC + xpiece;
+            if (i + 16 > ninput) i = 0;                // columns past the end meet zero digits
+            lds_dma16(xsrc[n] + i, l + BI_WCHUNK + (wave * BI_XSLOTS + n) * 1024);
+        }
     };
+    // the 16 row scales this lane needs in the epilogue: fetched now, off the critical path
+    float sc[16];
+#pragma unroll
+    for (int g = 0; g < 16; g++) sc[g] = scale[(size_t)(c * nbtile + bt) * 32 + (g & 3) + 8 * (g >> 2) + 4 * h];
     typedef int v4i_ __attribute__((ext_vector_type(4)));
     typedef int v16i_ __attribute__((ext_vector_type(16)));
     v16i_ acc_re[3], acc_im[3];
@@ -453,29 +471,40 @@ __global__ __launch_bounds__(256, 3) void beamform_i8x3_kernel(const uint8_t* __
 #pragma unroll
     for (int k = 0; k < BI_RING - 1; k++) issue(k, k);
     int buf = 0, nbuf = BI_RING - 1;
+    unsigned long long r1 = 0;
     for (int ch = 0; ch < nchunk; ch++) {
         // this wave's pieces of chunk ch have landed (the BI_RING-2 younger chunks stay in flight)
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (BI_RING - 2)) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((BI_WSLOTS + BI_XSLOTS) * (BI_RING - 2)) : "memory");
         __builtin_amdgcn_s_barrier();                  // ... for all waves; and everybody is done reading chunk ch-1,
         issue(ch + BI_RING - 1, nbuf);                 // whose buffer the DMA of chunk ch+BI_RING-1 now overwrites
-        const uint8_t* lw = lds + buf * BI_STAGE + lane * 16;
-        const v4i_ xraw = *reinterpret_cast<const v4i_*>(lds + buf * BI_STAGE + BI_WCHUNK + (wave * 32 + j) * BI_KC + h * 16);
+        if (stamps && ch == 0) r1 = __builtin_amdgcn_s_memrealtime();
         const v4i_ M = (v4i_)(0xF0F0F0F0);
-        const v4i_ Xr = xraw & M, Xi = (xraw << 4) & M;    // 16*re, 16*im (hi nibble real, lo nibble imag; beamformer_test.py:69-73)
 #pragma unroll
-        for (int t = 2; t >= 0; t--) {
-            const v4i_ Wr = *reinterpret_cast<const v4i_*>(lw + (t * 3 + 0) * 1024);
-            const v4i_ Wi = *reinterpret_cast<const v4i_*>(lw + (t * 3 + 1) * 1024);
-            const v4i_ nWi = *reinterpret_cast<const v4i_*>(lw + (t * 3 + 2) * 1024);
-            acc_re[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(Wr, Xr, acc_re[t], 0, 0, 0);
-            acc_im[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(Wr, Xi, acc_im[t], 0, 0, 0);
-            acc_re[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(nWi, Xi, acc_re[t], 0, 0, 0);
-            acc_im[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(Wi, Xr, acc_im[t], 0, 0, 0);
+        for (int ks = 0; ks < BI_KS; ks++) {
+            const uint8_t* lw = lds + buf * BI_STAGE + ks * BI_WSTEP + lane * 16;
+            const v4i_ xraw = *reinterpret_cast<const v4i_*>(lds + buf * BI_STAGE + BI_WCHUNK + (wave * 32 + j) * BI_KC +
+                                                              (((2 * ks + h) ^ ((j >> 2) & 1)) * 16));
+            const v4i_ Xr = xraw & M, Xi = (xraw << 4) & M;    // 16*re, 16*im (hi nibble real, lo nibble imag; beamformer_test.py:69-73)
+#pragma unroll
+            for (int t = 2; t >= 0; t--) {
+                const v4i_ Wr = *reinterpret_cast<const v4i_*>(lw + (t * 3 + 0) * 1024);
+                const v4i_ Wi = *reinterpret_cast<const v4i_*>(lw + (t * 3 + 1) * 1024);
+                const v4i_ nWi = *reinterpret_cast<const v4i_*>(lw + (t * 3 + 2) * 1024);
+                acc_re[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(Wr, Xr, acc_re[t], 0, 0, 0);
+                acc_im[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(Wr, Xi, acc_im[t], 0, 0, 0);
+                acc_re[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(nWi, Xi, acc_re[t], 0, 0, 0);
+                acc_im[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(Wi, Xr, acc_im[t], 0, 0, 0);
+            }
         }
         buf = buf + 1 == BI_RING ? 0 : buf + 1;
         nbuf = nbuf + 1 == BI_RING ? 0 : nbuf + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may be in flight when the wave ends
+    unsigned long long r2 = 0;
+    if (stamps) {
+        asm volatile("" :: "v"(acc_re[0][15]), "v"(acc_im[2][15]));
+        r2 = __builtin_amdgcn_s_memrealtime();
+    }
     // C/D map: col (sample) = lane&31, row (beam) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     const int t = t0 + wave * 32 + j;
     if (t < ntime) {
@@ -484,12 +513,16 @@ __global__ __launch_bounds__(256, 3) void beamform_i8x3_kernel(const uint8_t* __
             const int brow = (g & 3) + 8 * (g >> 2) + 4 * h;
             const int b = bt * 32 + brow;
             if (b < nbeam) {
-                const float s = scale[(size_t)(c * nbtile + bt) * 32 + brow];
+                const float s = sc[g];
                 const float re = s * (((float)acc_re[0][g] * 65025.f + (float)acc_re[1][g] * 255.f) + (float)acc_re[2][g]);
                 const float im = s * (((float)acc_im[0][g] * 65025.f + (float)acc_im[1][g] * 255.f) + (float)acc_im[2][g]);
                 *reinterpret_cast<float2*>(out + (((size_t)c * nbeam + b) * ntime + t) * 2) = make_float2(re, im);
             }
         }
+    }
+    if (stamps && lane == 0) {
+        unsigned long long* o = stamps + ((size_t)blockIdx.x * 4 + wave) * 4;
+        o[0] = r0; o[1] = r1; o[2] = r2; o[3] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
