@@ -156,3 +156,85 @@ def test_corr_reads_gulps_in_place_from_the_in_repo_ring():
     assert len(spans) == 2
     for k, sp in enumerate(spans):
         assert np.array_equal(sp.view(np.int32), orc.xgpu_correlate(vin[k * acc:(k + 1) * acc], S, C))
+
+
+def test_full_topology_packets_in_packets_out():
+    """The hot path and its neighbours wired as scripts/lwa352-pipeline.py:147-155,232-285 wires them, all blocks as
+    concurrent threads on one GPU, each on its own HIP stream:
+
+        F-engine packets -> Snap2Ingest -> gpu-input (cuda, two readers)
+            |- Corr -> corr-output -> CorrAcc -> corr-slow-output (cuda_host) -> CorrOutputFull -> packets
+            |- Beamform -> bf-output -> BeamformSumBeams -> bf-pow-output (cuda_host) -> BeamformOutput -> packets
+
+    Every visibility packet and every power-beam packet is checked against the oracle."""
+    import struct
+    import threading
+    import time
+    from caltech_bifrost_dsp_amd.blocks import BeamformOutput, CorrOutputFull, Snap2Ingest
+    C, S, g, acc, lacc, nbeam, ns = 8, 32, 96, 192, 384, 4, 24
+    ninput = S * 2
+    T = 2 * lacc
+    rng = np.random.default_rng(2024)
+    vin = rng.integers(0, 256, (T, C, S, 2), dtype=np.uint8)
+    seq0, chan0 = 7680, 96
+    pk = orc.snap2_packets(vin, seq0=seq0, sync_time=11, nchan_blocks=1, nstand_per_pkt=32, chan0_pipeline=chan0)
+    per_win = len(pk) // (T // g)
+    slabs = b"".join(b"".join(pk[w * per_win + i] for i in rng.permutation(per_win)) for w in range(T // g))
+    r_pk = Ring("packets", space="cuda_host")
+    r_in = Ring("gpu-input", space="cuda")
+    r_vis, r_slow = Ring("corr-output", space="cuda"), Ring("corr-slow-output", space="cuda_host")
+    r_bf, r_pow = Ring("bf-output", space="cuda"), Ring("bf-pow-output", space="cuda_host")
+    ing = Snap2Ingest(LOG, r_pk, r_in, ntime_gulp=g, nchan=C, nstand=S, npol=2, nchan_per_pkt=C, nstand_per_pkt=32, gpu=0,
+                      buffer_multiplier=T // g + 1, system_nchan=C * 4)
+    hdr = source_header(C, S, 2)
+    corr = Corr(LOG, r_in, r_vis, ntime_gulp=g, nchan=C, npol=2, nstand=S, acc_len=acc, autostartat=seq0, gpu=0,
+                ant_to_input=hdr['ant_to_input'])
+    cacc = CorrAcc(LOG, r_vis, r_slow, nchan=C, npol=2, nstand=S, acc_len=lacc, autostartat=seq0, gpu=0)
+    vis_pk, beam_pk = [], []
+    cout = CorrOutputFull(LOG, r_slow, nchan=C, npol=2, nstand=S, antpol_to_bl=corr.antpol_to_bl.numpy(),
+                          bl_is_conj=corr.bl_is_conj.numpy(), use_cor_fmt=False, gpu=0, sink=vis_pk.append)
+    bf = Beamform(LOG, r_in, r_bf, nchan=C, nbeam=nbeam, ninput=ninput, ntime_gulp=g, gpu=0)
+    sb = BeamformSumBeams(LOG, r_bf, r_pow, nchan=C, ntime_gulp=g, ntime_sum=ns, gpu=0)
+    bout = BeamformOutput(LOG, r_pow, ntime_gulp=g // ns, pipeline_idx=1, nchan=C, nbeam=nbeam // 2,
+                          sink=lambda b, p: beam_pk.append((b, p)))
+    bf.freqs = chan0 * 23925.78125 + 23925.78125 * np.arange(C)
+    cmds, cal, delays, amps = _beam_cmds(C, nbeam, ninput, rng)
+    bf.process_command_strings(cmds)
+    blocks = [ing, corr, cacc, cout, bf, sb, bout]
+    ths = [threading.Thread(target=b.main, daemon=True) for b in blocks]
+    for t in ths:
+        t.start()
+    t0 = time.time()
+    while len(r_in._readers) < 2 and time.time() - t0 < 20:      # both consumers attached before data flows
+        time.sleep(0.01)
+    src = Source(r_pk, [({'seq0': seq0, 'chan0': chan0, 'sync_time': 11}, slabs, ing.igulp_size)], wait_readers=1)
+    src.start()
+    for t in [src] + ths:
+        t.join(120)
+        assert not t.is_alive(), "pipeline thread did not finish: %r" % (t,)
+    # --- slow visibilities: two long integrations, one packet per baseline
+    nbl = S * (S + 1) // 2
+    assert len(vis_pk) == 2 * nbl
+    bl, cj = corr.antpol_to_bl.numpy(), corr.bl_is_conj.numpy()
+    for it in range(2):
+        planar = orc.xgpu_correlate(vin[it * lacc:(it + 1) * lacc], S, C)
+        pay = orc.corr_packet_payloads(orc.xgpu_reorder(planar, bl, cj, C), False)
+        for k in range(nbl):
+            p = vis_pk[it * nbl + k]
+            assert np.array_equal(np.frombuffer(p[56:], dtype=np.int32), pay[k]), (it, k)
+        f = struct.unpack(">QQ2d4I2I", vis_pk[it * nbl][:56])
+        assert f[0] == 11 and f[1] == seq0 + it * lacc and f[4:8] == (lacc, C, chan0, 2)
+    # --- power beams: one packet per (dual-pol beam, integrated sample)
+    nblk = g // ns
+    assert len(beam_pk) == (T // g) * (nbeam // 2) * nblk
+    k = 0
+    for sp in range(T // g):
+        beams = orc.beamform(vin[sp * g:(sp + 1) * g].reshape(g, C, ninput), bf.gains_cpu, g, C, ninput, nbeam)
+        power = orc.beamform_integrate(beams, ns)
+        for b in range(nbeam // 2):
+            for t in range(nblk):
+                bb, p = beam_pk[k]
+                k += 1
+                got = np.frombuffer(p[18:], dtype=np.float32).reshape(C, 4)
+                assert bb == b and np.allclose(got, power[b, t], rtol=2e-5, atol=2e-5 * np.abs(power).max())
+    assert ing.stats['packets_placed'] == len(pk)
