@@ -424,6 +424,24 @@ def main():
             "note": "same kernel, one integration at a time (outside the timed region): in the timed streaming "
                     "region consecutive launches overlap (the next one takes over CUs as work-groups of the "
                     "previous one run out of items), which lengthens each launch but shortens the step"}
+    # outside the timed region: SURVEY 8d's other device-resident case, one 2400-sample call per integration
+    # (xGPU's NTIME = acc_len; needs its own context, so it runs last)
+    if args.beamform and rank == 0 and world == 1 and args.ring_gulps >= 2 * gulps_per_step:
+        ffi.call("xengXgpuSync")
+        ffi.call("xengXgpuConfigure", NINPUT // 2, 2, NCHAN, ACC_LEN, 1)
+        ffi.call("xengXgpuInitialize", gpu)
+        nrep, nwarm = 300, 100
+        for k in range(nwarm + nrep):
+            if k == nwarm:
+                ffi.call("xengXgpuSync")
+                t1 = time.perf_counter()
+            ffi.check(kern, L.xengXgpuKernelAsync(ring.ptr + (k & 1) * gulps_per_step * gulp_bytes, outs[k & 1].ptr, 1))
+            ffi.call("xengXgpuSyncLag", 1)
+        ffi.call("xengXgpuSync")
+        el3 = time.perf_counter() - t1
+        res["single_call_t2400"] = {"value": round(8 * NINPUT * units_per_step_c * nrep / el3 / 1e9, 1), "unit": "Gb/s",
+                                    "ms_per_step": round(el3 / nrep * 1e3, 4),
+                                    "note": "ntime_gulp = acc_len = 2400: one enqueue-only call per integration, same streaming pattern"}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
