@@ -50,10 +50,22 @@ def cpu_baseline(budget_s=12.0):
         if el > budget_s or ngulp >= 64:
             break
     units = ngulp * NTIME_GULP * NCHAN
+    # for honesty: the reference's own golden loop, restated in numpy (make_golden_inputs.py:156-158:
+    # per time sample an outer product x conj(x)^T over all 704 inputs, full square), one core, 2 spectra x 24 channels
+    nsp, ncg = 2, 24
+    re, im = orc.decode(vin[:nsp, :ncg])
+    x = (re + 1j * im).reshape(nsp, ncg, NINPUT)
+    t1 = time.time()
+    g = np.zeros((ncg, NINPUT, NINPUT), dtype=complex)
+    for t in range(nsp):
+        g += x[t, :, :, None] * np.conj(x[t, :, None, :])
+    el_np = time.time() - t1
     return {"value": round(8 * NINPUT * units / el / 1e9, 4), "unit": "Gb/s",
             "cores": int(orc.lib().orc_num_threads()), "kind": "port",
             "cmac_per_s": units * CMAC_PER_UNIT / el,
-            "sample": "%d gulps of %d samples x %d chan x %d inputs (%.1f s)" % (ngulp, NTIME_GULP, NCHAN, NINPUT, el)}
+            "sample": "%d gulps of %d samples x %d chan x %d inputs (%.1f s)" % (ngulp, NTIME_GULP, NCHAN, NINPUT, el),
+            "reference_numpy_golden_loop": {"cmac_per_s": round(nsp * ncg * NINPUT * NINPUT / el_np, 1), "cores": 1,
+                                            "sample": "%d spectra x %d chan, full-square outer products (%.1f s)" % (nsp, ncg, el_np)}}
 
 
 def main():
