@@ -71,10 +71,10 @@ def cpu_baseline(budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # steady state of the streaming pipeline is reached after ~100 integrations (clock ramp, launch overlap
-    # pattern): the defaults time 1000 integrations (0.22 s) after 200 untimed ones
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=200)
+    # steady state of the streaming pipeline is reached after a few hundred integrations (clock / power ramp of a
+    # cold GPU, launch overlap pattern): the defaults time 2000 integrations (0.43 s) after 1000 untimed ones
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=1000)
     ap.add_argument("--ring-gulps", type=int, default=10, help="device-resident replay ring depth (gulps)")
     ap.add_argument("--lag", type=int, default=1, choices=[1, 2, 3],
                     help="streaming depth: after enqueueing integration n wait for dump n-lag (lag+1 output spans)")
