@@ -547,6 +547,7 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
     // ---- issue side: the stage stream (item, gulp, stage in gulp) DEPTH stages ahead of the MFMAs ----
     int is_k = 0, is_c = 0, is_wg = 0, is_g = 0, is_sl = 0, is_issued = 0, is_nst = 0;
     uint32_t is_lane_off = 0;
+    uint32_t is_voff[NLOAD] = {};
     const uint8_t* is_stage = nullptr;
     auto is_setup = [&](const Item& it) {
         is_c = it.c; is_wg = it.wg; is_nst = it.nst;
@@ -556,6 +557,8 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
         const int blk0 = (slots >> (8 * (wave & 2))) & 0xFF, blk1 = (slots >> (8 * (wave & 2) + 8)) & 0xFF;
         const uint32_t col = (uint32_t)((chunk >> 2) ? blk1 : blk0) * 64u + (uint32_t)(chunk & 3) * 16u;
         is_lane_off = (uint32_t)(lane >> 3) * row_stride + (col + 16u <= (uint32_t)p.ninput ? col : 0u);
+#pragma unroll
+        for (int n = 0; n < NLOAD; n++) is_voff[n] = is_lane_off + (uint32_t)n * 8u * row_stride - (uint32_t)((n & 3) * 1024);
         is_g = it.stage0 / p.spg;
         is_sl = it.stage0 - is_g * p.spg;
         is_issued = 0;
@@ -577,12 +580,21 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
     // end of each stage is the real ordering.
     // M0 (the LDS base of the transfer) is written without saving it: nothing else in this kernel uses M0
     // (no builtin LDS-DMA, no s_movrel/sendmsg; hipcc rejects "m0" as a clobber, so the ISA was checked).
+    // The six pieces of a stage are issued in order 0..5.  The instruction's immediate offset is added to the global
+    // AND to the LDS address, so with per-lane offsets that subtract it again on the global side
+    // (raw_voff[n] = lane offset + n * 8 rows - imm) the pieces share one scalar base per stage and M0 is written
+    // twice per stage (pieces 0-3: imm 0..3072, pieces 4-5: M0 + 4096, imm 0, 1024) instead of once per piece.
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(const __attribute__((address_space(3))) void*)lds);
     auto issue_piece = [&](int ring_slot, int n) {
-        const uint8_t* sb = is_stage + (size_t)(48 * (wave & 1) + 8 * n) * row_stride;    // scalar base; lane part is 32-bit
-        const uint32_t la = lds_base + ring_slot * STAGE_BYTES + wave * SLOT_BYTES + n * FRAG_BYTES;
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                     :: "v"(is_lane_off), "s"(sb), "s"(la) : "memory");
+        const uint8_t* sb = is_stage + (size_t)(48 * (wave & 1)) * row_stride;                  // scalar base of this wave's rows
+        const uint32_t la = lds_base + ring_slot * STAGE_BYTES + wave * SLOT_BYTES + (n < 4 ? 0 : 4096);
+        const uint32_t vo = is_voff[n];
+        if (n == 0) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(vo), "s"(sb), "s"(la) : "memory");
+        if (n == 1) asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" :: "v"(vo), "s"(sb) : "memory");
+        if (n == 2) asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" :: "v"(vo), "s"(sb) : "memory");
+        if (n == 3) asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" :: "v"(vo), "s"(sb) : "memory");
+        if (n == 4) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(vo), "s"(sb), "s"(la) : "memory");
+        if (n == 5) asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" :: "v"(vo), "s"(sb) : "memory");
     };
 
     // read side: lane 16*grp + 2q + pp addresses row 16*(grp>>1) + q (+8 for the second read), chunk position
