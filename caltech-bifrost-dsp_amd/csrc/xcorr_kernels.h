@@ -650,6 +650,29 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
             return r;
         };
 
+        if (!active) {
+            // A wave without a tile (the tiling leaves 2 of 68 wave slots empty) only keeps the stage stream and the
+            // barriers going: running the MFMAs on dummy data, as the two-pass kernel does, would cost 3 % of the
+            // launch's MFMA energy in a power-limited kernel.  Nothing is live across this branch.
+            for (int s = 0; s < it.nst; s++) {
+                next_stage();
+                if (!(ABL & 1)) {
+#pragma unroll
+                    for (int n = 0; n < NLOAD; n++) issue_piece(rf, n);
+                }
+                if (!(ABL & 8)) {
+                    if (!(ABL & 1)) wait_vmcnt<(DEPTH - 2) * NLOAD>();
+                    __builtin_amdgcn_s_barrier();
+                }
+                bump(rs); bump(rs1); bump(rf);
+            }
+            if (it.slice + 1 < it.nslices) {   // split-K hand-over: same barrier count as the storing waves (wave 0,
+                                               // which publishes the flag, always has a tile)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            continue;
+        }
         v16i accR[2][2], accP[2][2], accQ[2][2];
 #pragma unroll
         for (int m = 0; m < 2; m++)

@@ -45,7 +45,7 @@ print("per wave us: prologue median %.2f p90 %.2f | loop %.2f | epilogue median 
     np.median(pro), np.percentile(pro, 90), np.median(st[ok, 1]) / 100.0, np.median(epi), np.percentile(epi, 90), np.median(tot)))
 # per work item (channel, tile group) = 4 consecutive stamp rows: first wave entry -> last wave exit
 it = st.reshape(-1, 4, 8)
-it_start = it[:, :, 4].min(axis=1)
+it_start = np.where(it[:, :, 4] > 0, it[:, :, 4], np.inf).min(axis=1)      # (waves without a tile leave no stamps)
 it_end = it[:, :, 5].max(axis=1)
 dur = (it_end - it_start) / 100.0
 print("per item us (entry of first wave -> exit of last): median %.2f mean %.2f p10 %.2f p90 %.2f max %.2f; sum/256 CUs = %.1f us" % (
