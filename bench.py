@@ -267,7 +267,33 @@ def main():
                   "roofline": {"bound": "hbm", "achieved": round(in_bytes / (in_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": round(in_bytes / (in_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
                   "note": "wall time of the synchronous call: memset of the gulp + scatter kernel (24 us on the device, profiles/r01/v5_kernel_stats_all_legs.csv) + counter read-back"}
-        dslab.free()
+        # packets -> visibilities, device resident (BASELINE: "throughput on synthetic F-engine packets"): every gulp of
+        # every integration is first scattered out of its packet slab (enqueue-only, on the X-engine's staging stream),
+        # then registered with the X-engine; same streaming pattern as the timed region
+        slabs = [dslab] + [ffi.DeviceBuffer(slab.nbytes) for _ in range(2 * gulps_per_step - 1)]
+        for k in range(1, len(slabs)):
+            ffi.call("xengMemcpy", slabs[k].ptr, dslab.ptr, slab.nbytes)
+        nrep, nwarm, kk = 300, 100, 0
+        for it in range(nwarm + nrep):
+            if it == nwarm:
+                ffi.call("xengXgpuSync")
+                t1 = time.perf_counter()
+            for g in range(gulps_per_step):
+                slot = kk % (2 * gulps_per_step)
+                dst = ring.ptr + slot * gulp_bytes
+                ffi.check("unpack", L.xengSnap2UnpackAsync(slabs[slot].ptr, npk, stride, dst, 0, NTIME_GULP, 0, NCHAN, NINPUT, 1))
+                ffi.check(kern, L.xengXgpuKernelAsync(dst, outs[it & 1].ptr, int(g == gulps_per_step - 1)))
+                kk += 1
+            ffi.call("xengXgpuSyncLag", 1)
+        ffi.call("xengXgpuSync")
+        el4 = time.perf_counter() - t1
+        ingest["packets_to_visibilities"] = {
+            "value": round(8 * NINPUT * units_per_step_c * nrep / el4 / 1e9, 1), "unit": "Gb/s",
+            "ms_per_step": round(el4 / nrep * 1e3, 4),
+            "note": "device-resident packet slabs (5280 packets per gulp) -> xengSnap2UnpackAsync -> xengXgpuKernelAsync, "
+                    "%d integrations" % nrep}
+        for b in slabs:
+            b.free()
         dgulp.free()
     # outside the timed region: BASELINE config 4 -- Beamform (32 beams, 96 chan, 960 samples, fp32 weights)
     # + BeamformSumBeams (16 dual-pol power beams, ntime_sum 24) on the same GPU

@@ -96,31 +96,64 @@ static int* g_counters[16] = {};
 
 using namespace xeng;
 
-extern "C" int xengSnap2Unpack(const void* packets_dev, int npkt, size_t pkt_stride, void* out_dev, uint64_t seq0, int ntime,
-                               int chan0_pipeline, int nchan_tot, int npol_tot, int clear, int* nplaced, int* ndropped) {
+static int snap2_launch(hipStream_t s, const void* packets_dev, int npkt, size_t pkt_stride, void* out_dev, uint64_t seq0,
+                        int ntime, int chan0_pipeline, int nchan_tot, int npol_tot, int clear, int* counters) {
+    if (clear) XENG_HIP(hipMemsetAsync(out_dev, 0, (size_t)ntime * nchan_tot * npol_tot, s));   // missing packets = blanked samples
+    if (npkt > 0) {
+        hipLaunchKernelGGL(snap2_unpack_kernel, dim3(npkt < 4096 ? npkt : 4096), dim3(256), 0, s, (const uint8_t*)packets_dev, npkt,
+                           pkt_stride, (uint8_t*)out_dev, (unsigned long long)seq0, ntime, chan0_pipeline, nchan_tot, npol_tot,
+                           (int)(pkt_stride - 32), counters);
+        XENG_HIP(hipGetLastError());
+    }
+    return XENG_STATUS_SUCCESS;
+}
+
+static int snap2_check(const void* packets_dev, int npkt, size_t pkt_stride, void* out_dev, int ntime, int nchan_tot, int npol_tot,
+                       int* dev) {
     if (!packets_dev || !out_dev) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Snap2Unpack: null buffer");
     if (npkt < 0 || ntime <= 0 || nchan_tot <= 0 || npol_tot <= 0 || pkt_stride < 33)
         XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Snap2Unpack: npkt=%d ntime=%d nchan_tot=%d npol_tot=%d stride=%zu", npkt, ntime,
                   nchan_tot, npol_tot, pkt_stride);
-    int dev = 0;
-    XENG_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 16) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "device %d out of range", dev);
-    hipStream_t s;
-    int rc = get_stream(STREAM_COPY, &s);
-    if (rc) return rc;
-    if (!g_counters[dev]) XENG_HIP(hipMalloc((void**)&g_counters[dev], 2 * sizeof(int)));
-    XENG_HIP(hipMemsetAsync(g_counters[dev], 0, 2 * sizeof(int), s));
-    if (clear) XENG_HIP(hipMemsetAsync(out_dev, 0, (size_t)ntime * nchan_tot * npol_tot, s));   // missing packets = blanked samples
-    if (npkt > 0) {
-        hipLaunchKernelGGL(snap2_unpack_kernel, dim3(npkt < 4096 ? npkt : 4096), dim3(256), 0, s, (const uint8_t*)packets_dev, npkt, pkt_stride,
-                           (uint8_t*)out_dev, (unsigned long long)seq0, ntime, chan0_pipeline, nchan_tot, npol_tot,
-                           (int)(pkt_stride - 32), g_counters[dev]);
-        XENG_HIP(hipGetLastError());
+    XENG_HIP(hipGetDevice(dev));
+    if (*dev < 0 || *dev >= 16) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "device %d out of range", *dev);
+    if (!g_counters[*dev]) {
+        XENG_HIP(hipMalloc((void**)&g_counters[*dev], 2 * sizeof(int)));
+        XENG_HIP(hipMemset(g_counters[*dev], 0, 2 * sizeof(int)));
     }
+    return XENG_STATUS_SUCCESS;
+}
+
+extern "C" int xengSnap2Unpack(const void* packets_dev, int npkt, size_t pkt_stride, void* out_dev, uint64_t seq0, int ntime,
+                               int chan0_pipeline, int nchan_tot, int npol_tot, int clear, int* nplaced, int* ndropped) {
+    int dev = 0;
+    int rc = snap2_check(packets_dev, npkt, pkt_stride, out_dev, ntime, nchan_tot, npol_tot, &dev);
+    if (rc) return rc;
+    hipStream_t s;
+    rc = get_stream(STREAM_COPY, &s);
+    if (rc) return rc;
+    XENG_HIP(hipMemsetAsync(g_counters[dev], 0, 2 * sizeof(int), s));
+    rc = snap2_launch(s, packets_dev, npkt, pkt_stride, out_dev, seq0, ntime, chan0_pipeline, nchan_tot, npol_tot, clear,
+                      g_counters[dev]);
+    if (rc) return rc;
     int host[2] = {0, 0};
     XENG_HIP(hipMemcpyAsync(host, g_counters[dev], sizeof(host), hipMemcpyDeviceToHost, s));
     XENG_HIP(hipStreamSynchronize(s));
     if (nplaced) *nplaced = npkt - host[1];
     if (ndropped) *ndropped = host[1];
     return XENG_STATUS_SUCCESS;
+}
+
+// Enqueue-only flavour on the X-engine's staging stream: a gulp unpacked this way and then handed to
+// xengXgpuKernelAsync is ordered before the contraction that reads it (the dump waits for that stream).  Drop
+// counts accumulate on the device until the next synchronous call; nothing is waited for.
+extern "C" int xengSnap2UnpackAsync(const void* packets_dev, int npkt, size_t pkt_stride, void* out_dev, uint64_t seq0, int ntime,
+                                    int chan0_pipeline, int nchan_tot, int npol_tot, int clear) {
+    int dev = 0;
+    int rc = snap2_check(packets_dev, npkt, pkt_stride, out_dev, ntime, nchan_tot, npol_tot, &dev);
+    if (rc) return rc;
+    hipStream_t s;
+    rc = get_stream(STREAM_XGPU, &s);
+    if (rc) return rc;
+    return snap2_launch(s, packets_dev, npkt, pkt_stride, out_dev, seq0, ntime, chan0_pipeline, nchan_tot, npol_tot, clear,
+                        g_counters[dev]);
 }

@@ -171,6 +171,10 @@ int xengXgpuGetTimes(double ms[2], int count[2]);
  * packets read as 0 (blanked).  Synchronous; the counters may be NULL. */
 int xengSnap2Unpack(const void *packets_dev, int npkt, size_t pkt_stride, void *out_dev, uint64_t seq0, int ntime,
                     int chan0_pipeline, int nchan_tot, int npol_tot, int clear, int *nplaced, int *ndropped);
+/* Same, enqueue only, on the X-engine's staging stream: a gulp unpacked this way and then passed to
+ * xengXgpuKernelAsync is complete before the contraction of its dump reads it.  No counters are returned. */
+int xengSnap2UnpackAsync(const void *packets_dev, int npkt, size_t pkt_stride, void *out_dev, uint64_t seq0, int ntime,
+                         int chan0_pipeline, int nchan_tot, int npol_tot, int clear);
 
 /* ---------------------------------------------------------------- CorrAcc
  * replaces bifrost.map "a = b" / "a += b" on int32 (corr_acc_block.py:304,306).  Device pointers;

@@ -97,3 +97,29 @@ def test_ingest_corr_on_device_rings():
     for k, sp in enumerate(spans):
         assert np.array_equal(sp.view(np.int32), orc.xgpu_correlate(vin[k * acc:(k + 1) * acc], S, C))
     assert ing.stats['packets_placed'] == len(pk) and ing.stats['missing_frac'] == 0.0
+
+
+def test_unpack_async_is_ordered_before_the_contraction():
+    """xengSnap2UnpackAsync + xengXgpuKernelAsync: the scatter runs on the X-engine's staging stream, so the dump's
+    contraction reads complete gulps; visibilities equal the oracle on the original voltages."""
+    T, C, S, g = 288, 8, 32, 96
+    rng = np.random.default_rng(3)
+    vin = rng.integers(0, 256, (T, C, S, 2), dtype=np.uint8)
+    pk = orc.snap2_packets(vin, seq0=0, nchan_blocks=1, nstand_per_pkt=32, chan0_pipeline=0)
+    stride, per_win = len(pk[0]), len(pk) // (T // g)
+    ffi.call("xengXgpuConfigure", S, 2, C, g, 0)
+    ffi.call("xengXgpuInitialize", 0)
+    matlen = orc.per_chan(S) * C
+    out = ffi.DeviceBuffer(matlen * 8)
+    slabs, gulps = [], []
+    for w in range(T // g):
+        slab = b"".join(pk[w * per_win + i] for i in rng.permutation(per_win))
+        slabs.append(ffi.DeviceBuffer(len(slab)).upload(np.frombuffer(slab, dtype=np.uint8)))
+        gulps.append(ffi.DeviceBuffer(g * C * S * 2))
+        ffi.call("xengMemset", gulps[-1].ptr, 0xEE, gulps[-1].nbytes)
+    for w in range(T // g):
+        ffi.call("xengSnap2UnpackAsync", slabs[w].ptr, per_win, stride, gulps[w].ptr, w * g, g, 0, C, S * 2, 1)
+        ffi.call("xengXgpuKernelAsync", gulps[w].ptr, out.ptr, int(w == T // g - 1))
+    ffi.call("xengXgpuSync")
+    assert np.array_equal(out.download(np.int32), orc.xgpu_correlate(vin, S, C))
+    ffi.call("xengXgpuDestroy")
