@@ -19,16 +19,17 @@ __device__ __forceinline__ uint32_t be32(const uint8_t* p) {
 }
 __device__ __forceinline__ uint32_t be16(const uint8_t* p) { return ((uint32_t)p[0] << 8) | p[1]; }
 
-// Work-groups of 256 threads walk the packets (grid-stride); the header is fetched with two 16-byte loads
-// (all lanes, same address) and byte-swapped in registers; payload rows move as 16-byte pieces when the
-// geometry is 16-byte aligned (the deployed 64-byte rows are), else byte by byte.
+// One wave per packet (four per work-group, grid-stride): the header is fetched with two 16-byte loads (all lanes,
+// same address) and byte-swapped in registers; payload rows move as 16-byte pieces, eight loads in flight per lane
+// before the first store, when the geometry is 16-byte aligned (the deployed 64-byte rows are), else byte by byte.
 __global__ __launch_bounds__(256) void snap2_unpack_kernel(const uint8_t* __restrict__ pkts, int npkt, size_t stride,
                                                            uint8_t* __restrict__ out, unsigned long long seq0, int ntime,
                                                            int chan0_pipe, int nchan_tot, int npol_tot, int payload_max,
                                                            int* __restrict__ counters) {
     const bool aligned = (((uintptr_t)pkts | (uintptr_t)out | stride) & 15) == 0;
-    int nplaced = 0, ndropped = 0;
-    for (int p = blockIdx.x; p < npkt; p += gridDim.x) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int ndropped = 0;
+    for (int p = blockIdx.x * 4 + wave; p < npkt; p += gridDim.x * 4) {
         const uint8_t* h = pkts + (size_t)p * stride;
         unsigned long long seq;
         int npol, nchan;
@@ -47,30 +48,28 @@ __global__ __launch_bounds__(256) void snap2_unpack_kernel(const uint8_t* __rest
             chan0 = (long long)be32(h + 24) - chan0_pipe;
             pol0 = be32(h + 28);
         }
-        // work-group-uniform validation: window, geometry, payload size
+        // wave-uniform validation: window, geometry, payload size
         const bool ok = seq >= seq0 && seq - seq0 < (unsigned long long)ntime && npol > 0 && nchan > 0 && chan0 >= 0 &&
                         chan0 + nchan <= nchan_tot && pol0 + npol <= npol_tot && (long long)nchan * npol <= payload_max;
         if (!ok) {
             ndropped++;
             continue;
         }
-        nplaced++;
         const uint8_t* src = h + 32;
         uint8_t* dst = out + (((size_t)(seq - seq0) * nchan_tot + (size_t)chan0) * npol_tot + (size_t)pol0);
         if (aligned && ((npol | npol_tot | (int)pol0) & 15) == 0) {
             const int per_row = npol >> 4;                       // 16-byte pieces per channel row
             const int n = nchan * per_row;
-            // batches of four pieces per thread: four loads in flight before the first store
-            for (int i0 = threadIdx.x; i0 < n; i0 += 4 * 256) {
-                uint4 v[4];
+            for (int i0 = lane; i0 < n; i0 += 8 * 64) {
+                uint4 v[8];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int i = i0 + u * 256;
+                for (int u = 0; u < 8; u++) {
+                    const int i = i0 + u * 64;
                     if (i < n) v[u] = *reinterpret_cast<const uint4*>(src + (size_t)i * 16);   // rows are contiguous in the packet
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int i = i0 + u * 256;
+                for (int u = 0; u < 8; u++) {
+                    const int i = i0 + u * 64;
                     if (i < n) {
                         const int c = i / per_row, j = i - c * per_row;
                         *reinterpret_cast<uint4*>(dst + (size_t)c * npol_tot + j * 16) = v[u];
@@ -78,16 +77,15 @@ __global__ __launch_bounds__(256) void snap2_unpack_kernel(const uint8_t* __rest
                 }
             }
         } else {
-            for (int i = threadIdx.x; i < nchan * npol; i += 256) {
+            for (int i = lane; i < nchan * npol; i += 64) {
                 const int c = i / npol, j = i - c * npol;
                 dst[(size_t)c * npol_tot + j] = src[i];
             }
         }
     }
-    // only drops are counted on the device (rare): thousands of work-groups adding to one counter serialise in L2
+    // only drops are counted on the device (rare): thousands of waves adding to one counter serialise in L2
     // (4096 same-address atomics cost ~40 us); placed = npkt - dropped on the host
-    (void)nplaced;
-    if (threadIdx.x == 0 && ndropped) atomicAdd(&counters[1], ndropped);
+    if (lane == 0 && ndropped) atomicAdd(&counters[1], ndropped);
 }
 
 static int* g_counters[16] = {};
@@ -100,7 +98,7 @@ static int snap2_launch(hipStream_t s, const void* packets_dev, int npkt, size_t
                         int ntime, int chan0_pipeline, int nchan_tot, int npol_tot, int clear, int* counters) {
     if (clear) XENG_HIP(hipMemsetAsync(out_dev, 0, (size_t)ntime * nchan_tot * npol_tot, s));   // missing packets = blanked samples
     if (npkt > 0) {
-        hipLaunchKernelGGL(snap2_unpack_kernel, dim3(npkt < 4096 ? npkt : 4096), dim3(256), 0, s, (const uint8_t*)packets_dev, npkt,
+        hipLaunchKernelGGL(snap2_unpack_kernel, dim3((npkt + 3) / 4 < 2048 ? (npkt + 3) / 4 : 2048), dim3(256), 0, s, (const uint8_t*)packets_dev, npkt,
                            pkt_stride, (uint8_t*)out_dev, (unsigned long long)seq0, ntime, chan0_pipeline, nchan_tot, npol_tot,
                            (int)(pkt_stride - 32), counters);
         XENG_HIP(hipGetLastError());
