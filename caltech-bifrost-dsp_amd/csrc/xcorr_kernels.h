@@ -280,6 +280,34 @@ __device__ __forceinline__ void xcorr_store_tile(const XcorrParams& p, int c, in
     // interior tiles (strictly below the block diagonal, no padded inputs) need no per-cell mask
     const bool interior = __builtin_amdgcn_readfirstlane((int)(blk_a > blk_b && blk_a * 64 + 64 <= 2 * p.nstand)) != 0;
     const bool accumulate = p.accumulate != 0 || add_to_stored;
+    if (interior && !accumulate) {
+        // the common case (55 of 66 tiles, first flush of an integration) as straight-line code: no per-cell
+        // branches, so the lane regrouping of one cell overlaps the arithmetic of the next
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int n = 0; n < 2; n++) {
+                const int ibase = blk_a * 64 + m * 32, jbase = blk_b * 64 + n * 32;
+                const int Ch = (jbase >> 2) + (lane & 7);
+                const int wcol = (quad * qs + Ch) * 4;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int Rh = (ibase >> 2) + 2 * u + (lane >> 5);
+                    int vr[4], vi[4];
+#pragma unroll
+                    for (int v = 0; v < 4; v++) {
+                        vr[v] = accR[m][n][4 * u + v] >> 8;
+                        vi[v] = (accP[m][n][4 * u + v] - accQ[m][n][4 * u + v]) >> 8;
+                    }
+                    const int4 cr = regroup(cell(vr[0], vr[1], vr[2], vr[3]));
+                    const int4 ci = regroup(cell(vi[0], vi[1], vi[2], vi[3]));
+                    const int w = wcol + ((Rh * (Rh + 1)) >> 1) * 4;
+                    *reinterpret_cast<int4*>(out_r + w) = cr;
+                    *reinterpret_cast<int4*>(out_i + w) = ci;
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int m = 0; m < 2; m++)
 #pragma unroll
