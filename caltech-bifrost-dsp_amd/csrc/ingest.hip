@@ -10,6 +10,8 @@
 //   u64 seq | u32 sync_time (magic) | u16 npol | u16 npol_tot | u16 nchan | u16 nchan_tot |
 //   u32 chan_block_id | u32 chan0 | u32 pol0 ; payload u8[nchan][npol] (4+4 bit, npol = stands*2 in the packet)
 // Destination of payload row c: gulp[seq - seq0][chan0 - chan0_pipeline + c][pol0 .. pol0 + npol).
+#include <mutex>
+
 #include "xeng_common.h"
 
 namespace xeng {
@@ -89,6 +91,7 @@ __global__ __launch_bounds__(256) void snap2_unpack_kernel(const uint8_t* __rest
 }
 
 static int* g_counters[16] = {};
+static std::mutex g_ingest_mu;     // the drop counter of a device is shared by all callers
 
 }  // namespace xeng
 
@@ -123,6 +126,7 @@ static int snap2_check(const void* packets_dev, int npkt, size_t pkt_stride, voi
 
 extern "C" int xengSnap2Unpack(const void* packets_dev, int npkt, size_t pkt_stride, void* out_dev, uint64_t seq0, int ntime,
                                int chan0_pipeline, int nchan_tot, int npol_tot, int clear, int* nplaced, int* ndropped) {
+    std::lock_guard<std::mutex> lk(g_ingest_mu);
     int dev = 0;
     int rc = snap2_check(packets_dev, npkt, pkt_stride, out_dev, ntime, nchan_tot, npol_tot, &dev);
     if (rc) return rc;
@@ -146,6 +150,7 @@ extern "C" int xengSnap2Unpack(const void* packets_dev, int npkt, size_t pkt_str
 // counts accumulate on the device until the next synchronous call; nothing is waited for.
 extern "C" int xengSnap2UnpackAsync(const void* packets_dev, int npkt, size_t pkt_stride, void* out_dev, uint64_t seq0, int ntime,
                                     int chan0_pipeline, int nchan_tot, int npol_tot, int clear) {
+    std::lock_guard<std::mutex> lk(g_ingest_mu);
     int dev = 0;
     int rc = snap2_check(packets_dev, npkt, pkt_stride, out_dev, ntime, nchan_tot, npol_tot, &dev);
     if (rc) return rc;
