@@ -7,9 +7,11 @@ as lwa352-pipeline.py runs it: acc_len 2400 = 5 gulps of 480 samples fed through
 (xengXgpuKernel*, dump on the 5th), on synthetic F-engine voltages already resident in HBM
 (a replay ring of pre-generated gulps; make_golden_inputs.py's generator, seed 0xdeadbeef).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): frequency channels shard
-embarrassingly, 96 channels per GPU (configs[2]); there is no data-path collective -- the
-process group (gloo) is only used for the barriers and the max-over-ranks of the wall time.
+N > 1: frequency channels shard embarrassingly, 96 channels per GPU (configs[2]); there is no data-path
+collective -- the process group (gloo) is only used for the barriers and the max-over-ranks of the wall time.
+Either torch.distributed.run starts one rank per GPU (RANK / WORLD_SIZE in the environment), or
+`python bench.py --gpus N` on its own starts N fresh child processes itself, one per GPU, before anything has
+touched the GPU (sharding.spawn_ranks), and relays rank 0's line.
 
 Prints ONE JSON line on rank 0.
 """
@@ -93,7 +95,22 @@ def main():
                     help="testing only: every rank uses GPU 0 (to rehearse the N>1 code path on a 1-GPU box)")
     ap.add_argument("--sync-per-integration", action="store_true",
                     help="enqueue the gulps of one integration, then wait for its dump before the next")
+    ap.add_argument("--selftest-spawn", action="store_true",
+                    help="testing only (no GPU): ranks skip the X-engine work and report a fixed fake time, so that the "
+                         "N-rank launch, the process group, the max-over-ranks and the JSON line can be checked on CPU")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under torch.distributed.run: be the launcher.  Nothing in this process has touched the GPU yet.
+        import caltech_bifrost_dsp_amd  # noqa: F401
+        from caltech_bifrost_dsp_amd import sharding
+        rc, out0, errs = sharding.spawn_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:])
+        sys.stdout.write(out0)
+        if rc:
+            for r, e in enumerate(errs):
+                if e.strip():
+                    sys.stderr.write("---- rank %d stderr ----\n%s\n" % (r, e))
+        sys.exit(rc)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -102,7 +119,38 @@ def main():
     if world > 1:
         import torch.distributed as dist  # plumbing only: barrier + max-reduce of the wall time
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        # gloo announces its connections on stdout: keep stdout for the one JSON line
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(keep, 1)
+            os.close(keep)
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    if args.selftest_spawn:
+        import torch
+        t = torch.tensor([1e-3 * (rank + 1)], dtype=torch.float64)
+        if dist is not None:
+            dist.barrier()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.barrier()
+        el = float(t.item())
+        if rank == 0:
+            units = ACC_LEN * NCHAN * args.steps * world
+            print(json.dumps({"metric": "xengine_ingest_gbps_704in_96ch", "value": round(8 * NINPUT * units / el / 1e9, 2),
+                              "unit": "Gb/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                              "vs_baseline": None, "data": "selftest (no GPU work; not a result)",
+                              "config": {"workload": "selftest", "nchan_total": NCHAN * world}}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     import caltech_bifrost_dsp_amd  # noqa: F401
     from caltech_bifrost_dsp_amd import ffi

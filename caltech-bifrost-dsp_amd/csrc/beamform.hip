@@ -7,6 +7,7 @@
 
 #include "beamform_kernels.h"
 #include <algorithm>
+#include <vector>
 
 #include "xeng_common.h"
 
@@ -25,7 +26,16 @@ struct BeamContext {
     bool use_i8 = false;              // default: fixed-point digits on the int8 MFMA (XENG_BEAM=bf16x3: the bf16 split)
     uint8_t* wq = nullptr;            // int8x3 digit planes
     float* wscale = nullptr;          // ... and their per-(channel, beam) scale
-    float* wmax = nullptr;            // row maxima (between the two prep passes)
+    float* wmax = nullptr;            // inlier row maxima (between the prep passes)
+    // precision control of the int8x3 route (beamform_kernels.h, "precision of the fixed-point weights")
+    int* row_out = nullptr;           // [nchan][nbtile*32][BI_ROW_OUT] outlier inputs per row
+    int* route = nullptr;             // [nchan*nbtile] 1 = the tile runs on the bf16x3 kernel; [nchan*nbtile] = any
+    int* out_n = nullptr;             // [nchan*nbtile] outlier inputs per tile
+    int* out_idx = nullptr;           // [nchan*nbtile][BI_TILE_OUT]
+    float2* out_R = nullptr;          // [nchan*nbtile][BI_TILE_OUT][32] their fp32 weights
+    int* any_host = nullptr;          // pinned copy of route[nchan*nbtile] ...
+    hipEvent_t ev_route = nullptr;    // ... valid once this event has completed
+    bool route_known = false, need_bf16 = true;
     unsigned long long* stamps = nullptr;   // diagnostic (XENG_BEAM_STAMPS=1): per wave {entry, first chunk, loop end, exit}
     int nchunk_i8 = 0;
     hipStream_t stream = nullptr;
@@ -43,6 +53,13 @@ static int beam_destroy_locked() {
     if (g_b.wq) (void)hipFree(g_b.wq);
     if (g_b.wscale) (void)hipFree(g_b.wscale);
     if (g_b.wmax) (void)hipFree(g_b.wmax);
+    if (g_b.row_out) (void)hipFree(g_b.row_out);
+    if (g_b.route) (void)hipFree(g_b.route);
+    if (g_b.out_n) (void)hipFree(g_b.out_n);
+    if (g_b.out_idx) (void)hipFree(g_b.out_idx);
+    if (g_b.out_R) (void)hipFree(g_b.out_R);
+    if (g_b.any_host) (void)hipHostFree(g_b.any_host);
+    if (g_b.ev_route) (void)hipEventDestroy(g_b.ev_route);
     if (g_b.stamps) (void)hipFree(g_b.stamps);
     g_b.timer.destroy();
     g_b = BeamContext();
@@ -61,19 +78,41 @@ static int run_locked(const void* in, float* out, const void* w, long long versi
         return XENG_STATUS_SUCCESS;
     }
     if (x.use_i8) {
+        const int ntile = x.nchan * x.nbtile;
         if (!(version != 0 && version == x.w_version && w == x.w_cached)) {
-            hipLaunchKernelGGL(beam_weights_rowmax_kernel, dim3(4 * x.nbtile, x.nchan), dim3(256), 0, x.stream,
-                               (const float*)w, x.wscale, x.wmax, x.nchan, x.nbeam, x.ninput, x.nbtile);
+            // row statistics -> outliers / routing -> digits (and, for routed tiles only, the bf16 split)
+            XENG_HIP(hipMemsetAsync(x.route, 0, (size_t)(ntile + 1) * sizeof(int), x.stream));
+            hipLaunchKernelGGL(beam_weights_rowstat_kernel, dim3(8 * x.nbtile, x.nchan), dim3(256), 0, x.stream,
+                               (const float*)w, x.wscale, x.wmax, x.row_out, x.route, x.nchan, x.nbeam, x.ninput, x.nbtile);
+            const size_t ol = (size_t)((x.ninput + 63) & ~63) + (BI_TILE_OUT + 1) * sizeof(int);
+            hipLaunchKernelGGL(beam_weights_outlier_kernel, dim3(x.nbtile, x.nchan), dim3(256), ol, x.stream,
+                               (const float*)w, x.row_out, x.out_n, x.out_idx, x.out_R, x.route, x.nchan, x.nbeam, x.ninput, x.nbtile);
             hipLaunchKernelGGL(beam_weights_prep_i8_kernel, dim3(x.nchunk_i8 * BI_KS, x.nbtile, x.nchan), dim3(256), 0, x.stream,
-                               (const float*)w, x.wq, x.wmax, x.nchan, x.nbeam, x.ninput, x.nchunk_i8 * BI_KS, x.nbtile);
+                               (const float*)w, x.wq, x.wmax, x.nchan, x.nbeam, x.ninput, x.nchunk_i8 * BI_KS, x.nbtile, x.route);
+            hipLaunchKernelGGL(beam_weights_prep_kernel, dim3((x.ninput + 63) / 64, x.nbtile, x.nchan), dim3(256), 0, x.stream,
+                               (const float*)w, x.wprep, x.nchan, x.nbeam, x.ninput, x.nchunk, x.nbtile, x.route);
             XENG_HIP(hipGetLastError());
+            // whether any tile was routed travels to the host without a wait: a caller that keeps its weights
+            // (versioned) skips the bf16x3 launch once the answer has arrived and is "none"
+            XENG_HIP(hipMemcpyAsync(x.any_host, x.route + ntile, sizeof(int), hipMemcpyDeviceToHost, x.stream));
+            XENG_HIP(hipEventRecord(x.ev_route, x.stream));
+            x.route_known = false;
+            x.need_bf16 = true;
             x.w_cached = w;
             x.w_version = version;
+        } else if (!x.route_known && hipEventQuery(x.ev_route) == hipSuccess) {
+            x.route_known = true;
+            x.need_bf16 = *x.any_host != 0;
         }
         dim3 grid(((x.ntime + BI_NT - 1) / BI_NT) * x.nchan * x.nbtile);
         int slot = x.timer.begin(x.stream, 0);
         hipLaunchKernelGGL(beamform_i8x3_kernel, grid, dim3(256), 0, x.stream, (const uint8_t*)in, x.wq, x.wscale, out,
-                           x.ntime, x.nchan, x.ninput, x.nbeam, x.nchunk_i8, x.nbtile, x.stamps);
+                           x.ntime, x.nchan, x.ninput, x.nbeam, x.nchunk_i8, x.nbtile, x.route, x.out_n, x.out_idx, x.out_R, x.stamps);
+        if (x.need_bf16) {
+            dim3 grid3(((x.ntime + BF3_NT - 1) / BF3_NT) * x.nchan * x.nbtile);
+            hipLaunchKernelGGL(beamform_bf16x3_kernel, grid3, dim3(64 * BF3_NW), 0, x.stream, (const uint8_t*)in, x.wprep, out,
+                               x.ntime, x.nchan, x.ninput, x.nbeam, x.nchunk, x.nbtile, x.route);
+        }
         x.timer.end(x.stream, slot);
         XENG_HIP(hipGetLastError());
         return XENG_STATUS_SUCCESS;
@@ -81,7 +120,7 @@ static int run_locked(const void* in, float* out, const void* w, long long versi
     // split the fp32 weights into three bf16 terms unless this exact (pointer, version) is already prepared
     if (!(version != 0 && version == x.w_version && w == x.w_cached)) {
         hipLaunchKernelGGL(beam_weights_prep_kernel, dim3((x.ninput + 63) / 64, x.nbtile, x.nchan), dim3(256), 0, x.stream,
-                           (const float*)w, x.wprep, x.nchan, x.nbeam, x.ninput, x.nchunk, x.nbtile);
+                           (const float*)w, x.wprep, x.nchan, x.nbeam, x.ninput, x.nchunk, x.nbtile, (const int*)nullptr);
         XENG_HIP(hipGetLastError());
         x.w_cached = w;
         x.w_version = version;
@@ -89,7 +128,7 @@ static int run_locked(const void* in, float* out, const void* w, long long versi
     dim3 grid(((x.ntime + BF3_NT - 1) / BF3_NT) * x.nchan * x.nbtile);
     int slot = x.timer.begin(x.stream, 0);
     hipLaunchKernelGGL(beamform_bf16x3_kernel, grid, dim3(64 * BF3_NW), 0, x.stream, (const uint8_t*)in, x.wprep, out,
-                       x.ntime, x.nchan, x.ninput, x.nbeam, x.nchunk, x.nbtile);
+                       x.ntime, x.nchan, x.ninput, x.nbeam, x.nchunk, x.nbtile, (const int*)nullptr);
     x.timer.end(x.stream, slot);
     XENG_HIP(hipGetLastError());
     return XENG_STATUS_SUCCESS;
@@ -144,6 +183,14 @@ int xengBeamformInitialize(int gpu, int ninput, int nchan, int ntime, int nbeam,
         XENG_HIP(hipMemset(x.wq, 0, qb));
         XENG_HIP(hipMalloc((void**)&x.wscale, (size_t)nchan * x.nbtile * 32 * sizeof(float)));
         XENG_HIP(hipMalloc((void**)&x.wmax, (size_t)nchan * x.nbtile * 32 * sizeof(float)));
+        const size_t ntile = (size_t)nchan * x.nbtile;
+        XENG_HIP(hipMalloc((void**)&x.row_out, ntile * 32 * BI_ROW_OUT * sizeof(int)));
+        XENG_HIP(hipMalloc((void**)&x.route, (ntile + 1) * sizeof(int)));
+        XENG_HIP(hipMalloc((void**)&x.out_n, ntile * sizeof(int)));
+        XENG_HIP(hipMalloc((void**)&x.out_idx, ntile * BI_TILE_OUT * sizeof(int)));
+        XENG_HIP(hipMalloc((void**)&x.out_R, ntile * BI_TILE_OUT * 32 * sizeof(float2)));
+        XENG_HIP(hipHostMalloc((void**)&x.any_host, sizeof(int)));
+        XENG_HIP(hipEventCreateWithFlags(&x.ev_route, hipEventDisableTiming));
         if (getenv("XENG_BEAM_STAMPS")) {
             const size_t nw = (size_t)((ntime + BI_NT - 1) / BI_NT) * nchan * x.nbtile * 4 * 4;
             XENG_HIP(hipMalloc((void**)&x.stamps, nw * sizeof(unsigned long long)));
@@ -215,6 +262,26 @@ int xengBeamformSync(void) {
     XENG_HIP(hipSetDevice(x.gpu));
     XENG_HIP(hipStreamSynchronize(x.stream));
     x.timer.drain();
+    return XENG_STATUS_SUCCESS;
+}
+
+int xengBeamformGetRouteInfo(int* tiles_total, int* tiles_bf16, int* outlier_inputs) {
+    std::lock_guard<std::mutex> lk(g_bmu);
+    BeamContext& x = g_b;
+    if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "Beamform: not initialized");
+    const int ntile = x.nchan * x.nbtile;
+    int nbf = 0, nout = 0;
+    if (x.use_i8) {
+        XENG_HIP(hipSetDevice(x.gpu));
+        XENG_HIP(hipStreamSynchronize(x.stream));
+        std::vector<int> r(ntile), n(ntile);
+        XENG_HIP(hipMemcpy(r.data(), x.route, ntile * sizeof(int), hipMemcpyDeviceToHost));
+        XENG_HIP(hipMemcpy(n.data(), x.out_n, ntile * sizeof(int), hipMemcpyDeviceToHost));
+        for (int k = 0; k < ntile; k++) { nbf += r[k] != 0; if (!r[k]) nout += n[k]; }
+    }
+    if (tiles_total) *tiles_total = ntile;
+    if (tiles_bf16) *tiles_bf16 = nbf;
+    if (outlier_inputs) *outlier_inputs = nout;
     return XENG_STATUS_SUCCESS;
 }
 

@@ -159,9 +159,12 @@ __device__ __forceinline__ uint32_t f32_to_bf16_rne(float f) {
 
 // grid (ceil(ninput/64), nbtile, nchan), 256 threads: thread = (beam tid/8, 8 inputs (tid%8)*8) of a 64-input
 // span = two chunks.  Layout Wp[c][beam tile][chunk][term][re|im][32 beams][32 inputs] bf16.
+// route (may be null): per (channel, beam tile) 0 = the tile runs on the int8x3 kernel (nothing to prepare here), 1 = here
 __global__ __launch_bounds__(256) void beam_weights_prep_kernel(const float* __restrict__ w, uint8_t* __restrict__ wp,
-                                                                int nchan, int nbeam, int ninput, int nchunk, int nbtile) {
+                                                                int nchan, int nbeam, int ninput, int nchunk, int nbtile,
+                                                                const int* __restrict__ route) {
     const int sp = blockIdx.x, bt = blockIdx.y, c = blockIdx.z;
+    if (route && !route[c * nbtile + bt]) return;
     const int beam = threadIdx.x >> 3, k0 = (threadIdx.x & 7) * 8;
     const int b = bt * 32 + beam;
     const int ch = 2 * sp + (k0 >> 5);                 // chunk of this thread's 8 inputs
@@ -211,7 +214,8 @@ __device__ __forceinline__ v8bf as_v8bf(uint32_t a, uint32_t b, uint32_t c, uint
 __global__ __launch_bounds__(64 * BF3_NW, BF3_NW == 8 ? 2 : 3) void beamform_bf16x3_kernel(const uint8_t* __restrict__ in,
                                                                  const uint8_t* __restrict__ wp,
                                                                  float* __restrict__ out, int ntime, int nchan,
-                                                                 int ninput, int nbeam, int nchunk, int nbtile) {
+                                                                 int ninput, int nbeam, int nchunk, int nbtile,
+                                                                 const int* __restrict__ route) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[BF3_RING * BF3_STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -222,6 +226,7 @@ __global__ __launch_bounds__(64 * BF3_NW, BF3_NW == 8 ? 2 : 3) void beamform_bf1
     if ((nchan & 7) == 0) { const int b = blockIdx.x, slot = b >> 3; c = (b & 7) + 8 * (slot / per_c); rem = slot % per_c; }
     else { c = blockIdx.x / per_c; rem = blockIdx.x % per_c; }
     const int bt = rem / nttile, t0 = (rem % nttile) * BF3_NT;
+    if (route && !route[c * nbtile + bt]) return;      // this (channel, beam tile) runs on the int8x3 kernel
     const int h = lane >> 5, j = lane & 31;
     const uint8_t* wsrc = wp + (((size_t)c * nbtile + bt) * nchunk) * BF3_WCHUNK + lane * 16;
     const size_t row_stride = (size_t)nchan * ninput;
@@ -340,34 +345,155 @@ constexpr int BI_XSLOTS = BI_XCHUNK / 1024 / 4;     // voltage pieces issued per
 constexpr int BI_RING = BI_RING_STAGES;
 constexpr int BI_QMAX = 127 * (255 * 255 + 255 + 1);
 
-// pass 1, grid (4 * nbtile, nchan), 256 threads = (beam tid/32 of the block's 8, lane32 tid%32): row maxima ->
-// scale[c][beam] (with the 1/16 of the voltage scaling folded in) and wmax[c][beam] for pass 2
-__global__ __launch_bounds__(256) void beam_weights_rowmax_kernel(const float* __restrict__ w, float* __restrict__ scale,
-                                                                  float* __restrict__ wmax, int nchan, int nbeam,
-                                                                  int ninput, int nbtile) {
-    const int c = blockIdx.y;
-    const int beam = blockIdx.x * 8 + (threadIdx.x >> 5), l32 = threadIdx.x & 31;   // beam index within the padded tiles
-    float m = 0.f;
-    if (beam < nbeam) {
-        const float* wrow = w + ((size_t)c * nbeam + beam) * ninput * 2;
-        for (int i = l32; i < ninput; i += 32) {
+// ---- precision of the fixed-point weights (what keeps the int8 route inside the 1e-5 bar for ANY weights) --------
+// A row scale taken from the row maximum makes the quantisation step of every weight 1.2e-7 of the LARGEST one.  A few
+// dominant weights (a huge calibration gain on a dead or quiet input) would then cost the ordinary weights their
+// significant bits while contributing nothing to the output.  So per (channel, beam) row:
+//   * up to BI_ROW_OUT entries that stand out by whole binades are *outliers*: their digits are zero and the
+//     product w * x is added in fp32 in the kernel's epilogue (exact to fp32 rounding, like the reference's CF32 GEMM,
+//     bf_src/cublas_beamform.cu:248-276).  Rule: E = the smallest fp32 exponent such that at most BI_ROW_OUT entries
+//     have a larger exponent of max(|re|, |im|) and none of those lies within BI_GAP_BINADES binades (they stand
+//     out: the top of a smooth distribution is not an outlier); the row scale is the exact maximum of the rest.
+//   * if the largest remaining entry is still more than BI_GUARD_BINADES binades above the row's MEDIAN non-zero entry
+//     (a heavy tail rather than a few outliers: the output may be made by weights that are small against the row
+//     scale), or a beam tile collects more than BI_TILE_OUT distinct outlier inputs, the (channel, beam tile) is
+//     routed to the bf16x3 kernel (every weight exact to 24 bits on its own scale); decided on the device:
+//     route[c][tile] = 1.  Inside the guard the step is < 2^-23 * 2^(BI_GUARD_BINADES+1) of the median weight.
+constexpr int BI_ROW_OUT = 8;
+constexpr int BI_TILE_OUT = 32;
+constexpr int BI_GUARD_BINADES = 4;
+constexpr int BI_GAP_BINADES = 3;
+
+// pass 1a, grid (8 * nbtile, nchan), 256 threads = 4 waves = 4 rows.  Outputs per row: scale (with the 1/16 of the
+// voltage scaling folded in), wmax (inlier maximum, for pass 2), row_out[BI_ROW_OUT] (outlier inputs, -1 = none);
+// route[nchan*nbtile] (+ route[nchan*nbtile] = "any tile routed"), zeroed by the caller.
+__global__ __launch_bounds__(256) void beam_weights_rowstat_kernel(const float* __restrict__ w, float* __restrict__ scale,
+                                                                   float* __restrict__ wmax, int* __restrict__ row_out,
+                                                                   int* __restrict__ route, int nchan, int nbeam,
+                                                                   int ninput, int nbtile) {
+    __shared__ int hist[4][256];
+    const int c = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;                  // beam index within the padded tiles
+    const bool live = row < nbeam;
+    for (int k = lane; k < 256; k += 64) hist[wave][k] = 0;
+    __syncthreads();
+    const float* wrow = w + ((size_t)c * nbeam + (live ? row : 0)) * ninput * 2;
+    if (live)
+        for (int i = lane; i < ninput; i += 64) {
             const float2 v = *reinterpret_cast<const float2*>(wrow + 2 * i);
-            m = fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y)));
+            atomicAdd(&hist[wave][(__float_as_uint(fmaxf(fabsf(v.x), fabsf(v.y))) >> 23) & 0xFF], 1);
         }
+    __syncthreads();
+    // E = the smallest exponent bucket with at most BI_ROW_OUT entries above it AND none of them within BI_GAP_BINADES
+    // binades (outliers stand out; the top of a smooth distribution is not an outlier).  Lane l owns buckets 4l..4l+3.
+    int cnt[4], tot = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { cnt[q] = hist[wave][4 * lane + q]; tot += cnt[q]; }
+    int suf = tot;                                           // inclusive suffix sum over lanes >= lane
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_down(suf, o); if (lane + o < 64) suf += v; }
+    // ... and the bucket of the median non-zero entry: the largest bucket b >= 1 with at least half of them at or above it
+    const int n_nz = __shfl(suf, 0) - __shfl(cnt[0], 0);
+    int above = suf - tot, Emed = 0;
+#pragma unroll
+    for (int q = 3; q >= 0; q--) {
+        hist[wave][4 * lane + q] = above;                    // entries strictly above bucket 4*lane+q (own buckets: no race)
+        above += cnt[q];                                     // now: entries at or above it
+        if (2 * above >= n_nz && 4 * lane + q >= 1) Emed = max(Emed, 4 * lane + q);
+    }
+    __syncthreads();
+    int E = 1 << 30;
+#pragma unroll
+    for (int q = 3; q >= 0; q--) {
+        const int b = 4 * lane + q, ab = hist[wave][b];
+        if (ab <= BI_ROW_OUT && ab == hist[wave][min(b + BI_GAP_BINADES, 255)]) E = b;
     }
 #pragma unroll
-    for (int o = 1; o < 32; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if (l32 == 0) {
-        scale[(size_t)c * nbtile * 32 + beam] = m > 0.f ? m / (float)BI_QMAX / 16.f : 0.f;
-        wmax[(size_t)c * nbtile * 32 + beam] = m;
+    for (int o = 32; o >= 1; o >>= 1) { E = min(E, __shfl_xor(E, o)); Emed = max(Emed, __shfl_xor(Emed, o)); }
+    // second sweep: inlier maximum / sum of squares, outlier list (wave-level compaction)
+    float m = 0.f;
+    int nout = 0;
+    int* ro = row_out + ((size_t)c * nbtile * 32 + row) * BI_ROW_OUT;
+    for (int i0 = 0; i0 < ninput; i0 += 64) {
+        const int i = i0 + lane;
+        bool is_out = false;
+        if (live && i < ninput) {
+            const float2 v = *reinterpret_cast<const float2*>(wrow + 2 * i);
+            const float a = fmaxf(fabsf(v.x), fabsf(v.y));
+            if ((int)((__float_as_uint(a) >> 23) & 0xFF) <= E) m = fmaxf(m, a);
+            else is_out = true;
+        }
+        const unsigned long long mask = __ballot(is_out);
+        if (is_out) ro[nout + __popcll(mask & ((1ull << lane) - 1))] = i;     // (at most BI_ROW_OUT by the choice of E)
+        nout += __popcll(mask);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane >= nout && lane < BI_ROW_OUT) ro[lane] = -1;
+    if (lane == 0) {
+        scale[(size_t)c * nbtile * 32 + row] = m > 0.f ? m / (float)BI_QMAX / 16.f : 0.f;
+        wmax[(size_t)c * nbtile * 32 + row] = m;
+        if (n_nz > 0 && (int)((__float_as_uint(m) >> 23) & 0xFF) - Emed > BI_GUARD_BINADES) {
+            route[c * nbtile + (row >> 5)] = 1;
+            route[nchan * nbtile] = 1;
+        }
+    }
+}
+
+// pass 1b, grid (nbtile, nchan), 256 threads = (row tid/8, outlier slot tid%8): union of the tile's outlier inputs
+// -> out_n[c][tile], out_idx[c][tile][BI_TILE_OUT], out_R[c][tile][BI_TILE_OUT][32 rows] (the fp32 weight of
+// (row, input) where the row lists that input, else 0)
+__global__ __launch_bounds__(256) void beam_weights_outlier_kernel(const float* __restrict__ w, const int* __restrict__ row_out,
+                                                                   int* __restrict__ out_n, int* __restrict__ out_idx,
+                                                                   float2* __restrict__ out_R, int* __restrict__ route,
+                                                                   int nchan, int nbeam, int ninput, int nbtile) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t ol_lds[];     // ninput bytes of marks (padded to 4) + list
+    uint8_t* mark = ol_lds;
+    int* list = reinterpret_cast<int*>(ol_lds + ((ninput + 63) & ~63));  // [BI_TILE_OUT] + count
+    const int bt = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
+    const int tile = c * nbtile + bt;
+    for (int i = tid; i < ninput; i += 256) mark[i] = 0;
+    float2* R = out_R + (size_t)tile * BI_TILE_OUT * 32;
+    for (int k = tid; k < BI_TILE_OUT * 32; k += 256) R[k] = make_float2(0.f, 0.f);
+    __syncthreads();
+    const int r = tid >> 3, sl = tid & 7;
+    const int idx = row_out[((size_t)tile * 32 + r) * BI_ROW_OUT + sl];
+    if (idx >= 0) mark[idx] = 1;
+    __syncthreads();
+    if (tid < 64) {                                          // one wave compacts the marks into the sorted union
+        int n = 0;
+        for (int i0 = 0; i0 < ninput; i0 += 64) {
+            const int i = i0 + tid;
+            const bool on = i < ninput && mark[i];
+            const unsigned long long mask = __ballot(on);
+            const int pos = n + __popcll(mask & ((1ull << tid) - 1));
+            if (on && pos < BI_TILE_OUT) list[pos] = i;
+            n += __popcll(mask);
+        }
+        if (tid == 0) {
+            list[BI_TILE_OUT] = n;
+            if (n > BI_TILE_OUT) { route[tile] = 1; route[nchan * nbtile] = 1; n = 0; }   // too many: bf16x3 takes the tile
+            out_n[tile] = n;
+        }
+    }
+    __syncthreads();
+    const int n = min(list[BI_TILE_OUT], BI_TILE_OUT);
+    if (tid < BI_TILE_OUT) out_idx[(size_t)tile * BI_TILE_OUT + tid] = tid < n ? list[tid] : 0;
+    if (idx >= 0 && list[BI_TILE_OUT] <= BI_TILE_OUT) {
+        int k = 0;
+        while (k < n && list[k] != idx) k++;
+        const int b = bt * 32 + r;
+        if (k < n && b < nbeam) R[k * 32 + r] = *reinterpret_cast<const float2*>(w + (((size_t)c * nbeam + b) * ninput + idx) * 2);
     }
 }
 
 // pass 2, grid (nchunk, nbtile, nchan), 256 threads = (beam tid/8, 4 inputs (tid%8)*4 of the chunk)
 __global__ __launch_bounds__(256) void beam_weights_prep_i8_kernel(const float* __restrict__ w, uint8_t* __restrict__ wq,
                                                                    const float* __restrict__ wmax, int nchan, int nbeam,
-                                                                   int ninput, int nchunk, int nbtile) {
+                                                                   int ninput, int nchunk, int nbtile,
+                                                                   const int* __restrict__ route) {
     const int ch = blockIdx.x, bt = blockIdx.y, c = blockIdx.z;      // ch: 32-input K step (nchunk = number of steps, padded to whole chunks)
+    if (route[c * nbtile + bt]) return;                              // the bf16x3 kernel takes this (channel, beam tile)
     const int beam = threadIdx.x >> 3, l8 = threadIdx.x & 7;
     const int b = bt * 32 + beam;
     const float* wrow = w + ((size_t)c * nbeam + (b < nbeam ? b : 0)) * ninput * 2;
@@ -391,9 +517,11 @@ __global__ __launch_bounds__(256) void beam_weights_prep_i8_kernel(const float* 
         int qr = 0, qi = 0;
         if (b < nbeam && i < ninput) {
             const float2 v = *reinterpret_cast<const float2*>(wrow + 2 * i);
-            // (the row maximum itself may round to QMAX + 1, whose leading digit would be 128: clamp)
-            qr = max(-BI_QMAX, min(BI_QMAX, (int)rintf(v.x * inv)));
-            qi = max(-BI_QMAX, min(BI_QMAX, (int)rintf(v.y * inv)));
+            if (fmaxf(fabsf(v.x), fabsf(v.y)) <= m) {     // (an outlier keeps zero digits: it is added in fp32 in the epilogue)
+                // (the row maximum itself may round to QMAX + 1, whose leading digit would be 128: clamp)
+                qr = max(-BI_QMAX, min(BI_QMAX, (int)rintf(v.x * inv)));
+                qi = max(-BI_QMAX, min(BI_QMAX, (int)rintf(v.y * inv)));
+            }
         }
         int dr[3], di[3];
         digits(qr, dr);
@@ -417,6 +545,8 @@ __global__ __launch_bounds__(256, 3) void beamform_i8x3_kernel(const uint8_t* __
                                                                const float* __restrict__ scale,
                                                                float* __restrict__ out, int ntime, int nchan,
                                                                int ninput, int nbeam, int nchunk, int nbtile,
+                                                               const int* __restrict__ route, const int* __restrict__ out_n,
+                                                               const int* __restrict__ out_idx, const float2* __restrict__ out_R,
                                                                unsigned long long* __restrict__ stamps) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[BI_RING * BI_STAGE];
     const unsigned long long r0 = stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;   // diagnostic (XENG_BEAM_STAMPS=1)
@@ -427,6 +557,8 @@ __global__ __launch_bounds__(256, 3) void beamform_i8x3_kernel(const uint8_t* __
     if ((nchan & 7) == 0) { const int b = blockIdx.x, slot = b >> 3; c = (b & 7) + 8 * (slot / per_c); rem = slot % per_c; }
     else { c = blockIdx.x / per_c; rem = blockIdx.x % per_c; }
     const int bt = rem / nttile, t0 = (rem % nttile) * BI_NT;
+    if (route[c * nbtile + bt]) return;                // this (channel, beam tile) runs on the bf16x3 kernel
+    const int n_outl = out_n[c * nbtile + bt];         // outlier inputs of this tile (epilogue)
     const int h = lane >> 5, j = lane & 31;
     const uint8_t* wsrc = wq + (((size_t)c * nbtile + bt) * nchunk) * BI_WCHUNK + lane * 16;
     const size_t row_stride = (size_t)nchan * ninput;
@@ -507,17 +639,34 @@ __global__ __launch_bounds__(256, 3) void beamform_i8x3_kernel(const uint8_t* __
     }
     // C/D map: col (sample) = lane&31, row (beam) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     const int t = t0 + wave * 32 + j;
+    float re[16], im[16];
+#pragma unroll
+    for (int g = 0; g < 16; g++) {
+        const float s = sc[g];
+        re[g] = s * (((float)acc_re[0][g] * 65025.f + (float)acc_re[1][g] * 255.f) + (float)acc_re[2][g]);
+        im[g] = s * (((float)acc_im[0][g] * 65025.f + (float)acc_im[1][g] * 255.f) + (float)acc_im[2][g]);
+    }
+    if (n_outl > 0) {
+        // the tile's outlier weights (zero digits above) times the voltages, in fp32
+        const uint8_t* xcol = in + (size_t)(t < ntime ? t : ntime - 1) * row_stride + (size_t)c * ninput;
+        const int tile = c * nbtile + bt;
+        for (int k = 0; k < n_outl; k++) {
+            const int xb = xcol[out_idx[(size_t)tile * BI_TILE_OUT + k]];
+            const float xr = (float)(int)__builtin_amdgcn_sbfe(xb, 4, 4), xi = (float)(int)__builtin_amdgcn_sbfe(xb, 0, 4);
+            const float2* Rk = out_R + ((size_t)tile * BI_TILE_OUT + k) * 32;
+#pragma unroll
+            for (int g = 0; g < 16; g++) {
+                const float2 R = Rk[(g & 3) + 8 * (g >> 2) + 4 * h];
+                re[g] += R.x * xr - R.y * xi;
+                im[g] += R.x * xi + R.y * xr;
+            }
+        }
+    }
     if (t < ntime) {
 #pragma unroll
         for (int g = 0; g < 16; g++) {
-            const int brow = (g & 3) + 8 * (g >> 2) + 4 * h;
-            const int b = bt * 32 + brow;
-            if (b < nbeam) {
-                const float s = sc[g];
-                const float re = s * (((float)acc_re[0][g] * 65025.f + (float)acc_re[1][g] * 255.f) + (float)acc_re[2][g]);
-                const float im = s * (((float)acc_im[0][g] * 65025.f + (float)acc_im[1][g] * 255.f) + (float)acc_im[2][g]);
-                *reinterpret_cast<float2*>(out + (((size_t)c * nbeam + b) * ntime + t) * 2) = make_float2(re, im);
-            }
+            const int b = bt * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+            if (b < nbeam) *reinterpret_cast<float2*>(out + (((size_t)c * nbeam + b) * ntime + t) * 2) = make_float2(re[g], im[g]);
         }
     }
     if (stamps && lane == 0) {

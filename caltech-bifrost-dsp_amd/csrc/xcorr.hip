@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "xcorr_kernels.h"
+#include "xcorr_fused8.h"
 #include "xeng_common.h"
 
 namespace xeng {
@@ -258,7 +259,9 @@ static void launch_xcorr(const XcorrParams& p, hipStream_t s, bool raw, int ncu)
             default: break;
         }
 #endif
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<0>), grid, dim3(256), 0, s, p);
+        static const int nwaves = getenv("XENG_WAVES") ? atoi(getenv("XENG_WAVES")) : 4;
+        if (nwaves == 8) hipLaunchKernelGGL(xcorr_fused8_kernel, grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<0>), grid, dim3(256), 0, s, p);
         return;
     }
 #ifdef XENG_DIAGNOSTICS

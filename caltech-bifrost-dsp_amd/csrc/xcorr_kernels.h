@@ -258,9 +258,11 @@ constexpr int XC_RING = 4;    // LDS ring depth (stages), two-pass kernel
 // contiguous (8 x 16 B = one 128-byte run).  Each 16-byte store of a lane would be its own request to
 // L2; so the cells are first moved across lanes (ds_bpermute: lane 8q+k takes the cell of lane 4k+q in
 // its 32-lane half) and every 8 adjacent lanes write one contiguous run.
+// NT = 32-column MFMA tiles per wave (2: a 64x64 wave tile; 1: a 64x32 wave tile whose column half is n0).
+template <int NT = 2>
 __device__ __forceinline__ void xcorr_store_tile(const XcorrParams& p, int c, int blk_a, int blk_b, bool skip01, int lane,
-                                                 const v16i (&accR)[2][2], const v16i (&accP)[2][2],
-                                                 const v16i (&accQ)[2][2], bool add_to_stored = false) {
+                                                 const v16i (&accR)[2][NT], const v16i (&accP)[2][NT],
+                                                 const v16i (&accQ)[2][NT], bool add_to_stored = false, int n0 = 0) {
     const int qs = (int)(((int64_t)(p.nstand / 2 + 1) * p.nstand) / 4);
     int32_t* out_r = p.out + (int64_t)c * p.per_chan;
     int32_t* out_i = out_r + p.matlen;
@@ -286,8 +288,8 @@ __device__ __forceinline__ void xcorr_store_tile(const XcorrParams& p, int c, in
 #pragma unroll
         for (int m = 0; m < 2; m++)
 #pragma unroll
-            for (int n = 0; n < 2; n++) {
-                const int ibase = blk_a * 64 + m * 32, jbase = blk_b * 64 + n * 32;
+            for (int n = 0; n < NT; n++) {
+                const int ibase = blk_a * 64 + m * 32, jbase = blk_b * 64 + (n0 + n) * 32;
                 const int Ch = (jbase >> 2) + (lane & 7);
                 const int wcol = (quad * qs + Ch) * 4;
 #pragma unroll
@@ -311,9 +313,9 @@ __device__ __forceinline__ void xcorr_store_tile(const XcorrParams& p, int c, in
 #pragma unroll
     for (int m = 0; m < 2; m++)
 #pragma unroll
-        for (int n = 0; n < 2; n++) {
-            if (m == 0 && n == 1 && skip01) continue;      // never stored (and not computed) on diagonal tiles
-            const int ibase = blk_a * 64 + m * 32, jbase = blk_b * 64 + n * 32;
+        for (int n = 0; n < NT; n++) {
+            if (m == 0 && n0 + n == 1 && skip01) continue;      // never stored (and not computed) on diagonal tiles
+            const int ibase = blk_a * 64 + m * 32, jbase = blk_b * 64 + (n0 + n) * 32;
             const int Ch = (jbase >> 2) + (lane & 7);
             const int C = 2 * Ch + cpar;
             const int wcol = (quad * qs + Ch) * 4;

@@ -55,6 +55,7 @@ SYMBOLS = {
     "xengBeamformRun": [_vp, _vp, _vp], "xengBeamformRunVersioned": [_vp, _vp, _vp, ctypes.c_longlong], "xengBeamformIntegrate": [_vp, _vp, _i],
     "xengBeamformIntegrateSingleBeam": [_vp, _vp, _i, _i], "xengBeamformSync": [],
     "xengBeamformSetProfiling": [_i], "xengBeamformGetTimes": [ctypes.POINTER(ctypes.c_double), _pi],
+    "xengBeamformGetRouteInfo": [_pi, _pi, _pi],
     "bfXgpuInitialize": [_pa, _pa, _i], "bfXgpuKernel": [_pa, _pa, _i], "bfXgpuCorrelate": [_pa, _pa, _i],
     "bfXgpuGetOrder": [_pa, _pa, _pa], "bfXgpuSubSelect": [_pa, _pa, _pa, _pa, _i, _i],
     "bfXgpuReorder": [_pa, _pa, _pa, _pa], "bfBeamformInitialize": [_i, _i, _i, _i, _i, _i],

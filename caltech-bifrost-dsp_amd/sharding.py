@@ -8,6 +8,9 @@ collective.  One process per GPU; rank r owns channels
 for barriers and for reducing timings -- never for data.
 """
 import os
+import socket
+import subprocess
+import sys
 
 CHAN_BW_HZ = 196e6 / 8192      # 23925.78125 (capture_block.py:165)
 
@@ -61,3 +64,41 @@ def max_over_ranks(dist, value):
     t = torch.tensor([float(value)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(nranks, argv, env_extra=None, timeout=None):
+    """Run `python argv...` as `nranks` fresh child processes, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT set as torch.distributed.run sets them), the way the reference starts one
+    pipeline process per channel block (lwa352-start-pipeline.sh:1-8).  The caller must not have touched the
+    GPU: the children are new processes (no fork of a HIP context, no exec of a process that holds one).
+    Returns (exit code, stdout of rank 0, list of per-rank stderr tails); rank 0 prints the job's result."""
+    port = free_port()
+    procs = []
+    for r in range(nranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks), LOCAL_WORLD_SIZE=str(nranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.update(env_extra or {})
+        procs.append(subprocess.Popen([sys.executable] + list(argv), env=env, text=True,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=subprocess.PIPE))
+    rc, out0, errs = 0, "", []
+    for r, pr in enumerate(procs):
+        try:
+            o, e = pr.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            o, e = pr.communicate()
+            rc = rc or 124
+        if r == 0:
+            out0 = o or ""
+        errs.append((e or "")[-2000:])
+        rc = rc or pr.returncode
+    return rc, out0, errs

@@ -210,6 +210,11 @@ int xengBeamformIntegrateSingleBeam(const void *in_dev, void *out_dev, int ntime
 int xengBeamformSync(void);
 int xengBeamformSetProfiling(int enable);
 int xengBeamformGetTimes(double ms[2], int count[2]);   /* [0]=Run, [1]=Integrate */
+/* How the last weight upload was routed (waits for the beam stream): (channel, beam tile) pairs in all, pairs that run on
+ * the bf16x3 kernel because their fixed-point image would not hold the 1e-5 bar, and outlier inputs that the int8x3
+ * kernel adds in fp32 (summed over tiles).  Zeros for the bf16x3 / f32 modes.  No reference counterpart: the
+ * reference's cuBLAS CF32 GEMM (bf_src/cublas_beamform.cu:248-276) has one route. */
+int xengBeamformGetRouteInfo(int *tiles_total, int *tiles_bf16, int *outlier_inputs);
 
 /* ---------------------------------------------------------------- bifrost-named adapters
  * Exact argument shapes of the reference's call sites; data pointers are taken from the

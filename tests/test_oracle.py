@@ -232,3 +232,30 @@ def test_snap2_packets_follow_the_reference_emulator_and_round_trip(golden_dir):
     seq, _, npol, _, nchan, _, _, chan0, pol0 = struct.unpack(orc.SNAP2_HDR, pk[lost][:32])
     exp[seq - 1000, chan0 - 192:chan0 - 192 + nchan, pol0:pol0 + npol] = 0
     assert np.array_equal(out2, exp)
+
+
+def _load_snap2_fixture(golden_dir):
+    with open(os.path.join(golden_dir, "snap2_8t_4c_64s_2p_deadbeef.bin"), "rb") as fh:
+        meta = json.loads(fh.readline().decode())
+        blob = fh.read()
+    n, b = meta["npkt"], meta["pkt_bytes"]
+    assert len(blob) == n * b
+    with open(os.path.join(golden_dir, "in_8t_4c_64s_2p_deadbeef.dat"), "rb") as fh:
+        hdr = json.loads(fh.readline().decode())
+        vin = np.frombuffer(fh.read(), dtype=np.uint8).reshape(hdr["shape"])
+    return meta, [blob[k * b:(k + 1) * b] for k in range(n)], vin
+
+
+def test_snap2_oracle_is_pinned_by_the_reference_transmitter(golden_dir):
+    """The fixture holds the datagrams the reference's own F-engine emulator (test_transmitters/test_tx_vectors.py,
+    run under a recording socket by oracle/make_golden_snap2.py) sends for the reference-generated input file:
+    oracle.snap2_packets must reproduce them byte for byte, and oracle.snap2_unpack must turn them back into that file."""
+    meta, pkts, vin = _load_snap2_fixture(golden_dir)
+    assert vin.shape == (meta["ntime"], meta["nchan"], meta["nstand"], meta["npol"])
+    mine = orc.snap2_packets(vin, seq0=0, sync_time=0, nchan_blocks=meta["nchan_blocks"], nstand_per_pkt=meta["nstand_per_pkt"])
+    assert len(mine) == len(pkts)
+    for k, (a, b) in enumerate(zip(mine, pkts)):
+        assert a == b, "packet %d differs from the reference transmitter's" % k
+    out, placed, dropped = orc.snap2_unpack(pkts, 0, meta["ntime"], 0, meta["nchan"], meta["nstand"] * meta["npol"])
+    assert placed == len(pkts) and dropped == 0
+    assert np.array_equal(out.reshape(vin.shape), vin)

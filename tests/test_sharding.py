@@ -62,3 +62,30 @@ def test_two_ranks_gloo(tmp_path):
     for s in shards:
         part = orc.xgpu_correlate(np.ascontiguousarray(full[:, s["chan0"]:s["chan0"] + s["nchan"]]), 8, s["nchan"])
         assert np.array_equal(part.reshape(2, s["nchan"], -1), allc[:, s["chan0"]:s["chan0"] + s["nchan"]])
+
+
+def test_bench_gpus_n_spawns_n_ranks():
+    """`python bench.py --gpus N` on its own (no torch.distributed.run, no WORLD_SIZE) starts N ranks itself and prints
+    one line with n_gpus = N whose time is the max over ranks; under torch.distributed.run the same flag is only checked
+    against WORLD_SIZE.  --selftest-spawn replaces the GPU work by a fixed per-rank time (rank r: (r+1) ms)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "1",
+                        "--selftest-spawn"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["nchan_total"] == 192
+    assert abs(res["ms_per_step"] - 0.2) < 1e-9          # max over ranks = rank 1's 2 ms over 10 steps
+    # the driver's launch line gives the same answer
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "1",
+           "--selftest-spawn"]
+    r2 = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-2000:]
+    res2 = json.loads([ln for ln in r2.stdout.splitlines() if ln.startswith("{")][0])
+    assert res2["n_gpus"] == 2 and res2["ms_per_step"] == res["ms_per_step"]
+    # a mismatch between --gpus and the launcher's world size is an error, not a silent 1-rank run
+    r3 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-spawn"], cwd=ROOT,
+                        env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=120)
+    assert r3.returncode != 0
