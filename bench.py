@@ -36,22 +36,30 @@ PEAK_INT8_OPS = PEAK_CUS * 8192 * PEAK_CLK_HZ         # 5.03e15 dense int8 MFMA 
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(budget_s=12.0):
+def cpu_baseline(budget_s=12.0, verify=None):
     """The CPU oracle (oracle/xeng_oracle.c, OpenMP over channels) on the host cores: a bounded
-    sample of the same workload (whole 480-sample x 96-channel x 704-input gulps)."""
+    sample of the same workload (whole 480-sample x 96-channel x 704-input gulps).  The oracle is the checker, never the
+    thing shipped: its first five gulps are the replay ring's gulps 0..4, so the integration it forms on the way also
+    verifies what the GPU produced in the config-5 leg (`verify`: arrays downloaded after that leg)."""
     from oracle import xeng_oracle as orc
     orc.build()
-    vin = np.random.RandomState(0xdeadbeef).randint(0, 255, size=(NTIME_GULP, NCHAN, NSTAND, NPOL), dtype=np.uint8)
+    rs = np.random.RandomState(0xdeadbeef)
+    gulps = [rs.randint(0, 255, size=NTIME_GULP * NCHAN * NINPUT, dtype=np.uint8).reshape(NTIME_GULP, NCHAN, NSTAND, NPOL)
+             for _ in range(ACC_LEN // NTIME_GULP)]
     acc = None
+    first_int = None
     t0 = time.time()
     ngulp = 0
     while True:
-        acc = orc.xgpu_correlate(vin, NSTAND, NCHAN, acc)
+        acc = orc.xgpu_correlate(gulps[ngulp % len(gulps)], NSTAND, NCHAN, acc)
         ngulp += 1
+        if ngulp == len(gulps):
+            first_int = acc.copy()
         el = time.time() - t0
-        if el > budget_s or ngulp >= 64:
+        if (el > budget_s and ngulp >= len(gulps)) or ngulp >= 64:
             break
     units = ngulp * NTIME_GULP * NCHAN
+    vin = gulps[0]
     # for honesty (SURVEY 8d): the reference's own golden loop, restated in numpy (make_golden_inputs.py:156-158:
     # per time sample an outer product x conj(x)^T over all 704 inputs, full square), one core, 2 spectra x 24 channels
     nsp, ncg = 2, 24
@@ -62,12 +70,77 @@ def cpu_baseline(budget_s=12.0):
     for t in range(nsp):
         g += x[t, :, :, None] * np.conj(x[t, :, None, :])
     el_np = time.time() - t1
-    return {"value": round(8 * NINPUT * units / el / 1e9, 4), "unit": "Gb/s",
-            "cores": int(orc.lib().orc_num_threads()), "kind": "port",
-            "cmac_per_s": units * CMAC_PER_UNIT / el,
-            "sample": "%d gulps of %d samples x %d chan x %d inputs (%.1f s)" % (ngulp, NTIME_GULP, NCHAN, NINPUT, el),
-            "reference_numpy_golden_loop": {"cmac_per_s": round(nsp * ncg * NINPUT * NINPUT / el_np, 1), "cores": 1,
-                                            "sample": "%d spectra x %d chan, full-square outer products (%.1f s)" % (nsp, ncg, el_np)}}
+    out = {"value": round(8 * NINPUT * units / el / 1e9, 4), "unit": "Gb/s",
+           "cores": int(orc.lib().orc_num_threads()), "kind": "port",
+           "cmac_per_s": units * CMAC_PER_UNIT / el,
+           "sample": "%d gulps of %d samples x %d chan x %d inputs (%.1f s)" % (ngulp, NTIME_GULP, NCHAN, NINPUT, el),
+           "reference_numpy_golden_loop": {"cmac_per_s": round(nsp * ncg * NINPUT * NINPUT / el_np, 1), "cores": 1,
+                                           "sample": "%d spectra x %d chan, full-square outer products (%.1f s)" % (nsp, ncg, el_np)}}
+    if verify is not None:
+        chk = {"visibilities_bit_exact": bool(np.array_equal(verify["vis"], first_int)),
+               "corracc_sum_bit_exact": bool(np.array_equal(verify["corracc"], 3 * first_int.astype(np.int64)))}
+        nt_b, nb = verify["beams"].shape[2], verify["beams"].shape[1]
+        v2 = np.concatenate([gulps[0], gulps[1]]).reshape(nt_b, NCHAN, NINPUT)
+        exp = orc.beamform(v2, verify["weights"].reshape(NCHAN, nb, NINPUT), nt_b, NCHAN, NINPUT, nb)
+        err = float(np.max(np.abs(verify["beams"].astype(np.complex128) - exp)) / np.sqrt(np.mean(np.abs(exp) ** 2)))
+        chk["beams_max_err_over_rms"] = err
+        chk["beams_within_1e-5"] = bool(err <= 1e-5)
+        chk["power_beams_ok"] = bool(np.all(np.isclose(verify["power"], orc.beamform_integrate(verify["beams"], verify["ntime_sum"]),
+                                                       rtol=1e-5, atol=1e-5 * np.abs(verify["power"]).max())))
+        chk["ok"] = bool(chk["visibilities_bit_exact"] and chk["corracc_sum_bit_exact"] and chk["beams_within_1e-5"] and chk["power_beams_ok"])
+        out["config5_check"] = chk
+    return out
+
+
+def corr_block_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=100):
+    """Corr.main on in-repo 'cuda' rings at config-2 size.  The source publishes the replay ring's gulps as spans without
+    copying them (WriteSequence.commit_external); the sink discards the visibility spans."""
+    import json as _json
+    import logging
+    import threading
+    from caltech_bifrost_dsp_amd.blocks import Corr
+    from caltech_bifrost_dsp_amd.ndarray import XArray
+    from caltech_bifrost_dsp_amd.ring import Ring
+    gulps_per_step = ACC_LEN // NTIME_GULP
+    r0, r1 = Ring("gpu-input", space="cuda"), Ring("corr-output", space="cuda")
+    r0.resize(gulp_bytes, total_span=2 * gulps_per_step * gulp_bytes)
+    blk = Corr(logging.getLogger("bench-corr"), r0, r1, ntime_gulp=NTIME_GULP, nchan=NCHAN, npol=NPOL, nstand=NSTAND,
+               acc_len=ACC_LEN, autostartat=0, gpu=gpu)
+    spans = [XArray(shape=(gulp_bytes,), dtype=np.uint8, space="cuda", _ptr=ring.ptr + g * gulp_bytes, _base=ring) for g in range(ring_gulps)]
+    hdr = {'nchan': NCHAN, 'chan0': 0, 'bw_hz': NCHAN * 23925.78125, 'fs_hz': 196000000, 'sfreq': 0.0, 'nstand': NSTAND, 'npol': NPOL,
+           'seq0': 0, 'sync_time': 0, 'pipeline_id': 0, 'system_nchan': 32 * NCHAN}
+    stamps = []
+
+    def source():
+        import time as _t
+        t0 = _t.time()
+        while len(r0._readers) < 1 and _t.time() - t0 < 10:
+            _t.sleep(0.002)
+        with r0.begin_writing() as w:
+            with w.begin_sequence(time_tag=0, header=_json.dumps(hdr), nringlet=1) as oseq:
+                for k in range((nwarm + nint) * gulps_per_step):
+                    oseq.commit_external(spans[k % ring_gulps])
+
+    gen = r1.read(guarantee=True)
+
+    def sink():
+        for iseq in gen:
+            for ispan in iseq.read(blk.ogulp_size):
+                stamps.append(time.perf_counter())
+
+    ths = [threading.Thread(target=f, daemon=True) for f in (sink, blk.main, source)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(300)
+    n = len(stamps)
+    rate = 8 * NINPUT * ACC_LEN * NCHAN * (n - 1 - nwarm) / (stamps[-1] - stamps[nwarm]) / 1e9 if n > nwarm + 1 else 0.0
+    return {"value": round(rate, 1), "unit": "Gb/s", "integrations": n,
+            "ms_per_integration": round((stamps[-1] - stamps[nwarm]) / max(n - 1 - nwarm, 1) * 1e3, 4) if n > nwarm + 1 else None,
+            "block_gbps_stat": round(float(blk.stats.get('throughput', 0.0)), 1),
+            "note": "Corr.main (one Python thread, streaming commits: span n closes after dump n+1 is enqueued) on in-repo device "
+                    "rings, zero-copy replay source; wall rate between the spans arriving at a sink, and the block's own "
+                    "`throughput` stat of its last integration (corr_block.py:453 formula)"}
 
 
 def main():
@@ -240,6 +313,7 @@ def main():
     ffi.call("xengXgpuSetProfiling", 0)
     # outside the timed region: PCIe-inclusive regime (SURVEY 8d "two reporting regimes", ii): gulps start in
     # pinned host memory, are copied H2D (xengMemcpy, the Copy block's copy_array) and then correlated
+    verify = None
     pcie = None
     if args.h2d and rank == 0 and world == 1:
         nh = 2 * gulps_per_step
@@ -434,6 +508,32 @@ def main():
             "ms_per_integration": round(elf / nfull * 1e3, 4),
             "note": "config 5 on one GPU: per 2400-sample integration 5 gulps registered in place + 1 fused MFMA contraction (X-engine streams), "
                     "2.5 beamformer gulps + power sums (beam stream), 1 CorrAcc int32 map over 191 MB (map stream)"}
+        # the same concurrent pattern once more on KNOWN inputs (three integrations of ring gulps 0..4, beams of gulps 0+1),
+        # kept for the oracle to check in the cpu_baseline leg: one dumped span, the CorrAcc sum (= 3 x that span) and one
+        # beam gulp with its power sums
+        if not args.no_cpu_baseline and not args.sync_per_call:
+            # (the PCIe and ingest legs above have rewritten the replay ring: put gulps 0..4 of the generator back)
+            rs5 = np.random.RandomState(0xdeadbeef)
+            for g in range(gulps_per_step):
+                ring.upload(rs5.randint(0, 255, size=gulp_bytes, dtype=np.uint8), offset=g * gulp_bytes)
+            for n in range(3):
+                o = outs3[n]
+                for g in range(gulps_per_step):
+                    ffi.check(kern, kfn(ring.ptr + g * gulp_bytes, o.ptr, int(g == gulps_per_step - 1)))
+                ffi.check("run", L.xengBeamformRunVersioned(ring.ptr, dbeam.ptr, dw.ptr, 1))
+                ffi.check("int", L.xengBeamformIntegrate(dbeam.ptr, dpow.ptr, NS))
+                ffi.call("xengXgpuSyncLag", 1)
+                if n >= 1:
+                    ffi.call("xengMapSync")
+                    ffi.check("map", (L.xengMapAssignI32 if n == 1 else L.xengMapAddI32)(acc_long.ptr, outs3[n - 1].ptr, 2 * matlen))
+            ffi.call("xengXgpuSync")
+            ffi.call("xengMapSync")
+            ffi.check("map", L.xengMapAddI32(acc_long.ptr, outs3[2].ptr, 2 * matlen))
+            ffi.call("xengMapSync")
+            ffi.call("xengBeamformSync")
+            verify = {"vis": outs3[2].download(np.int32), "corracc": acc_long.download(np.int32).astype(np.int64),
+                      "beams": dbeam.download(np.complex64).reshape(NCHAN, NB, NT_B), "weights": wts, "ntime_sum": NS,
+                      "power": dpow.download(np.float32).reshape(NB // 2, NT_B // NS, NCHAN, 4)}
         ffi.call("xengBeamformDestroy")
     if dist is not None:
         import torch
@@ -458,7 +558,7 @@ def main():
     kname = "xcorr_fused_kernel" if fused.value else ("xcorr_fp6_kernel" if fp6.value else "xcorr_mfma_kernel")
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")) as fh:
             traffic = json.load(fh).get(kname + "_bytes_per_launch")
     except (OSError, ValueError):
         pass
@@ -476,18 +576,22 @@ def main():
         "cmac_per_s": cmacs,
         "mfma_peak_frac_end_to_end": round(8 * cmacs / (PEAK_INT8_OPS * world), 4),
         "design_rate_x": round(gbps / world / 12.94, 1),
-        "roofline": {"kernel": kname, "bound": "mfma", "achieved": round(achieved, 1),
+        # one launch of the dominant kernel per step: achieved = algorithmic ops per launch / time per step on this GPU
+        # (in the streaming mode two consecutive launches share the GPU, so the HIP-event duration of ONE launch is
+        # longer than a step -- it is kept as a side key together with the duration of a launch that runs alone)
+        "roofline": {"kernel": kname, "bound": "mfma",
+                     "achieved": round(ops_per_launch / (el / args.steps) / 1e12, 1),
                      "peak": round(PEAK_INT8_OPS / 1e12, 1), "unit": "TFLOP/s",
-                     "frac": round(achieved / (PEAK_INT8_OPS / 1e12), 4), "traffic": traffic,
+                     "frac": round(ops_per_launch / (el / args.steps) / PEAK_INT8_OPS, 4), "traffic": traffic,
                      "algorithmic_bytes_per_launch": units_per_step * NINPUT + 2 * matlen * 4,
+                     "avg_launch_us_overlapped": round(mm_ms * 1e3, 1),
                      "launch_concurrency": round(mm_ms / (el / args.steps * 1e3), 2) if el > 0 else None,
-                     "frac_concurrency_corrected": round(8 * cmacs / (PEAK_INT8_OPS * world), 4),
-                     "note": "int8 TOP/s; algorithmic ops = 8*704*705/2 per (sample,chan) x %d units per launch; "
-                             "avg launch %.1f us over %d launches (HIP events on the X-engine streams).  In the "
-                             "streaming call mode consecutive launches share the GPU (launch_concurrency = avg launch "
-                             "/ step time), so a launch lasts longer than a step: per-GPU rate / peak is "
-                             "mfma_peak_frac_end_to_end"
-                             % (units_per_step, mm_ms * 1e3, cn[1])},
+                     "frac_of_overlapped_launch": round(achieved / (PEAK_INT8_OPS / 1e12), 4),
+                     "note": "int8 TOP/s; algorithmic ops = 8*704*705/2 per (sample,chan) x %d units per launch; frac = ops "
+                             "per launch / (time per step = one launch) / peak.  HIP events on the X-engine streams: avg "
+                             "launch %.1f us over %d launches while %.2f launches share the GPU (avg_launch_us_overlapped); "
+                             "roofline_isolated_launches times the same kernel alone"
+                             % (units_per_step, mm_ms * 1e3, cn[1], mm_ms / (el / args.steps * 1e3) if el > 0 else 0.0)},
         "device": info,
     }
     if cn[0] > 0:
@@ -516,6 +620,29 @@ def main():
             "note": "same kernel, one integration at a time (outside the timed region): in the timed streaming "
                     "region consecutive launches overlap (the next one takes over CUs as work-groups of the "
                     "previous one run out of items), which lengthens each launch but shortens the step"}
+    # outside the timed region: the reference's own call semantics (corr_block.py:445: synchronous bfXgpuKernel per gulp:
+    # the input may be recycled on return, the dump is complete on return) -- what an unmodified Corr on a circular
+    # bifrost ring would see
+    if rank == 0 and world == 1 and not args.sync_per_call and not args.sync_per_integration:
+        ffi.call("xengXgpuSync")
+        nrep, nwarm = 200, 50
+        for k in range(nwarm + nrep):
+            if k == nwarm:
+                t1 = time.perf_counter()
+            for g in range(gulps_per_step):
+                ffi.check("xengXgpuKernel", L.xengXgpuKernel(ring.ptr + (gi[0] % args.ring_gulps) * gulp_bytes, outs[k & 1].ptr,
+                                                             int(g == gulps_per_step - 1)))
+                gi[0] += 1
+        el5 = time.perf_counter() - t1
+        res["sync_per_call"] = {"value": round(8 * NINPUT * units_per_step_c * nrep / el5 / 1e9, 1), "unit": "Gb/s",
+                                "ms_per_step": round(el5 / nrep * 1e3, 4),
+                                "note": "the drop-in synchronous call per gulp (raw device copy of every non-dump gulp + wait; the "
+                                        "dump gulp is read in place and the call returns when the visibilities are complete), %d integrations" % nrep}
+    # outside the timed region: the Corr BLOCK itself (blocks/corr_block.py: ring protocol, header handling, state machine,
+    # one Python thread) on in-repo device rings at config-2 size, fed by a zero-copy replay source: the rate a pipeline
+    # user of the block sees, next to the C-ABI rate above
+    if rank == 0 and world == 1 and args.beamform and not args.sync_per_call and not args.sync_per_integration:
+        res["corr_block"] = corr_block_leg(ffi, ring, gulp_bytes, args.ring_gulps, gpu)
     # outside the timed region: SURVEY 8d's other device-resident case, one 2400-sample call per integration
     # (xGPU's NTIME = acc_len; needs its own context, so it runs last)
     if args.beamform and rank == 0 and world == 1 and args.ring_gulps >= 2 * gulps_per_step:
@@ -536,7 +663,9 @@ def main():
                                     "note": "ntime_gulp = acc_len = 2400: one enqueue-only call per integration, same streaming pattern"}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline()
+            res["cpu_baseline"] = cpu_baseline(verify=verify)
+            if verify is not None and beam is not None:
+                beam["full_xengine_concurrent"]["verified"] = res["cpu_baseline"].pop("config5_check")
         print(json.dumps(res))
     ffi.call("xengXgpuDestroy")
     if dist is not None:

@@ -26,7 +26,17 @@ class HipBackend:
         return g.value
 
     def stream_synchronize(self):
+        """Every library stream of the device (bifrost.device.stream_synchronize has one stream to wait for; here each
+        block works on its own, so the blocks use the per-stream waits below and leave the others running)."""
         ffi.call("xengStreamSynchronize")
+
+    def map_sync(self):
+        """CorrAcc's stream (corr_acc_block.py:317)."""
+        ffi.call("xengMapSync")
+
+    def beam_sync(self):
+        """The beamformer's stream: Beamform / BeamformSumBeams (beamform_block.py:450, beamform_sum_beams_block.py:247)."""
+        ffi.call("xengBeamformSync")
 
     # ---- X-engine (corr_block.py:253,331,445)
     def xgpu_configure(self, nstand, npol, nchan, ntime_gulp, max_gulps=0):
@@ -46,6 +56,10 @@ class HipBackend:
 
     def xgpu_sync(self):
         return self._lib.xengXgpuSync()
+
+    def xgpu_sync_lag(self, lag):
+        """Wait until the dump issued `lag` dumps before the latest one is complete (lag 0 = the latest)."""
+        return self._lib.xengXgpuSyncLag(int(lag))
 
     def bfXgpuGetOrder(self, antpol_to_input, antpol_to_bl, is_conj):
         return self._lib.bfXgpuGetOrder(antpol_to_input, antpol_to_bl, is_conj)

@@ -175,7 +175,7 @@ class Beamform(Block):
                                                         version=self._gains_version)
                             if rv != self._bf.BF_STATUS_SUCCESS:
                                 raise RuntimeError("bfBeamformRun returned %d: %s" % (rv, self._bf.last_error()))
-                            self._bf.stream_synchronize()
+                            self._bf.beam_sync()              # BFSync() of beamform_block.py:450, this block's stream only
                         this_gulp_time += self.ntime_gulp
                         curr_time = time.time()
                         process_time = curr_time - prev_time

@@ -73,9 +73,8 @@ class BeamformSumBeams(Block):
                             rv = self._bf.bfBeamformIntegrate(idata.as_BFarray(), self.bf_output.as_BFarray(), self.ntime_sum)
                             if rv != self._bf.BF_STATUS_SUCCESS:
                                 raise RuntimeError("bfBeamformIntegrate returned %d: %s" % (rv, self._bf.last_error()))
-                            self._bf.stream_synchronize()
-                            odata[...] = self.bf_output
-                            self._bf.stream_synchronize()
+                            self._bf.beam_sync()
+                            odata[...] = self.bf_output           # (synchronous copy)
                         curr_time = time.time()
                         process_time = curr_time - prev_time
                         prev_time = curr_time

@@ -120,16 +120,16 @@ class CorrAcc(Block):
                         rv = self._bf.map_add_i32(self.accdata, idata)         # "a += b"
                     if rv != self._bf.BF_STATUS_SUCCESS:
                         raise RuntimeError("CorrAcc map returned %d: %s" % (rv, self._bf.last_error()))
-                    # the input span is recycled when the loop advances: the map must have read it
-                    self._bf.stream_synchronize()
+                    # the input span is recycled when the loop advances: the map must have read it (this block's
+                    # stream only: the X-engine and beamformer streams keep running)
+                    self._bf.map_sync()
                     curr_time = time.time()
                     process_time += curr_time - prev_time
                     prev_time = curr_time
                     if now == gate.last:
                         ospan = WriteSpan(oseq.ring, self.ogulp_size, nonblocking=False)
                         odata = ospan.data_view('i32').reshape(self.accdata.shape)
-                        copy_array(odata, self.accdata)
-                        self._bf.stream_synchronize()         # copy complete before committing the span
+                        copy_array(odata, self.accdata)       # (synchronous: complete before the span is committed)
                         ospan.close()
                         ospan = None
                         curr_time = time.time()

@@ -139,7 +139,13 @@ class Corr(Block):
             # a raw copy of every gulp until the dump.
             in_place = (getattr(self.iring, 'span_memory_outlives_release', False)
                         and hasattr(self._bf, 'bfXgpuKernelAsync') and hasattr(self._bf, 'xgpu_sync'))
+            # ... and the block streams: the dump of integration n is only enqueued; its output span is committed
+            # (and its gulps released) when the dump of integration n+1 has been enqueued and n's has completed
+            # (xengXgpuSyncLag(1)), so the GPU never idles between integrations.  `_pending` = (span, held gulps) of
+            # the integration whose dump is in flight.
+            streaming = in_place and hasattr(self._bf, 'xgpu_sync_lag')
             self._held = []
+            self._pending = None
             for iseq in self.iring.read(guarantee=self.guarantee):
                 self.log.info('CORR >> new input sequence!')
                 process_time = 0
@@ -173,6 +179,7 @@ class Corr(Block):
                     if gate.acc_len == 0:
                         # acc_len = 0 is the stop command (:423-428); made a clean stop here
                         self.update_stats({'state': 'stopped'})
+                        self._finish_pending()
                         if oseq:
                             oseq.end()
                         oseq = None
@@ -181,6 +188,7 @@ class Corr(Block):
                         continue
                     if gate.try_start(now, self.ntime_gulp):
                         self.log.info("CORR >> Start time %d reached." % gate.start_time)
+                        self._finish_pending()
                         if oseq:
                             oseq.end()
                         self.sequence_proclog.update(ohdr)
@@ -211,8 +219,15 @@ class Corr(Block):
                         self._held.append(ispan.data)      # keeps the gulp's memory alive until the dump has run
                         rv = self._bf.bfXgpuKernelAsync(ispan.data.as_BFarray(), ospan.data.as_BFarray(), int(now == gate.last))
                         if rv == self._bf.BF_STATUS_SUCCESS and now == gate.last:
-                            rv = self._bf.xgpu_sync()      # the output span is complete before it is committed
-                            self._held = []
+                            if streaming:
+                                prev, self._pending = self._pending, (ospan, self._held)
+                                self._held = []
+                                if prev is not None:
+                                    rv = self._bf.xgpu_sync_lag(1)     # the previous dump is complete: commit its span
+                                    prev[0].close()
+                            else:
+                                rv = self._bf.xgpu_sync()      # the output span is complete before it is committed
+                                self._held = []
                     else:
                         rv = self._bf.bfXgpuKernel(ispan.data.as_BFarray(), ospan.data.as_BFarray(), int(now == gate.last))
                     if rv != self._bf.BF_STATUS_SUCCESS:
@@ -222,8 +237,10 @@ class Corr(Block):
                     prev_time = curr_time
                     if now == gate.last:
                         if self.test:
+                            self._finish_pending()
                             self._compare(test_out, ospan.data, ihdr['nchan'], ihdr['nstand'], ihdr['npol'])
-                        ospan.close()
+                        if self._pending is None or self._pending[0] is not ospan:
+                            ospan.close()
                         ospan = None
                         gbps = 8 * gate.acc_len * ihdr['nchan'] * ihdr['nstand'] * ihdr['npol'] / max(process_time, 1e-9) / 1e9
                         self.perf_proclog.update({'acquire_time': acquire_time, 'reserve_time': reserve_time,
@@ -235,11 +252,22 @@ class Corr(Block):
                 if ospan is not None:
                     self._abort_integration()       # upstream sequence ended mid-integration
                     ospan = None
+                self._finish_pending()
                 if oseq:
                     oseq.end()
                 oseq = None
 
+    def _finish_pending(self):
+        """Streaming mode: wait for the dump in flight and commit its span."""
+        pend, self._pending = getattr(self, '_pending', None), None
+        if pend is not None:
+            rv = self._bf.xgpu_sync()
+            pend[0].close()
+            if rv != self._bf.BF_STATUS_SUCCESS:
+                raise RuntimeError("xgpuSync returned %d: %s" % (rv, self._bf.last_error()))
+
     def _abort_integration(self):
+        self._finish_pending()                      # a completed integration whose dump is in flight is still good
         reset = getattr(self._bf, 'xgpu_reset', None)
         if reset is not None:
             reset()                                 # synchronises: nothing reads the held gulps afterwards

@@ -214,20 +214,17 @@ class CorrOutputFull(Block):
         if idata.space != self._bf.space_in:                  # host ring (the pipeline's cuda_host CorrAcc output)
             if self._in_dev is None:
                 self._in_dev = XArray(shape=[2 * self.matlen], dtype='i32', space=self._bf.space_in)
-            copy_array(self._in_dev, idata)
-            self._bf.stream_synchronize()
+            copy_array(self._in_dev, idata)                   # (copies are complete on return)
             idata = self._in_dev
         if self._maps_dirty:
             copy_array(self._bl_dev, XArray(np.ascontiguousarray(self.antpol_to_bl)))
             copy_array(self._cj_dev, XArray(np.ascontiguousarray(self.bl_is_conj)))
-            self._bf.stream_synchronize()
             self._maps_dirty = False
         rv = self._bf.xgpu_packetize(idata, self._payload_dev, self._bl_dev, self._cj_dev, 1 if self.use_cor_fmt else 0)
         if rv != self._bf.BF_STATUS_SUCCESS:
             self.log.error("xgpuPacketize returned %d" % rv)
             raise RuntimeError("xgpuPacketize returned %d: %s" % (rv, self._bf.last_error()))
         copy_array(self._payload_host, self._payload_dev)
-        self._bf.stream_synchronize()
         self.payloads = self._payload_host.numpy().reshape(self.nbl, self.payload_words)
 
     def _update_destination(self):

@@ -109,8 +109,7 @@ class CorrSubsel(Block):
                             self.log.error("xgpuSubSelect returned %d" % rv)
                             raise RuntimeError("xgpuSubSelect returned %d: %s" % (rv, self._bf.last_error()))
                         odata = ospan.data_view('i32').reshape(self.obuf_gpu.shape)
-                        copy_array(odata, self.obuf_gpu)
-                        self._bf.stream_synchronize()
+                        copy_array(odata, self.obuf_gpu)      # (SubSelect and the copy are complete on return)
                         curr_time = time.time()
                         process_time = curr_time - prev_time
                         prev_time = curr_time

@@ -1,22 +1,40 @@
 // CorrAcc long accumulation: replaces bifrost.map("a = b") / ("a += b") on the planar
 // int32 xGPU buffer (corr_acc_block.py:304,306).  HBM-bound: 16 B per lane, grid-stride,
 // 2048 blocks (8 per CU) so every XCD streams.
+#include <cstdlib>
+
 #include "xeng_common.h"
 
 namespace xeng {
 
-template <bool ADD>
+// U = 16-byte pieces in flight per lane: every wave instruction covers one contiguous KiB, a work-group 4 KiB per
+// piece; all loads of an iteration are issued before the first add.  NT: non-temporal loads and stores (the 574 MB of
+// an "a += b" over config-2 planes pass through the caches once).
+template <bool ADD, int U, bool NT>
 __global__ __launch_bounds__(256) void map_i32_kernel(int4* __restrict__ a, const int4* __restrict__ b,
                                                       size_t n16, int32_t* __restrict__ a_tail,
                                                       const int32_t* __restrict__ b_tail, int ntail) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n16; k += stride) {
-        int4 y = b[k];
-        if (ADD) {
-            const int4 x = a[k];
-            y.x += x.x; y.y += x.y; y.z += x.z; y.w += x.w;
+    typedef int v4i_ __attribute__((ext_vector_type(4)));
+    const size_t stride = (size_t)gridDim.x * blockDim.x * U;
+    for (size_t k0 = (size_t)blockIdx.x * blockDim.x * U + threadIdx.x; k0 < n16; k0 += stride) {
+        v4i_ x[U], y[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const size_t k = k0 + (size_t)u * blockDim.x;
+            if (k < n16) {
+                y[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const v4i_*>(b) + k) : reinterpret_cast<const v4i_*>(b)[k];
+                if (ADD) x[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const v4i_*>(a) + k) : reinterpret_cast<const v4i_*>(a)[k];
+            }
         }
-        a[k] = y;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const size_t k = k0 + (size_t)u * blockDim.x;
+            if (k < n16) {
+                if (ADD) y[u] += x[u];
+                if (NT) __builtin_nontemporal_store(y[u], reinterpret_cast<v4i_*>(a) + k);
+                else reinterpret_cast<v4i_*>(a)[k] = y[u];
+            }
+        }
     }
     if (blockIdx.x == 0 && (int)threadIdx.x < ntail) {
         if (ADD) a_tail[threadIdx.x] += b_tail[threadIdx.x];
@@ -33,15 +51,33 @@ static int map_i32(void* a, const void* b, size_t nwords, bool add) {
     if (rc) return rc;
     const size_t n16 = nwords / 4;
     const int ntail = (int)(nwords % 4);
-    size_t blocks = (n16 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    if (blocks == 0) blocks = 1;
     int32_t* at = (int32_t*)a + n16 * 4;
     const int32_t* bt = (const int32_t*)b + n16 * 4;
-    if (add)
-        hipLaunchKernelGGL(map_i32_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, (int4*)a, (const int4*)b, n16, at, bt, ntail);
-    else
-        hipLaunchKernelGGL(map_i32_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, (int4*)a, (const int4*)b, n16, at, bt, ntail);
+    // XENG_MAP_VAR = U*10 + NT overrides the defaults measured on config-2 planes (profiles/side_kernels.py map):
+    // "a += b" one piece per lane, non-temporal (88.8 us = 6.46 TB/s); "a = b" four pieces, non-temporal (62.6 us = 6.11 TB/s)
+    static const int var_env = getenv("XENG_MAP_VAR") ? atoi(getenv("XENG_MAP_VAR")) : 0;
+    const int var = var_env ? var_env : (add ? 11 : 41);
+    static const int maxb = getenv("XENG_MAP_BLOCKS") ? atoi(getenv("XENG_MAP_BLOCKS")) : 2048;
+    const int U = var / 10 == 1 ? 1 : var / 10 == 2 ? 2 : var / 10 == 8 ? 8 : 4;
+    size_t blocks = (n16 + 256 * (size_t)U - 1) / (256 * (size_t)U);
+    if (blocks > (size_t)maxb) blocks = (size_t)maxb;
+    if (blocks == 0) blocks = 1;
+    const dim3 g((unsigned)blocks), t(256);
+#define XENG_MAP_LAUNCH(ADD_, U_, NT_) hipLaunchKernelGGL(HIP_KERNEL_NAME(map_i32_kernel<ADD_, U_, NT_>), g, t, 0, s, (int4*)a, (const int4*)b, n16, at, bt, ntail)
+#define XENG_MAP_PICK(ADD_)                                                      \
+    switch (var) {                                                               \
+        case 10: XENG_MAP_LAUNCH(ADD_, 1, false); break;                         \
+        case 11: XENG_MAP_LAUNCH(ADD_, 1, true); break;                          \
+        case 20: XENG_MAP_LAUNCH(ADD_, 2, false); break;                         \
+        case 21: XENG_MAP_LAUNCH(ADD_, 2, true); break;                          \
+        case 40: XENG_MAP_LAUNCH(ADD_, 4, false); break;                         \
+        case 80: XENG_MAP_LAUNCH(ADD_, 8, false); break;                         \
+        case 81: XENG_MAP_LAUNCH(ADD_, 8, true); break;                          \
+        default: XENG_MAP_LAUNCH(ADD_, 4, true); break;                          \
+    }
+    if (add) { XENG_MAP_PICK(true) } else { XENG_MAP_PICK(false) }
+#undef XENG_MAP_PICK
+#undef XENG_MAP_LAUNCH
     XENG_HIP(hipGetLastError());
     return XENG_STATUS_SUCCESS;
 }

@@ -14,134 +14,6 @@
 
 namespace xeng {
 
-// --------------------------------------------------------------------------------------
-// Triangular tiling of the nblk64 x nblk64 grid of 64x64-input wave tiles onto work-groups
-// of 4 waves that share at most 4 staged 64-input blocks (hard part 2).
-//   * off-diagonal 128x128 squares: 4 tiles, 4 blocks
-//   * diagonal pairs: 3 tiles (+1 tile of the unpaired last block row when nblk64 is odd)
-//   * what is left of the last block row is packed 3-4 tiles per work-group
-// 704 inputs -> 11 blocks -> 66 tiles in 17 work-groups (97 % of wave slots busy).
-// --------------------------------------------------------------------------------------
-static std::vector<WgDesc> build_wg_descs(int nblk64) {
-    std::vector<WgDesc> out;
-    auto blank = []() {
-        WgDesc d;
-        memset(&d, 0, sizeof(d));
-        for (int w = 0; w < 4; w++) d.wave_a[w] = d.wave_b[w] = 0xFF;
-        return d;
-    };
-    auto finish = [&](WgDesc d, int nslot) {
-        for (int s = nslot; s < XC_NSLOT; s++) d.slot_blk[s] = d.slot_blk[0];  // harmless duplicate loads
-        out.push_back(d);
-    };
-    const int np = nblk64 / 2;
-    const int L = (nblk64 & 1) ? nblk64 - 1 : -1;
-    std::vector<int> left;  // column blocks j of the remaining tiles (L, j)
-    if (L >= 0)
-        for (int j = 0; j <= L; j++) left.push_back(j);
-    for (int k = 1; k < np; k++)
-        for (int m = 0; m < k; m++) {
-            WgDesc d = blank();
-            d.slot_blk[0] = 2 * k; d.slot_blk[1] = 2 * k + 1; d.slot_blk[2] = 2 * m; d.slot_blk[3] = 2 * m + 1;
-            const uint8_t wa[4] = {0, 0, 1, 1}, wb[4] = {2, 3, 2, 3};
-            for (int w = 0; w < 4; w++) { d.wave_a[w] = wa[w]; d.wave_b[w] = wb[w]; }
-            d.nwave = 4;
-            finish(d, 4);
-        }
-    for (int k = 0; k < np; k++) {
-        WgDesc d = blank();
-        d.slot_blk[0] = 2 * k; d.slot_blk[1] = 2 * k + 1;
-        d.wave_a[0] = 0; d.wave_b[0] = 0;
-        d.wave_a[1] = 1; d.wave_b[1] = 0;
-        d.wave_a[2] = 1; d.wave_b[2] = 1;
-        d.nwave = 3;
-        int nslot = 2;
-        auto it = std::find(left.begin(), left.end(), 2 * k);
-        if (it != left.end()) {
-            left.erase(it);
-            d.slot_blk[2] = (uint8_t)L; nslot = 3;
-            d.wave_a[3] = 2; d.wave_b[3] = 0;
-            d.nwave = 4;
-        }
-        finish(d, nslot);
-    }
-    while (!left.empty()) {
-        WgDesc d = blank();
-        d.slot_blk[0] = (uint8_t)L;
-        int nslot = 1, nw = 0;
-        for (size_t q = 0; q < left.size() && nw < 4;) {
-            const int j = left[q];
-            int slot = -1;
-            if (j == L) slot = 0;
-            else if (nslot < XC_NSLOT) { slot = nslot; d.slot_blk[nslot++] = (uint8_t)j; }
-            if (slot < 0) { q++; continue; }
-            d.wave_a[nw] = 0; d.wave_b[nw] = (uint8_t)slot; nw++;
-            left.erase(left.begin() + q);
-        }
-        d.nwave = (uint8_t)nw;
-        finish(d, nslot);
-    }
-    return out;
-}
-
-// --------------------------------------------------------------------------------------
-// Work lists of the persistent fused kernel (WorkEntry[grid][maxi], xcorr_kernels.h).
-// Work-groups b with the same b & 7 sit on one XCD and share that XCD's items (channels = xcd mod 8), dealt
-// round-robin so that concurrent work-groups contract neighbouring tile groups of the same channels.  With
-// n items for W work-groups every work-group gets n / W whole items and the first n % W one more
-// (704 inputs x 96 channels on 256 CUs: 204 items per XCD for 32 work-groups = 7 items for 12 of them, 6 for
-// 20; the next launch's work-groups take over the CUs of the latter).  Opt-in (XENG_SPLITK=1): the left-over
-// items are cut along K into W slices in all, one per work-group, with an ordered read-modify-write hand-over
-// between the slices of an item -- balanced, but not faster (see xengXgpuInitialize).
-// --------------------------------------------------------------------------------------
-struct WorkList {
-    std::vector<WorkEntry> entries;
-    int maxi = 0, nchains = 0;
-    uint32_t* dev = nullptr;
-};
-
-static WorkList build_work(int grid, int nchan, int nwg, int nstage, bool splitk) {
-    WorkList wl;
-    const bool xcd_map = (nchan & 7) == 0 && (grid & 7) == 0;
-    const int ngroup = xcd_map ? 8 : 1;
-    const int W = grid / ngroup;
-    const int n = xcd_map ? (nchan / 8) * nwg : nchan * nwg;
-    const int f = n / W, r = n % W;
-    wl.maxi = f + (r ? 1 : 0);
-    wl.entries.assign((size_t)grid * wl.maxi, WorkEntry{0, 0, 0, 0});
-    // (only per-XCD lists are split: the slices of an item exchange partial sums through one XCD's L2)
-    const bool split = splitk && xcd_map && r > 0 && nstage >= (W + r - 1) / r;
-    wl.nchains = split ? ngroup * r : 0;
-    auto put = [&](int b, int k, int x, int idx, int stage0, int nst, int slice, int nslices, int chain) {
-        const int q = idx / nwg, wg = idx - q * nwg;
-        const int c = xcd_map ? x + 8 * q : q;
-        WorkEntry& e = wl.entries[(size_t)b * wl.maxi + k];
-        e.c_wg = (uint32_t)c | ((uint32_t)wg << 16);
-        e.stages = (uint32_t)stage0 | ((uint32_t)nst << 16);
-        e.slice = (uint32_t)slice | ((uint32_t)nslices << 8) | (1u << 16);
-        e.chain = (uint32_t)chain;
-    };
-    for (int x = 0; x < ngroup; x++) {
-        auto block_of = [&](int j) { return xcd_map ? j * 8 + x : j; };
-        for (int j = 0; j < W; j++)
-            for (int k = 0; k < f; k++) put(block_of(j), k, x, j + k * W, 0, nstage, 0, 1, 0);
-        if (!r) continue;
-        if (!split) {
-            for (int i = 0; i < r; i++) put(block_of(i), f, x, f * W + i, 0, nstage, 0, 1, 0);
-            continue;
-        }
-        int j = 0;
-        for (int i = 0; i < r; i++) {
-            const int ns = W / r + (i < W % r ? 1 : 0);
-            for (int sl = 0; sl < ns; sl++, j++) {
-                const int s0 = (int)((int64_t)sl * nstage / ns), s1 = (int)((int64_t)(sl + 1) * nstage / ns);
-                put(block_of(j), f, x, f * W + i, s0, s1 - s0, sl, ns, x * r + i);
-            }
-        }
-    }
-    return wl;
-}
-
 struct XgpuConfig {
     int nstand = 352, npol = 2, nchan = 96, ntime_gulp = 480, max_gulps = 0;
 };
@@ -206,9 +78,9 @@ static std::mutex g_mu;
 static XgpuConfig g_cfg;
 static XgpuContext g_ctx;
 
+// frees whatever the context holds -- also the partial state of an Initialize that failed half way (x.live false)
 static int destroy_locked() {
     XgpuContext& x = g_ctx;
-    if (!x.live) return XENG_STATUS_SUCCESS;
     (void)hipSetDevice(x.gpu);
     if (x.stream) (void)hipStreamSynchronize(x.stream);
     for (int b = 0; b < XgpuContext::NMM; b++) {
@@ -237,12 +109,6 @@ static int destroy_locked() {
 template <int ABL>
 static void launch_abl(const XcorrParams& p, hipStream_t s) {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_mfma_kernel<ABL>), dim3(p.nchan * p.nwg), dim3(256), 0, s, p);
-}
-// persistent grid of the fused kernel: one work-group per CU, a multiple of 8 when channels are dealt per XCD
-static int fused_grid(int nchan, int nwg, int ncu) {
-    const int nitems = nchan * nwg;
-    if ((nchan & 7) == 0 && ncu >= 8) return 8 * std::min(ncu / 8, (nchan / 8) * nwg);
-    return std::min(ncu, nitems);
 }
 static void launch_xcorr(const XcorrParams& p, hipStream_t s, bool raw, int ncu) {
     if (raw) {
@@ -359,7 +225,25 @@ static int flush_locked(void* out, bool dump) {
     return XENG_STATUS_SUCCESS;
 }
 
-static int kernel_locked(const void* in_dev, void* out_dev, int doDump, bool sync) {
+// What a call still has to wait for after it has released the context lock: the staging stream (the caller's
+// input has been copied / corner-turned) and, for a dump, the completion event of that dump.
+struct PendingWait {
+    int gpu = 0;
+    hipStream_t staging = nullptr;
+    hipEvent_t dump = nullptr;
+};
+
+// Waits happen OUTSIDE g_mu (the other blocks' calls -- SubSelect, Packetize, GetOrder -- must not stall for a whole
+// contraction: lwa352-pipeline.py:232-262 runs them on their own threads); the lock is retaken only to fold finished
+// timing events into the profile.
+static int wait_unlocked(const PendingWait& w) {
+    XENG_HIP(hipSetDevice(w.gpu));
+    if (w.staging) XENG_HIP(hipStreamSynchronize(w.staging));
+    if (w.dump) XENG_HIP(hipEventSynchronize(w.dump));
+    return XENG_STATUS_SUCCESS;
+}
+
+static int kernel_locked(const void* in_dev, void* out_dev, int doDump, bool sync, PendingWait* pw) {
     XgpuContext& x = g_ctx;
     if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized (call xengXgpuInitialize)");
     if (!in_dev || !out_dev) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "xgpu: null buffer");
@@ -409,13 +293,11 @@ static int kernel_locked(const void* in_dev, void* out_dev, int doDump, bool syn
     } else if (x.acc_started && x.acc_out != out_dev) {
         XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: output buffer changed inside one integration");
     }
-    if (sync) {
-        // input consumed = its corner turn is done; on a dump the output must be complete too
-        XENG_HIP(hipStreamSynchronize(x.stream));
-        if (doDump) {
-            for (int t = 0; t < x.nmm; t++) XENG_HIP(hipStreamSynchronize(x.stream_mm2[t]));
-            x.timer.drain();
-        }
+    if (sync && pw) {
+        // input consumed = its copy / corner turn is done; on a dump the output must be complete too
+        pw->gpu = x.gpu;
+        pw->staging = x.stream;
+        if (doDump) pw->dump = x.ev_dump[(x.ndump - 1) & 3];      // contractions that touch one span are ordered
     }
     return XENG_STATUS_SUCCESS;
 }
@@ -438,9 +320,17 @@ int xengXgpuConfigure(int nstand, int npol, int nchan, int ntime_gulp, int max_g
     return XENG_STATUS_SUCCESS;
 }
 
+static int initialize_locked(int gpu);
+
 int xengXgpuInitialize(int gpu) {
     std::lock_guard<std::mutex> lk(g_mu);
     destroy_locked();
+    const int rc = initialize_locked(gpu);
+    if (rc) destroy_locked();          // (keeps the error message: destroy does not touch it)
+    return rc;
+}
+
+static int initialize_locked(int gpu) {
     XgpuContext& x = g_ctx;
     x.cfg = g_cfg;
     x.gpu = gpu < 0 ? 0 : gpu;
@@ -516,12 +406,12 @@ int xengXgpuInitialize(int gpu) {
     XENG_HIP(hipMemcpy(x.descs_dev, descs.data(), descs.size() * sizeof(WgDesc), hipMemcpyHostToDevice));
     int rc = get_stream(STREAM_XGPU, &x.stream);
     if (rc) return rc;
-    for (int t = 0; t < XgpuContext::NMM; t++) {
+    if (const char* e = getenv("XENG_MM_STREAMS")) x.nmm = std::max(1, std::min(XgpuContext::NMM, atoi(e)));   // experiment
+    for (int t = 0; t < x.nmm; t++) {      // (only the streams in use: every stream takes a share of a hardware queue)
         rc = get_stream((StreamId)(STREAM_XGPU_MM + t), &x.stream_mm2[t]);
         if (rc) return rc;
         XENG_HIP(hipEventCreateWithFlags(&x.ev_last[t], hipEventDisableTiming));
     }
-    if (const char* e = getenv("XENG_MM_STREAMS")) x.nmm = std::max(1, std::min(XgpuContext::NMM, atoi(e)));   // experiment
     x.stream_mm = x.stream_mm2[0];
     if (getenv("XENG_DBG_STAMPS")) {
         XENG_HIP(hipMalloc((void**)&x.stamps, (size_t)x.cfg.nchan * x.nwg * 4 * 8 * sizeof(unsigned long long)));
@@ -536,36 +426,59 @@ int xengXgpuDestroy(void) {
     return destroy_locked();
 }
 
-int xengXgpuKernel(const void* in_dev, void* out_dev, int doDump) {
+static void drain_timer() {
     std::lock_guard<std::mutex> lk(g_mu);
-    return kernel_locked(in_dev, out_dev, doDump, true);
+    if (g_ctx.live) g_ctx.timer.drain();
+}
+
+int xengXgpuKernel(const void* in_dev, void* out_dev, int doDump) {
+    PendingWait pw;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        int rc = kernel_locked(in_dev, out_dev, doDump, true, &pw);
+        if (rc) return rc;
+    }
+    int rc = wait_unlocked(pw);
+    if (rc) return rc;
+    if (doDump) drain_timer();
+    return XENG_STATUS_SUCCESS;
 }
 
 int xengXgpuKernelAsync(const void* in_dev, void* out_dev, int doDump) {
     std::lock_guard<std::mutex> lk(g_mu);
-    return kernel_locked(in_dev, out_dev, doDump, false);
+    return kernel_locked(in_dev, out_dev, doDump, false, nullptr);
 }
 
 int xengXgpuSync(void) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    XgpuContext& x = g_ctx;
-    if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized");
-    XENG_HIP(hipSetDevice(x.gpu));
-    XENG_HIP(hipStreamSynchronize(x.stream));
-    for (int t = 0; t < x.nmm; t++) XENG_HIP(hipStreamSynchronize(x.stream_mm2[t]));
-    x.timer.drain();
+    int gpu, nmm;
+    hipStream_t st, mm[XgpuContext::NMM];
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        XgpuContext& x = g_ctx;
+        if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized");
+        gpu = x.gpu; nmm = x.nmm; st = x.stream;
+        for (int t = 0; t < nmm; t++) mm[t] = x.stream_mm2[t];
+    }
+    XENG_HIP(hipSetDevice(gpu));
+    XENG_HIP(hipStreamSynchronize(st));
+    for (int t = 0; t < nmm; t++) XENG_HIP(hipStreamSynchronize(mm[t]));
+    drain_timer();
     return XENG_STATUS_SUCCESS;
 }
 
 int xengXgpuSyncLag(int lag) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    XgpuContext& x = g_ctx;
-    if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized");
-    if (lag < 0 || lag > 3) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "SyncLag: lag must be 0..3 (got %d)", lag);
-    XENG_HIP(hipSetDevice(x.gpu));
-    if (x.ndump > (unsigned long long)lag)
-        XENG_HIP(hipEventSynchronize(x.ev_dump[(x.ndump - 1 - lag) & 3]));
-    x.timer.drain();
+    PendingWait pw;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        XgpuContext& x = g_ctx;
+        if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized");
+        if (lag < 0 || lag > 3) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "SyncLag: lag must be 0..3 (got %d)", lag);
+        pw.gpu = x.gpu;
+        if (x.ndump > (unsigned long long)lag) pw.dump = x.ev_dump[(x.ndump - 1 - lag) & 3];
+    }
+    int rc = wait_unlocked(pw);
+    if (rc) return rc;
+    drain_timer();
     return XENG_STATUS_SUCCESS;
 }
 
@@ -594,22 +507,17 @@ int xengXgpuCorrelate(const void* in_host, void* out_host, int doDump) {
     if (!x.in_dev) XENG_HIP(hipMalloc((void**)&x.in_dev, in_bytes));
     if (!x.out_dev) XENG_HIP(hipMalloc((void**)&x.out_dev, out_bytes));
     XENG_HIP(hipMemcpyAsync(x.in_dev, in_host, in_bytes, hipMemcpyHostToDevice, x.stream));
-    int rc = kernel_locked(x.in_dev, x.out_dev, doDump, true);
+    PendingWait pw;
+    int rc = kernel_locked(x.in_dev, x.out_dev, doDump, true, &pw);
+    if (rc) return rc;
+    // (host-buffer convenience path of xgpu_test.py:86-89, one caller: the waits stay under the lock)
+    rc = wait_unlocked(pw);
     if (rc) return rc;
     if (doDump) {
-        XENG_HIP(hipMemcpyAsync(out_host, x.out_dev, out_bytes, hipMemcpyDeviceToHost, x.stream_mm));
-        for (int t = 0; t < x.nmm; t++) XENG_HIP(hipStreamSynchronize(x.stream_mm2[t]));
+        XENG_HIP(hipMemcpyAsync(out_host, x.out_dev, out_bytes, hipMemcpyDeviceToHost, x.stream));
+        XENG_HIP(hipStreamSynchronize(x.stream));
     }
     return XENG_STATUS_SUCCESS;
-}
-
-static inline int64_t regtile_index_host(int in0, int in1, int nstand) {
-    // corr_block.py:37-58
-    const int a0 = in0 >> 1, a1 = in1 >> 1, p0 = in0 & 1, p1 = in1 & 1;
-    const int64_t qi = ((int64_t)(a1 / 2) * (a1 / 2 + 1)) / 2 + a0 / 2;
-    const int64_t quadrant = 2 * (a0 & 1) + (a1 & 1);
-    const int64_t qs = ((int64_t)(nstand / 2 + 1) * nstand) / 4;
-    return (quadrant * qs + qi) * 4 + 2 * p1 + p0;
 }
 
 int xengXgpuGetOrder(const int32_t* antpol_to_input, int32_t* antpol_to_bl, int32_t* is_conj) {
@@ -619,62 +527,83 @@ int xengXgpuGetOrder(const int32_t* antpol_to_input, int32_t* antpol_to_bl, int3
         cfg = g_ctx.live ? g_ctx.cfg : g_cfg;
     }
     if (!antpol_to_input || !antpol_to_bl || !is_conj) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "GetOrder: null array");
-    const int ns = cfg.nstand, np = cfg.npol, ninput = ns * np;
-    for (int k = 0; k < ninput; k++)
-        if (antpol_to_input[k] < 0 || antpol_to_input[k] >= ninput)
-            XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "GetOrder: input id %d out of range at [%d]", antpol_to_input[k], k);
-    for (int s0 = 0; s0 < ns; s0++)
-        for (int s1 = 0; s1 < ns; s1++)
-            for (int p0 = 0; p0 < np; p0++)
-                for (int p1 = 0; p1 < np; p1++) {
-                    const int i0 = antpol_to_input[s0 * np + p0], i1 = antpol_to_input[s1 * np + p1];
-                    const size_t k = (((size_t)s0 * ns + s1) * np + p0) * np + p1;
-                    // stored word at regtile_index(lo,hi) is conj(x[lo])*x[hi] (xgpu_test.py:111-131);
-                    // the consumer wants x[s0,p0]*conj(x[s1,p1]) (corr_output_full_block.py:582-591)
-                    if (i1 >= i0) { antpol_to_bl[k] = (int32_t)regtile_index_host(i0, i1, ns); is_conj[k] = 1; }
-                    else          { antpol_to_bl[k] = (int32_t)regtile_index_host(i1, i0, ns); is_conj[k] = 0; }
-                }
+    const int bad = get_order_host(antpol_to_input, antpol_to_bl, is_conj, cfg.nstand, cfg.npol);
+    if (bad >= 0) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "GetOrder: input id %d out of range at [%d]", antpol_to_input[bad], bad);
+    return XENG_STATUS_SUCCESS;
+}
+
+// The consumers of a visibility span (CorrSubsel, CorrOutputFull: their own threads in the reference,
+// lwa352-pipeline.py:232-262) run on a stream of their own, ordered behind the contraction that produced the span
+// by its completion event -- not by the X-engine's context lock, and they wait for their own kernel only.
+static std::mutex g_consumer_mu;          // serialises the consumers among themselves (one stream, one event)
+static hipEvent_t g_consumer_ev = nullptr;
+
+// under g_mu: make `s` wait for every enqueued contraction that writes `span`
+static int order_after_producers(hipStream_t s, const void* span) {
+    XgpuContext& x = g_ctx;
+    for (int t = 0; t < x.nmm; t++)
+        if (x.mm_used[t] && x.last_out[t] == span) XENG_HIP(hipStreamWaitEvent(s, x.ev_last[t], 0));
     return XENG_STATUS_SUCCESS;
 }
 
 int xengXgpuSubSelect(const void* in_dev, void* out_dev, const int32_t* vismap_dev, const int32_t* conj_dev,
                       int nvis, int nchan_sum) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    XgpuContext& x = g_ctx;
-    if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized");
-    if (!in_dev || !out_dev || !vismap_dev || !conj_dev) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "SubSelect: null buffer");
-    if (nvis <= 0 || nchan_sum <= 0 || x.cfg.nchan % nchan_sum)
-        XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "SubSelect: nvis=%d nchan_sum=%d nchan=%d", nvis, nchan_sum, x.cfg.nchan);
-    XENG_HIP(hipSetDevice(x.gpu));
-    hipLaunchKernelGGL(subselect_kernel, dim3((nvis + 255) / 256, x.cfg.nchan / nchan_sum), dim3(256), 0, x.stream_mm,
-                       (const int32_t*)in_dev, (int32_t*)out_dev, vismap_dev, conj_dev, nvis, nchan_sum,
-                       x.per_chan, x.matlen);
-    XENG_HIP(hipGetLastError());
-    for (int t = 0; t < x.nmm; t++) XENG_HIP(hipStreamSynchronize(x.stream_mm2[t]));
+    std::lock_guard<std::mutex> clk(g_consumer_mu);
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        XgpuContext& x = g_ctx;
+        if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized");
+        if (!in_dev || !out_dev || !vismap_dev || !conj_dev) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "SubSelect: null buffer");
+        if (nvis <= 0 || nchan_sum <= 0 || x.cfg.nchan % nchan_sum)
+            XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "SubSelect: nvis=%d nchan_sum=%d nchan=%d", nvis, nchan_sum, x.cfg.nchan);
+        XENG_HIP(hipSetDevice(x.gpu));
+        hipStream_t s;
+        int rc = get_stream(STREAM_CONSUMER, &s);
+        if (rc) return rc;
+        if (!g_consumer_ev) XENG_HIP(hipEventCreateWithFlags(&g_consumer_ev, hipEventDisableTiming));
+        rc = order_after_producers(s, in_dev);
+        if (rc) return rc;
+        hipLaunchKernelGGL(subselect_kernel, dim3((nvis + 255) / 256, x.cfg.nchan / nchan_sum), dim3(256), 0, s,
+                           (const int32_t*)in_dev, (int32_t*)out_dev, vismap_dev, conj_dev, nvis, nchan_sum,
+                           x.per_chan, x.matlen);
+        XENG_HIP(hipGetLastError());
+        XENG_HIP(hipEventRecord(g_consumer_ev, s));
+    }
+    XENG_HIP(hipEventSynchronize(g_consumer_ev));
     return XENG_STATUS_SUCCESS;
 }
 
 int xengXgpuPacketize(const void* in_dev, void* out_dev, const int32_t* antpol_to_bl_dev, const int32_t* is_conj_dev,
                       int fmt) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    XgpuContext& x = g_ctx;
-    if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized");
-    if (!in_dev || !out_dev || !antpol_to_bl_dev || !is_conj_dev) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Packetize: null buffer");
-    if (fmt != 0 && fmt != 1) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Packetize: fmt must be 0 ([pol][pol][chan][2]) or 1 ([chan][pol][pol][2])");
-    if ((uintptr_t)out_dev & 7) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Packetize: out must be 8-byte aligned");
-    // LDS row pitch (int2 units): >= nchan and 1 mod 32, i.e. 2 mod 64 dwords: the 64 rows of phase A fall on distinct banks
-    int pitch = x.cfg.nchan;
-    while ((pitch & 31) != 1) pitch++;
-    const size_t lds = (size_t)64 * pitch * sizeof(int2);
-    if (lds > 160 * 1024) XENG_FAIL(XENG_STATUS_UNSUPPORTED, "Packetize: nchan=%d needs %zu B of LDS", x.cfg.nchan, lds);
-    XENG_HIP(hipSetDevice(x.gpu));
-    if (lds > 64 * 1024)
-        XENG_HIP(hipFuncSetAttribute((const void*)packetize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(packetize_kernel, dim3(x.cfg.nstand, (x.cfg.nstand + 15) / 16), dim3(256), lds, x.stream_mm,
-                       (const int32_t*)in_dev, (int2*)out_dev, antpol_to_bl_dev, is_conj_dev, x.cfg.nstand, x.cfg.nchan,
-                       x.per_chan, x.matlen, pitch, fmt);
-    XENG_HIP(hipGetLastError());
-    XENG_HIP(hipStreamSynchronize(x.stream_mm));
+    std::lock_guard<std::mutex> clk(g_consumer_mu);
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        XgpuContext& x = g_ctx;
+        if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized");
+        if (!in_dev || !out_dev || !antpol_to_bl_dev || !is_conj_dev) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Packetize: null buffer");
+        if (fmt != 0 && fmt != 1) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Packetize: fmt must be 0 ([pol][pol][chan][2]) or 1 ([chan][pol][pol][2])");
+        if ((uintptr_t)out_dev & 7) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Packetize: out must be 8-byte aligned");
+        // LDS row pitch (int2 units): >= nchan and 1 mod 32, i.e. 2 mod 64 dwords: the 64 rows of phase A fall on distinct banks
+        int pitch = x.cfg.nchan;
+        while ((pitch & 31) != 1) pitch++;
+        const size_t lds = (size_t)64 * pitch * sizeof(int2);
+        if (lds > 160 * 1024) XENG_FAIL(XENG_STATUS_UNSUPPORTED, "Packetize: nchan=%d needs %zu B of LDS", x.cfg.nchan, lds);
+        XENG_HIP(hipSetDevice(x.gpu));
+        if (lds > 64 * 1024)
+            XENG_HIP(hipFuncSetAttribute((const void*)packetize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipStream_t s;
+        int rc = get_stream(STREAM_CONSUMER, &s);
+        if (rc) return rc;
+        if (!g_consumer_ev) XENG_HIP(hipEventCreateWithFlags(&g_consumer_ev, hipEventDisableTiming));
+        rc = order_after_producers(s, in_dev);
+        if (rc) return rc;
+        hipLaunchKernelGGL(packetize_kernel, dim3(x.cfg.nstand, (x.cfg.nstand + 15) / 16), dim3(256), lds, s,
+                           (const int32_t*)in_dev, (int2*)out_dev, antpol_to_bl_dev, is_conj_dev, x.cfg.nstand, x.cfg.nchan,
+                           x.per_chan, x.matlen, pitch, fmt);
+        XENG_HIP(hipGetLastError());
+        XENG_HIP(hipEventRecord(g_consumer_ev, s));
+    }
+    XENG_HIP(hipEventSynchronize(g_consumer_ev));
     return XENG_STATUS_SUCCESS;
 }
 
@@ -687,18 +616,9 @@ int xengXgpuReorder(const void* in_host, void* out_host, const int32_t* bl, cons
     if (!in_host || !out_host || !bl || !conj) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Reorder: null buffer");
     const int64_t per_chan = (int64_t)(cfg.nstand / 2 + 1) * (cfg.nstand / 4) * cfg.npol * cfg.npol * 4;
     const int64_t matlen = per_chan * cfg.nchan;
-    const int32_t* xg = (const int32_t*)in_host;
-    int32_t* out = (int32_t*)out_host;
     const size_t nbl = (size_t)cfg.nstand * cfg.nstand * cfg.npol * cfg.npol;
-    for (size_t k = 0; k < nbl; k++) {
-        if (bl[k] < 0 || bl[k] >= per_chan) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Reorder: baseline index %d out of range", bl[k]);
-        int32_t* o = out + k * cfg.nchan * 2;
-        for (int c = 0; c < cfg.nchan; c++) {
-            const int64_t w = (int64_t)c * per_chan + bl[k];
-            o[2 * c] = xg[w];
-            o[2 * c + 1] = conj[k] ? -xg[matlen + w] : xg[matlen + w];
-        }
-    }
+    const long bad = reorder_host((const int32_t*)in_host, (int32_t*)out_host, bl, conj, nbl, cfg.nchan, per_chan, matlen);
+    if (bad >= 0) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Reorder: baseline index %d out of range", bl[bad]);
     return XENG_STATUS_SUCCESS;
 }
 

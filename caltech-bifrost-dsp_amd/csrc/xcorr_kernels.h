@@ -36,6 +36,8 @@
 #include <stdint.h>
 #include <type_traits>
 
+#include "xcorr_tiling.h"
+
 namespace xeng {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -46,17 +48,6 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 constexpr int FRAG_BYTES = 1024;          // one 32-input x 32-sample fragment
 constexpr int KT_BYTES = 2 * FRAG_BYTES;  // one 64-input block x 32 samples
 constexpr int XC_NBUF = 3;                // LDS ring depth
-constexpr int XC_NSLOT = 4;               // 64-input blocks resident per stage
-
-// Work-group descriptor: which 64-input blocks a work-group stages (one per wave),
-// and which (row block, col block) tile each of its 4 waves contracts.
-struct WgDesc {
-    uint8_t slot_blk[XC_NSLOT];  // 64-input block loaded by wave w into LDS slot w
-    uint8_t wave_a[4];           // LDS slot of the wave's row block (0xFF: wave idle)
-    uint8_t wave_b[4];           // LDS slot of the wave's column block
-    uint8_t nwave;
-    uint8_t pad[3];
-};
 
 // ---------------------------------------------------------------------------------------
 // stage 1: corner turn (time-major 4+4 bit -> fragment-major stash)
@@ -206,17 +197,6 @@ struct XcorrParams {
     int maxi;
     uint32_t* flags;
     uint32_t epoch;
-};
-
-// One entry of a work-group's list: a (channel, tile group) item, or one K slice of it.  Whole items cover all
-// stages; the items left over after dealing whole items evenly are cut along K into slices, one per work-group,
-// so that every work-group of a launch contracts (almost) the same number of stages.  Slice j > 0 adds to what
-// slice j-1 stored: it waits for flags[chain] >= epoch*16 + j before its read-modify-write.
-struct WorkEntry {
-    uint32_t c_wg;        // channel | tile group << 16
-    uint32_t stages;      // first stage | number of stages << 16
-    uint32_t slice;       // slice index | slices of the item << 8 | valid << 16
-    uint32_t chain;       // flag index of a split item
 };
 
 struct Frags {   // the 8 unpacked int8 operand fragments of one 64x64 wave tile and one K-tile

@@ -31,7 +31,7 @@ void set_error(const char* fmt, ...);
 // Streams owned by the library on the current device: one per block thread of the
 // reference pipeline (Corr, CorrAcc map, Beamform, copies) so they overlap
 // (lwa352-pipeline.py:296-302 runs one thread per block on the same GPU).
-enum StreamId { STREAM_XGPU = 0, STREAM_MAP = 1, STREAM_BEAM = 2, STREAM_COPY = 3, STREAM_XGPU_MM = 4, STREAM_XGPU_MM2 = 5, STREAM_XGPU_MM3 = 6, STREAM_XGPU_MM4 = 7, STREAM_COUNT = 8 };
+enum StreamId { STREAM_XGPU = 0, STREAM_MAP = 1, STREAM_BEAM = 2, STREAM_COPY = 3, STREAM_XGPU_MM = 4, STREAM_XGPU_MM2 = 5, STREAM_XGPU_MM3 = 6, STREAM_XGPU_MM4 = 7, STREAM_CONSUMER = 8, STREAM_COUNT = 9 };
 int get_stream(StreamId which, hipStream_t* out);   // lazily created per device
 int sync_all_streams();
 

@@ -28,7 +28,15 @@ int get_stream(StreamId which, hipStream_t* out) {
     if (dev < 0 || dev >= MAXDEV) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "device %d out of range", dev);
     std::lock_guard<std::mutex> lk(g_stream_mu);
     if (!g_stream_ok[dev][which]) {
-        XENG_HIP(hipStreamCreateWithFlags(&g_streams[dev][which], hipStreamNonBlocking));
+        // HIP multiplexes its streams onto a few hardware queues per priority class (4 by default); streams that share
+        // a hardware queue run in order, so a short kernel of one block would wait behind every queued contraction of
+        // another.  Two classes keep them apart: the long-running X-engine work (staging, contractions, bulk copies)
+        // at normal priority -- at most four such streams exist -- and the short kernels of the other blocks (CorrAcc
+        // map, beamformer, span consumers) at high priority.
+        int lo = 0, hi = 0;
+        XENG_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));       // numerically lower = higher priority
+        const bool high = which == STREAM_MAP || which == STREAM_BEAM || which == STREAM_CONSUMER;
+        XENG_HIP(hipStreamCreateWithPriority(&g_streams[dev][which], hipStreamNonBlocking, high ? hi : 0 < lo ? 0 : lo));
         g_stream_ok[dev][which] = true;
     }
     *out = g_streams[dev][which];

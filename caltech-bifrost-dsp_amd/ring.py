@@ -17,11 +17,38 @@ held as committed spans in the ring's space ('system' = numpy memory, so config 
 GPU; 'cuda' / 'cuda_host' = HIP allocations through libxeng).  Readers that ask for
 `guarantee=True` apply back-pressure once `total_span` bytes are outstanding.
 """
+import collections
 import threading
+import weakref
 
 import numpy as np
 
-from .ndarray import XArray, copy_array, to_dtype
+from . import ffi
+from .ndarray import XArray, copy_array, to_dtype, _SPACE_ID
+
+
+class _PooledBuffer:
+    """Owner of one span allocation in a device / pinned space.  When the last array that references it goes away
+    the allocation returns to its ring's free list instead of hipFree (which synchronises the whole device and
+    would stall the other blocks' streams: Corr alone turns over a 191 MB span per integration)."""
+
+    def __init__(self, ring, buf):
+        self._ring = weakref.ref(ring)
+        self.buf = buf
+        self.ptr = buf.ptr
+        self.nbytes = buf.nbytes
+
+    def __del__(self):
+        ring = self._ring()
+        buf, self.buf = self.buf, None
+        if buf is None:
+            return
+        try:
+            if ring is not None and ring._pool_put(buf):
+                return
+            buf.free()
+        except Exception:          # interpreter shutdown: the process is going away with its allocations
+            pass
 
 
 class _Header(bytes):
@@ -46,7 +73,7 @@ class _Sequence:
         self.ring, self.index = ring, index
         self.time_tag, self.nringlet = time_tag, nringlet
         self.header = _Header(header.encode() if isinstance(header, str) else bytes(header))
-        self.chunks = []          # committed spans, in order
+        self.chunks = collections.deque()     # committed spans still held, in order
         self.committed = 0        # bytes committed so far
         self.ended = False
 
@@ -60,6 +87,14 @@ class WriteSequence:
 
     def reserve(self, nbytes, nonblocking=False):
         return WriteSpan(self.ring, nbytes, nonblocking=nonblocking, _seq=self._seq)
+
+    def commit_external(self, data):
+        """Publish an existing array of the ring's space as the next span without copying it (a replay source:
+        DummySource's test-file mode, dummy_source_block.py:207-222, re-sends the same gulps over and over).  The
+        caller keeps the array unchanged while readers may still hold it."""
+        assert data.space == self.ring.space, (data.space, self.ring.space)
+        self.ring._wait_for_room(data.nbytes, False)
+        self.ring._commit(self._seq, data.view(np.uint8), data.nbytes)
 
     def end(self):
         self.ring._end_sequence(self._seq)
@@ -83,7 +118,7 @@ class WriteSpan:
             raise RuntimeError("WriteSpan: no open sequence on ring %r" % ring.name)
         self.size = int(nbytes)
         ring._wait_for_room(self.size, nonblocking)
-        self.data = XArray(shape=(self.size,), dtype=np.uint8, space=ring.space)
+        self.data = ring._alloc_span(self.size)
         self._closed = False
 
     def data_view(self, dtype=np.uint8, shape=None):
@@ -186,6 +221,37 @@ class Ring:
         self._readers = []
         self._capacity = 0
         self._live_bytes = 0
+        self._gc_seq = 0           # sequences before this index hold no data any more
+        self._pool = {}            # nbytes -> [free allocations] (device / pinned spaces)
+        self._pool_bytes = 0
+        self._pool_lock = threading.Lock()
+
+    # ------------------------------------------------------------------ span memory
+    def _alloc_span(self, nbytes):
+        """Span memory in the ring's space.  'system': fresh zeroed numpy memory.  Device / pinned spaces: recycled
+        from the ring's free list when a span of that size has been released (contents then are whatever the last
+        user left, as in a circular bifrost ring); a first-time allocation is zero-filled."""
+        if self.space == "system":
+            return XArray(shape=(nbytes,), dtype=np.uint8, space="system")
+        with self._pool_lock:
+            lst = self._pool.get(nbytes)
+            buf = lst.pop() if lst else None
+            if buf is not None:
+                self._pool_bytes -= nbytes
+        if buf is None:
+            buf = ffi.DeviceBuffer(max(nbytes, 1), _SPACE_ID[self.space])
+            ffi.call("xengMemset", buf.ptr, 0, max(nbytes, 1))
+        owner = _PooledBuffer(self, buf)
+        return XArray(shape=(nbytes,), dtype=np.uint8, space=self.space, _ptr=buf.ptr, _base=owner)
+
+    def _pool_put(self, buf):
+        """Keep a released allocation for reuse (up to the ring's capacity in bytes); False = caller frees it."""
+        with self._pool_lock:
+            if self._pool_bytes + buf.nbytes > max(self._capacity, 2 * buf.nbytes):
+                return False
+            self._pool.setdefault(buf.nbytes, []).append(buf)
+            self._pool_bytes += buf.nbytes
+        return True
 
     # ------------------------------------------------------------------ writer side
     def resize(self, contig_bytes, total_span=None, nringlet=1):
@@ -245,38 +311,45 @@ class Ring:
 
     # ------------------------------------------------------------------ bookkeeping (hold _cond)
     def _gc(self):
-        """Free committed spans every registered reader has moved past."""
+        """Free committed spans every registered reader has moved past.  Released chunks leave the head of their
+        sequence's list, so the cost per call is the number of chunks released, not the length of the sequence."""
         if not self._readers:
             return
         lo_seq = min(r.seq_index for r in self._readers)
-        for seq in self._seqs[:lo_seq + 1]:
+        for seq in self._seqs[self._gc_seq:lo_seq + 1]:
             lo_off = None
             if seq.index == lo_seq:
                 lo_off = min(r.offset for r in self._readers if r.seq_index == lo_seq)
-            for ch in seq.chunks:
-                if ch.data is not None and (lo_off is None or ch.offset + ch.nbytes <= lo_off):
-                    ch.data = None
-                    self._live_bytes -= ch.nbytes
+            ch = seq.chunks
+            while ch and (lo_off is None or ch[0].offset + ch[0].nbytes <= lo_off):
+                c = ch.popleft()
+                if c.data is not None:
+                    c.data = None
+                    self._live_bytes -= c.nbytes
+        self._gc_seq = max(self._gc_seq, lo_seq)      # sequences before the slowest reader are empty for good
 
     def _drop_oldest(self):
-        for seq in self._seqs:
-            for ch in seq.chunks:
+        for seq in self._seqs[self._gc_seq:]:
+            if seq.chunks:
+                ch = seq.chunks.popleft()
                 if ch.data is not None:
                     ch.data = None
                     self._live_bytes -= ch.nbytes
-                    return
+                return
         self._live_bytes = 0
 
     def _assemble(self, seq, offset, nbytes):
         """Bytes [offset, offset+nbytes) of a sequence as one array: a zero-copy window when they
         lie inside one committed span, else a gathered copy in the ring's space."""
         pieces = []
+        if not seq.chunks or seq.chunks[0].offset > offset:
+            raise RuntimeError("ring %r: data at %d was overwritten before it was read" % (self.name, offset))
         for ch in seq.chunks:
+            if ch.offset >= offset + nbytes:
+                break
             lo, hi = max(offset, ch.offset), min(offset + nbytes, ch.offset + ch.nbytes)
             if lo < hi:
-                if ch.data is None:
-                    raise RuntimeError("ring %r: data at %d was overwritten before it was read" % (self.name, lo))
-                pieces.append(ch.data.byte_slice(lo - ch.offset, hi - lo))
+                pieces.append(ch.data if (lo == ch.offset and hi == ch.offset + ch.nbytes) else ch.data.byte_slice(lo - ch.offset, hi - lo))
         if len(pieces) == 1:
             return pieces[0]
         out = XArray(shape=(nbytes,), dtype=np.uint8, space=self.space)

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Diagnostic: device time of the HBM-bound side kernels at config-2 / config-4 sizes (HIP events around back-to-back
+launches through the C ABI).  usage: side_kernels.py map|integrate|unpack|packetize   (env switches as in DESIGN.md)"""
+import ctypes
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import caltech_bifrost_dsp_amd  # noqa
+from caltech_bifrost_dsp_amd import ffi
+
+L = ffi.lib()
+what = sys.argv[1] if len(sys.argv) > 1 else "map"
+NCHAN, NINPUT = 96, 704
+matlen = NCHAN * 249216
+
+
+def timed(fn, sync, nrep=50, nwarm=5):
+    for _ in range(nwarm):
+        fn()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(nrep):
+        fn()
+    sync()
+    return (time.perf_counter() - t0) / nrep
+
+
+if what == "map":
+    a, b = ffi.DeviceBuffer(2 * matlen * 4), ffi.DeviceBuffer(2 * matlen * 4)
+    ffi.call("xengMemset", a.ptr, 1, a.nbytes)
+    ffi.call("xengMemset", b.ptr, 2, b.nbytes)
+    for name, fn, nb in (("add", L.xengMapAddI32, 3), ("assign", L.xengMapAssignI32, 2)):
+        t = timed(lambda: fn(a.ptr, b.ptr, 2 * matlen), lambda: ffi.call("xengMapSync"))
+        print("map %-6s XENG_MAP_VAR=%s XENG_MAP_BLOCKS=%s: %.1f us  %.2f TB/s" % (
+            name, os.environ.get("XENG_MAP_VAR", "default"), os.environ.get("XENG_MAP_BLOCKS", "default"), t * 1e6, nb * a.nbytes / t / 1e12))
+elif what == "integrate":
+    NT, NB, NS = 960, 32, 24
+    ffi.call("xengBeamformInitialize", 0, NINPUT, NCHAN, NT, NB, 0)
+    beams = ffi.DeviceBuffer(NCHAN * NB * NT * 8)
+    ffi.call("xengMemset", beams.ptr, 0, beams.nbytes)
+    pw = ffi.DeviceBuffer((NB // 2) * (NT // NS) * NCHAN * 16)
+    t = timed(lambda: L.xengBeamformIntegrate(beams.ptr, pw.ptr, NS), lambda: ffi.call("xengBeamformSync"), nrep=200)
+    print("integrate: %.1f us  %.2f TB/s of %d MB" % (t * 1e6, beams.nbytes / t / 1e12, beams.nbytes >> 20))

@@ -36,6 +36,12 @@ class OracleBackend:
     def stream_synchronize(self):
         pass
 
+    def map_sync(self):
+        pass
+
+    def beam_sync(self):
+        pass
+
     def last_error(self):
         return ""
 
@@ -65,6 +71,10 @@ class OracleBackend:
         return self.bfXgpuKernel(in_arr, out_arr, do_dump)
 
     def xgpu_sync(self):
+        return 0
+
+    def xgpu_sync_lag(self, lag):
+        self.lag_syncs = getattr(self, "lag_syncs", 0) + 1
         return 0
 
     def xgpu_reset(self):

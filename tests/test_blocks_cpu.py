@@ -141,6 +141,17 @@ def test_corr_command_validation_and_update():
     assert blk.command_key.endswith('/Corr/%d' % blk.instance_id)
 
 
+def test_corr_streams_with_lag_one_commits():
+    """On the in-repo ring Corr only enqueues its gulps and dumps; the span of integration n is committed after the dump
+    of integration n+1 has been enqueued (one xgpu_sync_lag per integration but the first), the last one at sequence end.
+    Spans still come out complete, in order, one per integration."""
+    seqs, be, data, blk = _corr_scenario([12])
+    (ohdr, tag, spans), = seqs
+    assert len(spans) == 6 and getattr(be, "async_calls", 0) == 12 and be.lag_syncs == 5
+    for k, sp in enumerate(spans):
+        assert np.array_equal(sp.view(np.int32), orc.xgpu_correlate(data[0][4 * k:4 * k + 4], 4, 2))
+
+
 def test_corr_acc_len_zero_is_a_clean_stop():
     seqs, be, data, blk = _corr_scenario([6], commands=[cmd(1, acc_len=0)])
     assert seqs == [] and be.kernel_calls == [] and blk.stats['state'] == 'stopped'

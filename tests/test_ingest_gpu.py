@@ -46,6 +46,31 @@ def test_unpack_matches_oracle(T, C, S, nchan_blocks, nstand_per_pkt):
     assert np.array_equal(got.reshape(vin.shape), vin)
 
 
+def test_unpack_reference_transmitter_fixture(golden_dir):
+    """Bytes the reference's own F-engine emulator sends (tests/golden/snap2_*.bin, recorded from
+    test_transmitters/test_tx_vectors.py by oracle/make_golden_snap2.py) -> xengSnap2Unpack == the reference-generated
+    input file those packets were cut from (tests/golden/in_8t_4c_64s_2p_deadbeef.dat)."""
+    import json
+    import os
+    with open(os.path.join(golden_dir, "snap2_8t_4c_64s_2p_deadbeef.bin"), "rb") as fh:
+        meta = json.loads(fh.readline().decode())
+        blob = fh.read()
+    with open(os.path.join(golden_dir, "in_8t_4c_64s_2p_deadbeef.dat"), "rb") as fh:
+        hdr = json.loads(fh.readline().decode())
+        vin = np.frombuffer(fh.read(), dtype=np.uint8).reshape(hdr["shape"])
+    T, C, S, P = vin.shape
+    got, placed, dropped = _unpack(blob, meta["npkt"], meta["pkt_bytes"], 0, T, 0, C, S * P)
+    assert placed == meta["npkt"] and dropped == 0
+    assert np.array_equal(got.reshape(vin.shape), vin)
+    # the same packets in reverse order, into a window that starts two spectra later: the first two spectra drop out
+    n, b = meta["npkt"], meta["pkt_bytes"]
+    rev = b"".join(blob[k * b:(k + 1) * b] for k in reversed(range(n)))
+    got2, placed2, dropped2 = _unpack(rev, n, b, 2, T, 0, C, S * P)
+    per_seq = n // T
+    assert placed2 == n - 2 * per_seq and dropped2 == 2 * per_seq
+    assert np.array_equal(got2.reshape(vin.shape)[:T - 2], vin[2:]) and not got2.reshape(vin.shape)[T - 2:].any()
+
+
 def test_unpack_drops_and_blanks():
     T, C, S = 8, 8, 64
     rng = np.random.default_rng(1)

@@ -256,9 +256,81 @@ def test_subselect(gpu):
     x.close()
 
 
+def test_consumers_do_not_wait_for_the_contraction(gpu):
+    """The reference runs Corr, CorrSubsel and CorrOutputFull on their own threads (lwa352-pipeline.py:232-262, 296-302).
+    While the Corr thread sits in a synchronous dump (xengXgpuKernel(..., doDump=1)) behind a queue of contractions,
+    a second thread's xengXgpuSubSelect on the PREVIOUS, completed span must return without waiting for that dump: the
+    library holds its context lock only while enqueueing, and SubSelect is ordered behind the producer of its own input
+    span alone.  Also: SubSelect on a span whose contraction is still queued waits for exactly that contraction."""
+    import threading
+    import time
+    nstand, nchan, ntime, ngulp = 352, 96, 480, 5
+    x = gpu.Xgpu(nstand, nchan, ntime, max_gulps=ngulp)
+    vin = gpu.synth_voltages(ntime * ngulp, nchan, nstand, "random", seed=5)
+    prev = gpu.ffi.DeviceBuffer(x.out.nbytes)
+    x.out, keep = prev, x.out
+    planar = x.run(vin)                               # completed span in `prev`
+    x.out = keep
+    bl, cj = orc.xgpu_get_order(np.arange(nstand * 2, dtype=np.int32).reshape(nstand, 2))
+    nvis = 4704
+    rng = np.random.default_rng(4)
+    s0, s1 = rng.integers(0, nstand, nvis), rng.integers(0, nstand, nvis)
+    vismap = bl[s0, s1, 0, 0].astype(np.int32)
+    conj = cj[s0, s1, 0, 0].astype(np.int32)
+    dv = gpu.ffi.DeviceBuffer(vismap.nbytes).upload(vismap)
+    dc = gpu.ffi.DeviceBuffer(conj.nbytes).upload(conj)
+    do = gpu.ffi.DeviceBuffer((nchan // 4) * nvis * 8)
+    exp = orc.xgpu_subselect(planar, vismap, conj, nchan, 4, nstand)
+    gpu.ffi.call("xengXgpuSubSelect", prev.ptr, do.ptr, dv.ptr, dc.ptr, nvis, 4)     # warm (first launch, event creation)
+    L = gpu.ffi.lib()
+    gb = x.gulp_bytes
+    nint = 150                                        # ~35 ms of queued contractions into x.out
+    t = {}
+    entered = threading.Event()
+
+    def corr_thread():
+        for n in range(nint):
+            for g in range(ngulp):
+                last = n == nint - 1 and g == ngulp - 1
+                if last:
+                    entered.set()
+                    t["dump_call"] = time.perf_counter()
+                    rc = L.xengXgpuKernel(x.inbuf.ptr + g * gb, x.out.ptr, 1)        # synchronous dump: waits for the whole queue
+                else:
+                    rc = L.xengXgpuKernelAsync(x.inbuf.ptr + g * gb, x.out.ptr, int(g == ngulp - 1))
+                assert rc == 0
+        t["dump_done"] = time.perf_counter()
+
+    def subsel_thread():
+        entered.wait()
+        time.sleep(0.002)                             # the Corr thread is inside its dump call now
+        t["sub_call"] = time.perf_counter()
+        assert L.xengXgpuSubSelect(prev.ptr, do.ptr, dv.ptr, dc.ptr, nvis, 4) == 0
+        t["sub_done"] = time.perf_counter()
+
+    a, b = threading.Thread(target=corr_thread), threading.Thread(target=subsel_thread)
+    a.start(); b.start(); a.join(); b.join()
+    assert np.array_equal(do.download(np.int32).reshape(nchan // 4, nvis, 2), exp)
+    dump_wait = t["dump_done"] - t["dump_call"]
+    assert dump_wait > 0.010, dump_wait               # the dump really was waiting behind the queue
+    assert t["sub_done"] < t["dump_done"] - 0.005, (t["sub_done"] - t["sub_call"], dump_wait)
+    # ordering with its own producer: enqueue one integration into `prev` asynchronously and sub-select it at once
+    vin2 = gpu.synth_voltages(ntime * ngulp, nchan, nstand, "random", seed=6)
+    x.inbuf.upload(vin2.reshape(-1))
+    for g in range(ngulp):
+        gpu.ffi.call("xengXgpuKernelAsync", x.inbuf.ptr + g * gb, prev.ptr, int(g == ngulp - 1))
+    gpu.ffi.call("xengXgpuSubSelect", prev.ptr, do.ptr, dv.ptr, dc.ptr, nvis, 4)
+    gpu.ffi.call("xengXgpuSync")
+    exp2 = orc.xgpu_subselect(oracle_run(vin2, nstand, nchan, ntime), vismap, conj, nchan, 4, nstand)
+    assert np.array_equal(do.download(np.int32).reshape(nchan // 4, nvis, 2), exp2)
+    prev.free()
+    x.close()
+
+
 def test_config2_full_size(gpu):
     """BASELINE config 2: 704 inputs, 96 channels, 5 gulps of 480 (acc_len 2400), bit-exact vs the
-    C oracle on every word of both planes -- random bytes (the golden generator), then all-0x88."""
+    C oracle on every word of both planes -- random bytes (the golden generator), all-0x88, and the generator's
+    --chanramp set."""
     nstand, nchan, ntime, ngulp = 352, 96, 480, 5
     vin = gpu.synth_voltages(ntime * ngulp, nchan, nstand, "random")
     exp = oracle_run(vin, nstand, nchan, ntime)
@@ -284,6 +356,16 @@ def test_config2_full_size(gpu):
     g88 = x.run(v88)
     # every product is (-8-8j)*conj(-8-8j) = 128: all words 128*ntime (re) / 0 (im), incl. the unaddressed ones
     assert np.all(g88[:matlen] == 128 * ntime) and np.all(g88[matlen:] == 0)
+    # the reference generator's third input set (make_golden_inputs.py:112-116, --chanramp: every sample of channel c
+    # is the byte c) at full size, one whole integration, against the oracle on every word; and in closed form: byte c
+    # = (re, im) nibbles, every visibility of channel c is acc_len * (re^2 + im^2) + 0j
+    vramp = gpu.synth_voltages(ntime * ngulp, nchan, nstand, "chanramp")
+    gramp = x.run(vramp, use_async=True)
+    assert np.array_equal(gramp, oracle_run(vramp, nstand, nchan, ntime))
+    cb = np.arange(nchan)
+    re, im = (cb >> 4) - 16 * ((cb >> 4) > 7), (cb & 15) - 16 * ((cb & 15) > 7)
+    planes = gramp.reshape(2, nchan, -1)
+    assert np.all(planes[0] == (ntime * ngulp * (re * re + im * im))[:, None]) and np.all(planes[1] == 0)
     x.close()
 
 
