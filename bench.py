@@ -534,6 +534,22 @@ def main():
             verify = {"vis": outs3[2].download(np.int32), "corracc": acc_long.download(np.int32).astype(np.int64),
                       "beams": dbeam.download(np.complex64).reshape(NCHAN, NB, NT_B), "weights": wts, "ntime_sum": NS,
                       "power": dpow.download(np.float32).reshape(NB // 2, NT_B // NS, NCHAN, 4)}
+        # the reference's "integrated" mode (bfBeamformInitialize ntime_blocks > 0, beamform_block.py:108-110): power sums
+        # formed in the beamformer kernel's epilogue, no voltage beams in memory
+        ffi.call("xengBeamformInitialize", gpu, NINPUT, NCHAN, NT_B, NB, NT_B // NS)
+        for i in range(6):
+            ffi.check("run", L.xengBeamformRunVersioned(ring.ptr, dpow.ptr, dw.ptr, 1))
+            ffi.call("xengBeamformSync")
+        ffi.call("xengBeamformSetProfiling", 1)
+        ffi.call("xengBeamformGetTimes", btm, bcn)
+        for i in range(40):
+            ffi.check("run", L.xengBeamformRunVersioned(ring.ptr + ((2 * i) % (args.ring_gulps - 1)) * gulp_bytes, dpow.ptr, dw.ptr, 1))
+        ffi.call("xengBeamformSync")
+        ffi.call("xengBeamformGetTimes", btm, bcn)
+        ffi.call("xengBeamformSetProfiling", 0)
+        beam["integrated_mode"] = {"run_us": round(btm[0] / max(bcn[0], 1) * 1e3, 1), "integrate_launches": int(bcn[1]),
+                                   "note": "ntime_blocks = %d: one launch per gulp, power sums in the epilogue (the composed path is "
+                                           "run_us + integrate_us above)" % (NT_B // NS)}
         ffi.call("xengBeamformDestroy")
     if dist is not None:
         import torch
@@ -556,10 +572,16 @@ def main():
     fused, fp6 = ctypes.c_int(), ctypes.c_int()
     ffi.call("xengXgpuGetPath", ctypes.byref(fused), ctypes.byref(fp6))
     kname = "xcorr_fused_kernel" if fused.value else ("xcorr_fp6_kernel" if fp6.value else "xcorr_mfma_kernel")
+    # (PMC counters cannot be collected inside this run; the committed figure counts only while it was taken from the
+    # very library that is loaded now, else traffic is null)
     traffic = None
     try:
+        import hashlib
         with open(os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")) as fh:
-            traffic = json.load(fh).get(kname + "_bytes_per_launch")
+            pmc = json.load(fh)
+        with open(ffi.LIB_PATH, "rb") as fh:
+            if hashlib.sha256(fh.read()).hexdigest() == pmc.get("libxeng_sha256"):
+                traffic = pmc.get(kname + "_bytes_per_launch")
     except (OSError, ValueError):
         pass
     res = {

@@ -66,8 +66,12 @@ static int beam_destroy_locked() {
     return XENG_STATUS_SUCCESS;
 }
 
-static int run_locked(const void* in, float* out, const void* w, long long version) {
+// pow_out != nullptr: integrated-power mode, fused into the int8x3 kernel when that is possible (see the kernel); returns
+// *fused = false when the caller has to run the voltage mode into its scratch and integrate separately
+static int run_locked(const void* in, float* out, const void* w, long long version, float* pow_out = nullptr, int ntime_sum = 0,
+                      bool* fused = nullptr) {
     BeamContext& x = g_b;
+    if (fused) *fused = false;
     if (x.use_f32) {
         dim3 grid((x.ntime + BF_NT - 1) / BF_NT, x.nchan, (x.nbeam + 31) / 32);
         int slot = x.timer.begin(x.stream, 0);
@@ -106,8 +110,16 @@ static int run_locked(const void* in, float* out, const void* w, long long versi
         }
         dim3 grid(((x.ntime + BI_NT - 1) / BI_NT) * x.nchan * x.nbtile);
         int slot = x.timer.begin(x.stream, 0);
+        // the fused power sums need every tile on this kernel (known once the routing answer of these weights has come
+        // back), time blocks that straddle at most two work-groups, and whole beam pairs
+        const bool fuse = pow_out && x.route_known && !x.need_bf16 && ntime_sum <= BI_NT && x.nbeam % 2 == 0;
+        if (fuse) {
+            XENG_HIP(hipMemsetAsync(pow_out, 0, (size_t)(x.nbeam / 2) * (x.ntime / ntime_sum) * x.nchan * 4 * sizeof(float), x.stream));
+            *fused = true;
+        }
         hipLaunchKernelGGL(beamform_i8x3_kernel, grid, dim3(256), 0, x.stream, (const uint8_t*)in, x.wq, x.wscale, out,
-                           x.ntime, x.nchan, x.ninput, x.nbeam, x.nchunk_i8, x.nbtile, x.route, x.out_n, x.out_idx, x.out_R, x.stamps);
+                           x.ntime, x.nchan, x.ninput, x.nbeam, x.nchunk_i8, x.nbtile, x.route, x.out_n, x.out_idx, x.out_R, x.stamps,
+                           fuse ? pow_out : (float*)nullptr, ntime_sum);
         if (x.need_bf16) {
             dim3 grid3(((x.ntime + BF3_NT - 1) / BF3_NT) * x.nchan * x.nbtile);
             hipLaunchKernelGGL(beamform_bf16x3_kernel, grid3, dim3(64 * BF3_NW), 0, x.stream, (const uint8_t*)in, x.wprep, out,
@@ -231,8 +243,9 @@ int xengBeamformRunVersioned(const void* in_dev, void* out_dev, const void* weig
         XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Beamform: weights/out must be 16-byte, in 4-byte aligned");
     XENG_HIP(hipSetDevice(x.gpu));
     if (x.ntime_blocks == 0) return run_locked(in_dev, (float*)out_dev, weights_dev, weights_version);
-    int rc = run_locked(in_dev, x.scratch, weights_dev, weights_version);
-    if (rc) return rc;
+    bool fused = false;
+    int rc = run_locked(in_dev, x.scratch, weights_dev, weights_version, (float*)out_dev, x.ntime / x.ntime_blocks, &fused);
+    if (rc || fused) return rc;
     return integrate_locked(x.scratch, out_dev, x.ntime / x.ntime_blocks, 0, x.nbeam / 2);
 }
 

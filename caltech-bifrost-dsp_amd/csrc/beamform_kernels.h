@@ -547,7 +547,8 @@ __global__ __launch_bounds__(256, 3) void beamform_i8x3_kernel(const uint8_t* __
                                                                int ninput, int nbeam, int nchunk, int nbtile,
                                                                const int* __restrict__ route, const int* __restrict__ out_n,
                                                                const int* __restrict__ out_idx, const float2* __restrict__ out_R,
-                                                               unsigned long long* __restrict__ stamps) {
+                                                               unsigned long long* __restrict__ stamps,
+                                                               float* __restrict__ pow_out, int ntime_sum) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[BI_RING * BI_STAGE];
     const unsigned long long r0 = stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;   // diagnostic (XENG_BEAM_STAMPS=1)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -662,7 +663,38 @@ __global__ __launch_bounds__(256, 3) void beamform_i8x3_kernel(const uint8_t* __
             }
         }
     }
-    if (t < ntime) {
+    if (pow_out) {
+        // Integrated-power mode (bfBeamformInitialize ntime_blocks > 0, "experimental" in the reference:
+        // beamform_block.py:108-110): the power sums of bfBeamformIntegrate (beamform_sum_beams_block.py:243-246,
+        // cublas_beamform.cu:46-79) are formed here and the voltage beams never go to memory.  Per sample and beam pair
+        // (X = beam 2p, Y = 2p+1, both rows in one lane) the four products go to LDS (the staging ring is free now);
+        // then every time block of ntime_sum samples is summed in sample order.  A block that lies inside this
+        // work-group's 128 samples is stored; one that straddles two work-groups is added atomically to the
+        // zero-initialised output -- two addends only (the caller requires ntime_sum <= 128), so the sum does not
+        // depend on their order.
+        __builtin_amdgcn_s_barrier();                  // all waves are past their last LDS read of the ring
+        float4* pl = reinterpret_cast<float4*>(lds);   // [128 samples][16 pairs]
+#pragma unroll
+        for (int g = 0; g < 16; g += 2) {
+            const int pr = ((g & 3) >> 1) + 4 * (g >> 2) + 2 * h;
+            const float xr = re[g], xi = im[g], yr = re[g + 1], yi = im[g + 1];
+            pl[(wave * 32 + j) * 16 + pr] = make_float4(xr * xr + xi * xi, yr * yr + yi * yi, xr * yr + xi * yi, xi * yr - xr * yi);
+        }
+        __syncthreads();
+        const int nblk = ntime / ntime_sum, tend = min(t0 + BI_NT, ntime);
+        const int pc = tid & 63, pr = pc >> 2, comp = pc & 3;
+        const int pair = bt * 16 + pr;
+        const float* pf = reinterpret_cast<const float*>(lds);
+        if (2 * pair + 1 < nbeam)
+            for (int b = t0 / ntime_sum + (tid >> 6); b < nblk && b * ntime_sum < tend; b += 4) {
+                const int s0 = max(b * ntime_sum, t0), s1 = min((b + 1) * ntime_sum, tend);
+                float acc = 0.f;
+                for (int sm = s0; sm < s1; sm++) acc += pf[((sm - t0) * 16 + pr) * 4 + comp];
+                float* dst = pow_out + (((size_t)pair * nblk + b) * nchan + c) * 4 + comp;
+                if (s0 == b * ntime_sum && s1 == (b + 1) * ntime_sum) *dst = acc;
+                else atomicAdd(dst, acc);
+            }
+    } else if (t < ntime) {
 #pragma unroll
         for (int g = 0; g < 16; g++) {
             const int b = bt * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;

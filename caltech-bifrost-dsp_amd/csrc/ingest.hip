@@ -27,7 +27,9 @@ __device__ __forceinline__ uint32_t be16(const uint8_t* p) { return ((uint32_t)p
 __global__ __launch_bounds__(256) void snap2_unpack_kernel(const uint8_t* __restrict__ pkts, int npkt, size_t stride,
                                                            uint8_t* __restrict__ out, unsigned long long seq0, int ntime,
                                                            int chan0_pipe, int nchan_tot, int npol_tot, int payload_max,
-                                                           int* __restrict__ counters) {
+                                                           int* __restrict__ counter,
+                                                           unsigned long long* __restrict__ row_cover,
+                                                           unsigned int* __restrict__ row_geom) {
     const bool aligned = (((uintptr_t)pkts | (uintptr_t)out | stride) & 15) == 0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int ndropped = 0;
@@ -56,6 +58,20 @@ __global__ __launch_bounds__(256) void snap2_unpack_kernel(const uint8_t* __rest
         if (!ok) {
             ndropped++;
             continue;
+        }
+        if (row_cover && lane == 0) {
+            // coverage of the gulp, so that the caller can skip the zero-fill when nothing is missing: per time row the
+            // set of packet cells (channel block, input block) that arrived.  Exact when the row's packets share one
+            // geometry, sit on its grid and the row has at most 63 cells; anything else sets bit 63 = "row irregular".
+            const int t = (int)(seq - seq0);
+            const unsigned int g = ((unsigned int)nchan << 16) | (unsigned int)npol;
+            const unsigned int g0 = atomicCAS(&row_geom[t], 0u, g);
+            unsigned long long bit = 1ull << 63;
+            if ((g0 == 0u || g0 == g) && nchan_tot % nchan == 0 && npol_tot % npol == 0 && chan0 % nchan == 0 && pol0 % npol == 0) {
+                const long long cell = (chan0 / nchan) * (npol_tot / npol) + pol0 / npol;
+                if ((long long)(nchan_tot / nchan) * (npol_tot / npol) <= 63) bit = 1ull << cell;
+            }
+            atomicOr(&row_cover[t], bit);
         }
         const uint8_t* src = h + 32;
         uint8_t* dst = out + (((size_t)(seq - seq0) * nchan_tot + (size_t)chan0) * npol_tot + (size_t)pol0);
@@ -87,23 +103,33 @@ __global__ __launch_bounds__(256) void snap2_unpack_kernel(const uint8_t* __rest
     }
     // only drops are counted on the device (rare): thousands of waves adding to one counter serialise in L2
     // (4096 same-address atomics cost ~40 us); placed = npkt - dropped on the host
-    if (lane == 0 && ndropped) atomicAdd(&counters[1], ndropped);
+    if (lane == 0 && ndropped) atomicAdd(counter, ndropped);
 }
 
-static int* g_counters[16] = {};
-static std::mutex g_ingest_mu;     // the drop counter of a device is shared by all callers
+// per device: the state block of the running synchronous call (drops + coverage of up to SNAP2_MAX_ROWS time rows) and the
+// drops of the enqueue-only calls since they were last read
+constexpr int SNAP2_MAX_ROWS = 8192;
+struct IngestState {
+    int* counters = nullptr;                 // state block of the synchronous call: [16 B: drops][row_cover][row_geom]
+    int* async_drops = nullptr;              // ... and, behind it, the drop counter of the enqueue-only calls
+    void* host = nullptr;                    // pinned mirror of the block
+    int* host_async = nullptr;
+};
+static IngestState g_ingest[16];
+static std::mutex g_ingest_mu;     // the state of a device is shared by all callers
 
 }  // namespace xeng
 
 using namespace xeng;
 
 static int snap2_launch(hipStream_t s, const void* packets_dev, int npkt, size_t pkt_stride, void* out_dev, uint64_t seq0,
-                        int ntime, int chan0_pipeline, int nchan_tot, int npol_tot, int clear, int* counters) {
+                        int ntime, int chan0_pipeline, int nchan_tot, int npol_tot, int clear, int* counter,
+                        unsigned long long* row_cover, unsigned int* row_geom) {
     if (clear) XENG_HIP(hipMemsetAsync(out_dev, 0, (size_t)ntime * nchan_tot * npol_tot, s));   // missing packets = blanked samples
     if (npkt > 0) {
         hipLaunchKernelGGL(snap2_unpack_kernel, dim3((npkt + 3) / 4 < 2048 ? (npkt + 3) / 4 : 2048), dim3(256), 0, s, (const uint8_t*)packets_dev, npkt,
                            pkt_stride, (uint8_t*)out_dev, (unsigned long long)seq0, ntime, chan0_pipeline, nchan_tot, npol_tot,
-                           (int)(pkt_stride - 32), counters);
+                           (int)(pkt_stride - 32), counter, row_cover, row_geom);
         XENG_HIP(hipGetLastError());
     }
     return XENG_STATUS_SUCCESS;
@@ -117,11 +143,30 @@ static int snap2_check(const void* packets_dev, int npkt, size_t pkt_stride, voi
                   nchan_tot, npol_tot, pkt_stride);
     XENG_HIP(hipGetDevice(dev));
     if (*dev < 0 || *dev >= 16) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "device %d out of range", *dev);
-    if (!g_counters[*dev]) {
-        XENG_HIP(hipMalloc((void**)&g_counters[*dev], 2 * sizeof(int)));
-        XENG_HIP(hipMemset(g_counters[*dev], 0, 2 * sizeof(int)));
+    IngestState& st = g_ingest[*dev];
+    if (!st.counters) {
+        const size_t nb = 16 + SNAP2_MAX_ROWS * (sizeof(unsigned long long) + sizeof(unsigned int)) + 16;
+        uint8_t* base = nullptr;
+        XENG_HIP(hipMalloc((void**)&base, nb));
+        XENG_HIP(hipMemset(base, 0, nb));
+        XENG_HIP(hipHostMalloc(&st.host, nb, hipHostMallocDefault));
+        st.async_drops = (int*)(base + nb - 16);
+        st.host_async = (int*)((uint8_t*)st.host + nb - 16);
+        st.counters = (int*)base;
     }
     return XENG_STATUS_SUCCESS;
+}
+
+// true iff every time row of the window received every cell of its packet grid (no loss; duplicates are harmless)
+static bool snap2_complete(const unsigned long long* cover, const unsigned int* geom, int ntime, int nchan_tot, int npol_tot) {
+    for (int t = 0; t < ntime; t++) {
+        const unsigned int g = geom[t];
+        const int nchan = (int)(g >> 16), npol = (int)(g & 0xFFFF);
+        if (!g || nchan <= 0 || npol <= 0 || nchan_tot % nchan || npol_tot % npol) return false;
+        const long long cells = (long long)(nchan_tot / nchan) * (npol_tot / npol);
+        if (cells > 63 || cover[t] != (1ull << cells) - 1) return false;       // (bit 63 = irregular row)
+    }
+    return true;
 }
 
 extern "C" int xengSnap2Unpack(const void* packets_dev, int npkt, size_t pkt_stride, void* out_dev, uint64_t seq0, int ntime,
@@ -130,24 +175,45 @@ extern "C" int xengSnap2Unpack(const void* packets_dev, int npkt, size_t pkt_str
     int dev = 0;
     int rc = snap2_check(packets_dev, npkt, pkt_stride, out_dev, ntime, nchan_tot, npol_tot, &dev);
     if (rc) return rc;
+    IngestState& st = g_ingest[dev];
     hipStream_t s;
     rc = get_stream(STREAM_COPY, &s);
     if (rc) return rc;
-    XENG_HIP(hipMemsetAsync(g_counters[dev], 0, 2 * sizeof(int), s));
-    rc = snap2_launch(s, packets_dev, npkt, pkt_stride, out_dev, seq0, ntime, chan0_pipeline, nchan_tot, npol_tot, clear,
-                      g_counters[dev]);
+    // With `clear`, a complete slab needs no zero-fill at all (the packets overwrite every byte): scatter first while
+    // recording which packet cells arrived, and fall back to zero-fill + scatter only when something is missing.  That
+    // saves one full write of the gulp (32 MB at config 2) in the normal, loss-free case.
+    const bool track = clear && npkt > 0 && ntime <= SNAP2_MAX_ROWS;
+    // the state of this call, packed so that one memset clears it and one copy brings it back:
+    // [16 B: drops | pad][row_cover: ntime x 8 B][row_geom: ntime x 4 B]
+    unsigned long long* cover = (unsigned long long*)((uint8_t*)st.counters + 16);
+    unsigned int* geom = (unsigned int*)((uint8_t*)st.counters + 16 + (size_t)ntime * sizeof(unsigned long long));
+    const size_t track_bytes = track ? (size_t)ntime * (sizeof(unsigned long long) + sizeof(unsigned int)) : 0;
+    XENG_HIP(hipMemsetAsync(st.counters, 0, 16 + track_bytes, s));
+    rc = snap2_launch(s, packets_dev, npkt, pkt_stride, out_dev, seq0, ntime, chan0_pipeline, nchan_tot, npol_tot, clear && !track,
+                      st.counters, track ? cover : nullptr, track ? geom : nullptr);
     if (rc) return rc;
-    int host[2] = {0, 0};
-    XENG_HIP(hipMemcpyAsync(host, g_counters[dev], sizeof(host), hipMemcpyDeviceToHost, s));
+    int* hc = (int*)st.host;
+    unsigned long long* hcov = (unsigned long long*)((uint8_t*)st.host + 16);
+    unsigned int* hgeom = (unsigned int*)((uint8_t*)st.host + 16 + (size_t)ntime * sizeof(unsigned long long));
+    XENG_HIP(hipMemcpyAsync(hc, st.counters, 16 + track_bytes, hipMemcpyDeviceToHost, s));
     XENG_HIP(hipStreamSynchronize(s));
-    if (nplaced) *nplaced = npkt - host[1];
-    if (ndropped) *ndropped = host[1];
+    const int dropped = hc[0];
+    if (track && !snap2_complete(hcov, hgeom, ntime, nchan_tot, npol_tot)) {
+        // something is missing (or the stream is irregular): blank the gulp and scatter again
+        rc = snap2_launch(s, packets_dev, npkt, pkt_stride, out_dev, seq0, ntime, chan0_pipeline, nchan_tot, npol_tot, 1,
+                          st.counters, nullptr, nullptr);
+        if (rc) return rc;
+        XENG_HIP(hipStreamSynchronize(s));
+    }
+    if (nplaced) *nplaced = npkt - dropped;
+    if (ndropped) *ndropped = dropped;
     return XENG_STATUS_SUCCESS;
 }
 
 // Enqueue-only flavour on the X-engine's staging stream: a gulp unpacked this way and then handed to
-// xengXgpuKernelAsync is ordered before the contraction that reads it (the dump waits for that stream).  Drop
-// counts accumulate on the device until the next synchronous call; nothing is waited for.
+// xengXgpuKernelAsync is ordered before the contraction that reads it (the dump waits for that stream).  Nothing is
+// waited for; the packets these calls drop are counted on the device in a counter of their own, read (and cleared)
+// with xengSnap2GetAsyncDrops.
 extern "C" int xengSnap2UnpackAsync(const void* packets_dev, int npkt, size_t pkt_stride, void* out_dev, uint64_t seq0, int ntime,
                                     int chan0_pipeline, int nchan_tot, int npol_tot, int clear) {
     std::lock_guard<std::mutex> lk(g_ingest_mu);
@@ -158,5 +224,23 @@ extern "C" int xengSnap2UnpackAsync(const void* packets_dev, int npkt, size_t pk
     rc = get_stream(STREAM_XGPU, &s);
     if (rc) return rc;
     return snap2_launch(s, packets_dev, npkt, pkt_stride, out_dev, seq0, ntime, chan0_pipeline, nchan_tot, npol_tot, clear,
-                        g_counters[dev]);
+                        g_ingest[dev].async_drops, nullptr, nullptr);
+}
+
+// Packets dropped by the enqueue-only calls since the last call of this function; waits for the staging stream.
+extern "C" int xengSnap2GetAsyncDrops(int* ndropped) {
+    std::lock_guard<std::mutex> lk(g_ingest_mu);
+    if (!ndropped) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Snap2GetAsyncDrops: null pointer");
+    int dev = 0;
+    XENG_HIP(hipGetDevice(&dev));
+    *ndropped = 0;
+    if (dev < 0 || dev >= 16 || !g_ingest[dev].counters) return XENG_STATUS_SUCCESS;    // nothing was ever unpacked
+    hipStream_t s;
+    int rc = get_stream(STREAM_XGPU, &s);
+    if (rc) return rc;
+    XENG_HIP(hipMemcpyAsync(g_ingest[dev].host_async, g_ingest[dev].async_drops, sizeof(int), hipMemcpyDeviceToHost, s));
+    XENG_HIP(hipMemsetAsync(g_ingest[dev].async_drops, 0, sizeof(int), s));
+    XENG_HIP(hipStreamSynchronize(s));
+    *ndropped = *g_ingest[dev].host_async;
+    return XENG_STATUS_SUCCESS;
 }

@@ -30,6 +30,7 @@ struct XgpuContext {
     // of it in the staging area (except the dump call, which waits for the contraction anyway).
     bool raw = false;
     bool splitk = false;                       // XENG_SPLITK=1: cut the left-over items along K (experiment, see Initialize)
+    bool stagger = false;                      // XENG_STAGGER=1: half-item skew between neighbouring work-groups (build_work)
     std::map<int, WorkList> work;              // per number of stages of a flush
     uint32_t* flags = nullptr;                 // [NMM][flags_per_stream] slice-ordering flags of split items
     int flags_per_stream = 0;
@@ -122,6 +123,9 @@ static void launch_xcorr(const XcorrParams& p, hipStream_t s, bool raw, int ncu)
             case 8: hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<8>), grid, dim3(256), 0, s, p); return;
             case 9: hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<9>), grid, dim3(256), 0, s, p); return;
             case 15: hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<15>), grid, dim3(256), 0, s, p); return;
+            case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<16>), grid, dim3(256), 0, s, p); return;
+            case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<32>), grid, dim3(256), 0, s, p); return;
+            case 48: hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<48>), grid, dim3(256), 0, s, p); return;
             default: break;
         }
 #endif
@@ -183,7 +187,7 @@ static int flush_locked(void* out, bool dump) {
         const int nstage = nkt / XC_KT;
         auto itw = x.work.find(nstage);
         if (itw == x.work.end()) {
-            WorkList wl = build_work(fused_grid(x.cfg.nchan, x.nwg, x.ncu), x.cfg.nchan, x.nwg, nstage, x.splitk);
+            WorkList wl = build_work(fused_grid(x.cfg.nchan, x.nwg, x.ncu), x.cfg.nchan, x.nwg, nstage, x.splitk, x.stagger);
             if (wl.nchains > x.flags_per_stream) XENG_FAIL(XENG_STATUS_DEVICE_ERROR, "xgpu: %d slice chains exceed the flag array", wl.nchains);
             XENG_HIP(hipMalloc((void**)&wl.dev, wl.entries.size() * sizeof(WorkEntry)));
             XENG_HIP(hipMemcpy(wl.dev, wl.entries.data(), wl.entries.size() * sizeof(WorkEntry), hipMemcpyHostToDevice));
@@ -398,6 +402,8 @@ static int initialize_locked(int gpu) {
         // cost what the balanced tail saves, and overlapping launches already fill the tail
         const char* e = getenv("XENG_SPLITK");
         x.splitk = e && !strcmp(e, "1");
+        const char* sg = getenv("XENG_STAGGER");
+        x.stagger = sg && !strcmp(sg, "1");
         x.flags_per_stream = fused_grid(x.cfg.nchan, x.nwg, x.ncu);   // split items < work-groups
         XENG_HIP(hipMalloc((void**)&x.flags, (size_t)XgpuContext::NMM * x.flags_per_stream * sizeof(uint32_t)));
         XENG_HIP(hipMemset(x.flags, 0, (size_t)XgpuContext::NMM * x.flags_per_stream * sizeof(uint32_t)));

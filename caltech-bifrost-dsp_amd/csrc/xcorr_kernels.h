@@ -221,6 +221,9 @@ __device__ __forceinline__ Frags unpack_frags(const RawFrags& r) {
 
 constexpr int XC_KT = 3;      // K-tiles (32 samples each) per LDS stage
 constexpr int XC_RING = 4;    // LDS ring depth (stages), two-pass kernel
+#ifndef XF_NO_RELAX
+#define XF_NO_RELAX 0         // 1: A/B build without the relaxed first-stage wait behind an epilogue
+#endif
 #ifndef XF_DEPTH
 #define XF_DEPTH 3            // fused kernel: stages of LDS-DMA in flight ahead of the MFMAs (ring = XF_DEPTH+1 stages of 24 KiB; 3, 4, 5 measure the same)
 #endif
@@ -264,7 +267,9 @@ __device__ __forceinline__ void xcorr_store_tile(const XcorrParams& p, int c, in
     const bool accumulate = p.accumulate != 0 || add_to_stored;
     if (interior && !accumulate) {
         // the common case (55 of 66 tiles, first flush of an integration) as straight-line code: no per-cell
-        // branches, so the lane regrouping of one cell overlaps the arithmetic of the next
+        // branches, so the lane regrouping of one cell overlaps the arithmetic of the next.  (Regrouping through a
+        // per-wave LDS scratch -- one ds_write_b128 + one ds_read_b128 per cell instead of four ds_bpermute -- measured
+        // the same: the epilogue's cost is the write traffic, 14 % of the step by ablation, not its instruction stream.)
 #pragma unroll
         for (int m = 0; m < 2; m++)
 #pragma unroll
@@ -580,6 +585,9 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
             is_k++;
             is_setup(nx);
         }
+        if (ABL & 32)   // timing only: every channel reads channel (c & 7)'s first stage of gulp 0 (a 1 MB window that stays in L2)
+            is_stage = p.gulps[0] + (size_t)(is_c & 7) * (size_t)p.ninput;
+        else
         is_stage = p.gulps[is_g] + ((size_t)(is_sl * (KT_STAGE * 32)) * p.nchan + is_c) * (size_t)p.ninput;
         is_issued++;
         if (++is_sl == p.spg) { is_sl = 0; is_g++; }
@@ -629,6 +637,7 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
     // the stage counter is continuous across items
     int rs = 0, rs1 = 1, rf = DEPTH;
     auto bump = [&](int& r) { r = (r + 1 == RING) ? 0 : r + 1; };
+    bool stores_in_flight = false;            // the previous item of this wave ended with the 32-store epilogue
     for (int k = 0; item(k, it); k++) {
         const int c = it.c, wg = it.wg;
         const unsigned long long r_entry = p.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -681,6 +690,7 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
+            stores_in_flight = false;
             continue;
         }
         v16i accR[2][2], accP[2][2], accQ[2][2];
@@ -733,7 +743,11 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
                 }
             }
             if (!(ABL & 8)) {
-                if (!(ABL & 1)) wait_vmcnt<(DEPTH - 2) * NLOAD>();
+                // (first stage behind a straight-line epilogue: the 32 tile stores of that epilogue sit between the DMA of
+                // stage S+2, which this wait is for, and the 6 pieces just issued; vmcnt retires in issue order, so
+                // allowing them to stay in flight does not let stage S+2 slip -- and the wave does not stall for the
+                // write acknowledgements of the previous item)
+                if (!(ABL & 1)) { if (s == 0 && stores_in_flight && !XF_NO_RELAX) wait_vmcnt<(DEPTH - 2) * NLOAD + 32>(); else wait_vmcnt<(DEPTH - 2) * NLOAD>(); }
                 __builtin_amdgcn_s_barrier();
             }
             bump(rs); bump(rs1); bump(rf);
@@ -757,6 +771,15 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
                 __builtin_amdgcn_s_sleep(4);
             asm volatile("" ::: "memory");
         }
+        // exactly 32 store instructions and nothing else: the straight-line path of xcorr_store_tile
+        stores_in_flight = !(ABL & 16) && __builtin_amdgcn_readfirstlane((int)(blk_a > blk_b && blk_a * 64 + 64 <= 2 * p.nstand &&
+                                                                                 p.accumulate == 0 && it.slice == 0)) != 0;
+        if (ABL & 16) {   // timing only: no epilogue (keep the accumulators live)
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int n = 0; n < 2; n++) asm volatile("" :: "v"(accR[m][n][0]), "v"(accP[m][n][5]), "v"(accQ[m][n][9]));
+        } else
         if (active) xcorr_store_tile(p, c, blk_a, blk_b, skip01, lane, accR, accP, accQ, it.slice > 0);
         if (it.slice + 1 < it.nslices) {
             // publish: every wave's stores have been acknowledged by the L2 (vmcnt counts stores too), then one

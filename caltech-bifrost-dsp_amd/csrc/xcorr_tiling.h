@@ -118,18 +118,22 @@ struct WorkList {
     uint32_t* dev = nullptr;
 };
 
-inline WorkList build_work(int grid, int nchan, int nwg, int nstage, bool splitk) {
+// stagger: every second work-group of an XCD class contracts its FIRST item in two K halves (the second half adds to what
+// the first stored), which shifts all its later item boundaries by half an item against its neighbours': the epilogues of
+// the 256 work-groups (128 KB of stores each) then no longer fall into the same few microseconds.
+inline WorkList build_work(int grid, int nchan, int nwg, int nstage, bool splitk, bool stagger = false) {
     WorkList wl;
     const bool xcd_map = (nchan & 7) == 0 && (grid & 7) == 0;
     const int ngroup = xcd_map ? 8 : 1;
     const int W = grid / ngroup;
     const int n = xcd_map ? (nchan / 8) * nwg : nchan * nwg;
     const int f = n / W, r = n % W;
-    wl.maxi = f + (r ? 1 : 0);
+    stagger = stagger && !splitk && f >= 1 && nstage >= 2;
+    wl.maxi = f + (r ? 1 : 0) + (stagger ? 1 : 0);
     wl.entries.assign((size_t)grid * wl.maxi, WorkEntry{0, 0, 0, 0});
     // (only per-XCD lists are split: the slices of an item exchange partial sums through one XCD's L2)
     const bool split = splitk && xcd_map && r > 0 && nstage >= (W + r - 1) / r;
-    wl.nchains = split ? ngroup * r : 0;
+    wl.nchains = split ? ngroup * r : (stagger ? grid : 0);
     auto put = [&](int b, int k, int x, int idx, int stage0, int nst, int slice, int nslices, int chain) {
         const int q = idx / nwg, wg = idx - q * nwg;
         const int c = xcd_map ? x + 8 * q : q;
@@ -141,11 +145,19 @@ inline WorkList build_work(int grid, int nchan, int nwg, int nstage, bool splitk
     };
     for (int x = 0; x < ngroup; x++) {
         auto block_of = [&](int j) { return xcd_map ? j * 8 + x : j; };
-        for (int j = 0; j < W; j++)
-            for (int k = 0; k < f; k++) put(block_of(j), k, x, j + k * W, 0, nstage, 0, 1, 0);
+        for (int j = 0; j < W; j++) {
+            const bool two = stagger && (j & 1);     // this work-group's first item goes in two halves
+            int k = 0;
+            if (two) {
+                put(block_of(j), 0, x, j, 0, nstage / 2, 0, 2, block_of(j));
+                put(block_of(j), 1, x, j, nstage / 2, nstage - nstage / 2, 1, 2, block_of(j));
+                k = 1;
+            }
+            for (int q = two ? 1 : 0; q < f; q++) put(block_of(j), q + k, x, j + q * W, 0, nstage, 0, 1, 0);
+        }
         if (!r) continue;
         if (!split) {
-            for (int i = 0; i < r; i++) put(block_of(i), f, x, f * W + i, 0, nstage, 0, 1, 0);
+            for (int i = 0; i < r; i++) put(block_of(i), f + ((stagger && (i & 1)) ? 1 : 0), x, f * W + i, 0, nstage, 0, 1, 0);
             continue;
         }
         int j = 0;

@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libxeng.so")
+# XENG_LIB: load another build of the same library (the -DXENG_DIAGNOSTICS build used by profiles/: timing-only ablations)
+LIB_PATH = os.environ.get("XENG_LIB") or os.path.join(_HERE, "libxeng.so")
 
 STATUS_SUCCESS = 0
 SPACE_SYSTEM, SPACE_CUDA, SPACE_CUDA_HOST = 1, 2, 3
@@ -49,6 +50,7 @@ SYMBOLS = {
     "xengXgpuPacketize": [_vp, _vp, _vp, _vp, _i],
     "xengSnap2Unpack": [_vp, _i, ctypes.c_size_t, _vp, ctypes.c_uint64, _i, _i, _i, _i, _i, _pi, _pi],
     "xengSnap2UnpackAsync": [_vp, _i, ctypes.c_size_t, _vp, ctypes.c_uint64, _i, _i, _i, _i, _i],
+    "xengSnap2GetAsyncDrops": [_pi],
     "xengXgpuSetProfiling": [_i], "xengXgpuGetTimes": [ctypes.POINTER(ctypes.c_double), _pi],
     "xengMapAssignI32": [_vp, _vp, _sz], "xengMapAddI32": [_vp, _vp, _sz], "xengMapSync": [],
     "xengBeamformInitialize": [_i, _i, _i, _i, _i, _i], "xengBeamformDestroy": [],

@@ -167,14 +167,18 @@ int xengXgpuGetTimes(double ms[2], int count[2]);
  * u8[nchan][npol] 4+4-bit samples.  packets_dev: npkt packets, pkt_stride bytes apart (any order, duplicates
  * allowed).  out_dev: u8[ntime][nchan_tot][npol_tot]; row c of a packet lands at
  * [seq - seq0][chan0 - chan0_pipeline + c][pol0 ..].  Packets outside the window [seq0, seq0+ntime) or outside
- * the gulp geometry are dropped and counted.  clear != 0 zero-fills the gulp first, so samples of missing
- * packets read as 0 (blanked).  Synchronous; the counters may be NULL. */
+ * the gulp geometry are dropped and counted.  clear != 0: samples that no packet covers read as 0 (blanked) -- a slab
+ * that covers the whole gulp is scattered without any zero-fill, otherwise the gulp is zero-filled and scattered again.
+ * Synchronous; the counters may be NULL. */
 int xengSnap2Unpack(const void *packets_dev, int npkt, size_t pkt_stride, void *out_dev, uint64_t seq0, int ntime,
                     int chan0_pipeline, int nchan_tot, int npol_tot, int clear, int *nplaced, int *ndropped);
 /* Same, enqueue only, on the X-engine's staging stream: a gulp unpacked this way and then passed to
  * xengXgpuKernelAsync is complete before the contraction of its dump reads it.  No counters are returned. */
 int xengSnap2UnpackAsync(const void *packets_dev, int npkt, size_t pkt_stride, void *out_dev, uint64_t seq0, int ntime,
                          int chan0_pipeline, int nchan_tot, int npol_tot, int clear);
+/* Packets the enqueue-only calls have dropped (out of window / foreign / malformed) since this was last called; waits for
+ * the staging stream and clears the count.  The synchronous call reports its own drops in *ndropped. */
+int xengSnap2GetAsyncDrops(int *ndropped);
 
 /* ---------------------------------------------------------------- CorrAcc
  * replaces bifrost.map "a = b" / "a += b" on int32 (corr_acc_block.py:304,306).  Device pointers;

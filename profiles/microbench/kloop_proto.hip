@@ -223,6 +223,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k(const uint8_t* __restrict__
     if (lane == 0) { st[2 * (blockIdx.x * NW + wave)] = t1 - t0; st[2 * (blockIdx.x * NW + wave) + 1] = r1 - r0; }
 }
 
+static int g_reps = 100;
 template <int SHAPE, int NW, int VAR = 0>
 void run(const char* name, const uint8_t* src, int* out, unsigned long long* st, uint32_t row_stride) {
     const int nstage = 1500, blocks = 256;     // 1500 stages of 64 samples = 96000 samples
@@ -230,7 +231,7 @@ void run(const char* name, const uint8_t* src, int* out, unsigned long long* st,
     for (int rep = 0; rep < 3; rep++) hipLaunchKernelGGL(HIP_KERNEL_NAME(k<SHAPE, NW, VAR>), dim3(blocks), dim3(64 * NW), 0, 0, src, out, st, nstage, row_stride);
     (void)hipDeviceSynchronize();
     (void)hipEventRecord(e0);
-    const int reps = 100;
+    const int reps = g_reps;
     for (int rep = 0; rep < reps; rep++) hipLaunchKernelGGL(HIP_KERNEL_NAME(k<SHAPE, NW, VAR>), dim3(blocks), dim3(64 * NW), 0, 0, src, out, st, nstage, row_stride);
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
@@ -244,7 +245,9 @@ void run(const char* name, const uint8_t* src, int* out, unsigned long long* st,
            ops / (ms * 1e-3) / 1e12, clk / 1e9, cyc / nstage, ms / reps);
 }
 
-int main() {
+int main(int argc, char** argv) {
+    const int only = argc > 1 ? atoi(argv[1]) : -1;      // run one variant for a long time (power sampling): index, reps
+    if (argc > 2) g_reps = atoi(argv[2]);
     const uint32_t row_stride = 96 * 704;
     const size_t bytes = (size_t)row_stride * (16 * 64 + 256) + (1 << 20);
     uint8_t* src; int* out; unsigned long long* st;
@@ -252,16 +255,14 @@ int main() {
     srand(1); for (auto& v : h) v = (uint8_t)(rand() >> 7);
     (void)hipMalloc(&src, bytes); (void)hipMemcpy(src, h.data(), bytes, hipMemcpyHostToDevice);
     (void)hipMalloc(&out, 256 * 512 * 4); (void)hipMalloc(&st, 256 * 8 * 16);
-    for (int rep = 0; rep < 2; rep++) {
-        run<32, 4>("32x32x32, 4 waves (64x64)", src, out, st, row_stride);
-        run<16, 8, 1>("16x16x64, 8 waves, base", src, out, st, row_stride);
-        run<16, 8, 1 + 16>("   - no DMA", src, out, st, row_stride);
-        run<16, 8, 1 + 32>("   - no barrier", src, out, st, row_stride);
-        run<16, 8, 1 + 64>("   - no LDS reads", src, out, st, row_stride);
-        run<16, 8, 1 + 128>("   - no unpack VALU", src, out, st, row_stride);
-        run<16, 8, 1 + 16 + 32>("   - no DMA, no barrier", src, out, st, row_stride);
-        run<16, 8, 1 + 16 + 32 + 64>("   - no DMA/barrier/LDS reads", src, out, st, row_stride);
-        run<16, 8, 1 + 16 + 32 + 64 + 128>("   - MFMA only", src, out, st, row_stride);
+    for (int rep = 0; rep < (only >= 0 ? 1 : 2); rep++) {
+        if (only < 0 || only == 0) run<32, 4>("32x32x32, 4 waves (64x64)", src, out, st, row_stride);
+        if (only < 0 || only == 1) run<32, 8>("32x32x32, 8 waves (64x32)", src, out, st, row_stride);
+        if (only < 0 || only == 2) run<16, 4, 2>("16x16x64, 4 waves, no hints", src, out, st, row_stride);
+        if (only < 0 || only == 3) run<16, 8, 1>("16x16x64, 8 waves, VALU 2-2-2-3", src, out, st, row_stride);
+        if (only < 0 || only == 4) run<16, 8, 1 + 64>("   - no LDS reads", src, out, st, row_stride);
+        if (only < 0 || only == 5) run<16, 8, 1 + 16 + 32 + 64>("   - no DMA/barrier/LDS reads", src, out, st, row_stride);
+        if (only < 0 || only == 6) run<16, 8, 1 + 16 + 32 + 64 + 128>("   - MFMA only", src, out, st, row_stride);
     }
     return 0;
 }

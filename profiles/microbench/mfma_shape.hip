@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256, 1) void k(const int* __restrict__ seed, int* _
     if ((threadIdx.x & 63) == 0) { st[2 * (t >> 6)] = t1 - t0; st[2 * (t >> 6) + 1] = r1 - r0; }
 }
 
+static int g_reps = 60;
 template <int MODE>
 void run(const char* name, double ops_per_iter, int mfma_per_iter, const int* seed, int* out, unsigned long long* st) {
     const int iters = 8000, blocks = 256;
@@ -73,7 +74,7 @@ void run(const char* name, double ops_per_iter, int mfma_per_iter, const int* se
     for (int rep = 0; rep < 3; rep++) hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, seed, out, st, iters);
     (void)hipDeviceSynchronize();
     (void)hipEventRecord(e0);
-    const int reps = 60;
+    const int reps = g_reps;
     for (int rep = 0; rep < reps; rep++) hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, seed, out, st, iters);
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
@@ -98,11 +99,13 @@ int main(int argc, char** argv) {
     (void)hipMalloc(&out, 256 * 256 * 4); (void)hipMalloc(&st, 256 * 4 * 16);
     printf("operand class %d (0 random bits, 1 zeros, 2 x16-scaled 4-bit, 4 unsigned 4-bit)\n", cls);
     const double ops = 2.0 * 64 * 64 * 64;     // per iteration: a 64x64 tile over 64 samples
-    for (int rep = 0; rep < 2; rep++) {
-        run<0>("i8 32x32x32 (8 per 64 samples)", ops, 8, seed, out, st);
-        run<1>("i8 16x16x64 (16 per 64 samples)", ops, 16, seed, out, st);
-        run<2>("i8 32x32x32 + 3 VALU/MFMA", ops, 8, seed, out, st);
-        run<3>("i8 16x16x64 + 1.5 VALU/MFMA", ops, 16, seed, out, st);
+    const int only = argc > 2 ? atoi(argv[2]) : -1;      // run one mode for a long time (power sampling): mode, reps
+    if (argc > 3) g_reps = atoi(argv[3]);
+    for (int rep = 0; rep < (only >= 0 ? 1 : 2); rep++) {
+        if (only < 0 || only == 0) run<0>("i8 32x32x32 (8 per 64 samples)", ops, 8, seed, out, st);
+        if (only < 0 || only == 1) run<1>("i8 16x16x64 (16 per 64 samples)", ops, 16, seed, out, st);
+        if (only < 0 || only == 2) run<2>("i8 32x32x32 + 3 VALU/MFMA", ops, 8, seed, out, st);
+        if (only < 0 || only == 3) run<3>("i8 16x16x64 + 1.5 VALU/MFMA", ops, 16, seed, out, st);
     }
     return 0;
 }

@@ -38,11 +38,11 @@ static void check_descs(int nblk) {
 }
 
 // every (channel, tile group) appears exactly once per launch; K slices of a split item tile [0, nstage) in order
-static void check_work(int ncu, int nchan, int nblk, int nstage, bool splitk) {
+static void check_work(int ncu, int nchan, int nblk, int nstage, bool splitk, bool stagger = false) {
     const int nwg = (int)build_wg_descs(nblk).size();
     const int grid = fused_grid(nchan, nwg, ncu);
     CHECK(grid >= 1 && grid <= std::max(ncu, 1) && grid <= nchan * nwg, "grid %d (ncu %d, items %d)", grid, ncu, nchan * nwg);
-    const WorkList wl = build_work(grid, nchan, nwg, nstage, splitk);
+    const WorkList wl = build_work(grid, nchan, nwg, nstage, splitk, stagger);
     CHECK((int)wl.entries.size() == grid * wl.maxi, "entries");
     std::map<std::pair<int, int>, std::vector<std::pair<int, int>>> items;     // (c, wg) -> [(stage0, nst)] by slice
     std::map<std::pair<int, int>, int> nslices;
@@ -108,7 +108,7 @@ int main() {
     const int shapes[][4] = {{256, 96, 11, 25}, {256, 96, 11, 5}, {256, 8, 2, 3}, {256, 3, 1, 1}, {64, 96, 11, 25}, {256, 5, 11, 7},
                              {304, 96, 11, 25}, {8, 16, 3, 2}, {1, 1, 1, 1}, {256, 192, 11, 50}};
     for (auto& s : shapes)
-        for (int sk = 0; sk < 2; sk++) check_work(s[0], s[1], s[2], s[3], sk != 0);
+        for (int sk = 0; sk < 3; sk++) check_work(s[0], s[1], s[2], s[3], sk == 1, sk == 2);
     for (int ns : {4, 8, 16, 32, 352}) check_order(ns);
     if (fails) { fprintf(stderr, "%d check(s) failed\n", fails); return 1; }
     printf("tiling_check: all properties hold\n");

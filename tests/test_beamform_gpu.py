@@ -153,6 +153,41 @@ def test_integrated_mode(gpu):
     gpu.ffi.call("xengBeamformDestroy")
 
 
+@pytest.mark.parametrize("ntime,nchan,ninput,nbeam,nblk", [
+    (960, 4, 704, 32, 40),      # config-4 shapes: 24-sample blocks straddle the 128-sample work-group tiles
+    (384, 2, 64, 6, 3),         # 128-sample blocks = one work-group each; 3 beam pairs
+    (200, 3, 48, 4, 8),         # ragged last work-group (200 = 128 + 72), 25-sample blocks
+])
+def test_integrated_mode_fused_epilogue(gpu, ntime, nchan, ninput, nbeam, nblk):
+    """ntime_blocks > 0 with weights the caller keeps (versioned): from the second call on the power sums are formed in the
+    beamformer kernel's epilogue (no voltage beams in memory, no Integrate launch); the first call, whose weight routing
+    is not known yet, composes Run + Integrate.  Both against the oracle; and bit-identical between repeated fused calls."""
+    import ctypes
+    rng = np.random.default_rng(ntime)
+    vin = rng.integers(0, 256, (ntime, nchan, ninput), dtype=np.uint8)
+    w = block_weights(nchan, nbeam, ninput)
+    gpu.ffi.call("xengBeamformInitialize", 0, ninput, nchan, ntime, nbeam, nblk)
+    di = gpu.ffi.DeviceBuffer(vin.size).upload(vin)
+    dw = gpu.ffi.DeviceBuffer(w.nbytes).upload(w)
+    do = gpu.ffi.DeviceBuffer((nbeam // 2) * nblk * nchan * 16)
+    exp = orc.beamform_integrate(orc.beamform(vin, w, ntime, nchan, ninput, nbeam), ntime // nblk)
+    tm, cn = (ctypes.c_double * 2)(), (ctypes.c_int * 2)()
+    gpu.ffi.call("xengBeamformSetProfiling", 1)
+    gpu.ffi.call("xengBeamformGetTimes", tm, cn)
+    outs = []
+    for k in range(3):
+        gpu.ffi.call("xengMemset", do.ptr, 0x7F, do.nbytes)
+        gpu.ffi.call("xengBeamformRunVersioned", di.ptr, do.ptr, dw.ptr, 9)
+        gpu.ffi.call("xengBeamformSync")
+        outs.append(do.download(np.float32).reshape(nbeam // 2, nblk, nchan, 4))
+        assert np.all(np.isclose(outs[-1], exp, rtol=1e-5, atol=1e-5 * np.abs(exp).max())), k
+    gpu.ffi.call("xengBeamformGetTimes", tm, cn)
+    gpu.ffi.call("xengBeamformSetProfiling", 0)
+    assert cn[0] == 3 and cn[1] == 1                     # one composed call (Integrate launched once), two fused ones
+    assert np.array_equal(outs[1], outs[2])
+    gpu.ffi.call("xengBeamformDestroy")
+
+
 def test_versioned_weights_are_resplit_only_on_change(gpu):
     """xengBeamformRunVersioned: same (pointer, version) reuses the bf16-split weights; a new version
     (or version 0) re-splits, so results always follow the current weights."""

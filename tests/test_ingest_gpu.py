@@ -71,6 +71,66 @@ def test_unpack_reference_transmitter_fixture(golden_dir):
     assert np.array_equal(got2.reshape(vin.shape)[:T - 2], vin[2:]) and not got2.reshape(vin.shape)[T - 2:].any()
 
 
+def test_unpack_zero_fill_only_when_packets_are_missing():
+    """clear=1 on a gulp that holds stale bytes: a complete slab overwrites every byte (no zero-fill pass is needed, and
+    none of the stale bytes may survive); with packets lost, duplicated or off the packet grid the missing samples read
+    as zero, never as stale data."""
+    T, C, S = 16, 8, 64
+    rng = np.random.default_rng(11)
+    vin = rng.integers(1, 256, (T, C, S, 2), dtype=np.uint8)
+    pk = orc.snap2_packets(vin, seq0=5, nchan_blocks=2, nstand_per_pkt=32, chan0_pipeline=0)
+    stride = len(pk[0])
+    out = ffi.DeviceBuffer(T * C * S * 2)
+
+    def stale():
+        ffi.call("xengMemset", out.ptr, 0xAA, out.nbytes)
+
+    stale()
+    got, placed, dropped = _unpack(b"".join(pk), len(pk), stride, 5, T, 0, C, S * 2, out=out)
+    assert placed == len(pk) and dropped == 0 and np.array_equal(got.reshape(vin.shape), vin)
+    for lost, extra in (([3, 40], []), ([], [pk[7]]), ([9], [pk[9 + 1], pk[2]])):        # loss; duplicate; loss + duplicates
+        stale()
+        sel = [p for i, p in enumerate(pk) if i not in lost] + extra
+        exp, ep, ed = orc.snap2_unpack(sel, 5, T, 0, C, S * 2)
+        got, placed, dropped = _unpack(b"".join(sel), len(sel), stride, 5, T, 0, C, S * 2, out=out)
+        assert (placed, dropped) == (ep, ed) and np.array_equal(got, exp)
+    # a second geometry in the same rows (whole-band packets on top of half-band ones): irregular -> blank + rescatter
+    stale()
+    wide = orc.snap2_packets(vin[:2], seq0=5, nchan_blocks=1, nstand_per_pkt=32, chan0_pipeline=0)
+    pad = [p + bytes(len(wide[0]) - len(p)) for p in pk[8:]]                              # same stride for both kinds
+    sel = wide + pad
+    exp, ep, ed = orc.snap2_unpack(sel, 5, T, 0, C, S * 2)
+    got, placed, dropped = _unpack(b"".join(sel), len(sel), len(wide[0]), 5, T, 0, C, S * 2, out=out)
+    assert (placed, dropped) == (ep, ed) and np.array_equal(got, exp)
+    out.free()
+
+
+def test_async_unpack_counts_its_own_drops():
+    """xengSnap2UnpackAsync keeps its drops in a counter of its own: xengSnap2GetAsyncDrops reads and clears it, and a
+    synchronous call in between neither sees nor disturbs it."""
+    T, C, S = 8, 8, 64
+    rng = np.random.default_rng(12)
+    vin = rng.integers(0, 256, (T, C, S, 2), dtype=np.uint8)
+    pk = orc.snap2_packets(vin, seq0=100, nchan_blocks=2, nstand_per_pkt=32, chan0_pipeline=0)
+    stride = len(pk[0])
+    stray = [orc.snap2_packets(vin[:1], seq0=100 + T, nchan_blocks=2)[0], orc.snap2_packets(vin[:1], seq0=99, nchan_blocks=2)[0], bytes(stride)]
+    slab = b"".join(pk + stray)
+    dpk = ffi.DeviceBuffer(len(slab)).upload(np.frombuffer(slab, dtype=np.uint8))
+    dout = ffi.DeviceBuffer(T * C * S * 2)
+    n = ctypes.c_int(-1)
+    ffi.call("xengSnap2GetAsyncDrops", ctypes.byref(n))
+    ffi.call("xengSnap2UnpackAsync", dpk.ptr, len(pk) + 3, stride, dout.ptr, 100, T, 0, C, S * 2, 1)
+    ffi.call("xengSnap2UnpackAsync", dpk.ptr, len(pk) + 3, stride, dout.ptr, 100, T, 0, C, S * 2, 1)
+    got, placed, dropped = _unpack(slab, len(pk) + 3, stride, 100, T, 0, C, S * 2)       # synchronous call in between
+    assert (placed, dropped) == (len(pk), 3)
+    ffi.call("xengSnap2GetAsyncDrops", ctypes.byref(n))
+    assert n.value == 6
+    ffi.call("xengSnap2GetAsyncDrops", ctypes.byref(n))
+    assert n.value == 0
+    assert np.array_equal(dout.download(np.uint8).reshape(vin.shape), vin)
+    dpk.free(); dout.free()
+
+
 def test_unpack_drops_and_blanks():
     T, C, S = 8, 8, 64
     rng = np.random.default_rng(1)
