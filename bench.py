@@ -85,8 +85,9 @@ def cpu_baseline(budget_s=12.0, verify=None):
         err = float(np.max(np.abs(verify["beams"].astype(np.complex128) - exp)) / np.sqrt(np.mean(np.abs(exp) ** 2)))
         chk["beams_max_err_over_rms"] = err
         chk["beams_within_1e-5"] = bool(err <= 1e-5)
-        chk["power_beams_ok"] = bool(np.all(np.isclose(verify["power"], orc.beamform_integrate(verify["beams"], verify["ntime_sum"]),
-                                                       rtol=1e-5, atol=1e-5 * np.abs(verify["power"]).max())))
+        pexp = orc.beamform_integrate(verify["beams"], verify["ntime_sum"])
+        chk["power_beams_max_err_over_max"] = float(np.max(np.abs(verify["power"] - pexp)) / np.abs(pexp).max())
+        chk["power_beams_ok"] = bool(chk["power_beams_max_err_over_max"] <= 1e-5)
         chk["ok"] = bool(chk["visibilities_bit_exact"] and chk["corracc_sum_bit_exact"] and chk["beams_within_1e-5"] and chk["power_beams_ok"])
         out["config5_check"] = chk
     return out
@@ -389,12 +390,13 @@ def main():
         for _ in range(nrep):
             ffi.call("xengSnap2Unpack", dslab.ptr, npk, stride, dgulp.ptr, 0, NTIME_GULP, 0, NCHAN, NINPUT, 1, None, None)
         in_ms = (time.perf_counter() - t1) / nrep * 1e3
-        in_bytes = slab.nbytes + 2 * gulp_bytes              # packets read, gulp zero-filled and written
+        in_bytes = slab.nbytes + gulp_bytes                  # packets read, gulp written once (a complete slab needs no zero-fill)
         ingest = {"kernel": "snap2_unpack_kernel", "avg_us": round(in_ms * 1e3, 1), "packets": npk, "packet_bytes": stride,
                   "ingest_gbps": round(8 * gulp_bytes / (in_ms * 1e-3) / 1e9, 1),
                   "roofline": {"bound": "hbm", "achieved": round(in_bytes / (in_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": round(in_bytes / (in_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-                  "note": "wall time of the synchronous call: memset of the gulp + scatter kernel (24 us on the device, profiles/r01/v5_kernel_stats_all_legs.csv) + counter read-back"}
+                  "note": "wall time of the synchronous call: clear of the call state + scatter kernel (device time: profiles/r02 kernel stats) + "
+                          "read-back of the drop counter and packet coverage + host check; no zero-fill pass for a complete slab"}
         # packets -> visibilities, device resident (BASELINE: "throughput on synthetic F-engine packets"): every gulp of
         # every integration is first scattered out of its packet slab (enqueue-only, on the X-engine's staging stream),
         # then registered with the X-engine; same streaming pattern as the timed region
