@@ -574,16 +574,19 @@ def main():
     fused, fp6 = ctypes.c_int(), ctypes.c_int()
     ffi.call("xengXgpuGetPath", ctypes.byref(fused), ctypes.byref(fp6))
     kname = "xcorr_fused_kernel" if fused.value else ("xcorr_fp6_kernel" if fp6.value else "xcorr_mfma_kernel")
-    # (PMC counters cannot be collected inside this run; the committed figure counts only while it was taken from the
-    # very library that is loaded now, else traffic is null)
+    # (PMC counters cannot be collected inside this run; the committed figure counts only while the X-engine sources it was
+    # taken from are the ones this library was built from, else traffic is null)
     traffic = None
     try:
         import hashlib
         with open(os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")) as fh:
             pmc = json.load(fh)
-        with open(ffi.LIB_PATH, "rb") as fh:
-            if hashlib.sha256(fh.read()).hexdigest() == pmc.get("libxeng_sha256"):
-                traffic = pmc.get(kname + "_bytes_per_launch")
+        hh = hashlib.sha256()
+        for f in pmc.get("xcorr_sources", []):
+            with open(os.path.join(ROOT, "caltech-bifrost-dsp_amd", "csrc", f), "rb") as fh:
+                hh.update(fh.read())
+        if hh.hexdigest() == pmc.get("xcorr_sources_sha256"):
+            traffic = pmc.get(kname + "_bytes_per_launch")
     except (OSError, ValueError):
         pass
     res = {

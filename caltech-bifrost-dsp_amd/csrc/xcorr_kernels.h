@@ -1141,6 +1141,7 @@ __global__ __launch_bounds__(256) void packetize_kernel(const int32_t* __restric
             const int cell = wv[0] & ~3;
             const bool one_cell = (wv[1] & ~3) == cell && (wv[2] & ~3) == cell && (wv[3] & ~3) == cell;
             const int rbase = ((bs >> 3) << 5) | ((bs & 7) << 2);
+#pragma unroll 6
             for (int c = cg; c < nchan; c += 16) {
                 const int64_t o = (int64_t)c * per_chan;
                 int re[4], im[4];
@@ -1167,16 +1168,25 @@ __global__ __launch_bounds__(256) void packetize_kernel(const int32_t* __restric
         }
     }
     __syncthreads();
+    // phase B: wave w writes the payloads of baselines w, w+4, ...; a lane moves two consecutive int2 (16 bytes) per step
     const int per_bl = 4 * nchan;                        // int2 elements per payload
-    for (int i = t; i < 16 * per_bl; i += 256) {
-        const int b = i / per_bl, e = i - b * per_bl;    // b = 2*k + parity: s0 = s0base + b
+    const int lane = t & 63, wave = t >> 6;
+    for (int b = wave; b < 16; b += 4) {                 // b = 2*k + parity: s0 = s0base + b
         const int s0 = s0base + b;
         if (s0 > s1 || s0 >= nstand) continue;
-        const int pp = fmt ? (e & 3) : e / nchan;
-        const int c = fmt ? (e >> 2) : e - pp * nchan;
-        const int row = ((b & 1) << 5) | ((b >> 1) << 2) | pp;
+        const int rowb = ((b & 1) << 5) | ((b >> 1) << 2);
         const int64_t k = (int64_t)s0 * nstand - ((int64_t)s0 * (s0 - 1)) / 2 + (s1 - s0);
-        out[k * per_bl + e] = tile[row * pitch + c];
+        int2* dst = out + k * per_bl;
+        if (fmt) {                                       // [chan][pol][pol][2]: e = 4c + pp
+            for (int e = 2 * lane; e < per_bl; e += 128) {
+                const int c = e >> 2, pp = e & 3;        // (pp is 0 or 2: the pair pp, pp+1 shares the channel)
+                const int2 v0 = tile[(rowb | pp) * pitch + c], v1 = tile[(rowb | (pp + 1)) * pitch + c];
+                *reinterpret_cast<int4*>(dst + e) = make_int4(v0.x, v0.y, v1.x, v1.y);
+            }
+        } else {                                         // [pol][pol][chan][2]: e = pp * nchan + c
+            for (int pp = 0; pp < 4; pp++)
+                for (int c = lane; c < nchan; c += 64) dst[pp * nchan + c] = tile[(rowb | pp) * pitch + c];
+        }
     }
 }
 

@@ -45,3 +45,19 @@ elif what == "integrate":
     pw = ffi.DeviceBuffer((NB // 2) * (NT // NS) * NCHAN * 16)
     t = timed(lambda: L.xengBeamformIntegrate(beams.ptr, pw.ptr, NS), lambda: ffi.call("xengBeamformSync"), nrep=200)
     print("integrate: %.1f us  %.2f TB/s of %d MB" % (t * 1e6, beams.nbytes / t / 1e12, beams.nbytes >> 20))
+elif what == "packetize":
+    nst = NINPUT // 2
+    ffi.call("xengXgpuConfigure", nst, 2, NCHAN, 480, 5)
+    ffi.call("xengXgpuInitialize", 0)
+    vis = ffi.DeviceBuffer(2 * matlen * 4)
+    ffi.call("xengMemset", vis.ptr, 3, vis.nbytes)
+    a2i = np.arange(NINPUT, dtype=np.int32)
+    blm = np.zeros(nst * nst * 4, dtype=np.int32)
+    cjm = np.zeros_like(blm)
+    ffi.call("xengXgpuGetOrder", a2i.ctypes.data, blm.ctypes.data, cjm.ctypes.data)
+    dbl, dcj = ffi.DeviceBuffer(blm.nbytes).upload(blm), ffi.DeviceBuffer(cjm.nbytes).upload(cjm)
+    nbl = nst * (nst + 1) // 2
+    dpay = ffi.DeviceBuffer(nbl * 4 * NCHAN * 8)
+    for fmt in (1, 0):
+        t = timed(lambda: L.xengXgpuPacketize(vis.ptr, dpay.ptr, dbl.ptr, dcj.ptr, fmt), lambda: None, nrep=30)
+        print("packetize fmt %d: %.1f us per synchronous call  %.2f TB/s (read + write %d MB)" % (fmt, t * 1e6, 2 * dpay.nbytes / t / 1e12, 2 * dpay.nbytes >> 20))
