@@ -9,6 +9,11 @@ Two layers:
   * ctypes bindings to oracle/libxeng_oracle.so (xeng_oracle.c), which is what
     the GPU parity tests compare the HIP path against at full size.
 Citations are relative to /root/reference/pipeline.
+
+Pinning (tests/test_oracle.py): visibilities / maps / reorder against the reference's own golden generator
+(oracle/make_golden.py), the beamformer against the reference's SoftwareBf functions (oracle/make_golden_beamform.py),
+the SNAP2 packet stream (snap2_packets / snap2_unpack) against datagrams recorded from the reference's own transmitter
+test_transmitters/test_tx_vectors.py (oracle/make_golden_snap2.py -> tests/golden/snap2_*.bin).
 """
 import ctypes
 import os
