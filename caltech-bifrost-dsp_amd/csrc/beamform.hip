@@ -27,6 +27,7 @@ struct BeamContext {
     uint8_t* wq = nullptr;            // int8x3 digit planes
     float* wscale = nullptr;          // ... and their per-(channel, beam) scale
     float* wmax = nullptr;            // inlier row maxima (between the prep passes)
+    int* wsum = nullptr;              // [nchan][nbtile][3][32] sums of the Wi digits (int8x3 kernel's accumulator start)
     // precision control of the int8x3 route (beamform_kernels.h, "precision of the fixed-point weights")
     int* row_out = nullptr;           // [nchan][nbtile*32][BI_ROW_OUT] outlier inputs per row
     int* route = nullptr;             // [nchan*nbtile] 1 = the tile runs on the bf16x3 kernel; [nchan*nbtile] = any
@@ -53,6 +54,7 @@ static int beam_destroy_locked() {
     if (g_b.wq) (void)hipFree(g_b.wq);
     if (g_b.wscale) (void)hipFree(g_b.wscale);
     if (g_b.wmax) (void)hipFree(g_b.wmax);
+    if (g_b.wsum) (void)hipFree(g_b.wsum);
     if (g_b.row_out) (void)hipFree(g_b.row_out);
     if (g_b.route) (void)hipFree(g_b.route);
     if (g_b.out_n) (void)hipFree(g_b.out_n);
@@ -87,12 +89,12 @@ static int run_locked(const void* in, float* out, const void* w, long long versi
             // row statistics -> outliers / routing -> digits (and, for routed tiles only, the bf16 split)
             XENG_HIP(hipMemsetAsync(x.route, 0, (size_t)(ntile + 1) * sizeof(int), x.stream));
             hipLaunchKernelGGL(beam_weights_rowstat_kernel, dim3(8 * x.nbtile, x.nchan), dim3(256), 0, x.stream,
-                               (const float*)w, x.wscale, x.wmax, x.row_out, x.route, x.nchan, x.nbeam, x.ninput, x.nbtile);
+                               (const float*)w, x.wscale, x.wmax, x.row_out, x.route, x.wsum, x.nchan, x.nbeam, x.ninput, x.nbtile);
             const size_t ol = (size_t)((x.ninput + 63) & ~63) + (BI_TILE_OUT + 1) * sizeof(int);
             hipLaunchKernelGGL(beam_weights_outlier_kernel, dim3(x.nbtile, x.nchan), dim3(256), ol, x.stream,
                                (const float*)w, x.row_out, x.out_n, x.out_idx, x.out_R, x.route, x.nchan, x.nbeam, x.ninput, x.nbtile);
             hipLaunchKernelGGL(beam_weights_prep_i8_kernel, dim3(x.nchunk_i8 * BI_KS, x.nbtile, x.nchan), dim3(256), 0, x.stream,
-                               (const float*)w, x.wq, x.wmax, x.nchan, x.nbeam, x.ninput, x.nchunk_i8 * BI_KS, x.nbtile, x.route);
+                               (const float*)w, x.wq, x.wmax, x.nchan, x.nbeam, x.ninput, x.nchunk_i8 * BI_KS, x.nbtile, x.route, x.wsum);
             hipLaunchKernelGGL(beam_weights_prep_kernel, dim3((x.ninput + 63) / 64, x.nbtile, x.nchan), dim3(256), 0, x.stream,
                                (const float*)w, x.wprep, x.nchan, x.nbeam, x.ninput, x.nchunk, x.nbtile, x.route);
             XENG_HIP(hipGetLastError());
@@ -117,7 +119,7 @@ static int run_locked(const void* in, float* out, const void* w, long long versi
             XENG_HIP(hipMemsetAsync(pow_out, 0, (size_t)(x.nbeam / 2) * (x.ntime / ntime_sum) * x.nchan * 4 * sizeof(float), x.stream));
             *fused = true;
         }
-        hipLaunchKernelGGL(beamform_i8x3_kernel, grid, dim3(256), 0, x.stream, (const uint8_t*)in, x.wq, x.wscale, out,
+        hipLaunchKernelGGL(beamform_i8x3_kernel, grid, dim3(256), 0, x.stream, (const uint8_t*)in, x.wq, x.wscale, x.wsum, out,
                            x.ntime, x.nchan, x.ninput, x.nbeam, x.nchunk_i8, x.nbtile, x.route, x.out_n, x.out_idx, x.out_R, x.stamps,
                            fuse ? pow_out : (float*)nullptr, ntime_sum);
         if (x.need_bf16) {
@@ -195,6 +197,7 @@ int xengBeamformInitialize(int gpu, int ninput, int nchan, int ntime, int nbeam,
         XENG_HIP(hipMemset(x.wq, 0, qb));
         XENG_HIP(hipMalloc((void**)&x.wscale, (size_t)nchan * x.nbtile * 32 * sizeof(float)));
         XENG_HIP(hipMalloc((void**)&x.wmax, (size_t)nchan * x.nbtile * 32 * sizeof(float)));
+        XENG_HIP(hipMalloc((void**)&x.wsum, (size_t)nchan * x.nbtile * 3 * 32 * sizeof(int)));
         const size_t ntile = (size_t)nchan * x.nbtile;
         XENG_HIP(hipMalloc((void**)&x.row_out, ntile * 32 * BI_ROW_OUT * sizeof(int)));
         XENG_HIP(hipMalloc((void**)&x.route, (ntile + 1) * sizeof(int)));

@@ -325,19 +325,24 @@ __global__ __launch_bounds__(64 * BF3_NW, BF3_NW == 8 ? 2 : 3) void beamform_bf1
 // <= 4e-6 * wmax/wrms of the output RMS in the worst (fully coherent) case and ~1e-7 for ordinary data, inside
 // the 1e-5 bar; measured in tests/test_beamform_gpu.py.
 //
-// Layout Wq[c][beam tile][32-input chunk][digit][Wr | Wi | -Wi][lane = 32h + beam][16 B]: the A-operand image of
-// v_mfma_i32_32x32x32_i8 (lane holds inputs 16h..16h+15 of its beam), 9 KiB per chunk; scale[c][beam].
-// Kernel structure as beamform_bf16x3_kernel: ring of three stages (9 KiB of digits + 4 KiB of voltages), LDS-DMA
-// two chunks ahead, one barrier per chunk, three work-groups per CU.
+// Layout Wq[c][beam tile][32-input K step][digit][Wr | Wi][lane = 32h + beam][16 B]: the A-operand image of
+// v_mfma_i32_32x32x32_i8 (lane holds inputs 16h..16h+15 of its beam), 6 KiB per K step; scale[c][beam];
+// wsum[c][beam tile][digit][beam] = sum over the inputs of the Wi digit (the "- di * 16xi" term runs as
+// di * 16*(~xi) = -di*16xi - 16*di, so no negated plane is stored, staged or read; the accumulator starts at 16*wsum).
+// Kernel structure as beamform_bf16x3_kernel: ring of BI_RING stages (two K steps: 12 KiB of digits + 8 KiB of
+// voltages), LDS-DMA one chunk ahead, one barrier per chunk, three work-groups per CU.
 // =======================================================================================
-constexpr int BI_KS = 2;                            // int8 MFMA K steps (32 inputs each) per chunk
+#ifndef BI_KSTEPS
+#define BI_KSTEPS 2
+#endif
+constexpr int BI_KS = BI_KSTEPS;                            // int8 MFMA K steps (32 inputs each) per chunk
 constexpr int BI_KC = 32 * BI_KS;                   // inputs per chunk
-constexpr int BI_WSTEP = 3 * 3 * 1024;              // per K step: digits x {Wr, Wi, -Wi} x 1 KiB operand image
-constexpr int BI_WCHUNK = BI_KS * BI_WSTEP;         // 18 KiB
+constexpr int BI_WSTEP = 3 * 2 * 1024;              // per K step: digits x {Wr, Wi} x 1 KiB operand image
+constexpr int BI_WCHUNK = BI_KS * BI_WSTEP;         // 12 KiB
 constexpr int BI_NT = 128;                          // samples per work-group (4 waves x 32)
 constexpr int BI_XCHUNK = BI_NT * BI_KC;            // 8 KiB of packed voltages per chunk
-constexpr int BI_STAGE = BI_WCHUNK + BI_XCHUNK;     // 26 KiB
-constexpr int BI_WSLOTS = (BI_KS * 9 + 3) / 4;      // weight pieces issued per wave and chunk
+constexpr int BI_STAGE = BI_WCHUNK + BI_XCHUNK;     // 20 KiB
+constexpr int BI_WSLOTS = (BI_KS * 6 + 3) / 4;      // weight pieces issued per wave and chunk
 constexpr int BI_XSLOTS = BI_XCHUNK / 1024 / 4;     // voltage pieces issued per wave and chunk
 #ifndef BI_RING_STAGES
 #define BI_RING_STAGES 2
@@ -369,8 +374,8 @@ constexpr int BI_GAP_BINADES = 3;
 // route[nchan*nbtile] (+ route[nchan*nbtile] = "any tile routed"), zeroed by the caller.
 __global__ __launch_bounds__(256) void beam_weights_rowstat_kernel(const float* __restrict__ w, float* __restrict__ scale,
                                                                    float* __restrict__ wmax, int* __restrict__ row_out,
-                                                                   int* __restrict__ route, int nchan, int nbeam,
-                                                                   int ninput, int nbtile) {
+                                                                   int* __restrict__ route, int* __restrict__ wsum,
+                                                                   int nchan, int nbeam, int ninput, int nbtile) {
     __shared__ int hist[4][256];
     const int c = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + wave;                  // beam index within the padded tiles
@@ -430,6 +435,7 @@ __global__ __launch_bounds__(256) void beam_weights_rowstat_kernel(const float* 
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if (lane >= nout && lane < BI_ROW_OUT) ro[lane] = -1;
+    if (lane < 3) wsum[((size_t)(c * nbtile + (row >> 5)) * 3 + lane) * 32 + (row & 31)] = 0;   // pass 2 adds the digits up
     if (lane == 0) {
         scale[(size_t)c * nbtile * 32 + row] = m > 0.f ? m / (float)BI_QMAX / 16.f : 0.f;
         wmax[(size_t)c * nbtile * 32 + row] = m;
@@ -491,7 +497,7 @@ __global__ __launch_bounds__(256) void beam_weights_outlier_kernel(const float* 
 __global__ __launch_bounds__(256) void beam_weights_prep_i8_kernel(const float* __restrict__ w, uint8_t* __restrict__ wq,
                                                                    const float* __restrict__ wmax, int nchan, int nbeam,
                                                                    int ninput, int nchunk, int nbtile,
-                                                                   const int* __restrict__ route) {
+                                                                   const int* __restrict__ route, int* __restrict__ wsum) {
     const int ch = blockIdx.x, bt = blockIdx.y, c = blockIdx.z;      // ch: 32-input K step (nchunk = number of steps, padded to whole chunks)
     if (route[c * nbtile + bt]) return;                              // the bf16x3 kernel takes this (channel, beam tile)
     const int beam = threadIdx.x >> 3, l8 = threadIdx.x & 7;
@@ -510,7 +516,8 @@ __global__ __launch_bounds__(256) void beam_weights_prep_i8_kernel(const float* 
         }
     };
     const int h = l8 >> 2, byte0 = (l8 & 3) * 4, lane = 32 * h + beam;
-    uint32_t pk[3][3] = {};                      // [digit][Wr | Wi | -Wi] 4 packed int8
+    uint32_t pk[3][2] = {};                      // [digit][Wr | Wi] 4 packed int8
+    int dsum[3] = {0, 0, 0};                     // this thread's share of sum_i Wi digit (see beamform_i8x3_kernel)
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int i = ch * 32 + l8 * 4 + j;
@@ -530,19 +537,26 @@ __global__ __launch_bounds__(256) void beam_weights_prep_i8_kernel(const float* 
         for (int t = 0; t < 3; t++) {
             pk[t][0] |= (uint32_t)(dr[t] & 0xFF) << (8 * j);
             pk[t][1] |= (uint32_t)(di[t] & 0xFF) << (8 * j);
-            pk[t][2] |= (uint32_t)((-di[t]) & 0xFF) << (8 * j);
+            dsum[t] += di[t];
         }
     }
     uint8_t* base = wq + (((size_t)c * nbtile + bt) * nchunk + ch) * BI_WSTEP + lane * 16 + byte0;
 #pragma unroll
     for (int t = 0; t < 3; t++)
 #pragma unroll
-        for (int k = 0; k < 3; k++) *reinterpret_cast<uint32_t*>(base + (t * 3 + k) * 1024) = pk[t][k];
+        for (int k = 0; k < 2; k++) *reinterpret_cast<uint32_t*>(base + (t * 2 + k) * 1024) = pk[t][k];
+    // per (row, digit): sum of the Wi digits over all inputs (integer atomics: order-independent)
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        int v = dsum[t];
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+        if (l8 == 0 && v != 0) atomicAdd(&wsum[((size_t)(c * nbtile + bt) * 3 + t) * 32 + beam], v);
+    }
 }
 
 __global__ __launch_bounds__(256, 3) void beamform_i8x3_kernel(const uint8_t* __restrict__ in,
                                                                const uint8_t* __restrict__ wq,
-                                                               const float* __restrict__ scale,
+                                                               const float* __restrict__ scale, const int* __restrict__ wsum,
                                                                float* __restrict__ out, int ntime, int nchan,
                                                                int ninput, int nbeam, int nchunk, int nbtile,
                                                                const int* __restrict__ route, const int* __restrict__ out_n,
@@ -582,7 +596,7 @@ __global__ __launch_bounds__(256, 3) void beamform_i8x3_kernel(const uint8_t* __
         const uint32_t l = lds0 + buf * BI_STAGE;
 #pragma unroll
         for (int n = 0; n < BI_WSLOTS; n++) {
-            const int pc = (wave + 4 * n) % (BI_KS * 9);
+            const int pc = (wave + 4 * n) % (BI_KS * 6);
             lds_dma16(wsrc + (size_t)cs * BI_WCHUNK + pc * 1024, l + pc * 1024);
         }
 #pragma unroll
@@ -592,6 +606,8 @@ __global__ __launch_bounds__(256, 3) void beamform_i8x3_kernel(const uint8_t* __
             lds_dma16(xsrc[n] + i, l + BI_WCHUNK + (wave * BI_XSLOTS + n) * 1024);
         }
     };
+#pragma unroll
+    for (int k = 0; k < BI_RING - 1; k++) issue(k, k);          // first: the DMA of the first chunk(s) is the critical path
     // the 16 row scales this lane needs in the epilogue: fetched now, off the critical path
     float sc[16];
 #pragma unroll
@@ -599,10 +615,16 @@ __global__ __launch_bounds__(256, 3) void beamform_i8x3_kernel(const uint8_t* __
     typedef int v4i_ __attribute__((ext_vector_type(4)));
     typedef int v16i_ __attribute__((ext_vector_type(16)));
     v16i_ acc_re[3], acc_im[3];
+    // Tre = sum(dr*xr - di*xi) without a negated digit plane: the MFMA gets ~xi = -xi - 1 (one XOR on the masked
+    // operand; -xi itself would not fit for xi = -8), sum(di * 16*(~xi)) = -sum(di * 16*xi) - 16 * sum(di), and the
+    // accumulator starts at +16 * sum(di) (exact integers; wsum from the prep pass)
 #pragma unroll
-    for (int t = 0; t < 3; t++) { acc_re[t] = (v16i_)(0); acc_im[t] = (v16i_)(0); }
+    for (int t = 0; t < 3; t++) {
+        acc_im[t] = (v16i_)(0);
 #pragma unroll
-    for (int k = 0; k < BI_RING - 1; k++) issue(k, k);
+        for (int g = 0; g < 16; g++)
+            acc_re[t][g] = 16 * wsum[((size_t)(c * nbtile + bt) * 3 + t) * 32 + (g & 3) + 8 * (g >> 2) + 4 * h];
+    }
     int buf = 0, nbuf = BI_RING - 1;
     unsigned long long r1 = 0;
     for (int ch = 0; ch < nchunk; ch++) {
@@ -618,14 +640,14 @@ __global__ __launch_bounds__(256, 3) void beamform_i8x3_kernel(const uint8_t* __
             const v4i_ xraw = *reinterpret_cast<const v4i_*>(lds + buf * BI_STAGE + BI_WCHUNK + (wave * 32 + j) * BI_KC +
                                                               (((2 * ks + h) ^ ((j >> 2) & 1)) * 16));
             const v4i_ Xr = xraw & M, Xi = (xraw << 4) & M;    // 16*re, 16*im (hi nibble real, lo nibble imag; beamformer_test.py:69-73)
+            const v4i_ nXi = Xi ^ M;                           // 16 * ~im = -16*im - 16
 #pragma unroll
             for (int t = 2; t >= 0; t--) {
-                const v4i_ Wr = *reinterpret_cast<const v4i_*>(lw + (t * 3 + 0) * 1024);
-                const v4i_ Wi = *reinterpret_cast<const v4i_*>(lw + (t * 3 + 1) * 1024);
-                const v4i_ nWi = *reinterpret_cast<const v4i_*>(lw + (t * 3 + 2) * 1024);
+                const v4i_ Wr = *reinterpret_cast<const v4i_*>(lw + (t * 2 + 0) * 1024);
+                const v4i_ Wi = *reinterpret_cast<const v4i_*>(lw + (t * 2 + 1) * 1024);
                 acc_re[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(Wr, Xr, acc_re[t], 0, 0, 0);
                 acc_im[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(Wr, Xi, acc_im[t], 0, 0, 0);
-                acc_re[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(nWi, Xi, acc_re[t], 0, 0, 0);
+                acc_re[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(Wi, nXi, acc_re[t], 0, 0, 0);
                 acc_im[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(Wi, Xr, acc_im[t], 0, 0, 0);
             }
         }
