@@ -376,11 +376,15 @@ __global__ __launch_bounds__(256) void beam_weights_rowstat_kernel(const float* 
                                                                    float* __restrict__ wmax, int* __restrict__ row_out,
                                                                    int* __restrict__ route, int* __restrict__ wsum,
                                                                    int nchan, int nbeam, int ninput, int nbtile) {
+    // (reductions go through LDS memory and LDS atomics, not through ds_bpermute: see beam_integrate_kernel)
     __shared__ int hist[4][256];
+    __shared__ int lanetot[4][64];
+    __shared__ int red[4][4];                                // per wave: E (min), Emed (max), inlier maximum (max, float bits), bucket 0
     const int c = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + wave;                  // beam index within the padded tiles
     const bool live = row < nbeam;
     for (int k = lane; k < 256; k += 64) hist[wave][k] = 0;
+    if (lane == 0) { red[wave][0] = 1 << 30; red[wave][1] = 0; red[wave][2] = 0; }
     __syncthreads();
     const float* wrow = w + ((size_t)c * nbeam + (live ? row : 0)) * ninput * 2;
     if (live)
@@ -394,11 +398,15 @@ __global__ __launch_bounds__(256) void beam_weights_rowstat_kernel(const float* 
     int cnt[4], tot = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) { cnt[q] = hist[wave][4 * lane + q]; tot += cnt[q]; }
-    int suf = tot;                                           // inclusive suffix sum over lanes >= lane
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_down(suf, o); if (lane + o < 64) suf += v; }
+    lanetot[wave][lane] = tot;
+    if (lane == 0) red[wave][3] = cnt[0];                    // entries with a zero exponent field (zeros, denormals)
+    __syncthreads();
+    int suf = 0;                                             // inclusive suffix sum over lanes >= lane
+    for (int l = lane; l < 64; l++) suf += lanetot[wave][l];
+    int all = suf;
+    for (int l = 0; l < lane; l++) all += lanetot[wave][l];
     // ... and the bucket of the median non-zero entry: the largest bucket b >= 1 with at least half of them at or above it
-    const int n_nz = __shfl(suf, 0) - __shfl(cnt[0], 0);
+    const int n_nz = all - red[wave][3];
     int above = suf - tot, Emed = 0;
 #pragma unroll
     for (int q = 3; q >= 0; q--) {
@@ -413,8 +421,11 @@ __global__ __launch_bounds__(256) void beam_weights_rowstat_kernel(const float* 
         const int b = 4 * lane + q, ab = hist[wave][b];
         if (ab <= BI_ROW_OUT && ab == hist[wave][min(b + BI_GAP_BINADES, 255)]) E = b;
     }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) { E = min(E, __shfl_xor(E, o)); Emed = max(Emed, __shfl_xor(Emed, o)); }
+    if (E < (1 << 30)) atomicMin(&red[wave][0], E);
+    if (Emed > 0) atomicMax(&red[wave][1], Emed);
+    __syncthreads();
+    E = red[wave][0];
+    Emed = red[wave][1];
     // second sweep: inlier maximum / sum of squares, outlier list (wave-level compaction)
     float m = 0.f;
     int nout = 0;
@@ -432,8 +443,9 @@ __global__ __launch_bounds__(256) void beam_weights_rowstat_kernel(const float* 
         if (is_out) ro[nout + __popcll(mask & ((1ull << lane) - 1))] = i;     // (at most BI_ROW_OUT by the choice of E)
         nout += __popcll(mask);
     }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (m > 0.f) atomicMax(&red[wave][2], __float_as_int(m));   // (non-negative floats order like their bit patterns)
+    __syncthreads();
+    m = __int_as_float(red[wave][2]);
     if (lane >= nout && lane < BI_ROW_OUT) ro[lane] = -1;
     if (lane < 3) wsum[((size_t)(c * nbtile + (row >> 5)) * 3 + lane) * 32 + (row & 31)] = 0;   // pass 2 adds the digits up
     if (lane == 0) {
@@ -548,8 +560,10 @@ __global__ __launch_bounds__(256) void beam_weights_prep_i8_kernel(const float* 
     // per (row, digit): sum of the Wi digits over all inputs (integer atomics: order-independent)
 #pragma unroll
     for (int t = 0; t < 3; t++) {
-        int v = dsum[t];
-        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+        int v = dsum[t];                         // 8-lane sum by DPP row shifts: the total lands in lane l8 == 0
+        v += __builtin_amdgcn_update_dpp(0, v, 0x104 /* row_shl:4 */, 0xF, 0xF, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x102, 0xF, 0xF, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x101, 0xF, 0xF, true);
         if (l8 == 0 && v != 0) atomicAdd(&wsum[((size_t)(c * nbtile + bt) * 3 + t) * 32 + beam], v);
     }
 }
@@ -754,13 +768,15 @@ __global__ __launch_bounds__(256) void beam_integrate_kernel(const float2* __res
             xyr += a.x * b.x + a.y * b.y;
             xyi += a.y * b.x - a.x * b.y;
         }
-#pragma unroll
-        for (int o = 4; o >= 1; o >>= 1) {
-            xx += __shfl_xor(xx, o);
-            yy += __shfl_xor(yy, o);
-            xyr += __shfl_xor(xyr, o);
-            xyi += __shfl_xor(xyi, o);
-        }
+        // 8-lane sums by DPP row shifts (lane i += lane i+4, i+2, i+1: the total lands in lane sub == 0; same association
+        // as an xor butterfly).  NOT ds_bpermute (__shfl_xor): with this kernel's packed-fp32 accumulators the
+        // bpermute form returned wrong sums in lanes 48-63 whenever an MFMA kernel shared the CU (profiles/soak.py,
+        // DESIGN.md 4.10) -- alone on the GPU it never failed.
+#define XENG_DPP_ADD(v, ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, true))
+        XENG_DPP_ADD(xx, 0x104); XENG_DPP_ADD(yy, 0x104); XENG_DPP_ADD(xyr, 0x104); XENG_DPP_ADD(xyi, 0x104);
+        XENG_DPP_ADD(xx, 0x102); XENG_DPP_ADD(yy, 0x102); XENG_DPP_ADD(xyr, 0x102); XENG_DPP_ADD(xyi, 0x102);
+        XENG_DPP_ADD(xx, 0x101); XENG_DPP_ADD(yy, 0x101); XENG_DPP_ADD(xyr, 0x101); XENG_DPP_ADD(xyi, 0x101);
+#undef XENG_DPP_ADD
         if (sub == 0) out[((size_t)bp * nblk + tb) * nchan + c] = make_float4(xx, yy, xyr, xyi);
     }
     (void)npair_out;
