@@ -31,15 +31,32 @@ __global__ __launch_bounds__(256) void snap2_unpack_kernel(const uint8_t* __rest
                                                            unsigned long long* __restrict__ row_cover,
                                                            unsigned int* __restrict__ row_geom) {
     const bool aligned = (((uintptr_t)pkts | (uintptr_t)out | stride) & 15) == 0;
+    const bool fast16 = aligned && (npol_tot & 15) == 0;         // 16-byte pieces are possible (wave-uniform)
+    const int n_spec = payload_max >> 4;                         // whole 16-byte pieces of a packet's payload area
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
     int ndropped = 0;
     for (int p = blockIdx.x * 4 + wave; p < npkt; p += gridDim.x * 4) {
         const uint8_t* h = pkts + (size_t)p * stride;
+        const uint8_t* src = h + 32;
         unsigned long long seq;
         int npol, nchan;
         long long chan0, pol0;
+        v4u v[8];
         if (aligned) {
             const uint4 h0 = *reinterpret_cast<const uint4*>(h), h1 = *reinterpret_cast<const uint4*>(h + 16);
+            // The first 8 x 64 payload pieces are fetched together with the header, before it has been looked at (they lie
+            // inside the slab whatever the header says): header, validation and payload are then one memory round trip,
+            // not two.  (The asm pins the loads here; the compiler otherwise sinks them behind the validation.)
+            if (fast16) {
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int i = lane + u * 64;
+                    v[u] = *reinterpret_cast<const v4u*>(src + (size_t)(i < n_spec ? i : 0) * 16);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) asm volatile("" : "+v"(v[u]));
+            }
             seq = ((unsigned long long)__builtin_bswap32(h0.x) << 32) | __builtin_bswap32(h0.y);
             npol = (int)(__builtin_bswap32(h0.w) >> 16);                  // bytes 12-13
             nchan = (int)(__builtin_bswap32(h1.x) >> 16);                 // bytes 16-17
@@ -59,10 +76,45 @@ __global__ __launch_bounds__(256) void snap2_unpack_kernel(const uint8_t* __rest
             ndropped++;
             continue;
         }
+        uint8_t* dst = out + (((size_t)(seq - seq0) * nchan_tot + (size_t)chan0) * npol_tot + (size_t)pol0);
+        if (fast16 && ((npol | (int)pol0) & 15) == 0) {
+            const int per_row = npol >> 4;                       // 16-byte pieces per channel row
+            const int n = nchan * per_row;                       // (<= n_spec: checked above)
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = lane + u * 64;
+                if (i < n) {
+                    const int c = i / per_row, j = i - c * per_row;
+                    *reinterpret_cast<v4u*>(dst + (size_t)c * npol_tot + j * 16) = v[u];
+                }
+            }
+            for (int i0 = lane + 8 * 64; i0 < n; i0 += 8 * 64) {     // payloads beyond 8 KiB
+                v4u w[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int i = i0 + u * 64;
+                    if (i < n) w[u] = *reinterpret_cast<const v4u*>(src + (size_t)i * 16);   // rows are contiguous in the packet
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int i = i0 + u * 64;
+                    if (i < n) {
+                        const int c = i / per_row, j = i - c * per_row;
+                        *reinterpret_cast<v4u*>(dst + (size_t)c * npol_tot + j * 16) = w[u];
+                    }
+                }
+            }
+        } else {
+            for (int i = lane; i < nchan * npol; i += 64) {
+                const int c = i / npol, j = i - c * npol;
+                dst[(size_t)c * npol_tot + j] = src[i];
+            }
+        }
         if (row_cover && lane == 0) {
             // coverage of the gulp, so that the caller can skip the zero-fill when nothing is missing: per time row the
             // set of packet cells (channel block, input block) that arrived.  Exact when the row's packets share one
             // geometry, sit on its grid and the row has at most 63 cells; anything else sets bit 63 = "row irregular".
+            // (After the stores have been issued: the compare-and-swap's round trip overlaps with them.)
             const int t = (int)(seq - seq0);
             const unsigned int g = ((unsigned int)nchan << 16) | (unsigned int)npol;
             const unsigned int g0 = atomicCAS(&row_geom[t], 0u, g);
@@ -72,33 +124,6 @@ __global__ __launch_bounds__(256) void snap2_unpack_kernel(const uint8_t* __rest
                 if ((long long)(nchan_tot / nchan) * (npol_tot / npol) <= 63) bit = 1ull << cell;
             }
             atomicOr(&row_cover[t], bit);
-        }
-        const uint8_t* src = h + 32;
-        uint8_t* dst = out + (((size_t)(seq - seq0) * nchan_tot + (size_t)chan0) * npol_tot + (size_t)pol0);
-        if (aligned && ((npol | npol_tot | (int)pol0) & 15) == 0) {
-            const int per_row = npol >> 4;                       // 16-byte pieces per channel row
-            const int n = nchan * per_row;
-            for (int i0 = lane; i0 < n; i0 += 8 * 64) {
-                uint4 v[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int i = i0 + u * 64;
-                    if (i < n) v[u] = *reinterpret_cast<const uint4*>(src + (size_t)i * 16);   // rows are contiguous in the packet
-                }
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int i = i0 + u * 64;
-                    if (i < n) {
-                        const int c = i / per_row, j = i - c * per_row;
-                        *reinterpret_cast<uint4*>(dst + (size_t)c * npol_tot + j * 16) = v[u];
-                    }
-                }
-            }
-        } else {
-            for (int i = lane; i < nchan * npol; i += 64) {
-                const int c = i / npol, j = i - c * npol;
-                dst[(size_t)c * npol_tot + j] = src[i];
-            }
         }
     }
     // only drops are counted on the device (rare): thousands of waves adding to one counter serialise in L2
