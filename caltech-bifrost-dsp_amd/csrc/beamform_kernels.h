@@ -586,8 +586,8 @@ __global__ __launch_bounds__(256, 3) void beamform_i8x3_kernel(const uint8_t* __
     if ((nchan & 7) == 0) { const int b = blockIdx.x, slot = b >> 3; c = (b & 7) + 8 * (slot / per_c); rem = slot % per_c; }
     else { c = blockIdx.x / per_c; rem = blockIdx.x % per_c; }
     const int bt = rem / nttile, t0 = (rem % nttile) * BI_NT;
-    if (route[c * nbtile + bt]) return;                // this (channel, beam tile) runs on the bf16x3 kernel
-    const int n_outl = out_n[c * nbtile + bt];         // outlier inputs of this tile (epilogue)
+    const int routed = route[c * nbtile + bt];         // this (channel, beam tile) runs on the bf16x3 kernel: checked below,
+    const int n_outl = out_n[c * nbtile + bt];         // behind the first DMA; outlier inputs of this tile (epilogue)
     const int h = lane >> 5, j = lane & 31;
     const uint8_t* wsrc = wq + (((size_t)c * nbtile + bt) * nchunk) * BI_WCHUNK + lane * 16;
     const size_t row_stride = (size_t)nchan * ninput;
@@ -622,6 +622,10 @@ __global__ __launch_bounds__(256, 3) void beamform_i8x3_kernel(const uint8_t* __
     };
 #pragma unroll
     for (int k = 0; k < BI_RING - 1; k++) issue(k, k);          // first: the DMA of the first chunk(s) is the critical path
+    if (routed) {                                                // (the route flag's load has travelled beside the DMA)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // no LDS-DMA may be in flight when the wave ends
+        return;
+    }
     // the 16 row scales this lane needs in the epilogue: fetched now, off the critical path
     float sc[16];
 #pragma unroll

@@ -38,3 +38,88 @@ def test_results_do_not_depend_on_concurrency():
     assert len(res) >= 9
     for name, n, bad in res:
         assert n > 0 and bad == 0, "%s: %d differing words / drops over %d results\n%s" % (name, bad, n, "\n".join(lines))
+
+
+def test_full_size_blocks_match_standalone_calls():
+    """The Python blocks on in-repo rings at BASELINE config-2 / config-4 size, all concurrent on one GPU
+    (gpu-input read in place by Corr and by Beamform; Corr -> CorrAcc; Beamform -> BeamformSumBeams): every span that
+    leaves a block equals, bit for bit, what the same C-ABI call returns alone on an idle GPU for the same gulps."""
+    import threading
+    import time
+
+    import caltech_bifrost_dsp_amd  # noqa: F401
+    from caltech_bifrost_dsp_amd import ffi
+    from caltech_bifrost_dsp_amd.blocks import Beamform, BeamformSumBeams, Corr, CorrAcc
+    from caltech_bifrost_dsp_amd.ring import Ring
+    from tests.gpu_util import Xgpu
+    from tests.pipeline_util import LOG, Sink, Source, source_header
+
+    C, S, g, acc, nbeam, ns, nrep = 96, 352, 480, 2400, 32, 24, 4
+    ninput, G = 2 * S, acc // g
+    gulp_bytes = g * C * ninput
+    rng = np.random.default_rng(4242)
+    vin = rng.integers(0, 256, (G * g, C, S, 2), dtype=np.uint8)          # one integration; the stream repeats it nrep times
+    W = (rng.uniform(-17, 17, (C, nbeam, ninput)) + 1j * rng.uniform(-17, 17, (C, nbeam, ninput))).astype(np.complex64)
+    x = Xgpu(S, C, g, max_gulps=G)
+    ref_vis = x.run(vin, use_async=True)
+    x.close()
+
+    r_in = Ring("gpu-input", space="cuda")
+    r_vis, r_slow = Ring("corr-output", space="cuda"), Ring("corr-slow-output", space="cuda_host")
+    r_bf, r_pow = Ring("bf-output", space="cuda"), Ring("bf-pow-output", space="cuda_host")
+    r_in.resize(gulp_bytes, total_span=2 * G * gulp_bytes)
+    corr = Corr(LOG, r_in, r_vis, ntime_gulp=g, nchan=C, npol=2, nstand=S, acc_len=acc, autostartat=0, gpu=0)
+    cacc = CorrAcc(LOG, r_vis, r_slow, nchan=C, npol=2, nstand=S, acc_len=2 * acc, autostartat=0, gpu=0)
+    bf = Beamform(LOG, r_in, r_bf, nchan=C, nbeam=nbeam, ninput=ninput, ntime_gulp=g, gpu=0)
+    sb = BeamformSumBeams(LOG, r_bf, r_pow, nchan=C, ntime_gulp=g, ntime_sum=ns, gpu=0)
+    bf.gains_cpu[...] = W                                                 # (uploaded at the start of the sequence)
+
+    class CheckSink(threading.Thread):
+        """compares every span with `expect` as it arrives and keeps only the verdicts"""
+        def __init__(self, ring, gulp, expect):
+            super().__init__(daemon=True)
+            self.gulp, self.expect, self.verdicts = gulp, expect, []
+            self._gen = ring.read(guarantee=True)
+
+        def run(self):
+            for iseq in self._gen:
+                for ispan in iseq.read(self.gulp):
+                    if ispan.size == self.gulp:
+                        self.verdicts.append(bool(np.array_equal(ispan.data.numpy().view(np.int32).reshape(-1), self.expect)))
+
+    fast = CheckSink(r_vis, corr.ogulp_size, ref_vis.reshape(-1))
+    slow = CheckSink(r_slow, cacc.ogulp_size, (2 * ref_vis.astype(np.int64)).astype(np.int32).reshape(-1))
+    beams, power = Sink(r_bf, g * C * nbeam * 8), Sink(r_pow, (nbeam // 2) * (g // ns) * C * 16)
+    data = np.tile(vin.reshape(-1), nrep)
+    src = Source(r_in, [(source_header(C, S, 2), data, gulp_bytes)], wait_readers=2)
+    ths = [threading.Thread(target=b.main, daemon=True) for b in (corr, cacc, bf, sb)]
+    for t in [fast, slow, beams, power] + ths:
+        t.start()
+    t0 = time.time()
+    while len(r_in._readers) < 2 and time.time() - t0 < 20:
+        time.sleep(0.01)
+    src.start()
+    for t in [src] + ths + [fast, slow, beams, power]:
+        t.join(180)
+        assert not t.is_alive(), "pipeline thread did not finish: %r" % (t,)
+    assert fast.verdicts == [True] * nrep, fast.verdicts
+    assert slow.verdicts == [True] * (nrep // 2), slow.verdicts
+
+    # the beamformer calls alone, same weights, same gulps
+    ffi.call("xengBeamformInitialize", 0, ninput, C, g, nbeam, 0)
+    dw = ffi.DeviceBuffer(W.nbytes).upload(bf.gains_cpu)
+    din = ffi.DeviceBuffer(G * gulp_bytes).upload(vin.reshape(-1))
+    dbeam, dpow = ffi.DeviceBuffer(g * C * nbeam * 8), ffi.DeviceBuffer((nbeam // 2) * (g // ns) * C * 16)
+    refs = []
+    for k in range(G):
+        ffi.call("xengBeamformRun", din.ptr + k * gulp_bytes, dbeam.ptr, dw.ptr)
+        ffi.call("xengBeamformIntegrate", dbeam.ptr, dpow.ptr, ns)
+        ffi.call("xengBeamformSync")
+        refs.append((dbeam.download(np.uint8), dpow.download(np.uint8)))
+    ffi.call("xengBeamformDestroy")
+    (_, _, bspans), = beams.sequences
+    (_, _, pspans), = power.sequences
+    assert len(bspans) == nrep * G and len(pspans) == nrep * G
+    for k in range(nrep * G):
+        assert np.array_equal(bspans[k].reshape(-1), refs[k % G][0]), "voltage beams of gulp %d differ from the stand-alone call" % k
+        assert np.array_equal(pspans[k].reshape(-1), refs[k % G][1]), "power beams of gulp %d differ from the stand-alone call" % k
