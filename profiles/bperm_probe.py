@@ -31,18 +31,41 @@ def run_probe(mode, label, nrep):
     first = 0
     for _ in range(nrep):
         h = np.zeros(8, dtype=np.uint64)
-        ffi.check("probe", probe(mode, 3000, 1024, h.ctypes.data))
+        ffi.check("probe", probe(mode, 3000 if mode < 2 else 600, 1024, h.ctypes.data))
         tot[:6] += h[:6]
         first = first or int(h[6])
-    checked = nrep * 3000 * 1024 * 256 * 4
+    checked = nrep * (3000 if mode < 2 else 600) * 1024 * 256 * 4
     print("%-46s %d wrong of %.2e reads; by position in the group of four %s; lanes 48-63: %d; first: got %08x want %08x" % (
         label, int(tot[0]), checked, [int(v) for v in tot[1:5]], int(tot[5]), first >> 32, first & 0xFFFFFFFF), flush=True)
 
 
-for mode, name in ((0, "ds_bpermute_b32"), (1, "DPP row_shl/row_shr")):
-    run_probe(mode, name + ", GPU otherwise idle:", 3)
-    for n in range(60):                               # ~12 ms of contractions queued, the probe runs beside them
+import threading
+import time
+
+stop = threading.Event()
+count = [0]
+
+
+def feeder():                                      # keeps the contraction running (lag-1 streaming) until told to stop
+    n = 0
+    while not stop.is_set():
         for g in range(5):
             ffi.check("k", L.xengXgpuKernelAsync(ring.ptr + g * gb, outs[n & 1].ptr, int(g == 4)))
-    run_probe(mode, name + ", beside the X-engine:", 3)
+        ffi.call("xengXgpuSyncLag", 1)
+        n += 1
     ffi.call("xengXgpuSync")
+    count[0] = n
+
+
+for mode, name in ((0, "ds_bpermute_b32"), (1, "DPP row_shl/row_shr"), (2, "packed-fp32 sums -> ds_bpermute_b32"), (3, "packed-fp32 sums -> DPP")):
+    run_probe(mode, name + ", GPU otherwise idle:", 2)
+    stop.clear()
+    th = threading.Thread(target=feeder)
+    th.start()
+    time.sleep(0.05)
+    t0 = time.perf_counter()
+    run_probe(mode, name + ", beside the X-engine:", 4)
+    el = time.perf_counter() - t0
+    stop.set()
+    th.join()
+    print("   (%d contractions ran during %.2f s of probing)" % (count[0], el), flush=True)
