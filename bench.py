@@ -436,8 +436,16 @@ def main():
         ffi.call("xengXgpuSync")
         NT_B, NB, NS = 960, 32, 24
         ffi.call("xengBeamformInitialize", gpu, NINPUT, NCHAN, NT_B, NB, 0)
+        # weights as the Beamform block builds them (beamform_block.py:343-350) from random delays in [0,12) ns, amplitudes in
+        # [10,17) and calibration gains as beamformer_test.py:131-139
         rng = np.random.default_rng(0xaabbccdd)
-        wts = (rng.uniform(-17, 17, NCHAN * NB * NINPUT) + 1j * rng.uniform(-17, 17, NCHAN * NB * NINPUT)).astype(np.complex64)
+        freqs = 50e6 + np.arange(NCHAN) * 23925.78125
+        wts = np.zeros((NCHAN, NB, NINPUT), np.complex64)
+        for b_ in range(NB):
+            delays_ns, amps = rng.uniform(0, 12, NINPUT), rng.uniform(10, 17, NINPUT)
+            cal = (rng.uniform(-1, 1, (NCHAN, NINPUT)) + 1j * rng.uniform(-1, 1, (NCHAN, NINPUT))).astype(np.complex64)
+            wts[:, b_, :] = amps * np.exp(1j * 2 * np.pi * freqs[:, None] * delays_ns * 1e-9) * cal
+        wts = np.ascontiguousarray(wts.reshape(-1))
         dw = ffi.DeviceBuffer(wts.nbytes).upload(wts)
         dbeam = ffi.DeviceBuffer(NCHAN * NB * NT_B * 8)
         dpow = ffi.DeviceBuffer((NB // 2) * (NT_B // NS) * NCHAN * 16)
