@@ -187,7 +187,10 @@ static int flush_locked(void* out, bool dump) {
         const int nstage = nkt / XC_KT;
         auto itw = x.work.find(nstage);
         if (itw == x.work.end()) {
-            WorkList wl = build_work(fused_grid(x.cfg.nchan, x.nwg, x.ncu), x.cfg.nchan, x.nwg, nstage, x.splitk, x.stagger);
+            static const bool plain_order = getenv("XENG_ITEM_ORDER") && !strcmp(getenv("XENG_ITEM_ORDER"), "plain");   // A/B switch
+            const std::vector<WgDesc> descs = build_wg_descs(x.nblk64);
+            WorkList wl = build_work(fused_grid(x.cfg.nchan, x.nwg, x.ncu), x.cfg.nchan, x.nwg, nstage, x.splitk, x.stagger,
+                                     plain_order ? nullptr : &descs);
             if (wl.nchains > x.flags_per_stream) XENG_FAIL(XENG_STATUS_DEVICE_ERROR, "xgpu: %d slice chains exceed the flag array", wl.nchains);
             XENG_HIP(hipMalloc((void**)&wl.dev, wl.entries.size() * sizeof(WorkEntry)));
             XENG_HIP(hipMemcpy(wl.dev, wl.entries.data(), wl.entries.size() * sizeof(WorkEntry), hipMemcpyHostToDevice));

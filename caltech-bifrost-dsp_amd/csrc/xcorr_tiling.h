@@ -121,7 +121,58 @@ struct WorkList {
 // stagger: every second work-group of an XCD class contracts its FIRST item in two K halves (the second half adds to what
 // the first stored), which shifts all its later item boundaries by half an item against its neighbours': the epilogues of
 // the 256 work-groups (128 KB of stores each) then no longer fall into the same few microseconds.
-inline WorkList build_work(int grid, int nchan, int nwg, int nstage, bool splitk, bool stagger = false) {
+// Order of a channel's tile groups in its XCD's item list.  The W work-groups of an XCD contract W consecutive items
+// at a time ("a round"); a channel whose nwg items straddle a round boundary is contracted in two parts, about one
+// item time apart, and whatever input blocks the second part needs have left the XCD's L2 by then.  So the groups of
+// such a channel are ordered to make (distinct blocks of the first part) + (distinct blocks of the second part) minimal
+// -- e.g. 704 inputs, 32 work-groups per XCD: 184 -> 171 block fetches per XCD and launch against 132 unavoidable.
+// Exhaustive over the subsets of the smaller part (17 groups: at most 24310); identity when that would be too many,
+// when the channel spans more than two rounds, or when it is not split.  start = index of the channel's first item.
+inline std::vector<int> channel_group_order(const std::vector<WgDesc>& descs, int start, int W) {
+    const int nwg = (int)descs.size();
+    std::vector<int> order(nwg);
+    for (int i = 0; i < nwg; i++) order[i] = i;
+    const int B = (start / W + 1) * W;                      // first round boundary behind `start`
+    const int head = B - start, tail = nwg - head;
+    if (tail <= 0 || tail > W || nwg > 30) return order;
+    std::vector<uint64_t> mask(nwg, 0);
+    for (int g = 0; g < nwg; g++)
+        for (int s = 0; s < XC_NSLOT; s++) mask[g] |= 1ull << (descs[g].slot_blk[s] & 63);
+    const int small = std::min(head, tail);
+    double combos = 1;
+    for (int i = 0; i < small; i++) combos = combos * (nwg - i) / (i + 1);
+    if (combos > 200000) return order;
+    auto cost = [&](uint32_t sel) {                         // sel: the groups of the smaller part
+        uint64_t a = 0, b = 0;
+        for (int g = 0; g < nwg; g++) ((sel >> g) & 1 ? a : b) |= mask[g];
+        return __builtin_popcountll(a) + __builtin_popcountll(b);
+    };
+    uint32_t best = 0;
+    int best_cost = 1 << 30;
+    // Gosper's hack over all `small`-subsets of nwg groups, in increasing order: ties keep the first subset found
+    for (uint32_t sel = (1u << small) - 1; sel < (1u << nwg);) {
+        const int c = cost(sel);
+        if (c < best_cost) { best_cost = c; best = sel; }
+        const uint32_t lo = sel & (0u - sel), r = sel + lo;
+        if (r >= (1u << nwg) || r == 0) break;
+        sel = (((r ^ sel) >> 2) / lo) | r;
+    }
+    // identity unless it really saves a block fetch
+    uint32_t ident = 0;
+    for (int g = 0; g < nwg; g++) if ((small == tail) == (g >= head)) ident |= 1u << g;   // the groups the identity puts in the smaller part
+    if (cost(ident) <= best_cost) return order;
+    std::vector<int> in_small, in_large;
+    for (int g = 0; g < nwg; g++) ((best >> g) & 1 ? in_small : in_large).push_back(g);
+    const std::vector<int>& first = small == head ? in_small : in_large;
+    const std::vector<int>& second = small == head ? in_large : in_small;
+    int k = 0;
+    for (int g : first) order[k++] = g;
+    for (int g : second) order[k++] = g;
+    return order;
+}
+
+inline WorkList build_work(int grid, int nchan, int nwg, int nstage, bool splitk, bool stagger = false,
+                           const std::vector<WgDesc>* descs = nullptr) {
     WorkList wl;
     const bool xcd_map = (nchan & 7) == 0 && (grid & 7) == 0;
     const int ngroup = xcd_map ? 8 : 1;
@@ -134,8 +185,13 @@ inline WorkList build_work(int grid, int nchan, int nwg, int nstage, bool splitk
     // (only per-XCD lists are split: the slices of an item exchange partial sums through one XCD's L2)
     const bool split = splitk && xcd_map && r > 0 && nstage >= (W + r - 1) / r;
     wl.nchains = split ? ngroup * r : (stagger ? grid : 0);
+    // (whole items dealt per XCD: the groups of a channel that is contracted in two rounds are ordered for L2 reuse)
+    std::vector<std::vector<int>> gorder;
+    if (descs && xcd_map && !splitk && !stagger && (int)descs->size() == nwg)
+        for (int q = 0; q < nchan / 8; q++) gorder.push_back(channel_group_order(*descs, q * nwg, W));
     auto put = [&](int b, int k, int x, int idx, int stage0, int nst, int slice, int nslices, int chain) {
-        const int q = idx / nwg, wg = idx - q * nwg;
+        const int q = idx / nwg;
+        const int wg = gorder.empty() ? idx - q * nwg : gorder[q][idx - q * nwg];
         const int c = xcd_map ? x + 8 * q : q;
         WorkEntry& e = wl.entries[(size_t)b * wl.maxi + k];
         e.c_wg = (uint32_t)c | ((uint32_t)wg << 16);

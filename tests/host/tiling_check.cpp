@@ -42,7 +42,8 @@ static void check_work(int ncu, int nchan, int nblk, int nstage, bool splitk, bo
     const int nwg = (int)build_wg_descs(nblk).size();
     const int grid = fused_grid(nchan, nwg, ncu);
     CHECK(grid >= 1 && grid <= std::max(ncu, 1) && grid <= nchan * nwg, "grid %d (ncu %d, items %d)", grid, ncu, nchan * nwg);
-    const WorkList wl = build_work(grid, nchan, nwg, nstage, splitk, stagger);
+    const std::vector<WgDesc> descs = build_wg_descs(nblk);
+    const WorkList wl = build_work(grid, nchan, nwg, nstage, splitk, stagger, &descs);
     CHECK((int)wl.entries.size() == grid * wl.maxi, "entries");
     std::map<std::pair<int, int>, std::vector<std::pair<int, int>>> items;     // (c, wg) -> [(stage0, nst)] by slice
     std::map<std::pair<int, int>, int> nslices;
@@ -70,6 +71,36 @@ static void check_work(int ncu, int nchan, int nblk, int nstage, bool splitk, bo
         CHECK((int)kv.second.size() == nslices[kv.first], "item slices");
         for (auto& sl : kv.second) { CHECK(sl.first == pos, "item (%d,%d): slice starts at %d, expected %d", kv.first.first, kv.first.second, sl.first, pos); pos += sl.second; }
         CHECK(pos == nstage, "item (%d,%d) covers %d of %d stages", kv.first.first, kv.first.second, pos, nstage);
+    }
+}
+
+// channel_group_order: a permutation, never worse than the plain order; config 2 (11 blocks, 32 work-groups per XCD):
+// 184 -> 171 block fetches per XCD and launch
+static void check_group_order() {
+    for (int nblk : {2, 3, 5, 8, 11, 12, 16}) {
+        const std::vector<WgDesc> d = build_wg_descs(nblk);
+        const int nwg = (int)d.size();
+        auto blocks = [&](const std::vector<int>& o, int a, int b) {
+            std::set<int> s;
+            for (int i = a; i < b; i++)
+                for (int k = 0; k < XC_NSLOT; k++) s.insert(d[o[i]].slot_blk[k]);
+            return (int)s.size();
+        };
+        for (int W : {4, 7, 13, 32}) {
+            int plain = 0, tuned = 0;
+            for (int q = 0; q < 12; q++) {
+                const std::vector<int> o = channel_group_order(d, q * nwg, W);
+                std::vector<int> id(nwg), sorted = o;
+                for (int i = 0; i < nwg; i++) id[i] = i;
+                std::sort(sorted.begin(), sorted.end());
+                CHECK(sorted == id, "nblk %d W %d channel %d: not a permutation", nblk, W, q);
+                const int B = (q * nwg / W + 1) * W, head = std::min(nwg, B - q * nwg);
+                plain += blocks(id, 0, head) + (head < nwg ? blocks(id, head, nwg) : 0);
+                tuned += blocks(o, 0, head) + (head < nwg ? blocks(o, head, nwg) : 0);
+            }
+            CHECK(tuned <= plain, "nblk %d W %d: %d block fetches, plain order %d", nblk, W, tuned, plain);
+            if (nblk == 11 && W == 32) CHECK(plain == 184 && tuned == 171, "config 2: %d -> %d block fetches per XCD", plain, tuned);
+        }
     }
 }
 
@@ -109,6 +140,7 @@ int main() {
                              {304, 96, 11, 25}, {8, 16, 3, 2}, {1, 1, 1, 1}, {256, 192, 11, 50}};
     for (auto& s : shapes)
         for (int sk = 0; sk < 3; sk++) check_work(s[0], s[1], s[2], s[3], sk == 1, sk == 2);
+    check_group_order();
     for (int ns : {4, 8, 16, 32, 352}) check_order(ns);
     if (fails) { fprintf(stderr, "%d check(s) failed\n", fails); return 1; }
     printf("tiling_check: all properties hold\n");
