@@ -78,7 +78,8 @@ def cpu_baseline(budget_s=12.0, verify=None):
                                            "sample": "%d spectra x %d chan, full-square outer products (%.1f s)" % (nsp, ncg, el_np)}}
     if verify is not None:
         chk = {"visibilities_bit_exact": bool(np.array_equal(verify["vis"], first_int)),
-               "corracc_sum_bit_exact": bool(np.array_equal(verify["corracc"], 3 * first_int.astype(np.int64)))}
+               "corracc_sum_bit_exact": bool(np.array_equal(verify["corracc"], 3 * first_int.astype(np.int64))),
+               "corracc_fused_in_dump_bit_exact": bool(np.array_equal(verify["corracc_fused"], 3 * first_int.astype(np.int64)))}
         nt_b, nb = verify["beams"].shape[2], verify["beams"].shape[1]
         v2 = np.concatenate([gulps[0], gulps[1]]).reshape(nt_b, NCHAN, NINPUT)
         exp = orc.beamform(v2, verify["weights"].reshape(NCHAN, nb, NINPUT), nt_b, NCHAN, NINPUT, nb)
@@ -88,7 +89,8 @@ def cpu_baseline(budget_s=12.0, verify=None):
         pexp = orc.beamform_integrate(verify["beams"], verify["ntime_sum"])
         chk["power_beams_max_err_over_max"] = float(np.max(np.abs(verify["power"] - pexp)) / np.abs(pexp).max())
         chk["power_beams_ok"] = bool(chk["power_beams_max_err_over_max"] <= 1e-5)
-        chk["ok"] = bool(chk["visibilities_bit_exact"] and chk["corracc_sum_bit_exact"] and chk["beams_within_1e-5"] and chk["power_beams_ok"])
+        chk["ok"] = bool(chk["visibilities_bit_exact"] and chk["corracc_sum_bit_exact"] and chk["corracc_fused_in_dump_bit_exact"] and
+                         chk["beams_within_1e-5"] and chk["power_beams_ok"])
         out["config5_check"] = chk
     return out
 
@@ -522,6 +524,35 @@ def main():
             "ms_per_integration": round(elf / nfull * 1e3, 4),
             "note": "config 5 on one GPU: per 2400-sample integration 5 gulps registered in place + 1 fused MFMA contraction (X-engine streams), "
                     "2.5 beamformer gulps + power sums (beam stream), 1 CorrAcc int32 map over 191 MB (map stream)"}
+        # ... and with CorrAcc's long accumulation fused into the dump's epilogue (xengXgpuKernelAsyncAcc): no map kernel, the
+        # two accumulators alternate so that consecutive dumps still overlap (they are added once per long integration)
+        acc_pair = [acc_long, ffi.DeviceBuffer(2 * matlen * 4)]
+        afn = L.xengXgpuKernelAsyncAcc
+
+        def full_step_fused(n, first):
+            o = outs3[n % 3]
+            for g in range(gulps_per_step):
+                ffi.check("kernel", afn(ring.ptr + (gi[0] % args.ring_gulps) * gulp_bytes, o.ptr, int(g == gulps_per_step - 1),
+                                        acc_pair[n & 1].ptr, 1 if first else 2))
+                gi[0] += 1
+            for _ in range(2 + (n & 1)):
+                bstep(bi[0])
+                bi[0] += 1
+            ffi.call("xengXgpuSyncLag", 1)
+        if not args.sync_per_call:
+            for n in range(6):
+                full_step_fused(n, n < 2)
+            ffi.call("xengDeviceSynchronize")
+            tf = time.perf_counter()
+            for n in range(6, 6 + nfull):
+                full_step_fused(n, False)
+            ffi.call("xengDeviceSynchronize")
+            elf2 = time.perf_counter() - tf
+            beam["full_xengine_concurrent"]["fused_corracc"] = {
+                "ingest_gbps": round(8 * NINPUT * units_per_step_c * nfull / elf2 / 1e9, 1),
+                "ms_per_integration": round(elf2 / nfull * 1e3, 4),
+                "note": "the same with the CorrAcc add done in the contraction's epilogue (xengXgpuKernelAsyncAcc, two alternating "
+                        "accumulators): one pass over the 191 MB accumulator per dump instead of a 574 MB map kernel"}
         # the same concurrent pattern once more on KNOWN inputs (three integrations of ring gulps 0..4, beams of gulps 0+1),
         # kept for the oracle to check in the cpu_baseline leg: one dumped span, the CorrAcc sum (= 3 x that span) and one
         # beam gulp with its power sums
@@ -545,7 +576,16 @@ def main():
             ffi.check("map", L.xengMapAddI32(acc_long.ptr, outs3[2].ptr, 2 * matlen))
             ffi.call("xengMapSync")
             ffi.call("xengBeamformSync")
-            verify = {"vis": outs3[2].download(np.int32), "corracc": acc_long.download(np.int32).astype(np.int64),
+            corracc_sum = acc_long.download(np.int32).astype(np.int64)
+            # the fused flavour on the same three integrations (accumulators alternate: A gets n = 0 and 2, B gets n = 1)
+            for n in range(3):
+                for g in range(gulps_per_step):
+                    ffi.check("kernel", afn(ring.ptr + g * gulp_bytes, outs3[n].ptr, int(g == gulps_per_step - 1),
+                                            acc_pair[n & 1].ptr, 1 if n < 2 else 2))
+                ffi.call("xengXgpuSyncLag", 1)
+            ffi.call("xengXgpuSync")
+            verify = {"vis": outs3[2].download(np.int32), "corracc": corracc_sum,
+                      "corracc_fused": acc_pair[0].download(np.int32).astype(np.int64) + acc_pair[1].download(np.int32).astype(np.int64),
                       "beams": dbeam.download(np.complex64).reshape(NCHAN, NB, NT_B), "weights": wts, "ntime_sum": NS,
                       "power": dpow.download(np.float32).reshape(NB // 2, NT_B // NS, NCHAN, 4)}
         # the reference's "integrated" mode (bfBeamformInitialize ntime_blocks > 0, beamform_block.py:108-110): power sums

@@ -56,6 +56,7 @@ struct XgpuContext {
     int nmm = 2;
     unsigned long long nlaunch = 0;
     hipStream_t stream_mm = nullptr;           // = stream_mm2[0] (sub-selection, D2H)
+    void* last_acc[NMM] = {};                  // long accumulator the last contraction on each stream added to (or null)
     void* last_out[NMM] = {};                  // output buffer of the last contraction on each stream
     hipEvent_t ev_last[NMM] = {};              // ... and its completion
     bool mm_used[NMM] = {};
@@ -131,6 +132,7 @@ static void launch_xcorr(const XcorrParams& p, hipStream_t s, bool raw, int ncu)
 #endif
         static const int nwaves = getenv("XENG_WAVES") ? atoi(getenv("XENG_WAVES")) : 4;
         if (nwaves == 8) hipLaunchKernelGGL(xcorr_fused8_kernel, grid, dim3(512), 0, s, p);
+        else if (p.acc2_mode) hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<0, true>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<0>), grid, dim3(256), 0, s, p);
         return;
     }
@@ -152,9 +154,11 @@ static void launch_xcorr(const XcorrParams& p, hipStream_t s, bool raw, int ncu)
 }
 
 // contracts the staged gulps into `out`; caller holds g_mu
-static int flush_locked(void* out, bool dump) {
+// acc / acc_mode: long accumulator that the dump also assigns (1) or adds (2) its values to (fused path only)
+static int flush_locked(void* out, bool dump, void* acc = nullptr, int acc_mode = 0) {
     XgpuContext& x = g_ctx;
     if (x.nfilled == 0) return XENG_STATUS_SUCCESS;
+    if (!dump) { acc = nullptr; acc_mode = 0; }       // partial sums of an integration never reach the long accumulator
     if (x.acc_started && x.acc_out != out)
         XENG_FAIL(XENG_STATUS_INVALID_STATE,
                   "xgpu: output buffer changed inside one integration (partial sums live in %p, got %p)",
@@ -183,6 +187,7 @@ static int flush_locked(void* out, bool dump) {
     p.spg = x.raw ? x.cfg.ntime_gulp / (XC_KT * 32) : 0;
     p.ninput = x.ninput;
     p.work = nullptr; p.maxi = 0; p.flags = nullptr; p.epoch = 0;
+    p.acc2 = (int32_t*)acc; p.acc2_mode = acc ? acc_mode : 0;
     if (x.raw) {
         const int nstage = nkt / XC_KT;
         auto itw = x.work.find(nstage);
@@ -210,7 +215,8 @@ static int flush_locked(void* out, bool dump) {
     // contractions that touch the same output (partial sums of one integration, or a caller that
     // reuses one buffer for consecutive integrations) stay ordered; independent ones may overlap
     for (int t = 0; t < x.nmm; t++)
-        if (t != si && x.mm_used[t] && x.last_out[t] == out) XENG_HIP(hipStreamWaitEvent(smm, x.ev_last[t], 0));
+        if (t != si && x.mm_used[t] && (x.last_out[t] == out || (acc && x.last_acc[t] == acc)))
+            XENG_HIP(hipStreamWaitEvent(smm, x.ev_last[t], 0));
     int slot = x.timer.begin(smm, 1);
     if (x.fp6) hipLaunchKernelGGL(xcorr_fp6_kernel, dim3(p.nchan * p.nwg), dim3(256), 0, smm, p);
     else launch_xcorr(p, smm, x.raw, x.ncu);
@@ -221,6 +227,7 @@ static int flush_locked(void* out, bool dump) {
     x.area_used[x.cur] = true;
     x.mm_used[si] = true;
     x.last_out[si] = out;
+    x.last_acc[si] = acc;
     if (dump) {
         XENG_HIP(hipEventRecord(x.ev_dump[x.ndump & 3], smm));
         x.ndump++;
@@ -250,10 +257,18 @@ static int wait_unlocked(const PendingWait& w) {
     return XENG_STATUS_SUCCESS;
 }
 
-static int kernel_locked(const void* in_dev, void* out_dev, int doDump, bool sync, PendingWait* pw) {
+static int kernel_locked(const void* in_dev, void* out_dev, int doDump, bool sync, PendingWait* pw, void* acc = nullptr,
+                         int acc_mode = 0) {
     XgpuContext& x = g_ctx;
     if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized (call xengXgpuInitialize)");
     if (!in_dev || !out_dev) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "xgpu: null buffer");
+    if (acc) {
+        static const bool w8 = getenv("XENG_WAVES") && atoi(getenv("XENG_WAVES")) == 8;
+        if (!x.raw || x.fp6 || x.splitk || x.stagger || w8)
+            XENG_FAIL(XENG_STATUS_UNSUPPORTED, "xgpu: the fused long accumulation needs the default contraction kernel (use xengMapAddI32)");
+        if (acc_mode != 1 && acc_mode != 2) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "xgpu: acc_mode must be 1 (assign) or 2 (add)");
+        if (((uintptr_t)acc & 15) || acc == out_dev) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "xgpu: accumulator must be 16-byte aligned and distinct from out");
+    }
     if (((uintptr_t)out_dev & 15) || ((uintptr_t)in_dev & (x.raw ? 15 : 3)))
         XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "xgpu: out must be 16-byte and in %d-byte aligned", x.raw ? 16 : 4);
     XENG_HIP(hipSetDevice(x.gpu));
@@ -295,7 +310,7 @@ static int kernel_locked(const void* in_dev, void* out_dev, int doDump, bool syn
     XENG_HIP(hipGetLastError());
     x.nfilled++;
     if (doDump || x.nfilled == x.cap_gulps) {
-        int rc = flush_locked(out_dev, doDump != 0);
+        int rc = flush_locked(out_dev, doDump != 0, acc, acc_mode);
         if (rc) return rc;
     } else if (x.acc_started && x.acc_out != out_dev) {
         XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: output buffer changed inside one integration");
@@ -458,6 +473,11 @@ int xengXgpuKernelAsync(const void* in_dev, void* out_dev, int doDump) {
     return kernel_locked(in_dev, out_dev, doDump, false, nullptr);
 }
 
+int xengXgpuKernelAsyncAcc(const void* in_dev, void* out_dev, int doDump, void* acc_dev, int acc_mode) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return kernel_locked(in_dev, out_dev, doDump, false, nullptr, acc_dev, acc_dev ? acc_mode : 0);
+}
+
 int xengXgpuSync(void) {
     int gpu, nmm;
     hipStream_t st, mm[XgpuContext::NMM];
@@ -551,7 +571,7 @@ static hipEvent_t g_consumer_ev = nullptr;
 static int order_after_producers(hipStream_t s, const void* span) {
     XgpuContext& x = g_ctx;
     for (int t = 0; t < x.nmm; t++)
-        if (x.mm_used[t] && x.last_out[t] == span) XENG_HIP(hipStreamWaitEvent(s, x.ev_last[t], 0));
+        if (x.mm_used[t] && (x.last_out[t] == span || x.last_acc[t] == span)) XENG_HIP(hipStreamWaitEvent(s, x.ev_last[t], 0));
     return XENG_STATUS_SUCCESS;
 }
 

@@ -197,6 +197,10 @@ struct XcorrParams {
     int maxi;
     uint32_t* flags;
     uint32_t epoch;
+    // long accumulation fused into the dump (CorrAcc's "a = b" / "a += b", corr_acc_block.py:298-306, applied to the
+    // values this launch stores): acc2 = planar int32 buffer like `out`; acc2_mode 0 none, 1 assign, 2 add
+    int32_t* acc2;
+    int acc2_mode;
 };
 
 struct Frags {   // the 8 unpacked int8 operand fragments of one 64x64 wave tile and one K-tile
@@ -242,13 +246,28 @@ constexpr int XC_RING = 4;    // LDS ring depth (stages), two-pass kernel
 // L2; so the cells are first moved across lanes (ds_bpermute: lane 8q+k takes the cell of lane 4k+q in
 // its 32-lane half) and every 8 adjacent lanes write one contiguous run.
 // NT = 32-column MFMA tiles per wave (2: a 64x64 wave tile; 1: a 64x32 wave tile whose column half is n0).
-template <int NT = 2>
+// LACC: every cell that is stored is also assigned / added to the long accumulator p.acc2 (XcorrParams).
+template <int NT = 2, bool LACC = false>
 __device__ __forceinline__ void xcorr_store_tile(const XcorrParams& p, int c, int blk_a, int blk_b, bool skip01, int lane,
                                                  const v16i (&accR)[2][NT], const v16i (&accP)[2][NT],
                                                  const v16i (&accQ)[2][NT], bool add_to_stored = false, int n0 = 0) {
     const int qs = (int)(((int64_t)(p.nstand / 2 + 1) * p.nstand) / 4);
     int32_t* out_r = p.out + (int64_t)c * p.per_chan;
     int32_t* out_i = out_r + p.matlen;
+    int32_t* acc_r = LACC ? p.acc2 + (int64_t)c * p.per_chan : nullptr;
+    int32_t* acc_i = LACC ? acc_r + p.matlen : nullptr;
+    const bool acc_add = LACC && p.acc2_mode == 2;
+    auto long_acc = [&](int w, int4 cr, int4 ci) {           // the stored cell -> the long accumulator
+        int4* ar = reinterpret_cast<int4*>(acc_r + w);
+        int4* ai = reinterpret_cast<int4*>(acc_i + w);
+        if (acc_add) {
+            const int4 o_r = *ar, o_i = *ai;
+            cr.x += o_r.x; cr.y += o_r.y; cr.z += o_r.z; cr.w += o_r.w;
+            ci.x += o_i.x; ci.y += o_i.y; ci.z += o_i.z; ci.w += o_i.w;
+        }
+        *ar = cr;
+        *ai = ci;
+    };
     const int odd = lane & 1;
     auto cell = [&](int v0, int v1, int v2, int v3) {
         const int g0 = dpp_xor1(odd ? v0 : v2), g1 = dpp_xor1(odd ? v1 : v3);
@@ -291,6 +310,7 @@ __device__ __forceinline__ void xcorr_store_tile(const XcorrParams& p, int c, in
                     const int w = wcol + ((Rh * (Rh + 1)) >> 1) * 4;
                     *reinterpret_cast<int4*>(out_r + w) = cr;
                     *reinterpret_cast<int4*>(out_i + w) = ci;
+                    if (LACC) long_acc(w, cr, ci);
                 }
             }
         return;
@@ -327,6 +347,7 @@ __device__ __forceinline__ void xcorr_store_tile(const XcorrParams& p, int c, in
                     }
                     *pr = cr;
                     *pi = ci;
+                    if (LACC) long_acc(w, cr, ci);
                 }
             }
         }
@@ -525,7 +546,7 @@ __global__ __launch_bounds__(256, 1) void xcorr_mfma_kernel(XcorrParams p) {
 // is paid once per CU instead of once per item.
 // =======================================================================================
 // ABL: timing-only ablation bits as for xcorr_mfma_kernel (diagnostic builds; results are wrong unless 0).
-template <int ABL>
+template <int ABL, bool LACC = false>
 __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
     constexpr int KT_STAGE = XC_KT;
     constexpr int SLOT_BYTES = KT_STAGE * KT_BYTES;
@@ -772,7 +793,7 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
             asm volatile("" ::: "memory");
         }
         // exactly 32 store instructions and nothing else: the straight-line path of xcorr_store_tile
-        stores_in_flight = !(ABL & 16) && __builtin_amdgcn_readfirstlane((int)(blk_a > blk_b && blk_a * 64 + 64 <= 2 * p.nstand &&
+        stores_in_flight = !(ABL & 16) && !LACC && __builtin_amdgcn_readfirstlane((int)(blk_a > blk_b && blk_a * 64 + 64 <= 2 * p.nstand &&
                                                                                  p.accumulate == 0 && it.slice == 0)) != 0;
         if (ABL & 16) {   // timing only: no epilogue (keep the accumulators live)
 #pragma unroll
@@ -780,7 +801,7 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
 #pragma unroll
                 for (int n = 0; n < 2; n++) asm volatile("" :: "v"(accR[m][n][0]), "v"(accP[m][n][5]), "v"(accQ[m][n][9]));
         } else
-        if (active) xcorr_store_tile(p, c, blk_a, blk_b, skip01, lane, accR, accP, accQ, it.slice > 0);
+        if (active) xcorr_store_tile<2, LACC>(p, c, blk_a, blk_b, skip01, lane, accR, accP, accQ, it.slice > 0);
         if (it.slice + 1 < it.nslices) {
             // publish: every wave's stores have been acknowledged by the L2 (vmcnt counts stores too), then one
             // lane bumps the flag

@@ -108,6 +108,14 @@ int xengXgpuKernel(const void *in_dev, void *out_dev, int doDump);
  * (corner turn fused into its LDS staging): no copy of the gulp is made, in_dev must be 16-byte
  * aligned.  (No reference counterpart; this is how a ring-resident pipeline streams gulps.) */
 int xengXgpuKernelAsync(const void *in_dev, void *out_dev, int doDump);
+/* The same with CorrAcc's long accumulation (corr_acc_block.py:298-306, "a = b" / "a += b") fused into the dump: when
+ * doDump is set and acc_dev is not NULL, every visibility the dump stores to out_dev is also assigned (acc_mode 1) or added
+ * (acc_mode 2) to acc_dev, a planar int32 buffer of the same size and layout -- one pass over the accumulator in the
+ * contraction's epilogue instead of a separate xengMapAssignI32 / xengMapAddI32 over both buffers (382 MB less HBM
+ * traffic per config-2 dump).  Dumps that name the same accumulator are ordered; consecutive dumps overlap only when the
+ * caller alternates between two accumulators (and adds them at the end of the long integration).  Readers of acc_dev:
+ * xengXgpuSync / xengXgpuSyncLag as for out_dev.  XENG_STATUS_UNSUPPORTED on the non-default contraction paths. */
+int xengXgpuKernelAsyncAcc(const void *in_dev, void *out_dev, int doDump, void *acc_dev, int acc_mode);
 int xengXgpuSync(void);
 /* Wait until all but the last `lag` (0..3) dumps are complete -- lag 1 lets a streaming caller enqueue
  * integration n+1 (into a different out_dev) before it waits for integration n, so the contraction of

@@ -476,3 +476,56 @@ def test_split_k_work_lists_are_bit_exact(gpu):
         x.close()
     finally:
         del os.environ["XENG_SPLITK"]
+
+
+@pytest.mark.parametrize("nstand,nchan,ntime,ngulp,max_gulps,two_accs", [
+    (80, 8, 96, 3, 3, True),      # 2.5 blocks: interior, diagonal and padded tiles; two accumulators (dumps may overlap)
+    (80, 8, 96, 3, 3, False),     # one accumulator: the dumps are ordered by the library
+    (48, 5, 96, 5, 2, True),      # staging depth 2 with 5 gulps: the dump is a read-modify-write flush
+    (352, 8, 96, 1, 1, True),     # 704 inputs: the config-2 tiling (17 tile groups per channel)
+])
+def test_long_accumulation_fused_into_the_dump(gpu, nstand, nchan, ntime, ngulp, max_gulps, two_accs):
+    """xengXgpuKernelAsyncAcc = xengXgpuKernelAsync + CorrAcc's "a = b" / "a += b" (corr_acc_block.py:298-306) on the
+    dumped span, done in the contraction's epilogue: every dump still equals the oracle, and the accumulator(s) hold
+    exactly the int32 sum of the dumps."""
+    nint = 6
+    x = gpu.Xgpu(nstand, nchan, ntime, max_gulps=max_gulps)
+    assert x.path() == (1, 0)
+    outs = [x.out, gpu.ffi.DeviceBuffer(x.out.nbytes)]
+    accs = [gpu.ffi.DeviceBuffer(x.out.nbytes) for _ in range(2 if two_accs else 1)]
+    for a in accs:
+        gpu.ffi.call("xengMemset", a.ptr, 0x77, a.nbytes)       # "assign" must not depend on what was there
+    vin = gpu.synth_voltages(ntime * ngulp * nint, nchan, nstand, "full", seed=5 + nstand).reshape(nint, ngulp, -1)
+    din = gpu.ffi.DeviceBuffer(vin.size).upload(vin)
+    results = {}
+    for n in range(nint):
+        acc = accs[n % len(accs)]
+        first_use = n < len(accs)
+        for g in range(ngulp):
+            gpu.ffi.call("xengXgpuKernelAsyncAcc", din.ptr + (n * ngulp + g) * x.gulp_bytes, outs[n & 1].ptr, int(g == ngulp - 1),
+                         acc.ptr, 1 if first_use else 2)
+        gpu.ffi.call("xengXgpuSyncLag", 1)
+        if n >= 1:
+            results[n - 1] = outs[(n - 1) & 1].download(np.int32)
+    gpu.ffi.call("xengXgpuSync")
+    results[nint - 1] = outs[(nint - 1) & 1].download(np.int32)
+    total = np.zeros_like(results[0], dtype=np.int64)
+    for n in range(nint):
+        exp = oracle_run(vin[n], nstand, nchan, ntime)
+        assert np.array_equal(results[n], exp), n
+        total += exp
+    got = sum(a.download(np.int32).astype(np.int64) for a in accs)
+    assert np.array_equal(got, total)
+    # the separate CorrAcc map gives the same accumulator
+    ref = gpu.ffi.DeviceBuffer(x.out.nbytes)
+    for n in range(nint):
+        outs[0].upload(results[n])
+        gpu.ffi.call("xengMapAssignI32" if n == 0 else "xengMapAddI32", ref.ptr, outs[0].ptr, results[n].size)
+    gpu.ffi.call("xengMapSync")
+    assert np.array_equal(ref.download(np.int32).astype(np.int64), total)
+    with pytest.raises(gpu.ffi.XengError):                       # accumulator == out
+        gpu.ffi.call("xengXgpuKernelAsyncAcc", din.ptr, outs[0].ptr, 1, outs[0].ptr, 1)
+    gpu.ffi.call("xengXgpuReset")
+    x.close()
+    for b in [outs[1], ref, din] + accs:
+        b.free()
