@@ -6,7 +6,7 @@ Each integration contracts the same five gulps, each beamformer gulp reads the s
 dump / beam gulp / power block / sub-selection / payload set / unpacked gulp must be bit-identical to the one computed
 alone on an idle GPU.  Results are added word-wise as int32 bit patterns (xengMapAddI32: wrap-around arithmetic, so floats
 are summed as their bit patterns too) and the sum is compared with N x the stand-alone pattern modulo 2^32.  Exercised
-together: contraction streams (lag-1 streaming), beam stream (weight re-split every third round, Run + Integrate, then the
+together: contraction streams (lag-1 streaming, the dumps of phase 1 also feed two alternating long accumulators), beam stream (weight re-split every third round, Run + Integrate, then the
 fused integrated-power mode), map stream, consumer stream (SubSelect, Packetize), staging stream (SNAP2 unpack).
 
 This is what found the wrong power sums of round 2: a kernel that is right alone on the GPU and in every
@@ -81,6 +81,7 @@ def soak(N=1500, packets=None, log=print):
     acc_vis, acc_beam = ffi.DeviceBuffer(2 * matlen * 4), ffi.DeviceBuffer(nbeam_words * 4)
     acc_pow, acc_sub = ffi.DeviceBuffer(npow_words * 4), ffi.DeviceBuffer(nsub_words * 4)
     acc_pay = ffi.DeviceBuffer(npay_words * 4)
+    acc_fused = [ffi.DeviceBuffer(2 * matlen * 4) for _ in range(2)]      # long accumulators of the fused dumps (alternating)
     if packets is not None:
         slab, npkt, stride, seq0, expect = packets
         dslab = ffi.DeviceBuffer(len(slab)).upload(np.frombuffer(slab, dtype=np.uint8))
@@ -88,9 +89,12 @@ def soak(N=1500, packets=None, log=print):
         acc_gulp = ffi.DeviceBuffer(gulp_bytes)
         ref_gulp = np.ascontiguousarray(expect, dtype=np.uint8).view(np.uint32)
 
-    def integration(out):
+    def integration(out, acc=None, mode=0):
         for g in range(G):
-            ffi.check("kernel", L.xengXgpuKernelAsync(ring.ptr + g * gulp_bytes, out.ptr, int(g == G - 1)))
+            if acc is None:
+                ffi.check("kernel", L.xengXgpuKernelAsync(ring.ptr + g * gulp_bytes, out.ptr, int(g == G - 1)))
+            else:       # CorrAcc's add fused into the dump
+                ffi.check("kernel", L.xengXgpuKernelAsyncAcc(ring.ptr + g * gulp_bytes, out.ptr, int(g == G - 1), acc.ptr, mode))
 
     # ---- stand-alone results: every call once, on an otherwise idle GPU
     ffi.call("xengBeamformInitialize", 0, NINPUT, NCHAN, NT_B, NB, 0)
@@ -116,7 +120,7 @@ def soak(N=1500, packets=None, log=print):
         ffi.call("xengMapSync")                       # the adds of the previous round have released their sources
         if packets is not None:
             ffi.check("unpack", L.xengSnap2UnpackAsync(dslab.ptr, npkt, stride, dgulp[n & 1].ptr, seq0, NTIME_GULP, 0, NCHAN, NINPUT, 1))
-        integration(outs[n % 3])
+        integration(outs[n % 3], acc_fused[n & 1], 1 if n < 2 else 2)
         # the weights "change" every third round (same values, new version): the split / routing kernels run beside the contraction
         ffi.check("run", L.xengBeamformRunVersioned(ring.ptr, dbeam[n & 1].ptr, dw.ptr, 1 + n // 3))
         ffi.check("int", L.xengBeamformIntegrate(dbeam[n & 1].ptr, dpow[n & 1].ptr, NS))
@@ -146,6 +150,9 @@ def soak(N=1500, packets=None, log=print):
     el = time.perf_counter() - t0
     log("phase 1: %d concurrent rounds in %.2f s (%.3f ms each)" % (N, el, el / N * 1e3))
     report("visibility dumps", acc_vis, ref_vis, N)
+    ffi.check("map", L.xengMapAddI32(acc_fused[0].ptr, acc_fused[1].ptr, 2 * matlen))
+    ffi.call("xengMapSync")
+    report("long accumulation in the dumps", acc_fused[0], ref_vis, N)
     report("voltage beams", acc_beam, ref_beam, N)
     report("power sums (Integrate)", acc_pow, ref_pow, N)
     report("sub-selections", acc_sub, ref_sub, nsubsel)

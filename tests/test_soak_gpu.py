@@ -35,7 +35,7 @@ def test_results_do_not_depend_on_concurrency():
     lines = []
     res = sk.soak(N=240, packets=(slab, len(pk), len(pk[0]), seq0, vin.reshape(-1)), log=lines.append)
     print("\n".join(lines))
-    assert len(res) >= 9
+    assert len(res) >= 10
     for name, n, bad in res:
         assert n > 0 and bad == 0, "%s: %d differing words / drops over %d results\n%s" % (name, bad, n, "\n".join(lines))
 
