@@ -9,7 +9,6 @@
 #include <vector>
 
 #include "xcorr_kernels.h"
-#include "xcorr_fused8.h"
 #include "xeng_common.h"
 
 namespace xeng {
@@ -29,15 +28,12 @@ struct XgpuContext {
     // transposes in LDS: asynchronous calls hand over the caller's buffer itself, synchronous calls a raw copy
     // of it in the staging area (except the dump call, which waits for the contraction anyway).
     bool raw = false;
-    bool splitk = false;                       // XENG_SPLITK=1: cut the left-over items along K (experiment, see Initialize)
-    bool stagger = false;                      // XENG_STAGGER=1: half-item skew between neighbouring work-groups (build_work)
-    std::map<int, WorkList> work;              // per number of stages of a flush
-    uint32_t* flags = nullptr;                 // [NMM][flags_per_stream] slice-ordering flags of split items
-    int flags_per_stream = 0;
-    uint32_t epoch = 0;
+    FragGroup* fgroups_dev = nullptr;          // fused kernel: fragment-level tile groups (xcorr_tiling.h) ...
+    int nfg = 0;
+    WorkList work;                             // ... and the persistent work-groups' item lists
     size_t gulp_bytes = 0;
     const uint8_t* gulp_ptr[XC_MAX_GULPS] = {};
-    bool fp6 = false;          // XENG_MFMA=fp6: E3M2 codes + block-scaled FP6 MFMA (exact), see xcorr_kernels.h
+    bool fp6 = false;          // -DXENG_EXPERIMENTS builds, XENG_MFMA=fp6: E3M2 codes + block-scaled FP6 MFMA (exact)
     int ghk = 0;               // fp6: 32-sample half-tiles per gulp; cap_kt then counts 64-sample K steps
     int64_t per_chan = 0, matlen = 0;
     // Two staging areas (raw gulp copies of the synchronous calls, or corner-turned fragments on the two-pass
@@ -56,9 +52,17 @@ struct XgpuContext {
     int nmm = 2;
     unsigned long long nlaunch = 0;
     hipStream_t stream_mm = nullptr;           // = stream_mm2[0] (sub-selection, D2H)
-    void* last_acc[NMM] = {};                  // long accumulator the last contraction on each stream added to (or null)
-    void* last_out[NMM] = {};                  // output buffer of the last contraction on each stream
-    hipEvent_t ev_last[NMM] = {};              // ... and its completion
+    // Last enqueued contraction that writes a buffer (output span or long accumulator): launch number and stream.
+    // A later launch or a consumer that names the buffer waits for that launch's own event (a ring of the last NEV
+    // launches; older than that: the stream's latest event, which is later in stream order) -- whichever stream it ran
+    // on and however many launches went to the streams since.
+    struct Writer { unsigned long long seq; int stream; };
+    std::map<const void*, Writer> writers;
+    static constexpr int NEV = 64;
+    hipEvent_t ev_ring[NEV] = {};              // completion of launch number n: ev_ring[n % NEV]
+    const void* ring_buf[NEV][2] = {};         // ... and the buffers it wrote (forgotten as writers when the slot is reused
+                                               // and the launch has completed)
+    hipEvent_t ev_last[NMM] = {};              // completion of the latest contraction on each stream
     bool mm_used[NMM] = {};
     hipEvent_t ev_ct = nullptr;                // staged gulps of the area about to be contracted are complete
     hipEvent_t ev_mm[2] = {nullptr, nullptr};  // the contraction reading staging area b is complete
@@ -89,6 +93,8 @@ static int destroy_locked() {
         if (x.stream_mm2[b]) (void)hipStreamSynchronize(x.stream_mm2[b]);
         if (x.ev_last[b]) (void)hipEventDestroy(x.ev_last[b]);
     }
+    for (int k = 0; k < XgpuContext::NEV; k++)
+        if (x.ev_ring[k]) (void)hipEventDestroy(x.ev_ring[k]);
     for (int b = 0; b < 2; b++) {
         if (x.stash[b]) (void)hipFree(x.stash[b]);
         if (x.ev_mm[b]) (void)hipEventDestroy(x.ev_mm[b]);
@@ -97,9 +103,8 @@ static int destroy_locked() {
     for (int k = 0; k < 4; k++)
         if (x.ev_dump[k]) (void)hipEventDestroy(x.ev_dump[k]);
     if (x.descs_dev) (void)hipFree(x.descs_dev);
-    for (auto& kv : x.work)
-        if (kv.second.dev) (void)hipFree(kv.second.dev);
-    if (x.flags) (void)hipFree(x.flags);
+    if (x.fgroups_dev) (void)hipFree(x.fgroups_dev);
+    if (x.work.dev) (void)hipFree(x.work.dev);
     if (x.in_dev) (void)hipFree(x.in_dev);
     if (x.stamps) (void)hipFree(x.stamps);
     if (x.out_dev) (void)hipFree(x.out_dev);
@@ -112,9 +117,9 @@ template <int ABL>
 static void launch_abl(const XcorrParams& p, hipStream_t s) {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_mfma_kernel<ABL>), dim3(p.nchan * p.nwg), dim3(256), 0, s, p);
 }
-static void launch_xcorr(const XcorrParams& p, hipStream_t s, bool raw, int ncu) {
+static void launch_xcorr(const XcorrParams& p, hipStream_t s, bool raw, int grid_size) {
     if (raw) {
-        const dim3 grid(fused_grid(p.nchan, p.nwg, ncu));
+        const dim3 grid(grid_size);
 #ifdef XENG_DIAGNOSTICS
         static const int fabl = getenv("XENG_ABLATE") ? atoi(getenv("XENG_ABLATE")) : 0;
         switch (fabl) {
@@ -130,9 +135,7 @@ static void launch_xcorr(const XcorrParams& p, hipStream_t s, bool raw, int ncu)
             default: break;
         }
 #endif
-        static const int nwaves = getenv("XENG_WAVES") ? atoi(getenv("XENG_WAVES")) : 4;
-        if (nwaves == 8) hipLaunchKernelGGL(xcorr_fused8_kernel, grid, dim3(512), 0, s, p);
-        else if (p.acc2_mode) hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<0, true>), grid, dim3(256), 0, s, p);
+        if (p.acc2_mode) hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<0, true>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<0>), grid, dim3(256), 0, s, p);
         return;
     }
@@ -153,6 +156,17 @@ static void launch_xcorr(const XcorrParams& p, hipStream_t s, bool raw, int ncu)
     launch_abl<0>(p, s);
 }
 
+// under g_mu: make stream `s` (contraction stream `self`, or -1 for a foreign stream) wait for the last enqueued writer of `buf`
+static int order_after_writer(hipStream_t s, int self, const void* buf) {
+    XgpuContext& x = g_ctx;
+    auto it = x.writers.find(buf);
+    if (it == x.writers.end() || it->second.stream == self) return XENG_STATUS_SUCCESS;   // (same stream: stream order)
+    const XgpuContext::Writer& w = it->second;
+    hipEvent_t ev = x.nlaunch - w.seq < (unsigned long long)XgpuContext::NEV ? x.ev_ring[w.seq % XgpuContext::NEV] : x.ev_last[w.stream];
+    XENG_HIP(hipStreamWaitEvent(s, ev, 0));
+    return XENG_STATUS_SUCCESS;
+}
+
 // contracts the staged gulps into `out`; caller holds g_mu
 // acc / acc_mode: long accumulator that the dump also assigns (1) or adds (2) its values to (fused path only)
 static int flush_locked(void* out, bool dump, void* acc = nullptr, int acc_mode = 0) {
@@ -164,6 +178,7 @@ static int flush_locked(void* out, bool dump, void* acc = nullptr, int acc_mode 
                   "xgpu: output buffer changed inside one integration (partial sums live in %p, got %p)",
                   x.acc_out, out);
     int nkt = x.nfilled * x.gkt;
+#ifdef XENG_EXPERIMENTS
     if (x.fp6) {
         const int nhk = x.nfilled * x.ghk;
         if (nhk & 1)   // the last 64-sample K step is half filled: its second half must hold the value 0
@@ -171,6 +186,7 @@ static int flush_locked(void* out, bool dump, void* acc = nullptr, int acc_mode 
                                x.stash[x.cur], x.nblk64, x.cap_kt, nhk >> 1);
         nkt = (nhk + 1) >> 1;
     }
+#endif
     const int rem = (x.fp6 || x.raw) ? 0 : nkt % x.kt_stage;
     if (rem) {  // zero-fill the K padding of every (channel, block) row of the stash
         const int padk = x.kt_stage - rem;
@@ -180,54 +196,59 @@ static int flush_locked(void* out, bool dump, void* acc = nullptr, int acc_mode 
     }
     XcorrParams p;
     p.stash = x.stash[x.cur]; p.out = (int32_t*)out; p.descs = x.descs_dev;
-    p.nwg = x.nwg; p.nchan = x.cfg.nchan; p.nblk64 = x.nblk64; p.cap_kt = x.cap_kt; p.nkt = nkt;
+    p.nwg = x.raw ? x.nfg : x.nwg; p.nchan = x.cfg.nchan; p.nblk64 = x.nblk64; p.cap_kt = x.cap_kt; p.nkt = nkt;
     p.nstand = x.cfg.nstand; p.per_chan = x.per_chan; p.matlen = x.matlen;
     p.accumulate = x.acc_started ? 1 : 0;
     p.stamps = x.stamps;
     p.spg = x.raw ? x.cfg.ntime_gulp / (XC_KT * 32) : 0;
     p.ninput = x.ninput;
-    p.work = nullptr; p.maxi = 0; p.flags = nullptr; p.epoch = 0;
+    p.fgroups = x.fgroups_dev; p.work = x.work.dev; p.maxi = x.work.maxi; p.nstage = nkt / XC_KT;
     p.acc2 = (int32_t*)acc; p.acc2_mode = acc ? acc_mode : 0;
-    if (x.raw) {
-        const int nstage = nkt / XC_KT;
-        auto itw = x.work.find(nstage);
-        if (itw == x.work.end()) {
-            static const bool plain_order = getenv("XENG_ITEM_ORDER") && !strcmp(getenv("XENG_ITEM_ORDER"), "plain");   // A/B switch
-            const std::vector<WgDesc> descs = build_wg_descs(x.nblk64);
-            WorkList wl = build_work(fused_grid(x.cfg.nchan, x.nwg, x.ncu), x.cfg.nchan, x.nwg, nstage, x.splitk, x.stagger,
-                                     plain_order ? nullptr : &descs);
-            if (wl.nchains > x.flags_per_stream) XENG_FAIL(XENG_STATUS_DEVICE_ERROR, "xgpu: %d slice chains exceed the flag array", wl.nchains);
-            XENG_HIP(hipMalloc((void**)&wl.dev, wl.entries.size() * sizeof(WorkEntry)));
-            XENG_HIP(hipMemcpy(wl.dev, wl.entries.data(), wl.entries.size() * sizeof(WorkEntry), hipMemcpyHostToDevice));
-            itw = x.work.emplace(nstage, std::move(wl)).first;
-        }
-        p.work = itw->second.dev;
-        p.maxi = itw->second.maxi;
-    }
     for (int g = 0; g < XC_MAX_GULPS; g++) p.gulps[g] = g < x.nfilled ? x.gulp_ptr[g] : nullptr;
     // the contraction starts when this area's corner turns are done and runs beside the next area's
     const int si = (int)(x.nlaunch++ % x.nmm);
     hipStream_t smm = x.stream_mm2[si];
-    p.flags = x.flags ? x.flags + (size_t)si * x.flags_per_stream : nullptr;   // launches on one stream are ordered
-    p.epoch = ++x.epoch;
     XENG_HIP(hipEventRecord(x.ev_ct, x.stream));
     XENG_HIP(hipStreamWaitEvent(smm, x.ev_ct, 0));
     // contractions that touch the same output (partial sums of one integration, or a caller that
     // reuses one buffer for consecutive integrations) stay ordered; independent ones may overlap
-    for (int t = 0; t < x.nmm; t++)
-        if (t != si && x.mm_used[t] && (x.last_out[t] == out || (acc && x.last_acc[t] == acc)))
-            XENG_HIP(hipStreamWaitEvent(smm, x.ev_last[t], 0));
+    const unsigned long long seq = x.nlaunch;          // this launch's number (>= 1)
+    if (x.writers.size() > 256) {             // a caller that never reuses a buffer: forget them behind a full join
+        for (int t = 0; t < x.nmm; t++)
+            if (t != si && x.mm_used[t]) XENG_HIP(hipStreamWaitEvent(smm, x.ev_last[t], 0));
+        x.writers.clear();
+    }
+    {
+        // this launch takes over the event slot of launch seq - NEV: if that one has completed (the normal case), nobody
+        // needs to wait for it any more; if not (a very deep queue), its buffers fall back to the stream's latest event
+        const int k = (int)(seq % XgpuContext::NEV);
+        if (seq > (unsigned long long)XgpuContext::NEV && hipEventQuery(x.ev_ring[k]) == hipSuccess)
+            for (const void* buf : x.ring_buf[k]) {
+                auto it = buf ? x.writers.find(buf) : x.writers.end();
+                if (it != x.writers.end() && it->second.seq == seq - XgpuContext::NEV) x.writers.erase(it);
+            }
+        (void)hipGetLastError();              // (hipErrorNotReady is not an error)
+        x.ring_buf[k][0] = out; x.ring_buf[k][1] = acc;
+    }
+    for (const void* buf : {(const void*)out, (const void*)acc}) {
+        if (!buf) continue;
+        int rc = order_after_writer(smm, si, buf);
+        if (rc) return rc;
+        x.writers[buf] = XgpuContext::Writer{seq, si};
+    }
     int slot = x.timer.begin(smm, 1);
+#ifdef XENG_EXPERIMENTS
     if (x.fp6) hipLaunchKernelGGL(xcorr_fp6_kernel, dim3(p.nchan * p.nwg), dim3(256), 0, smm, p);
-    else launch_xcorr(p, smm, x.raw, x.ncu);
+    else
+#endif
+    launch_xcorr(p, smm, x.raw, fused_grid(x.cfg.nchan, x.nfg, x.ncu));
     x.timer.end(smm, slot);
     XENG_HIP(hipGetLastError());
     XENG_HIP(hipEventRecord(x.ev_mm[x.cur], smm));
     XENG_HIP(hipEventRecord(x.ev_last[si], smm));
+    XENG_HIP(hipEventRecord(x.ev_ring[seq % XgpuContext::NEV], smm));
     x.area_used[x.cur] = true;
     x.mm_used[si] = true;
-    x.last_out[si] = out;
-    x.last_acc[si] = acc;
     if (dump) {
         XENG_HIP(hipEventRecord(x.ev_dump[x.ndump & 3], smm));
         x.ndump++;
@@ -263,8 +284,7 @@ static int kernel_locked(const void* in_dev, void* out_dev, int doDump, bool syn
     if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized (call xengXgpuInitialize)");
     if (!in_dev || !out_dev) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "xgpu: null buffer");
     if (acc) {
-        static const bool w8 = getenv("XENG_WAVES") && atoi(getenv("XENG_WAVES")) == 8;
-        if (!x.raw || x.fp6 || x.splitk || x.stagger || w8)
+        if (!x.raw)
             XENG_FAIL(XENG_STATUS_UNSUPPORTED, "xgpu: the fused long accumulation needs the default contraction kernel (use xengMapAddI32)");
         if (acc_mode != 1 && acc_mode != 2) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "xgpu: acc_mode must be 1 (assign) or 2 (add)");
         if (((uintptr_t)acc & 15) || acc == out_dev) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "xgpu: accumulator must be 16-byte aligned and distinct from out");
@@ -286,12 +306,14 @@ static int kernel_locked(const void* in_dev, void* out_dev, int doDump, bool syn
         } else {
             x.gulp_ptr[x.nfilled] = (const uint8_t*)in_dev;
         }
+#ifdef XENG_EXPERIMENTS
     } else if (x.fp6) {
         slot = x.timer.begin(x.stream, 0);
         const size_t l6 = (((size_t)32 * x.ninput + 1023) & ~(size_t)1023) + (size_t)x.nblk64 * 2 * F6_FRAG;
         hipLaunchKernelGGL(corner_turn_fp6_kernel, dim3(x.cfg.nchan, x.ghk), dim3(192), l6, x.stream,
                            (const uint8_t*)in_dev, stash, x.cfg.ntime_gulp, x.cfg.nchan, x.ninput, x.nblk64,
                            x.cap_kt, x.nfilled * x.ghk);
+#endif
     } else if (x.ct_pitch > 0) {
         slot = x.timer.begin(x.stream, 0);
         const size_t l8 = (((size_t)16 * x.ct_pitch + 1023) & ~(size_t)1023);
@@ -376,7 +398,11 @@ static int initialize_locked(int gpu) {
         // default: fused corner turn whenever the shape allows it (whole 16-byte input chunks, gulps made
         // of whole 96-sample stages); XENG_RAW=0 keeps the two-pass path
         const char* r = getenv("XENG_RAW");
+#ifdef XENG_EXPERIMENTS
         const char* m = getenv("XENG_MFMA");
+#else
+        const char* m = nullptr;
+#endif
         x.gulp_bytes = (size_t)x.cfg.ntime_gulp * x.cfg.nchan * x.ninput;
         x.raw = !(m && !strcmp(m, "fp6")) && !(r && !strcmp(r, "0")) && x.ninput % 16 == 0 &&
                 x.cfg.ntime_gulp % (XC_KT * 32) == 0 && x.gulp_bytes + (size_t)16 * x.cfg.nchan * x.ninput < (1ull << 32);
@@ -393,6 +419,7 @@ static int initialize_locked(int gpu) {
         while (((pitch / 4) & 63) != 8) pitch += 16;
         if ((size_t)16 * pitch + 1024 <= 64 * 1024) x.ct_pitch = pitch;
     }
+#ifdef XENG_EXPERIMENTS
     {
         const char* m = getenv("XENG_MFMA");
         const size_t l6 = (((size_t)32 * x.ninput + 1023) & ~(size_t)1023) + (size_t)x.nblk64 * 2 * F6_FRAG;
@@ -403,6 +430,7 @@ static int initialize_locked(int gpu) {
             x.stash_bytes = (size_t)x.cfg.nchan * x.nblk64 * x.cap_kt * F6_KT_BYTES;
         }
     }
+#endif
     if (x.raw) x.stash_bytes = (size_t)cap * x.gulp_bytes;   // raw copies of synchronously handed gulps
 
     for (int b = 0; b < 2; b++) {
@@ -415,16 +443,18 @@ static int initialize_locked(int gpu) {
     std::vector<WgDesc> descs = build_wg_descs(x.nblk64);
     x.nwg = (int)descs.size();
     if (x.raw) {
-        // opt-in: measured 233-236 us per launch alone (whole items: 230-236) and 0.235 ms per streaming step
-        // (whole items: 0.219): the extra read-modify-write epilogues and the ordered hand-over between slices
-        // cost what the balanced tail saves, and overlapping launches already fill the tail
-        const char* e = getenv("XENG_SPLITK");
-        x.splitk = e && !strcmp(e, "1");
-        const char* sg = getenv("XENG_STAGGER");
-        x.stagger = sg && !strcmp(sg, "1");
-        x.flags_per_stream = fused_grid(x.cfg.nchan, x.nwg, x.ncu);   // split items < work-groups
-        XENG_HIP(hipMalloc((void**)&x.flags, (size_t)XgpuContext::NMM * x.flags_per_stream * sizeof(uint32_t)));
-        XENG_HIP(hipMemset(x.flags, 0, (size_t)XgpuContext::NMM * x.flags_per_stream * sizeof(uint32_t)));
+        // fragment-level tile groups and the persistent work-groups' item lists (the same for every K length)
+        const bool tiles64 = getenv("XENG_TILING") && !strcmp(getenv("XENG_TILING"), "64");        // A/B switch: the 64x64 tiling
+        const bool plain_order = getenv("XENG_ITEM_ORDER") && !strcmp(getenv("XENG_ITEM_ORDER"), "plain");   // A/B switch
+        const std::vector<FragGroup> groups = tiles64 ? frag_groups_from_tiles(x.nblk64) : build_frag_groups(x.nblk64);
+        if (check_frag_groups(groups, x.nblk64) != -1) XENG_FAIL(XENG_STATUS_DEVICE_ERROR, "xgpu: the tiling of %d blocks is not an exact cover", x.nblk64);
+        x.nfg = (int)groups.size();
+        XENG_HIP(hipMalloc((void**)&x.fgroups_dev, groups.size() * sizeof(FragGroup)));
+        XENG_HIP(hipMemcpy(x.fgroups_dev, groups.data(), groups.size() * sizeof(FragGroup), hipMemcpyHostToDevice));
+        const std::vector<uint64_t> masks = group_block_masks(groups);
+        x.work = build_work(fused_grid(x.cfg.nchan, x.nfg, x.ncu), x.cfg.nchan, x.nfg, plain_order ? nullptr : &masks);
+        XENG_HIP(hipMalloc((void**)&x.work.dev, x.work.entries.size() * sizeof(WorkEntry)));
+        XENG_HIP(hipMemcpy(x.work.dev, x.work.entries.data(), x.work.entries.size() * sizeof(WorkEntry), hipMemcpyHostToDevice));
     }
     XENG_HIP(hipMalloc((void**)&x.descs_dev, descs.size() * sizeof(WgDesc)));
     XENG_HIP(hipMemcpy(x.descs_dev, descs.data(), descs.size() * sizeof(WgDesc), hipMemcpyHostToDevice));
@@ -436,10 +466,12 @@ static int initialize_locked(int gpu) {
         if (rc) return rc;
         XENG_HIP(hipEventCreateWithFlags(&x.ev_last[t], hipEventDisableTiming));
     }
+    for (int k = 0; k < XgpuContext::NEV; k++) XENG_HIP(hipEventCreateWithFlags(&x.ev_ring[k], hipEventDisableTiming));
     x.stream_mm = x.stream_mm2[0];
     if (getenv("XENG_DBG_STAMPS")) {
-        XENG_HIP(hipMalloc((void**)&x.stamps, (size_t)x.cfg.nchan * x.nwg * 4 * 8 * sizeof(unsigned long long)));
-        XENG_HIP(hipMemset(x.stamps, 0, (size_t)x.cfg.nchan * x.nwg * 4 * 8 * sizeof(unsigned long long)));
+        const int ng = std::max(x.nwg, x.nfg);
+        XENG_HIP(hipMalloc((void**)&x.stamps, (size_t)x.cfg.nchan * ng * 4 * 8 * sizeof(unsigned long long)));
+        XENG_HIP(hipMemset(x.stamps, 0, (size_t)x.cfg.nchan * ng * 4 * 8 * sizeof(unsigned long long)));
     }
     x.live = true;
     return XENG_STATUS_SUCCESS;
@@ -511,40 +543,58 @@ int xengXgpuSyncLag(int lag) {
     return XENG_STATUS_SUCCESS;
 }
 
+// Drops the partial integration.  The state is reset under the lock; the wait for what was already enqueued happens
+// outside it (other blocks' calls must not stall behind a whole contraction).
 int xengXgpuReset(void) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    XgpuContext& x = g_ctx;
-    if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized");
-    XENG_HIP(hipSetDevice(x.gpu));
-    XENG_HIP(hipStreamSynchronize(x.stream));
-    for (int t = 0; t < x.nmm; t++) XENG_HIP(hipStreamSynchronize(x.stream_mm2[t]));
-    x.timer.drain();
-    x.nfilled = 0;
-    x.acc_started = false;
-    x.acc_out = nullptr;
+    int gpu, nmm;
+    hipStream_t st, mm[XgpuContext::NMM];
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        XgpuContext& x = g_ctx;
+        if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized");
+        x.nfilled = 0;
+        x.acc_started = false;
+        x.acc_out = nullptr;
+        gpu = x.gpu; nmm = x.nmm; st = x.stream;
+        for (int t = 0; t < nmm; t++) mm[t] = x.stream_mm2[t];
+    }
+    XENG_HIP(hipSetDevice(gpu));
+    XENG_HIP(hipStreamSynchronize(st));
+    for (int t = 0; t < nmm; t++) XENG_HIP(hipStreamSynchronize(mm[t]));
+    drain_timer();
     return XENG_STATUS_SUCCESS;
 }
 
+// Host-buffer convenience path of xgpu_test.py:86-89.  One caller at a time (g_correlate_mu keeps the private device
+// buffers to one call); the context lock is held to enqueue only.
+static std::mutex g_correlate_mu;
 int xengXgpuCorrelate(const void* in_host, void* out_host, int doDump) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    XgpuContext& x = g_ctx;
-    if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized");
-    if (!in_host || !out_host) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "xgpu: null buffer");
-    XENG_HIP(hipSetDevice(x.gpu));
-    const size_t in_bytes = (size_t)x.cfg.ntime_gulp * x.cfg.nchan * x.ninput;
-    const size_t out_bytes = (size_t)x.matlen * 2 * sizeof(int32_t);
-    if (!x.in_dev) XENG_HIP(hipMalloc((void**)&x.in_dev, in_bytes));
-    if (!x.out_dev) XENG_HIP(hipMalloc((void**)&x.out_dev, out_bytes));
-    XENG_HIP(hipMemcpyAsync(x.in_dev, in_host, in_bytes, hipMemcpyHostToDevice, x.stream));
+    std::lock_guard<std::mutex> clk(g_correlate_mu);
     PendingWait pw;
-    int rc = kernel_locked(x.in_dev, x.out_dev, doDump, true, &pw);
-    if (rc) return rc;
-    // (host-buffer convenience path of xgpu_test.py:86-89, one caller: the waits stay under the lock)
-    rc = wait_unlocked(pw);
+    hipStream_t st;
+    int32_t* out_dev;
+    size_t out_bytes;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        XgpuContext& x = g_ctx;
+        if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized");
+        if (!in_host || !out_host) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "xgpu: null buffer");
+        XENG_HIP(hipSetDevice(x.gpu));
+        const size_t in_bytes = (size_t)x.cfg.ntime_gulp * x.cfg.nchan * x.ninput;
+        out_bytes = (size_t)x.matlen * 2 * sizeof(int32_t);
+        if (!x.in_dev) XENG_HIP(hipMalloc((void**)&x.in_dev, in_bytes));
+        if (!x.out_dev) XENG_HIP(hipMalloc((void**)&x.out_dev, out_bytes));
+        XENG_HIP(hipMemcpyAsync(x.in_dev, in_host, in_bytes, hipMemcpyHostToDevice, x.stream));
+        int rc = kernel_locked(x.in_dev, x.out_dev, doDump, true, &pw);
+        if (rc) return rc;
+        st = x.stream; out_dev = x.out_dev;
+    }
+    int rc = wait_unlocked(pw);
     if (rc) return rc;
     if (doDump) {
-        XENG_HIP(hipMemcpyAsync(out_host, x.out_dev, out_bytes, hipMemcpyDeviceToHost, x.stream));
-        XENG_HIP(hipStreamSynchronize(x.stream));
+        XENG_HIP(hipMemcpyAsync(out_host, out_dev, out_bytes, hipMemcpyDeviceToHost, st));
+        XENG_HIP(hipStreamSynchronize(st));
+        drain_timer();
     }
     return XENG_STATUS_SUCCESS;
 }
@@ -564,20 +614,32 @@ int xengXgpuGetOrder(const int32_t* antpol_to_input, int32_t* antpol_to_bl, int3
 // The consumers of a visibility span (CorrSubsel, CorrOutputFull: their own threads in the reference,
 // lwa352-pipeline.py:232-262) run on a stream of their own, ordered behind the contraction that produced the span
 // by its completion event -- not by the X-engine's context lock, and they wait for their own kernel only.
-static std::mutex g_consumer_mu;          // serialises the consumers among themselves (one stream, one event)
-static hipEvent_t g_consumer_ev = nullptr;
-
-// under g_mu: make `s` wait for every enqueued contraction that writes `span`
-static int order_after_producers(hipStream_t s, const void* span) {
-    XgpuContext& x = g_ctx;
-    for (int t = 0; t < x.nmm; t++)
-        if (x.mm_used[t] && (x.last_out[t] == span || x.last_acc[t] == span)) XENG_HIP(hipStreamWaitEvent(s, x.ev_last[t], 0));
+// Every call waits on an event of its own (a small pool), so CorrSubsel's call never waits behind CorrOutputFull's.
+static std::mutex g_evpool_mu;
+static std::vector<hipEvent_t> g_evpool;
+static int take_event(hipEvent_t* ev) {
+    {
+        std::lock_guard<std::mutex> lk(g_evpool_mu);
+        if (!g_evpool.empty()) { *ev = g_evpool.back(); g_evpool.pop_back(); return XENG_STATUS_SUCCESS; }
+    }
+    XENG_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+    return XENG_STATUS_SUCCESS;
+}
+static void give_event(hipEvent_t ev) {
+    std::lock_guard<std::mutex> lk(g_evpool_mu);
+    g_evpool.push_back(ev);
+}
+// waits for the caller's own kernel, outside every lock
+static int finish_consumer(hipEvent_t ev) {
+    const hipError_t e = hipEventSynchronize(ev);
+    give_event(ev);
+    XENG_HIP(e);
     return XENG_STATUS_SUCCESS;
 }
 
 int xengXgpuSubSelect(const void* in_dev, void* out_dev, const int32_t* vismap_dev, const int32_t* conj_dev,
                       int nvis, int nchan_sum) {
-    std::lock_guard<std::mutex> clk(g_consumer_mu);
+    hipEvent_t ev;
     {
         std::lock_guard<std::mutex> lk(g_mu);
         XgpuContext& x = g_ctx;
@@ -589,22 +651,23 @@ int xengXgpuSubSelect(const void* in_dev, void* out_dev, const int32_t* vismap_d
         hipStream_t s;
         int rc = get_stream(STREAM_CONSUMER, &s);
         if (rc) return rc;
-        if (!g_consumer_ev) XENG_HIP(hipEventCreateWithFlags(&g_consumer_ev, hipEventDisableTiming));
-        rc = order_after_producers(s, in_dev);
+        rc = order_after_writer(s, -1, in_dev);
         if (rc) return rc;
         hipLaunchKernelGGL(subselect_kernel, dim3((nvis + 255) / 256, x.cfg.nchan / nchan_sum), dim3(256), 0, s,
                            (const int32_t*)in_dev, (int32_t*)out_dev, vismap_dev, conj_dev, nvis, nchan_sum,
                            x.per_chan, x.matlen);
         XENG_HIP(hipGetLastError());
-        XENG_HIP(hipEventRecord(g_consumer_ev, s));
+        rc = take_event(&ev);
+        if (rc) return rc;
+        const hipError_t re = hipEventRecord(ev, s);
+        if (re != hipSuccess) { give_event(ev); XENG_HIP(re); }
     }
-    XENG_HIP(hipEventSynchronize(g_consumer_ev));
-    return XENG_STATUS_SUCCESS;
+    return finish_consumer(ev);
 }
 
 int xengXgpuPacketize(const void* in_dev, void* out_dev, const int32_t* antpol_to_bl_dev, const int32_t* is_conj_dev,
                       int fmt) {
-    std::lock_guard<std::mutex> clk(g_consumer_mu);
+    hipEvent_t ev;
     {
         std::lock_guard<std::mutex> lk(g_mu);
         XgpuContext& x = g_ctx;
@@ -623,17 +686,18 @@ int xengXgpuPacketize(const void* in_dev, void* out_dev, const int32_t* antpol_t
         hipStream_t s;
         int rc = get_stream(STREAM_CONSUMER, &s);
         if (rc) return rc;
-        if (!g_consumer_ev) XENG_HIP(hipEventCreateWithFlags(&g_consumer_ev, hipEventDisableTiming));
-        rc = order_after_producers(s, in_dev);
+        rc = order_after_writer(s, -1, in_dev);
         if (rc) return rc;
         hipLaunchKernelGGL(packetize_kernel, dim3(x.cfg.nstand, (x.cfg.nstand + 15) / 16), dim3(256), lds, s,
                            (const int32_t*)in_dev, (int2*)out_dev, antpol_to_bl_dev, is_conj_dev, x.cfg.nstand, x.cfg.nchan,
                            x.per_chan, x.matlen, pitch, fmt);
         XENG_HIP(hipGetLastError());
-        XENG_HIP(hipEventRecord(g_consumer_ev, s));
+        rc = take_event(&ev);
+        if (rc) return rc;
+        const hipError_t re = hipEventRecord(ev, s);
+        if (re != hipSuccess) { give_event(ev); XENG_HIP(re); }
     }
-    XENG_HIP(hipEventSynchronize(g_consumer_ev));
-    return XENG_STATUS_SUCCESS;
+    return finish_consumer(ev);
 }
 
 int xengXgpuReorder(const void* in_host, void* out_host, const int32_t* bl, const int32_t* conj) {
@@ -701,8 +765,9 @@ int xengXgpuDebugReadStamps(unsigned long long* host, size_t nwords, int* nwaves
     std::lock_guard<std::mutex> lk(g_mu);
     XgpuContext& x = g_ctx;
     if (!x.live || !x.stamps) XENG_FAIL(XENG_STATUS_INVALID_STATE, "stamps not enabled");
-    const size_t n = (size_t)x.cfg.nchan * x.nwg * 4 * 8;
-    if (nwaves) *nwaves = x.cfg.nchan * x.nwg * 4;
+    const int ng = x.raw ? x.nfg : x.nwg;
+    const size_t n = (size_t)x.cfg.nchan * ng * 4 * 8;
+    if (nwaves) *nwaves = x.cfg.nchan * ng * 4;
     for (int t = 0; t < x.nmm; t++) XENG_HIP(hipStreamSynchronize(x.stream_mm2[t]));
     if (host) XENG_HIP(hipMemcpy(host, x.stamps, std::min(nwords, n) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return XENG_STATUS_SUCCESS;

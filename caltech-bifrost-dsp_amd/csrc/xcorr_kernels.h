@@ -191,12 +191,11 @@ struct XcorrParams {
     const uint8_t* gulps[XC_MAX_GULPS];
     int spg;                      // 96-sample stages per gulp
     int ninput;
-    // fused kernel: per work-group list of work entries (WorkEntry[gridDim.x][maxi]) and the flags that order the
-    // K slices of a split item (one per split item; value = epoch*16 + slices stored so far)
+    // fused kernel: fragment-level tile groups, per work-group list of items (WorkEntry[gridDim.x][maxi]), stages per item
+    const FragGroup* fgroups;
     const uint32_t* work;
     int maxi;
-    uint32_t* flags;
-    uint32_t epoch;
+    int nstage;
     // long accumulation fused into the dump (CorrAcc's "a = b" / "a += b", corr_acc_block.py:298-306, applied to the
     // values this launch stores): acc2 = planar int32 buffer like `out`; acc2_mode 0 none, 1 assign, 2 add
     int32_t* acc2;
@@ -522,7 +521,7 @@ __global__ __launch_bounds__(256, 1) void xcorr_mfma_kernel(XcorrParams p) {
 }
 
 // =======================================================================================
-// Default path: corner turn fused into the LDS staging, persistent work-groups.
+// Default path: corner turn fused into the LDS staging, persistent work-groups, fragment-level tiling.
 //
 // The kernel reads the gulps where they lie (time-major rows of ninput bytes per channel).  Per stage
 // (96 samples) and pair of 64-input blocks the LDS-DMA brings 96 rows x 128 B; the operand fragments come
@@ -539,13 +538,148 @@ __global__ __launch_bounds__(256, 1) void xcorr_mfma_kernel(XcorrParams p) {
 // most pairs adjacent blocks (2k, 2k+1), whose halves then form whole 128-byte lines (half as many L2
 // requests as 64-byte row segments).
 //
+// Tiling (xcorr_tiling.h, FragGroup): a wave contracts four 32x32 cells from four operand fragments, each of which may
+// be either 32-input half of any staged block -- as a 2x2 outer product (an off-diagonal 64x64 tile), or in the Z
+// pattern (the three stored cells of a diagonal 64x64 tile plus one free cell of an off-diagonal tile): the K loop
+// exists in both wirings, selected per item by a wave-uniform branch outside the loop.  704 inputs: 16 tile groups.
+//
 // Persistence: the grid is one work-group per CU; each walks a list of (channel, tile group) items
 // (whole channels per XCD, as above).  The LDS-DMA stream runs ahead of the MFMA stream by three stages
 // ACROSS items: while an item's last K-tiles are contracted and its tiles are stored, the first stages of
 // the next item are already landing, so the fill of the pipeline (and the dispatch of a new work-group)
 // is paid once per CU instead of once per item.
 // =======================================================================================
-// ABL: timing-only ablation bits as for xcorr_mfma_kernel (diagnostic builds; results are wrong unless 0).
+
+// the 16 (12 when cell 1 is dead) int8 MFMAs of one K-tile: for every cell R += xr*yr + xi*yi, P += xi*yr, Q += xr*yi.
+// Operands: u.a = fragments 0, 1; u.b = fragments 2, 3 of the wave (FragGroup).  Unpacked fragments are the same thing
+// whether they enter as A or B operand, so the Z wiring multiplies a diagonal fragment with itself.
+template <bool Z>
+__device__ __forceinline__ void xcorr_mfma_cells(const Frags& u, bool skip1, v16i (&accR)[2][2], v16i (&accP)[2][2],
+                                                 v16i (&accQ)[2][2]) {
+    auto cell = [&](int m, int n, const v4i& xr, const v4i& xi, const v4i& yr, const v4i& yi) {
+        accR[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xr, yr, accR[m][n], 0, 0, 0);
+        accP[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xi, yr, accP[m][n], 0, 0, 0);
+        accQ[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xr, yi, accQ[m][n], 0, 0, 0);
+        accR[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xi, yi, accR[m][n], 0, 0, 0);
+    };
+    if (Z) {
+        cell(0, 0, u.ar[0], u.ai[0], u.ar[0], u.ai[0]);                 // (d0, d0)
+        if (!skip1) cell(0, 1, u.br[0], u.bi[0], u.br[1], u.bi[1]);     // the free cell (r, c)
+        cell(1, 0, u.ar[1], u.ai[1], u.ar[0], u.ai[0]);                 // (d1, d0)
+        cell(1, 1, u.ar[1], u.ai[1], u.ar[1], u.ai[1]);                 // (d1, d1)
+    } else {
+        cell(0, 0, u.ar[0], u.ai[0], u.br[0], u.bi[0]);
+        if (!skip1) cell(0, 1, u.ar[0], u.ai[0], u.br[1], u.bi[1]);
+        cell(1, 0, u.ar[1], u.ai[1], u.br[0], u.bi[0]);
+        cell(1, 1, u.ar[1], u.ai[1], u.br[1], u.bi[1]);
+    }
+}
+
+// Epilogue of the fragment-tiled kernel: accumulator (m, n) is cell p = 2m + n with rows = inputs 32*row[p].., columns =
+// inputs 32*col[p].. (wave-uniform).  Same register-tile order, lane regrouping and masks as xcorr_store_tile.
+// fast: all four cells live, strictly below the diagonal, no padded inputs, nothing to add to -- exactly 32 stores.
+template <bool LACC>
+__device__ __forceinline__ void xcorr_store_cells(const XcorrParams& p, int c, const int (&row)[4], const int (&col)[4],
+                                                  int live, bool fast, bool accumulate, int lane, const v16i (&accR)[2][2],
+                                                  const v16i (&accP)[2][2], const v16i (&accQ)[2][2]) {
+    const int qs = (int)(((int64_t)(p.nstand / 2 + 1) * p.nstand) / 4);
+    int32_t* out_r = p.out + (int64_t)c * p.per_chan;
+    int32_t* out_i = out_r + p.matlen;
+    int32_t* acc_r = LACC ? p.acc2 + (int64_t)c * p.per_chan : nullptr;
+    int32_t* acc_i = LACC ? acc_r + p.matlen : nullptr;
+    const bool acc_add = LACC && p.acc2_mode == 2;
+    auto long_acc = [&](int w, int4 cr, int4 ci) {           // the stored cell -> the long accumulator
+        int4* ar = reinterpret_cast<int4*>(acc_r + w);
+        int4* ai = reinterpret_cast<int4*>(acc_i + w);
+        if (acc_add) {
+            const int4 o_r = *ar, o_i = *ai;
+            cr.x += o_r.x; cr.y += o_r.y; cr.z += o_r.z; cr.w += o_r.w;
+            ci.x += o_i.x; ci.y += o_i.y; ci.z += o_i.z; ci.w += o_i.w;
+        }
+        *ar = cr;
+        *ai = ci;
+    };
+    const int odd = lane & 1;
+    auto cell = [&](int v0, int v1, int v2, int v3) {
+        const int g0 = dpp_xor1(odd ? v0 : v2), g1 = dpp_xor1(odd ? v1 : v3);
+        return odd ? make_int4(g0, v2, g1, v3) : make_int4(v0, g0, v1, g1);
+    };
+    const int pull = ((lane & 32) | (4 * (lane & 7) + ((lane >> 3) & 3))) * 4;   // byte address of the source lane
+    auto regroup = [&](int4 v) {
+        return make_int4(__builtin_amdgcn_ds_bpermute(pull, v.x), __builtin_amdgcn_ds_bpermute(pull, v.y),
+                         __builtin_amdgcn_ds_bpermute(pull, v.z), __builtin_amdgcn_ds_bpermute(pull, v.w));
+    };
+    const int quad = (lane >> 3) & 3;          // 2*(C&1) + (R&1) of the cell this lane stores after the regrouping
+    const int cpar = quad >> 1, rpar = quad & 1;
+    if (fast) {
+        // straight-line code: no per-cell branches, so the lane regrouping of one cell overlaps the arithmetic of the next
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int n = 0; n < 2; n++) {
+                const int ibase = row[2 * m + n] * 32, jbase = col[2 * m + n] * 32;
+                const int Ch = (jbase >> 2) + (lane & 7);
+                const int wcol = (quad * qs + Ch) * 4;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int Rh = (ibase >> 2) + 2 * u + (lane >> 5);
+                    int vr[4], vi[4];
+#pragma unroll
+                    for (int v = 0; v < 4; v++) {
+                        vr[v] = accR[m][n][4 * u + v] >> 8;
+                        vi[v] = (accP[m][n][4 * u + v] - accQ[m][n][4 * u + v]) >> 8;
+                    }
+                    const int4 cr = regroup(cell(vr[0], vr[1], vr[2], vr[3]));
+                    const int4 ci = regroup(cell(vi[0], vi[1], vi[2], vi[3]));
+                    const int w = wcol + ((Rh * (Rh + 1)) >> 1) * 4;
+                    *reinterpret_cast<int4*>(out_r + w) = cr;
+                    *reinterpret_cast<int4*>(out_i + w) = ci;
+                    if (LACC) long_acc(w, cr, ci);
+                }
+            }
+        return;
+    }
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+            if (!((live >> (2 * m + n)) & 1)) continue;          // wave-uniform
+            const int ibase = row[2 * m + n] * 32, jbase = col[2 * m + n] * 32;
+            const bool interior = row[2 * m + n] > col[2 * m + n] && ibase + 32 <= 2 * p.nstand;
+            const int Ch = (jbase >> 2) + (lane & 7);
+            const int C = 2 * Ch + cpar;
+            const int wcol = (quad * qs + Ch) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int Rh = (ibase >> 2) + 2 * u + (lane >> 5);
+                const int R = 2 * Rh + rpar;
+                int vr[4], vi[4];
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    vr[v] = accR[m][n][4 * u + v] >> 8;
+                    vi[v] = (accP[m][n][4 * u + v] - accQ[m][n][4 * u + v]) >> 8;
+                }
+                int4 cr = regroup(cell(vr[0], vr[1], vr[2], vr[3]));
+                int4 ci = regroup(cell(vi[0], vi[1], vi[2], vi[3]));
+                const int w = wcol + ((Rh * (Rh + 1)) >> 1) * 4;
+                int4* pr = reinterpret_cast<int4*>(out_r + w);
+                int4* pi = reinterpret_cast<int4*>(out_i + w);
+                if (interior || (Rh >= Ch && R < p.nstand && C < p.nstand)) {
+                    if (accumulate) {
+                        const int4 o_r = *pr, o_i = *pi;
+                        cr.x += o_r.x; cr.y += o_r.y; cr.z += o_r.z; cr.w += o_r.w;
+                        ci.x += o_i.x; ci.y += o_i.y; ci.z += o_i.z; ci.w += o_i.w;
+                    }
+                    *pr = cr;
+                    *pi = ci;
+                    if (LACC) long_acc(w, cr, ci);
+                }
+            }
+        }
+}
+
+// ABL: timing-only ablation bits as for xcorr_mfma_kernel (diagnostic builds; results are wrong unless 0);
+// 16: no epilogue, 32: every channel reads a 1 MB window of gulp 0 that stays in L2.
 template <int ABL, bool LACC = false>
 __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
     constexpr int KT_STAGE = XC_KT;
@@ -561,46 +695,42 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
     const uint32_t row_stride = (uint32_t)p.nchan * (uint32_t)p.ninput;
     // tile-group table through the constant address space: wave-uniform reads become scalar loads (a vector
     // load would make the compiler wait for vmcnt(0), i.e. for the whole LDS-DMA stream, at every item switch)
-    // (16-byte descriptors read as aligned dwords: slot_blk | wave_a | wave_b)
+    // (32-byte groups read as aligned dwords: slot_blk | wave[0..3])
     typedef const __attribute__((address_space(4))) uint32_t* DescPtr;
-    const DescPtr descs = (DescPtr)(uintptr_t)p.descs;
-    static_assert(sizeof(WgDesc) == 16, "descriptor layout");
+    const DescPtr groups = (DescPtr)(uintptr_t)p.fgroups;
+    static_assert(sizeof(FragGroup) == 32, "group layout");
 
     // entry k of this work-group's list; false past the end
-    const DescPtr work = (DescPtr)(uintptr_t)p.work + (size_t)blockIdx.x * p.maxi * 4;
-    struct Item { int c, wg, stage0, nst, slice, nslices, chain; };
+    const DescPtr work = (DescPtr)(uintptr_t)p.work + (size_t)blockIdx.x * p.maxi;
+    struct Item { int c, wg; };
     auto item = [&](int k, Item& it) {
         if (k >= p.maxi) return false;
-        const uint32_t w0 = work[k * 4], w1 = work[k * 4 + 1], w2 = work[k * 4 + 2];
-        if (!(w2 >> 16)) return false;
-        it.c = (int)(w0 & 0xFFFF); it.wg = (int)(w0 >> 16);
-        it.stage0 = (int)(w1 & 0xFFFF); it.nst = (int)(w1 >> 16);
-        it.slice = (int)(w2 & 0xFF); it.nslices = (int)((w2 >> 8) & 0xFF);
-        it.chain = (int)work[k * 4 + 3];
+        const uint32_t w = work[k];
+        if (!(w & WORK_VALID)) return false;
+        it.c = (int)(w & 0xFFFF); it.wg = (int)((w >> 16) & 0x7FFF);
         return true;
     };
 
     // ---- issue side: the stage stream (item, gulp, stage in gulp) DEPTH stages ahead of the MFMAs ----
-    int is_k = 0, is_c = 0, is_wg = 0, is_g = 0, is_sl = 0, is_issued = 0, is_nst = 0;
-    uint32_t is_lane_off = 0;
+    int is_k = 0, is_c = 0, is_g = 0, is_sl = 0, is_issued = 0;
     uint32_t is_voff[NLOAD] = {};
     const uint8_t* is_stage = nullptr;
     auto is_setup = [&](const Item& it) {
-        is_c = it.c; is_wg = it.wg; is_nst = it.nst;
+        is_c = it.c;
         // (columns past ninput in the last block: any valid bytes of the row; their products are never stored)
-        const uint32_t slots = descs[is_wg * 4];                          // slot_blk[0..3]
+        const uint32_t slots = groups[it.wg * 8];                         // slot_blk[0..3]
         const int chunk = (lane & 7) ^ (((lane >> 4) & 3) << 1);          // source chunk 0..7 of the 128-byte pair row
         const int blk0 = (slots >> (8 * (wave & 2))) & 0xFF, blk1 = (slots >> (8 * (wave & 2) + 8)) & 0xFF;
         const uint32_t col = (uint32_t)((chunk >> 2) ? blk1 : blk0) * 64u + (uint32_t)(chunk & 3) * 16u;
-        is_lane_off = (uint32_t)(lane >> 3) * row_stride + (col + 16u <= (uint32_t)p.ninput ? col : 0u);
+        const uint32_t lane_off = (uint32_t)(lane >> 3) * row_stride + (col + 16u <= (uint32_t)p.ninput ? col : 0u);
 #pragma unroll
-        for (int n = 0; n < NLOAD; n++) is_voff[n] = is_lane_off + (uint32_t)n * 8u * row_stride - (uint32_t)((n & 3) * 1024);
-        is_g = it.stage0 / p.spg;
-        is_sl = it.stage0 - is_g * p.spg;
+        for (int n = 0; n < NLOAD; n++) is_voff[n] = lane_off + (uint32_t)n * 8u * row_stride - (uint32_t)((n & 3) * 1024);
+        is_g = 0;
+        is_sl = 0;
         is_issued = 0;
     };
     auto next_stage = [&]() {
-        if (is_issued == is_nst) {           // this entry is fully issued: go on with the next one, if any
+        if (is_issued == p.nstage) {         // this item is fully issued: go on with the next one, if any
             Item nx;
             if (!item(is_k + 1, nx)) return;   // past the end: keep re-reading the last stage (never consumed)
             is_k++;
@@ -638,7 +768,7 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
 
     // read side: lane 16*grp + 2q + pp addresses row 16*(grp>>1) + q (+8 for the second read), chunk position
     // (4*slot parity + 2*sub + (grp&1)) ^ 2*((q>>1)&3), bytes 8pp..8pp+7: slot parity flips address bit 6,
-    // sub = 1 flips bit 5
+    // sub = 1 (the upper 32 inputs of a block) flips bit 5
     const int tr_off = ((lane >> 5) * 16 + ((lane & 15) >> 1)) * 128 +
                        (((lane >> 4) & 1) ^ (((lane >> 2) & 3) << 1)) * 16 + (lane & 1) * 8;
 
@@ -662,39 +792,11 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
     for (int k = 0; item(k, it); k++) {
         const int c = it.c, wg = it.wg;
         const unsigned long long r_entry = p.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
-        const uint32_t slots = descs[wg * 4], wa4 = descs[wg * 4 + 1], wb4 = descs[wg * 4 + 2];
-        const int a_slot = (wa4 >> (8 * wave)) & 0xFF, b_slot = (wb4 >> (8 * wave)) & 0xFF;
-        // Idle waves (a_slot == 0xFF) run the same loop on slot 0 and skip the stores: keeping the MFMA chain
-        // unconditional keeps the 192 accumulator registers in place
-        const bool active = a_slot != 0xFF;
-        const int sa = active ? a_slot : 0, sb = active ? b_slot : 0;
-        const int blk_a = (slots >> (8 * sa)) & 0xFF, blk_b = (slots >> (8 * sb)) & 0xFF;
-        const int a_off = (sa >> 1) * (2 * SLOT_BYTES) + (tr_off ^ ((sa & 1) * 64));
-        const int b_off = (sb >> 1) * (2 * SLOT_BYTES) + (tr_off ^ ((sb & 1) * 64));
-        // Diagonal wave tiles never store the upper-right 32x32 MFMA tile: skip its 4 MFMAs
-        const bool skip01 = __builtin_amdgcn_readfirstlane((int)(!active || blk_a == blk_b)) != 0;
-
-        auto load_raw = [&](int ring_slot, int j) {     // fragments of K-tile j (0..KT_STAGE-1) of a landed stage
-            const uint8_t* base = lds + ring_slot * STAGE_BYTES + j * (2 * KT_BYTES);
-            auto tr = [&](int off) {
-                return __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) v2i*)(base + off));
-            };
-            RawFrags r;
-#pragma unroll
-            for (int sub = 0; sub < 2; sub++) {
-                const v2i a0 = tr(a_off ^ (sub * 32)), a1 = tr((a_off ^ (sub * 32)) + 1024);
-                const v2i b0 = tr(b_off ^ (sub * 32)), b1 = tr((b_off ^ (sub * 32)) + 1024);
-                r.a[sub] = (v4i){a0.x, a0.y, a1.x, a1.y};
-                r.b[sub] = (v4i){b0.x, b0.y, b1.x, b1.y};
-            }
-            return r;
-        };
-
-        if (!active) {
-            // A wave without a tile (the tiling leaves 2 of 68 wave slots empty) only keeps the stage stream and the
-            // barriers going: running the MFMAs on dummy data, as the two-pass kernel does, would cost 3 % of the
-            // launch's MFMA energy in a power-limited kernel.  Nothing is live across this branch.
-            for (int s = 0; s < it.nst; s++) {
+        const uint32_t slots = groups[wg * 8], ww = groups[wg * 8 + 1 + wave];
+        if (!(ww & FRAG_BUSY)) {
+            // A wave without a cell only keeps the stage stream and the barriers going (no MFMAs on dummy data: the
+            // kernel is power-limited).  Nothing is live across this branch.
+            for (int s = 0; s < p.nstage; s++) {
                 next_stage();
                 if (!(ABL & 1)) {
 #pragma unroll
@@ -706,14 +808,45 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
                 }
                 bump(rs); bump(rs1); bump(rf);
             }
-            if (it.slice + 1 < it.nslices) {   // split-K hand-over: same barrier count as the storing waves (wave 0,
-                                               // which publishes the flag, always has a tile)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-            }
             stores_in_flight = false;
             continue;
         }
+        // operand fragments: LDS offsets and 32-input block numbers (wave-uniform positions)
+        const int live = (int)((ww >> 16) & 15);
+        const bool zpat = (ww & FRAG_Z) != 0;
+        const bool skip1 = !(live & 2);         // cell 1 is dead: its 4 MFMAs per K-tile are skipped
+        int off[4], b32[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int pos = (int)((ww >> (3 * q)) & 7);
+            off[q] = (pos >> 2) * (2 * SLOT_BYTES) + (tr_off ^ (((pos >> 1) & 1) * 64) ^ ((pos & 1) * 32));
+            b32[q] = (int)((slots >> (8 * (pos >> 1))) & 0xFF) * 2 + (pos & 1);
+        }
+        int row[4], col[4];
+        if (zpat) {
+            row[0] = b32[0]; col[0] = b32[0]; row[1] = b32[2]; col[1] = b32[3];
+            row[2] = b32[1]; col[2] = b32[0]; row[3] = b32[1]; col[3] = b32[1];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) { row[q] = b32[q >> 1]; col[q] = b32[2 + (q & 1)]; }
+        }
+
+        auto load_raw = [&](int ring_slot, int j) {     // fragments of K-tile j (0..KT_STAGE-1) of a landed stage
+            const uint8_t* base = lds + ring_slot * STAGE_BYTES + j * (2 * KT_BYTES);
+            auto tr = [&](int o) {
+                return __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) v2i*)(base + o));
+            };
+            RawFrags r;
+#pragma unroll
+            for (int f = 0; f < 2; f++) {
+                const v2i a0 = tr(off[f]), a1 = tr(off[f] + 1024);
+                const v2i b0 = tr(off[2 + f]), b1 = tr(off[2 + f] + 1024);
+                r.a[f] = (v4i){a0.x, a0.y, a1.x, a1.y};
+                r.b[f] = (v4i){b0.x, b0.y, b1.x, b1.y};
+            }
+            return r;
+        };
+
         v16i accR[2][2], accP[2][2], accQ[2][2];
 #pragma unroll
         for (int m = 0; m < 2; m++)
@@ -724,55 +857,60 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
                 accQ[m][n] = (v16i)(0);
             }
 
-        // ---- software pipeline over K-tiles: MFMA(g) || unpack(g+1) || LDS read(g+2) || LDS-DMA of stage S+DEPTH.
-        // At the end of stage S every wave waits until its own pieces of stage S+2 have landed (counted
-        // vmcnt: the younger stages stay in flight), then one barrier: stages S+1 and S+2 are visible to all
-        // waves and everybody is done reading stage S, whose buffer the DMA of stage S+DEPTH+1 overwrites.
-        Frags cur = unpack_frags(load_raw(rs, 0));
-        RawFrags raw = load_raw(rs, 1);
         unsigned long long t_start = 0, r_start = 0;
         if (p.stamps) {   // diagnostic: shader clock vs 100 MHz reference (MI355X_MICROARCH, DVFS item 6)
             t_start = __builtin_amdgcn_s_memtime();
             r_start = __builtin_amdgcn_s_memrealtime();
         }
-        for (int s = 0; s < it.nst; s++) {
-            next_stage();
+        // ---- software pipeline over K-tiles: MFMA(g) || unpack(g+1) || LDS read(g+2) || LDS-DMA of stage S+DEPTH.
+        // At the end of stage S every wave waits until its own pieces of stage S+2 have landed (counted
+        // vmcnt: the younger stages stay in flight), then one barrier: stages S+1 and S+2 are visible to all
+        // waves and everybody is done reading stage S, whose buffer the DMA of stage S+DEPTH+1 overwrites.
+        auto kloop = [&](auto zc) {
+            constexpr bool Z = decltype(zc)::value;
+            Frags cur = unpack_frags(load_raw(rs, 0));
+            RawFrags raw = load_raw(rs, 1);
+            for (int s = 0; s < p.nstage; s++) {
+                next_stage();
 #pragma unroll
-            for (int j = 0; j < KT_STAGE; j++) {
-                if (!(ABL & 1)) {
-                    issue_piece(rf, 2 * j);
-                    issue_piece(rf, 2 * j + 1);
-                }
-                xcorr_mfma_tile(cur, skip01, accR, accP, accQ);
-                if (ABL & 2) {
+                for (int j = 0; j < KT_STAGE; j++) {
+                    if (!(ABL & 1)) {
+                        issue_piece(rf, 2 * j);
+                        issue_piece(rf, 2 * j + 1);
+                    }
+                    xcorr_mfma_cells<Z>(cur, skip1, accR, accP, accQ);
+                    if (ABL & 2) {
 #pragma unroll
-                    for (int m = 0; m < 2; m++) { cur.ar[m] = raw.a[m]; cur.ai[m] = raw.a[m]; cur.br[m] = raw.b[m]; cur.bi[m] = raw.b[m]; }
-                } else {
-                    cur = unpack_frags(raw);
-                }
-                // K-tile g+2: same stage for j < KT_STAGE-2, else the next stage (already visible; at the end
-                // of an item the read lands in a valid ring buffer and is not used)
-                if (!(ABL & 4)) raw = (j + 2 < KT_STAGE) ? load_raw(rs, j + 2) : load_raw(rs1, j + 2 - KT_STAGE);
-                else { asm volatile("" : "+v"(raw.a[0]), "+v"(raw.a[1]), "+v"(raw.b[0]), "+v"(raw.b[1])); }
-                // pin the interleave: 1 MFMA : 3 VALU (the 48 mask/shift ops of the next K-tile hide under the
-                // 16 MFMAs of this one), the eight transposing LDS reads in the second half
+                        for (int m = 0; m < 2; m++) { cur.ar[m] = raw.a[m]; cur.ai[m] = raw.a[m]; cur.br[m] = raw.b[m]; cur.bi[m] = raw.b[m]; }
+                    } else {
+                        cur = unpack_frags(raw);
+                    }
+                    // K-tile g+2: same stage for j < KT_STAGE-2, else the next stage (already visible; at the end
+                    // of an item the read lands in a valid ring buffer and is not used)
+                    if (!(ABL & 4)) raw = (j + 2 < KT_STAGE) ? load_raw(rs, j + 2) : load_raw(rs1, j + 2 - KT_STAGE);
+                    else { asm volatile("" : "+v"(raw.a[0]), "+v"(raw.a[1]), "+v"(raw.b[0]), "+v"(raw.b[1])); }
+                    // pin the interleave: 1 MFMA : 3 VALU (the 48 mask/shift ops of the next K-tile hide under the
+                    // 16 MFMAs of this one), the eight transposing LDS reads in the second half
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                   // VALU
-                    if (i >= 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // DS read
+                    for (int i = 0; i < 16; i++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                   // VALU
+                        if (i >= 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // DS read
+                    }
                 }
+                if (!(ABL & 8)) {
+                    // (first stage behind a straight-line epilogue: the 32 tile stores of that epilogue sit between the DMA of
+                    // stage S+2, which this wait is for, and the 6 pieces just issued; vmcnt retires in issue order, so
+                    // allowing them to stay in flight does not let stage S+2 slip -- and the wave does not stall for the
+                    // write acknowledgements of the previous item)
+                    if (!(ABL & 1)) { if (s == 0 && stores_in_flight && !XF_NO_RELAX) wait_vmcnt<(DEPTH - 2) * NLOAD + 32>(); else wait_vmcnt<(DEPTH - 2) * NLOAD>(); }
+                    __builtin_amdgcn_s_barrier();
+                }
+                bump(rs); bump(rs1); bump(rf);
             }
-            if (!(ABL & 8)) {
-                // (first stage behind a straight-line epilogue: the 32 tile stores of that epilogue sit between the DMA of
-                // stage S+2, which this wait is for, and the 6 pieces just issued; vmcnt retires in issue order, so
-                // allowing them to stay in flight does not let stage S+2 slip -- and the wave does not stall for the
-                // write acknowledgements of the previous item)
-                if (!(ABL & 1)) { if (s == 0 && stores_in_flight && !XF_NO_RELAX) wait_vmcnt<(DEPTH - 2) * NLOAD + 32>(); else wait_vmcnt<(DEPTH - 2) * NLOAD>(); }
-                __builtin_amdgcn_s_barrier();
-            }
-            bump(rs); bump(rs1); bump(rf);
-        }
+        };
+        if (zpat) kloop(std::true_type{});
+        else kloop(std::false_type{});
         if (p.stamps) {
             asm volatile("" :: "v"(accR[1][1][15]), "v"(accQ[1][1][15]), "v"(accP[1][1][15]));
             const unsigned long long t_end = __builtin_amdgcn_s_memtime(), r_end = __builtin_amdgcn_s_memrealtime();
@@ -781,328 +919,22 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
                 o[0] = t_end - t_start; o[1] = r_end - r_start; o[2] = r_start; o[3] = r_end; o[4] = r_entry;
             }
         }
-        if (it.slice > 0) {
-            // K slice j adds to what slices 0..j-1 stored: wait for them.  All slices of an item run on one XCD
-            // (the host only splits per-XCD item lists), so the data is exchanged through that XCD's L2: no
-            // agent-scope fence (an L2 write-back / invalidate costs tens of microseconds here).  The flag is read
-            // at agent scope (bypasses the L1); the lines read by the read-modify-write below cannot be in this
-            // CU's L1: nothing in this launch has touched them, and the L1 is invalidated between launches.
-            const uint32_t target = p.epoch * 16u + (uint32_t)it.slice;
-            while (__hip_atomic_load(p.flags + it.chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
-                __builtin_amdgcn_s_sleep(4);
-            asm volatile("" ::: "memory");
-        }
-        // exactly 32 store instructions and nothing else: the straight-line path of xcorr_store_tile
-        stores_in_flight = !(ABL & 16) && !LACC && __builtin_amdgcn_readfirstlane((int)(blk_a > blk_b && blk_a * 64 + 64 <= 2 * p.nstand &&
-                                                                                 p.accumulate == 0 && it.slice == 0)) != 0;
+        // fast epilogue = exactly 32 store instructions and nothing else
+        bool fast = live == 15 && p.accumulate == 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) fast = fast && row[q] > col[q] && row[q] * 32 + 32 <= 2 * p.nstand;
+        fast = __builtin_amdgcn_readfirstlane((int)fast) != 0;
+        stores_in_flight = !(ABL & 16) && !LACC && fast;
         if (ABL & 16) {   // timing only: no epilogue (keep the accumulators live)
 #pragma unroll
             for (int m = 0; m < 2; m++)
 #pragma unroll
                 for (int n = 0; n < 2; n++) asm volatile("" :: "v"(accR[m][n][0]), "v"(accP[m][n][5]), "v"(accQ[m][n][9]));
         } else
-        if (active) xcorr_store_tile<2, LACC>(p, c, blk_a, blk_b, skip01, lane, accR, accP, accQ, it.slice > 0);
-        if (it.slice + 1 < it.nslices) {
-            // publish: every wave's stores have been acknowledged by the L2 (vmcnt counts stores too), then one
-            // lane bumps the flag
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (threadIdx.x == 0)
-                __hip_atomic_store(p.flags + it.chain, p.epoch * 16u + (uint32_t)it.slice + 1u, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-        }
+        xcorr_store_cells<LACC>(p, c, row, col, live, fast, p.accumulate != 0, lane, accR, accP, accQ);
         if (p.stamps && lane == 0) p.stamps[((size_t)(c * p.nwg + wg) * 4 + wave) * 8 + 5] = __builtin_amdgcn_s_memrealtime();
     }
     wait_vmcnt<0>();   // no LDS-DMA may still be in flight when the wave ends
-}
-
-// =======================================================================================
-// FP6 (E3M2) route -- opt-in (XENG_MFMA=fp6).  Every integer -8..8 is exactly representable in the
-// OCP FP6 E3M2 format, and gfx950's block-scaled MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, scale 2^0)
-// runs FP6 at twice the int8 rate with fp32 accumulation: the products (|.| <= 64) and their sums
-// (< 2^24 for K <= 131071 samples) are exact, so the visibilities stay bit-exact
-// (profiles/microbench/fp6_exact_probe.hip).  The corner turn emits the 6-bit codes, so the
-// contraction kernel has no unpack work at all: fragments go LDS -> VGPR -> MFMA.
-//
-//   stash6[c][ib][kt64][sub][plane re|im][1536 B]      (6144 B per 64-input block and 64 samples)
-//   fragment = MFMA operand image of 32 inputs x 64 samples: lane = 32h + r holds the 32 codes of
-//   input r, samples 32h..32h+31, as a 192-bit string (field j at bit 6j): dwords 0-3 at
-//   [lane*16], dwords 4-5 at [1024 + lane*8]  (ds_read_b128 + ds_read_b64, both conflict-free).
-// =======================================================================================
-typedef int v8i __attribute__((ext_vector_type(8)));
-constexpr int F6_FRAG = 1536;
-constexpr int F6_KT_BYTES = 4 * F6_FRAG;     // (sub, plane) x 1536 per 64-input block per 64 samples
-
-// four two's-complement nibbles (one per byte, 0..15) -> four E3M2 codes (one per byte)
-__device__ __forceinline__ uint32_t nib4_to_e3m2(uint32_t n) {
-    const uint32_t idx = n & 0x07070707u;
-    const uint32_t lo = __builtin_amdgcn_perm(0x17161514u, 0x12100C00u, idx);   //  0..7  -> 0,12,16,18,20,21,22,23
-    const uint32_t hi = __builtin_amdgcn_perm(0x2C303234u, 0x35363738u, idx);   // -8..-1 -> sign | code(|v|)
-    const uint32_t sel = ((n & 0x08080808u) >> 1) | 0x03020100u;               // byte k: k (>=0) or 4+k (<0)
-    return __builtin_amdgcn_perm(hi, lo, sel);
-}
-// four 6-bit codes (one per byte) -> 24 contiguous bits
-__device__ __forceinline__ uint32_t pack4x6(uint32_t w) {
-    const uint32_t t = (w & 0x003F003Fu) | ((w >> 2) & 0x0FC00FC0u);
-    return (t & 0xFFFu) | ((t >> 4) & 0xFFF000u);
-}
-// eight 24-bit groups -> 192 bits
-__device__ __forceinline__ void pack8x24(const uint32_t (&g)[8], uint32_t (&d)[6]) {
-    d[0] = g[0] | (g[1] << 24);
-    d[1] = (g[1] >> 8) | (g[2] << 16);
-    d[2] = (g[2] >> 16) | (g[3] << 8);
-    d[3] = g[4] | (g[5] << 24);
-    d[4] = (g[5] >> 8) | (g[6] << 16);
-    d[5] = (g[6] >> 16) | (g[7] << 8);
-}
-
-// grid (channel, 32-sample half-tile of the gulp), 192 threads.  hk_off = index of the gulp's first
-// half-tile in the staging area (a 64-sample fragment may be completed by two gulps).
-__global__ __launch_bounds__(192) void corner_turn_fp6_kernel(const uint8_t* __restrict__ in,
-                                                              uint8_t* __restrict__ stash, int ntime,
-                                                              int nchan, int ninput, int nblk64,
-                                                              int cap_kt64, int hk_off) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t ct_lds[];
-    const int c = blockIdx.x, hkl = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwave = blockDim.x >> 6;
-    const int in_bytes = 32 * ninput;
-    uint8_t* lin = ct_lds;
-    uint8_t* lout = ct_lds + ((in_bytes + 1023) & ~1023);
-    const size_t row_stride = (size_t)nchan * ninput;
-    const uint8_t* src_c = in + (size_t)c * ninput;
-    const int t_base = hkl * 32;
-    const int t_valid = max(0, min(32, ntime - t_base));
-
-    const int npiece = (in_bytes + 1023) >> 10;
-    for (int n = wave; n < npiece; n += nwave) {
-        const int off = n * 1024 + lane * 16;
-        int t = off / ninput, i = off - t * ninput;
-        if (t >= t_valid) { t = 0; i = 0; }
-        const uint8_t* g = src_c + (size_t)(t_valid > 0 ? t_base + t : 0) * row_stride + i;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(lin + n * 1024), 16, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    // each thread: 4 inputs x 32 samples -> 4 x (re 24 B, im 24 B)
-    const int nq = nblk64 * 16;
-    for (int q = tid; q < nq; q += blockDim.x) {
-        const int i0 = q * 4;
-        uint32_t o[4][8];          // o[input][group of 4 samples], bytes = packed 4+4-bit samples
-#pragma unroll
-        for (int g = 0; g < 8; g++) {
-            uint32_t v[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int t = 4 * g + j;
-                v[j] = (i0 < ninput && t < t_valid) ? *reinterpret_cast<const uint32_t*>(lin + t * ninput + i0) : 0u;
-            }
-            transpose4x4_bytes(v[0], v[1], v[2], v[3], o[0][g], o[1][g], o[2][g], o[3][g]);
-        }
-        // half-fragment image in LDS: [frag = i0>>5][plane][512 B: r*16 | 256 B: r*8]
-        uint8_t* fb = lout + (i0 >> 5) * (2 * 768) + (i0 & 31) * 16;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            uint32_t gr[8], gi[8], dr[6], di[6];
-#pragma unroll
-            for (int g = 0; g < 8; g++) {
-                const uint32_t w = o[j][g];
-                gr[g] = pack4x6(nib4_to_e3m2((w >> 4) & 0x0F0F0F0Fu));   // hi nibble = real
-                gi[g] = pack4x6(nib4_to_e3m2(w & 0x0F0F0F0Fu));          // lo nibble = imag
-            }
-            pack8x24(gr, dr);
-            pack8x24(gi, di);
-            *reinterpret_cast<uint4*>(fb + 16 * j) = make_uint4(dr[0], dr[1], dr[2], dr[3]);
-            *reinterpret_cast<uint2*>(fb + 512 - (i0 & 31) * 8 + 8 * j) = make_uint2(dr[4], dr[5]);
-            *reinterpret_cast<uint4*>(fb + 768 + 16 * j) = make_uint4(di[0], di[1], di[2], di[3]);
-            *reinterpret_cast<uint2*>(fb + 768 + 512 - (i0 & 31) * 8 + 8 * j) = make_uint2(di[4], di[5]);
-        }
-    }
-    __syncthreads();
-
-    // stream the image out: per (fragment, plane) a 512-B run (dwords 0-3) and a 256-B run (dwords 4-5)
-    const int hk = hk_off + hkl, kt64 = hk >> 1, h = hk & 1;
-    const int nchunk = nblk64 * 2 * 2 * 48;      // 16-byte chunks
-    for (int ci = tid; ci < nchunk; ci += blockDim.x) {
-        const int fp = ci / 48, w = ci - fp * 48;
-        const int f = fp >> 1, plane = fp & 1;
-        const uint4 val = *reinterpret_cast<const uint4*>(lout + ci * 16);
-        uint8_t* frag = stash + (((size_t)c * nblk64 + (f >> 1)) * cap_kt64 + kt64) * F6_KT_BYTES + ((f & 1) * 2 + plane) * F6_FRAG;
-        uint8_t* dst = w < 32 ? frag + h * 512 + w * 16 : frag + 1024 + h * 256 + (w - 32) * 16;
-        *reinterpret_cast<uint4*>(dst) = val;
-    }
-}
-
-// zero the second (h = 1) half of every fragment of K tile kt64 (an odd number of 32-sample half-tiles
-// was staged: code 0 is the value 0)
-__global__ void fp6_zero_half_kernel(uint8_t* __restrict__ stash, int nblk64, int cap_kt64, int kt64) {
-    const int cb = blockIdx.x;   // channel * nblk64 + ib
-    uint8_t* base = stash + ((size_t)cb * cap_kt64 + kt64) * F6_KT_BYTES;
-    for (int ci = threadIdx.x; ci < 4 * 48; ci += blockDim.x) {
-        const int fr = ci / 48, w = ci - fr * 48;
-        uint8_t* dst = w < 32 ? base + fr * F6_FRAG + 512 + w * 16 : base + fr * F6_FRAG + 1024 + 256 + (w - 32) * 16;
-        *reinterpret_cast<uint4*>(dst) = make_uint4(0, 0, 0, 0);
-    }
-}
-
-typedef int v6i __attribute__((ext_vector_type(6)));
-// One block-scaled MFMA, E3M2 x E3M2 (cbsz/blgp 3), scales 2^0, from inline asm: the builtin takes 8-dword
-// operands and hipcc assembles the 6 live dwords through AGPR copies (144 v_accvgpr_write per K step);
-// here the operands are 192-bit VGPR tuples and the accumulator stays in AGPRs.  `s_nop 1` covers the
-// VALU-write -> MFMA-read wait states hipcc does not insert inside asm (guide 5.7 item 2).
-__device__ __forceinline__ void mfma_e3m2(v16f& acc, const v6i& a, const v6i& b, int scale127) {
-    asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0] cbsz:3 blgp:3"
-                 : "+a"(acc) : "v"(a), "v"(b), "v"(scale127) : "memory");   // "memory": keeps the hand-placed
-                 // LDS reads / LDS-DMA issues between the MFMAs where the source puts them
-}
-
-__global__ __launch_bounds__(256, 1) void xcorr_fp6_kernel(XcorrParams p) {
-    constexpr int SLOT_BYTES = F6_KT_BYTES;            // one K step (64 samples) per stage
-    constexpr int STAGE_BYTES = XC_NSLOT * SLOT_BYTES;  // 24 KB
-    constexpr int NLOAD = SLOT_BYTES / 1024;            // 6 LDS-DMA pieces per wave per stage
-    __shared__ __attribute__((aligned(16))) uint8_t lds[XC_RING * STAGE_BYTES];
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int c, wg;
-    {
-        const int b = blockIdx.x;
-        if ((p.nchan & 7) == 0) { const int xcd = b & 7, slot = b >> 3; c = xcd + 8 * (slot / p.nwg); wg = slot % p.nwg; }
-        else { c = b / p.nwg; wg = b % p.nwg; }
-    }
-    const WgDesc* dp = p.descs + wg;
-    const int a_slot = dp->wave_a[wave], b_slot = dp->wave_b[wave];
-    const bool active = a_slot != 0xFF;
-    const int blk_a = active ? dp->slot_blk[a_slot] : 0, blk_b = active ? dp->slot_blk[b_slot] : 0;
-    const uint8_t* gsrc = p.stash + ((size_t)c * p.nblk64 + dp->slot_blk[wave]) * (size_t)p.cap_kt * SLOT_BYTES + lane * 16;
-    const int nstage = p.nkt;    // K steps of 64 samples
-
-    auto issue_piece = [&](int s, int n) {
-        const int ssrc = s < nstage ? s : nstage - 1;
-        const uint8_t* g = gsrc + (size_t)ssrc * SLOT_BYTES + n * 1024;
-        uint8_t* l = lds + (s & (XC_RING - 1)) * STAGE_BYTES + wave * SLOT_BYTES + n * 1024;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-    };
-    v16f accR[2][2], accP[2][2], accQ[2][2];
-#pragma unroll
-    for (int m = 0; m < 2; m++)
-#pragma unroll
-        for (int n = 0; n < 2; n++) { accR[m][n] = (v16f)(0.f); accP[m][n] = (v16f)(0.f); accQ[m][n] = (v16f)(0.f); }
-
-    const int a_base = (active ? a_slot : 0) * SLOT_BYTES, b_base = (active ? b_slot : 0) * SLOT_BYTES;
-    // Operand fragments, double-buffered in registers: set [s & 1] holds K step s.  Index f = sub*2 + plane
-    // (re|im); dwords 0-3 (Lo) and 4-5 (Hi).  All indices are compile-time (the K loop is unrolled by two).
-    v4i aLo[2][4], bLo[2][4];
-    v2i aHi[2][4], bHi[2][4];
-    const bool skip01 = __builtin_amdgcn_readfirstlane((int)(!active || blk_a == blk_b)) != 0;
-    const int scale127 = 127;     // E8M0 exponent 127 = 2^0 in byte 0 of the scale operand
-
-    // one of the 16 register loads of K step s into set SET: part 0..15 = (A|B, fragment f, Lo|Hi)
-    auto load_part = [&](auto setc, int s, int part) {
-        constexpr int SET = decltype(setc)::value;
-        const uint8_t* base = lds + (s & (XC_RING - 1)) * STAGE_BYTES;
-        const int f = (part >> 1) & 3;
-        const uint8_t* fb = base + ((part & 8) ? b_base : a_base) + f * F6_FRAG;
-        if (part & 8) {
-            if (part & 1) bHi[SET][f] = *reinterpret_cast<const v2i*>(fb + 1024 + lane * 8);
-            else bLo[SET][f] = *reinterpret_cast<const v4i*>(fb + lane * 16);
-        } else {
-            if (part & 1) aHi[SET][f] = *reinterpret_cast<const v2i*>(fb + 1024 + lane * 8);
-            else aLo[SET][f] = *reinterpret_cast<const v4i*>(fb + lane * 16);
-        }
-    };
-
-    // K step s from register set CUR, hand-interleaved in program order:
-    //   MFMA t  |  LDS read part t of K step s+1 into the other set  |  after every odd MFMA one LDS-DMA piece
-    // so the DMA issue (~37 cycles a piece) and the LDS latency run under the 35-cycle MFMAs.
-    auto kstep = [&](auto curc, int s) {
-        constexpr int CUR = decltype(curc)::value;
-        using NXT = std::integral_constant<int, CUR ^ 1>;
-        v6i A[4], B[4];
-#pragma unroll
-        for (int f = 0; f < 4; f++) {
-            A[f] = (v6i){aLo[CUR][f].x, aLo[CUR][f].y, aLo[CUR][f].z, aLo[CUR][f].w, aHi[CUR][f].x, aHi[CUR][f].y};
-            B[f] = (v6i){bLo[CUR][f].x, bLo[CUR][f].y, bLo[CUR][f].z, bLo[CUR][f].w, bHi[CUR][f].x, bHi[CUR][f].y};
-        }
-#pragma unroll
-        for (int t = 0; t < 16; t++) {
-            const int m = t >> 3, n = (t >> 2) & 1, k = t & 3;
-            // (no diagonal-tile skip here: a branch around asm MFMAs makes hipcc copy the accumulators)
-            if (k == 0) mfma_e3m2(accR[m][n], A[2 * m], B[2 * n], scale127);
-            else if (k == 1) mfma_e3m2(accP[m][n], A[2 * m + 1], B[2 * n], scale127);
-            else if (k == 2) mfma_e3m2(accQ[m][n], A[2 * m], B[2 * n + 1], scale127);
-            else mfma_e3m2(accR[m][n], A[2 * m + 1], B[2 * n + 1], scale127);
-            load_part(NXT{}, s + 1, t);
-            if ((t & 1) && (t >> 1) < NLOAD) issue_piece(s + 3, t >> 1);
-        }
-        wait_vmcnt<NLOAD>();
-        __builtin_amdgcn_s_barrier();                   // stages s+1, s+2 visible; stage s free
-    };
-
-    // same ring protocol as xcorr_mfma_kernel with one K step per stage
-#pragma unroll
-    for (int st = 0; st < 3; st++)
-#pragma unroll
-        for (int n = 0; n < NLOAD; n++) issue_piece(st, n);
-    wait_vmcnt<NLOAD>();
-    __builtin_amdgcn_s_barrier();                       // stages 0 and 1 visible
-#pragma unroll
-    for (int part = 0; part < 16; part++) load_part(std::integral_constant<int, 0>{}, 0, part);
-    for (int s = 0; s < nstage; s += 2) {
-        kstep(std::integral_constant<int, 0>{}, s);
-        if (s + 1 < nstage) kstep(std::integral_constant<int, 1>{}, s + 1);
-    }
-    wait_vmcnt<0>();
-    // the last asm MFMA's result must have retired before the epilogue reads the accumulators
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-    if (!active) return;
-
-    const int qs = (int)(((int64_t)(p.nstand / 2 + 1) * p.nstand) / 4);
-    int32_t* out_r = p.out + (int64_t)c * p.per_chan;
-    int32_t* out_i = out_r + p.matlen;
-    const int odd = lane & 1, cpar = (lane >> 1) & 1, quad = 2 * cpar + odd;
-    auto cell = [&](int v0, int v1, int v2, int v3) {
-        const int g0 = dpp_xor1(odd ? v0 : v2), g1 = dpp_xor1(odd ? v1 : v3);
-        return odd ? make_int4(g0, v2, g1, v3) : make_int4(v0, g0, v1, g1);
-    };
-    const bool interior = __builtin_amdgcn_readfirstlane((int)(blk_a > blk_b && blk_a * 64 + 64 <= 2 * p.nstand)) != 0;
-    const bool accumulate = p.accumulate != 0;
-#pragma unroll
-    for (int m = 0; m < 2; m++)
-#pragma unroll
-        for (int n = 0; n < 2; n++) {
-            if (m == 0 && n == 1 && skip01) continue;
-            const int ibase = blk_a * 64 + m * 32, jbase = blk_b * 64 + n * 32;
-            const int Ch = (jbase >> 2) + ((lane & 31) >> 2), C = 2 * Ch + cpar;
-            const int wcol = (quad * qs + Ch) * 4;
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int Rh = (ibase >> 2) + 2 * u + (lane >> 5), R = 2 * Rh + odd;
-                int vr[4], vi[4];
-#pragma unroll
-                for (int v = 0; v < 4; v++) {       // integers < 2^24: exact in fp32, exact conversion
-                    vr[v] = (int)accR[m][n][4 * u + v];
-                    vi[v] = (int)(accP[m][n][4 * u + v] - accQ[m][n][4 * u + v]);
-                }
-                int4 cr = cell(vr[0], vr[1], vr[2], vr[3]);
-                int4 ci = cell(vi[0], vi[1], vi[2], vi[3]);
-                const int w = wcol + ((Rh * (Rh + 1)) >> 1) * 4;
-                int4* pr = reinterpret_cast<int4*>(out_r + w);
-                int4* pi = reinterpret_cast<int4*>(out_i + w);
-                if (interior || (Rh >= Ch && R < p.nstand && C < p.nstand)) {
-                    if (accumulate) {
-                        const int4 o_r = *pr, o_i = *pi;
-                        cr.x += o_r.x; cr.y += o_r.y; cr.z += o_r.z; cr.w += o_r.w;
-                        ci.x += o_i.x; ci.y += o_i.y; ci.z += o_i.z; ci.w += o_i.w;
-                    }
-                    *pr = cr;
-                    *pi = ci;
-                }
-            }
-        }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1210,5 +1042,9 @@ __global__ __launch_bounds__(256) void packetize_kernel(const int32_t* __restric
         }
     }
 }
+
+#ifdef XENG_EXPERIMENTS
+#include "experiments/xcorr_fp6.h"
+#endif
 
 }  // namespace xeng

@@ -21,16 +21,10 @@ struct WgDesc {
     uint8_t pad[3];
 };
 
-// One entry of a work-group's list: a (channel, tile group) item, or one K slice of it.  Whole items cover all
-// stages; the items left over after dealing whole items evenly are cut along K into slices, one per work-group,
-// so that every work-group of a launch contracts (almost) the same number of stages.  Slice j > 0 adds to what
-// slice j-1 stored: it waits for flags[chain] >= epoch*16 + j before its read-modify-write.
-struct WorkEntry {
-    uint32_t c_wg;        // channel | tile group << 16
-    uint32_t stages;      // first stage | number of stages << 16
-    uint32_t slice;       // slice index | slices of the item << 8 | valid << 16
-    uint32_t chain;       // flag index of a split item
-};
+// One entry of a persistent work-group's list: a (channel, tile group) item, all K stages of it.
+//   channel | tile group << 16 | valid << 31
+typedef uint32_t WorkEntry;
+constexpr uint32_t WORK_VALID = 1u << 31;
 
 // --------------------------------------------------------------------------------------
 // Triangular tiling of the nblk64 x nblk64 grid of 64x64-input wave tiles onto work-groups
@@ -103,41 +97,221 @@ inline std::vector<WgDesc> build_wg_descs(int nblk64) {
 }
 
 // --------------------------------------------------------------------------------------
+// Fragment-level tiling of the fused kernel (round 3).  The unit is the 32x32-input MFMA tile ("cell" (i, j) of the
+// triangle of 32-input blocks, j <= i); a wave contracts four cells from four operand fragments, in one of two patterns:
+//   2x2   operands a0 a1 | b0 b1:  cells (a0,b0) (a0,b1) (a1,b0) (a1,b1)           -- a 64x64 off-diagonal tile
+//   Z     operands d0 d1 | r  c :  cells (d0,d0) (r,c) (d1,d0) (d1,d1)             -- a diagonal 64x64 tile, whose
+//         upper-right cell is never stored, plus one FREE cell (r, c) taken from an off-diagonal tile
+// (same cost either way: 4 fragments read and unpacked, 16 MFMAs per K-tile).  A tile group = 4 waves sharing <= 4 staged
+// 64-input blocks.  With nblk64 = 2 np + 1 blocks (L = the last one):
+//   * squares: blocks {2k, 2k+1} x {2m, 2m+1}, k > m: four whole off-diagonal tiles
+//   * per k: blocks {2k, 2k+1, L (, 4j+1)}: Z(2k), Z(2k+1), tile (2k+1, 2k), tile (L, 2k); the two free cells come from a
+//     DONOR tile: k = 2j and k = 2j+1 share the donor (L, 4j+1), and (L, 4j+3) stays whole; an unpaired last k takes two
+//     cells of (L, 2k+1) and leaves one to Z(L) and one to a wave of its own
+//   * collectors: block L + up to three others: the whole tiles (L, 4j+3), Z(L), the left-over cell
+// 704 inputs: 10 + 5 + 1 = 16 tile groups, 253 cells in 256 wave slots (the 64x64 tiling below: 17 groups), so a round
+// of an XCD's 32 work-groups is exactly two channels: no item tail, and no channel is contracted in two parts.
+// Even block counts (and whatever the construction above does not improve) use the 64x64 tiling, one 2x2 wave per tile.
+// --------------------------------------------------------------------------------------
+struct FragGroup {               // read by the device as 8 aligned dwords (scalar loads)
+    uint8_t slot_blk[XC_NSLOT];  // 64-input block staged in LDS slot s (slots are staged in pairs 0|1 and 2|3)
+    uint32_t wave[4];            // see frag_wave()
+    uint32_t pad[3];
+};
+constexpr uint32_t FRAG_Z = 1u << 12;       // Z pattern
+constexpr uint32_t FRAG_BUSY = 1u << 31;    // the wave has at least one live cell
+// operand position = slot * 2 + 32-input half; pos[] = a0 a1 b0 b1 (Z: d0 d1 r c); live bit p = 2m + n <-> accumulator
+// (m, n): 2x2 cell (a_m, b_n); Z: p = 0 (d0,d0), 1 (r,c), 2 (d1,d0), 3 (d1,d1)
+inline uint32_t frag_wave(const int pos[4], bool z, int live) {
+    uint32_t w = 0;
+    for (int q = 0; q < 4; q++) w |= (uint32_t)(pos[q] & 7) << (3 * q);
+    return w | (z ? FRAG_Z : 0) | ((uint32_t)(live & 15) << 16) | (live ? FRAG_BUSY : 0);
+}
+// the four cells of a wave as (row 32-block, column 32-block), in accumulator order p = 2m + n
+inline void frag_wave_cells(const FragGroup& g, int w, int (&row)[4], int (&col)[4]) {
+    int b32[4];
+    for (int q = 0; q < 4; q++) {
+        const int pos = (g.wave[w] >> (3 * q)) & 7;
+        b32[q] = g.slot_blk[pos >> 1] * 2 + (pos & 1);
+    }
+    if (g.wave[w] & FRAG_Z) {
+        row[0] = b32[0]; col[0] = b32[0]; row[1] = b32[2]; col[1] = b32[3];
+        row[2] = b32[1]; col[2] = b32[0]; row[3] = b32[1]; col[3] = b32[1];
+    } else {
+        for (int p = 0; p < 4; p++) { row[p] = b32[p >> 1]; col[p] = b32[2 + (p & 1)]; }
+    }
+}
+
+namespace detail {
+struct GroupBuilder {
+    FragGroup g;
+    int nslot = 0, nwave = 0;
+    GroupBuilder() { memset(&g, 0, sizeof(g)); }
+    int slot_of(int blk) {                       // -1: no slot left
+        for (int s = 0; s < nslot; s++) if (g.slot_blk[s] == blk) return s;
+        if (nslot == XC_NSLOT) return -1;
+        g.slot_blk[nslot] = (uint8_t)blk;
+        return nslot++;
+    }
+    bool fits(const std::vector<int>& blks) const {
+        int need = 0;
+        for (size_t i = 0; i < blks.size(); i++) {
+            bool have = false;
+            for (int s = 0; s < nslot; s++) have = have || g.slot_blk[s] == blks[i];
+            for (size_t k = 0; k < i; k++) have = have || blks[k] == blks[i];
+            need += have ? 0 : 1;
+        }
+        return nwave < 4 && nslot + need <= XC_NSLOT;
+    }
+    int pos32(int b32) { return slot_of(b32 >> 1) * 2 + (b32 & 1); }
+    // whole (or partly live) off-diagonal 64x64 tile (A, B): cells (2A+m, 2B+n)
+    void tile(int A, int B, int live = 15) {
+        const int pos[4] = {pos32(2 * A), pos32(2 * A + 1), pos32(2 * B), pos32(2 * B + 1)};
+        g.wave[nwave++] = frag_wave(pos, false, live);
+    }
+    // diagonal tile of block D plus the free cell (r32, c32) (r32 < 0: none)
+    void ztile(int D, int r32, int c32) {
+        const int d0 = pos32(2 * D), d1 = pos32(2 * D + 1);
+        const int pos[4] = {d0, d1, r32 < 0 ? d0 : pos32(r32), r32 < 0 ? d1 : pos32(c32)};
+        g.wave[nwave++] = frag_wave(pos, true, r32 < 0 ? 13 : 15);
+    }
+    FragGroup finish() {
+        for (int s = nslot; s < XC_NSLOT; s++) g.slot_blk[s] = g.slot_blk[0];   // harmless duplicate loads
+        return g;
+    }
+};
+}  // namespace detail
+
+// the 64x64 tiling above in fragment form
+inline std::vector<FragGroup> frag_groups_from_tiles(int nblk64) {
+    std::vector<FragGroup> out;
+    for (const WgDesc& d : build_wg_descs(nblk64)) {
+        FragGroup g;
+        memset(&g, 0, sizeof(g));
+        memcpy(g.slot_blk, d.slot_blk, XC_NSLOT);
+        for (int w = 0; w < 4; w++) {
+            if (d.wave_a[w] == 0xFF) continue;
+            const int a = d.wave_a[w], b = d.wave_b[w];
+            const int pos[4] = {2 * a, 2 * a + 1, 2 * b, 2 * b + 1};
+            g.wave[w] = frag_wave(pos, false, d.slot_blk[a] == d.slot_blk[b] ? 13 : 15);
+        }
+        out.push_back(g);
+    }
+    return out;
+}
+
+inline std::vector<FragGroup> build_frag_groups(int nblk64) {
+    using detail::GroupBuilder;
+    std::vector<FragGroup> tiles = frag_groups_from_tiles(nblk64);
+    if (!(nblk64 & 1) || nblk64 < 3) return tiles;
+    std::vector<FragGroup> out;
+    const int np = nblk64 / 2, L = nblk64 - 1;
+    for (int k = 1; k < np; k++)
+        for (int m = 0; m < k; m++) {
+            GroupBuilder b;
+            b.slot_of(2 * k); b.slot_of(2 * k + 1); b.slot_of(2 * m); b.slot_of(2 * m + 1);   // adjacent pairs: whole 128-byte lines
+            b.tile(2 * k, 2 * m); b.tile(2 * k, 2 * m + 1); b.tile(2 * k + 1, 2 * m); b.tile(2 * k + 1, 2 * m + 1);
+            out.push_back(b.finish());
+        }
+    // cell q = 2 (row half) + (column half) of the off-diagonal tile (L, t)
+    auto cell_r = [&](int q) { return 2 * L + (q >> 1); };
+    auto cell_c = [&](int t, int q) { return 2 * t + (q & 1); };
+    std::vector<int> whole;                               // column blocks t of the tiles (L, t) left whole
+    for (int k = 0; k < np; k++) {
+        const int j = k >> 1;
+        const bool paired = 2 * j + 1 < np;
+        const int donor = paired ? 4 * j + 1 : 2 * k + 1;
+        const int q0 = (paired && (k & 1)) ? 2 : 0;      // the odd member of a pair takes the donor's second row
+        GroupBuilder b;
+        b.slot_of(2 * k); b.slot_of(2 * k + 1);           // the adjacent pair first: its rows are whole 128-byte lines
+        b.ztile(2 * k, cell_r(q0), cell_c(donor, q0));
+        b.ztile(2 * k + 1, cell_r(q0 + 1), cell_c(donor, q0 + 1));
+        b.tile(2 * k + 1, 2 * k);
+        b.tile(L, 2 * k);
+        out.push_back(b.finish());
+        if (paired && (k & 1)) whole.push_back(2 * k + 1);
+    }
+    // collectors
+    std::vector<GroupBuilder> coll;
+    auto place = [&](const std::vector<int>& blks) -> GroupBuilder& {
+        for (auto& c : coll) if (c.fits(blks)) return c;
+        coll.emplace_back();
+        if (blks.size() > 1 && blks[1] == L - 1) coll.back().slot_of(L - 1);        // (L-1, L) in memory order
+        coll.back().slot_of(L);
+        return coll.back();
+    };
+    if (np & 1) {                                         // the unpaired k left cells 2 and 3 of (L, L-1)
+        GroupBuilder& c = place({L, L - 1});
+        c.ztile(L, cell_r(2), cell_c(L - 1, 2));
+        GroupBuilder& c2 = place({L, L - 1});
+        c2.tile(L, L - 1, 1 << 3);
+    } else if (!whole.empty()) {                          // Z(L) takes cell 0 of one of the whole tiles
+        const int t = whole.back();
+        whole.pop_back();
+        GroupBuilder& c = place({L, t});
+        c.ztile(L, cell_r(0), cell_c(t, 0));
+        GroupBuilder& c2 = place({L, t});
+        c2.tile(L, t, 14);
+    } else {
+        place({L}).ztile(L, -1, -1);
+    }
+    for (int t : whole) place({L, t}).tile(L, t);
+    for (auto& c : coll) out.push_back(c.finish());
+    return out.size() < tiles.size() ? out : tiles;
+}
+
+// every cell (i, j), j <= i < n32, is live in exactly one wave; operands sit in staged blocks; -1 or the first bad group
+inline int check_frag_groups(const std::vector<FragGroup>& gs, int nblk64) {
+    const int n32 = 2 * nblk64;
+    std::vector<int> seen((size_t)n32 * n32, 0);
+    for (size_t gi = 0; gi < gs.size(); gi++) {
+        for (int s = 0; s < XC_NSLOT; s++) if (gs[gi].slot_blk[s] >= nblk64) return (int)gi;
+        for (int w = 0; w < 4; w++) {
+            const uint32_t ww = gs[gi].wave[w];
+            const int live = (ww >> 16) & 15;
+            if (!!(ww & FRAG_BUSY) != (live != 0)) return (int)gi;
+            int row[4], col[4];
+            frag_wave_cells(gs[gi], w, row, col);
+            for (int p = 0; p < 4; p++) {
+                if (!((live >> p) & 1)) continue;
+                if (row[p] >= n32 || col[p] > row[p]) return (int)gi;
+                if (seen[(size_t)row[p] * n32 + col[p]]++) return (int)gi;
+            }
+        }
+    }
+    for (int i = 0; i < n32; i++)
+        for (int j = 0; j <= i; j++) if (seen[(size_t)i * n32 + j] != 1) return (int)gs.size();
+    return -1;
+}
+
+// --------------------------------------------------------------------------------------
 // Work lists of the persistent fused kernel (WorkEntry[grid][maxi], xcorr_kernels.h).
 // Work-groups b with the same b & 7 sit on one XCD and share that XCD's items (channels = xcd mod 8), dealt
 // round-robin so that concurrent work-groups contract neighbouring tile groups of the same channels.  With
 // n items for W work-groups every work-group gets n / W whole items and the first n % W one more
-// (704 inputs x 96 channels on 256 CUs: 204 items per XCD for 32 work-groups = 7 items for 12 of them, 6 for
-// 20; the next launch's work-groups take over the CUs of the latter).  Opt-in (XENG_SPLITK=1): the left-over
-// items are cut along K into W slices in all, one per work-group, with an ordered read-modify-write hand-over
-// between the slices of an item -- balanced, but not faster (see xengXgpuInitialize).
+// (704 inputs x 96 channels on 256 CUs: 12 x 16 = 192 items per XCD for 32 work-groups = 6 each, two whole channels
+// per round).
 // --------------------------------------------------------------------------------------
 struct WorkList {
     std::vector<WorkEntry> entries;
-    int maxi = 0, nchains = 0;
+    int maxi = 0;
     uint32_t* dev = nullptr;
 };
 
-// stagger: every second work-group of an XCD class contracts its FIRST item in two K halves (the second half adds to what
-// the first stored), which shifts all its later item boundaries by half an item against its neighbours': the epilogues of
-// the 256 work-groups (128 KB of stores each) then no longer fall into the same few microseconds.
 // Order of a channel's tile groups in its XCD's item list.  The W work-groups of an XCD contract W consecutive items
 // at a time ("a round"); a channel whose nwg items straddle a round boundary is contracted in two parts, about one
 // item time apart, and whatever input blocks the second part needs have left the XCD's L2 by then.  So the groups of
-// such a channel are ordered to make (distinct blocks of the first part) + (distinct blocks of the second part) minimal
-// -- e.g. 704 inputs, 32 work-groups per XCD: 184 -> 171 block fetches per XCD and launch against 132 unavoidable.
-// Exhaustive over the subsets of the smaller part (17 groups: at most 24310); identity when that would be too many,
-// when the channel spans more than two rounds, or when it is not split.  start = index of the channel's first item.
-inline std::vector<int> channel_group_order(const std::vector<WgDesc>& descs, int start, int W) {
-    const int nwg = (int)descs.size();
+// such a channel are ordered to make (distinct blocks of the first part) + (distinct blocks of the second part) minimal.
+// Exhaustive over the subsets of the smaller part; identity when that would be too many, when the channel spans more
+// than two rounds, or when it is not split (the 16 groups of 704 inputs never are).  start = index of the channel's
+// first item.  blocks[g] = bit mask of the 64-input blocks group g stages.
+inline std::vector<int> channel_group_order(const std::vector<uint64_t>& mask, int start, int W) {
+    const int nwg = (int)mask.size();
     std::vector<int> order(nwg);
     for (int i = 0; i < nwg; i++) order[i] = i;
     const int B = (start / W + 1) * W;                      // first round boundary behind `start`
     const int head = B - start, tail = nwg - head;
     if (tail <= 0 || tail > W || nwg > 30) return order;
-    std::vector<uint64_t> mask(nwg, 0);
-    for (int g = 0; g < nwg; g++)
-        for (int s = 0; s < XC_NSLOT; s++) mask[g] |= 1ull << (descs[g].slot_blk[s] & 63);
     const int small = std::min(head, tail);
     double combos = 1;
     for (int i = 0; i < small; i++) combos = combos * (nwg - i) / (i + 1);
@@ -170,60 +344,38 @@ inline std::vector<int> channel_group_order(const std::vector<WgDesc>& descs, in
     for (int g : second) order[k++] = g;
     return order;
 }
+inline std::vector<uint64_t> group_block_masks(const std::vector<FragGroup>& gs) {
+    std::vector<uint64_t> m(gs.size(), 0);
+    for (size_t g = 0; g < gs.size(); g++)
+        for (int s = 0; s < XC_NSLOT; s++) m[g] |= 1ull << (gs[g].slot_blk[s] & 63);
+    return m;
+}
 
-inline WorkList build_work(int grid, int nchan, int nwg, int nstage, bool splitk, bool stagger = false,
-                           const std::vector<WgDesc>* descs = nullptr) {
+// masks: per tile group the blocks it stages (null: groups in their natural order)
+inline WorkList build_work(int grid, int nchan, int nwg, const std::vector<uint64_t>* masks = nullptr) {
     WorkList wl;
     const bool xcd_map = (nchan & 7) == 0 && (grid & 7) == 0;
     const int ngroup = xcd_map ? 8 : 1;
     const int W = grid / ngroup;
     const int n = xcd_map ? (nchan / 8) * nwg : nchan * nwg;
     const int f = n / W, r = n % W;
-    stagger = stagger && !splitk && f >= 1 && nstage >= 2;
-    wl.maxi = f + (r ? 1 : 0) + (stagger ? 1 : 0);
-    wl.entries.assign((size_t)grid * wl.maxi, WorkEntry{0, 0, 0, 0});
-    // (only per-XCD lists are split: the slices of an item exchange partial sums through one XCD's L2)
-    const bool split = splitk && xcd_map && r > 0 && nstage >= (W + r - 1) / r;
-    wl.nchains = split ? ngroup * r : (stagger ? grid : 0);
+    wl.maxi = f + (r ? 1 : 0);
+    wl.entries.assign((size_t)grid * wl.maxi, 0u);
     // (whole items dealt per XCD: the groups of a channel that is contracted in two rounds are ordered for L2 reuse)
     std::vector<std::vector<int>> gorder;
-    if (descs && xcd_map && !splitk && !stagger && (int)descs->size() == nwg)
-        for (int q = 0; q < nchan / 8; q++) gorder.push_back(channel_group_order(*descs, q * nwg, W));
-    auto put = [&](int b, int k, int x, int idx, int stage0, int nst, int slice, int nslices, int chain) {
+    if (masks && xcd_map && (int)masks->size() == nwg)
+        for (int q = 0; q < nchan / 8; q++) gorder.push_back(channel_group_order(*masks, q * nwg, W));
+    auto put = [&](int b, int k, int x, int idx) {
         const int q = idx / nwg;
         const int wg = gorder.empty() ? idx - q * nwg : gorder[q][idx - q * nwg];
         const int c = xcd_map ? x + 8 * q : q;
-        WorkEntry& e = wl.entries[(size_t)b * wl.maxi + k];
-        e.c_wg = (uint32_t)c | ((uint32_t)wg << 16);
-        e.stages = (uint32_t)stage0 | ((uint32_t)nst << 16);
-        e.slice = (uint32_t)slice | ((uint32_t)nslices << 8) | (1u << 16);
-        e.chain = (uint32_t)chain;
+        wl.entries[(size_t)b * wl.maxi + k] = (uint32_t)c | ((uint32_t)wg << 16) | WORK_VALID;
     };
     for (int x = 0; x < ngroup; x++) {
         auto block_of = [&](int j) { return xcd_map ? j * 8 + x : j; };
-        for (int j = 0; j < W; j++) {
-            const bool two = stagger && (j & 1);     // this work-group's first item goes in two halves
-            int k = 0;
-            if (two) {
-                put(block_of(j), 0, x, j, 0, nstage / 2, 0, 2, block_of(j));
-                put(block_of(j), 1, x, j, nstage / 2, nstage - nstage / 2, 1, 2, block_of(j));
-                k = 1;
-            }
-            for (int q = two ? 1 : 0; q < f; q++) put(block_of(j), q + k, x, j + q * W, 0, nstage, 0, 1, 0);
-        }
-        if (!r) continue;
-        if (!split) {
-            for (int i = 0; i < r; i++) put(block_of(i), f + ((stagger && (i & 1)) ? 1 : 0), x, f * W + i, 0, nstage, 0, 1, 0);
-            continue;
-        }
-        int j = 0;
-        for (int i = 0; i < r; i++) {
-            const int ns = W / r + (i < W % r ? 1 : 0);
-            for (int sl = 0; sl < ns; sl++, j++) {
-                const int s0 = (int)((int64_t)sl * nstage / ns), s1 = (int)((int64_t)(sl + 1) * nstage / ns);
-                put(block_of(j), f, x, f * W + i, s0, s1 - s0, sl, ns, x * r + i);
-            }
-        }
+        for (int j = 0; j < W; j++)
+            for (int q = 0; q < f; q++) put(block_of(j), q, x, j + q * W);
+        for (int i = 0; i < r; i++) put(block_of(i), f, x, f * W + i);
     }
     return wl;
 }

@@ -33,7 +33,7 @@ print(open(out + "/summary.txt").read())
 # HBM traffic per launch of the X-engine kernel for bench.py's roofline.traffic, tied to the binary it was taken from
 import hashlib, json, os
 root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
-srcs = ["xcorr_kernels.h", "xcorr_fused8.h", "xcorr_tiling.h", "xcorr.hip"]
+srcs = ["xcorr_kernels.h", "xcorr_tiling.h", "xcorr.hip"]
 h = hashlib.sha256()
 for f in srcs:
     h.update(open(os.path.join(root, "caltech-bifrost-dsp_amd", "csrc", f), "rb").read())
@@ -42,7 +42,7 @@ res = {"xcorr_sources_sha256": h.hexdigest(), "xcorr_sources": srcs,
                      "WRITE_SIZE exact for 16-B-per-lane stores; separate --pmc passes (profiles/pmc_run.sh)"}
 for k, d in agg.items():
     if "xcorr_" in k and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
-        name = "xcorr_fused_kernel" if "fused_kernel" in k else ("xcorr_fused8_kernel" if "fused8" in k else k.strip())
+        name = "xcorr_fused_kernel" if "fused_kernel" in k else k.strip()
         f, w = d["FETCH_SIZE"][0] / d["FETCH_SIZE"][1], d["WRITE_SIZE"][0] / d["WRITE_SIZE"][1]
         res[name + "_bytes_per_launch"] = int(round((2 * f + w) * 1024))
         res[name] = {"FETCH_SIZE_KB_per_dispatch": round(f, 1), "WRITE_SIZE_KB_per_dispatch": round(w, 1),

@@ -37,69 +37,113 @@ static void check_descs(int nblk) {
     CHECK(slots_busy == nblk * (nblk + 1) / 2, "nblk %d slots", nblk);
 }
 
-// every (channel, tile group) appears exactly once per launch; K slices of a split item tile [0, nstage) in order
-static void check_work(int ncu, int nchan, int nblk, int nstage, bool splitk, bool stagger = false) {
-    const int nwg = (int)build_wg_descs(nblk).size();
-    const int grid = fused_grid(nchan, nwg, ncu);
-    CHECK(grid >= 1 && grid <= std::max(ncu, 1) && grid <= nchan * nwg, "grid %d (ncu %d, items %d)", grid, ncu, nchan * nwg);
-    const std::vector<WgDesc> descs = build_wg_descs(nblk);
-    const WorkList wl = build_work(grid, nchan, nwg, nstage, splitk, stagger, &descs);
-    CHECK((int)wl.entries.size() == grid * wl.maxi, "entries");
-    std::map<std::pair<int, int>, std::vector<std::pair<int, int>>> items;     // (c, wg) -> [(stage0, nst)] by slice
-    std::map<std::pair<int, int>, int> nslices;
-    for (int b = 0; b < grid; b++) {
-        bool ended = false;
-        for (int k = 0; k < wl.maxi; k++) {
-            const WorkEntry& e = wl.entries[(size_t)b * wl.maxi + k];
-            if (!(e.slice >> 16)) { ended = true; continue; }
-            CHECK(!ended, "work-group %d: valid entry after the end of its list", b);
-            const int c = e.c_wg & 0xFFFF, wg = e.c_wg >> 16, s0 = e.stages & 0xFFFF, nst = e.stages >> 16;
-            const int sl = e.slice & 0xFF, ns = (e.slice >> 8) & 0xFF;
-            CHECK(c < nchan && wg < nwg && nst >= 1 && s0 + nst <= nstage && sl < ns, "entry (%d,%d) stages %d+%d slice %d/%d", c, wg, s0, nst, sl, ns);
-            if ((nchan & 7) == 0 && (grid & 7) == 0) CHECK((c & 7) == (b & 7), "channel %d on work-group %d: wrong XCD class", c, b);
-            auto& v = items[{c, wg}];
-            if ((int)v.size() <= sl) v.resize(sl + 1, {-1, -1});
-            CHECK(v[sl].first < 0, "item (%d,%d) slice %d twice", c, wg, sl);
-            v[sl] = {s0, nst};
-            nslices[{c, wg}] = ns;
-            if (ns > 1) CHECK((int)e.chain < wl.nchains, "chain %u of %d", e.chain, wl.nchains);
+// fragment-level tiling: every 32x32 cell of the triangle is live in exactly one wave, every operand sits in a staged
+// block, Z waves hold a diagonal 64x64 tile; 704 inputs (11 blocks) come out as 16 groups with 253 cells in 256 slots
+static void check_frag(int nblk) {
+    const std::vector<FragGroup> gs = build_frag_groups(nblk);
+    CHECK(check_frag_groups(gs, nblk) == -1, "nblk %d: fragment tiling is not an exact cover (group %d)", nblk, check_frag_groups(gs, nblk));
+    CHECK(check_frag_groups(frag_groups_from_tiles(nblk), nblk) == -1, "nblk %d: 64x64 tiling in fragment form", nblk);
+    CHECK(gs.size() <= build_wg_descs(nblk).size(), "nblk %d: %zu groups, 64x64 tiling %zu", nblk, gs.size(), build_wg_descs(nblk).size());
+    std::map<std::pair<int, int>, int> seen;
+    int live_cells = 0;
+    for (size_t g = 0; g < gs.size(); g++) {
+        for (int w = 0; w < 4; w++) {
+            const uint32_t ww = gs[g].wave[w];
+            int row[4], col[4];
+            frag_wave_cells(gs[g], w, row, col);
+            for (int p = 0; p < 4; p++)
+                if ((ww >> (16 + p)) & 1) { seen[{row[p], col[p]}]++; live_cells++; }
+            if (ww & FRAG_Z) {
+                CHECK(row[0] == col[0] && row[3] == col[3] && row[2] == row[3] && col[2] == col[0] && row[3] == row[0] + 1 && !(row[0] & 1),
+                      "nblk %d group %zu wave %d: Z wave is not a diagonal tile", nblk, g, w);
+                CHECK(((ww >> 16) & 13) == 13, "nblk %d group %zu wave %d: Z wave with a dead diagonal cell", nblk, g, w);
+            }
         }
     }
-    CHECK((int)items.size() == nchan * nwg, "%zu items of %d", items.size(), nchan * nwg);
-    for (auto& kv : items) {
-        int pos = 0;
-        CHECK((int)kv.second.size() == nslices[kv.first], "item slices");
-        for (auto& sl : kv.second) { CHECK(sl.first == pos, "item (%d,%d): slice starts at %d, expected %d", kv.first.first, kv.first.second, sl.first, pos); pos += sl.second; }
-        CHECK(pos == nstage, "item (%d,%d) covers %d of %d stages", kv.first.first, kv.first.second, pos, nstage);
+    const int n32 = 2 * nblk;
+    CHECK(live_cells == n32 * (n32 + 1) / 2 && (int)seen.size() == live_cells, "nblk %d: %d live cells, %zu distinct, %d needed", nblk, live_cells, seen.size(), n32 * (n32 + 1) / 2);
+    if (nblk == 11) CHECK(gs.size() == 16 && live_cells == 253, "config 2: %zu groups, %d cells", gs.size(), live_cells);
+    // a corrupted tiling is caught: kill one live cell / duplicate one
+    if (!gs.empty()) {
+        std::vector<FragGroup> bad = gs;
+        bad[0].wave[0] &= ~(1u << 16);
+        CHECK(check_frag_groups(bad, nblk) != -1, "nblk %d: missing cell not reported", nblk);
+        bad = gs;
+        bad.push_back(gs[0]);
+        CHECK(check_frag_groups(bad, nblk) != -1, "nblk %d: duplicated cells not reported", nblk);
     }
 }
 
-// channel_group_order: a permutation, never worse than the plain order; config 2 (11 blocks, 32 work-groups per XCD):
-// 184 -> 171 block fetches per XCD and launch
+// every (channel, tile group) appears exactly once per launch, on the right XCD class, lists end once
+static void check_work(int ncu, int nchan, int nblk) {
+    const std::vector<FragGroup> gs = build_frag_groups(nblk);
+    const int nwg = (int)gs.size();
+    const int grid = fused_grid(nchan, nwg, ncu);
+    CHECK(grid >= 1 && grid <= std::max(ncu, 1) && grid <= nchan * nwg, "grid %d (ncu %d, items %d)", grid, ncu, nchan * nwg);
+    const std::vector<uint64_t> masks = group_block_masks(gs);
+    const WorkList wl = build_work(grid, nchan, nwg, &masks);
+    CHECK((int)wl.entries.size() == grid * wl.maxi, "entries");
+    std::map<std::pair<int, int>, int> items;
+    int longest = 0, shortest = 1 << 30;
+    for (int b = 0; b < grid; b++) {
+        bool ended = false;
+        int n = 0;
+        for (int k = 0; k < wl.maxi; k++) {
+            const WorkEntry e = wl.entries[(size_t)b * wl.maxi + k];
+            if (!(e & WORK_VALID)) { ended = true; continue; }
+            CHECK(!ended, "work-group %d: valid entry after the end of its list", b);
+            const int c = e & 0xFFFF, wg = (e >> 16) & 0x7FFF;
+            CHECK(c < nchan && wg < nwg, "entry (%d,%d)", c, wg);
+            if ((nchan & 7) == 0 && (grid & 7) == 0) CHECK((c & 7) == (b & 7), "channel %d on work-group %d: wrong XCD class", c, b);
+            items[{c, wg}]++;
+            n++;
+        }
+        longest = std::max(longest, n); shortest = std::min(shortest, n);
+    }
+    CHECK((int)items.size() == nchan * nwg, "%zu items of %d", items.size(), nchan * nwg);
+    for (auto& kv : items) CHECK(kv.second == 1, "item (%d,%d) %d times", kv.first.first, kv.first.second, kv.second);
+    CHECK(longest - shortest <= 1, "lists of %d and %d items", shortest, longest);
+    // config 2 on 256 CUs: six items for every work-group, and every round of an XCD's 32 work-groups is two whole channels
+    if (ncu == 256 && nchan == 96 && nblk == 11) {
+        CHECK(longest == 6 && shortest == 6, "config 2: %d..%d items per work-group", shortest, longest);
+        for (int x = 0; x < 8; x++)
+            for (int k = 0; k < 6; k++) {
+                std::set<int> chans;
+                for (int j = 0; j < 32; j++) chans.insert(wl.entries[(size_t)(j * 8 + x) * wl.maxi + k] & 0xFFFF);
+                CHECK(chans.size() == 2, "config 2: round %d of XCD %d touches %zu channels", k, x, chans.size());
+            }
+    }
+}
+
+// channel_group_order: a permutation, never worse than the plain order
 static void check_group_order() {
     for (int nblk : {2, 3, 5, 8, 11, 12, 16}) {
-        const std::vector<WgDesc> d = build_wg_descs(nblk);
-        const int nwg = (int)d.size();
-        auto blocks = [&](const std::vector<int>& o, int a, int b) {
-            std::set<int> s;
-            for (int i = a; i < b; i++)
-                for (int k = 0; k < XC_NSLOT; k++) s.insert(d[o[i]].slot_blk[k]);
-            return (int)s.size();
-        };
-        for (int W : {4, 7, 13, 32}) {
-            int plain = 0, tuned = 0;
-            for (int q = 0; q < 12; q++) {
-                const std::vector<int> o = channel_group_order(d, q * nwg, W);
-                std::vector<int> id(nwg), sorted = o;
-                for (int i = 0; i < nwg; i++) id[i] = i;
-                std::sort(sorted.begin(), sorted.end());
-                CHECK(sorted == id, "nblk %d W %d channel %d: not a permutation", nblk, W, q);
-                const int B = (q * nwg / W + 1) * W, head = std::min(nwg, B - q * nwg);
-                plain += blocks(id, 0, head) + (head < nwg ? blocks(id, head, nwg) : 0);
-                tuned += blocks(o, 0, head) + (head < nwg ? blocks(o, head, nwg) : 0);
+        for (int frag = 0; frag < 2; frag++) {
+            const std::vector<FragGroup> d = frag ? build_frag_groups(nblk) : frag_groups_from_tiles(nblk);
+            const std::vector<uint64_t> masks = group_block_masks(d);
+            const int nwg = (int)d.size();
+            auto blocks = [&](const std::vector<int>& o, int a, int b) {
+                uint64_t s = 0;
+                for (int i = a; i < b; i++) s |= masks[o[i]];
+                return __builtin_popcountll(s);
+            };
+            for (int W : {4, 7, 13, 32}) {
+                int plain = 0, tuned = 0;
+                for (int q = 0; q < 12; q++) {
+                    const std::vector<int> o = channel_group_order(masks, q * nwg, W);
+                    std::vector<int> id(nwg), sorted = o;
+                    for (int i = 0; i < nwg; i++) id[i] = i;
+                    std::sort(sorted.begin(), sorted.end());
+                    CHECK(sorted == id, "nblk %d W %d channel %d: not a permutation", nblk, W, q);
+                    const int B = (q * nwg / W + 1) * W, head = std::min(nwg, B - q * nwg);
+                    plain += blocks(id, 0, head) + (head < nwg ? blocks(id, head, nwg) : 0);
+                    tuned += blocks(o, 0, head) + (head < nwg ? blocks(o, head, nwg) : 0);
+                }
+                CHECK(tuned <= plain, "nblk %d W %d: %d block fetches, plain order %d", nblk, W, tuned, plain);
+                // the 17-group 64x64 tiling of config 2 needed 184 -> 171 block fetches per XCD and launch; the 16 groups
+                // of the fragment tiling are never split over two rounds: 12 channels x 11 blocks, the unavoidable minimum
+                if (nblk == 11 && W == 32) CHECK(frag ? (plain == 132 && tuned == 132) : (plain == 184 && tuned == 171), "config 2 (%d): %d -> %d block fetches per XCD", frag, plain, tuned);
             }
-            CHECK(tuned <= plain, "nblk %d W %d: %d block fetches, plain order %d", nblk, W, tuned, plain);
-            if (nblk == 11 && W == 32) CHECK(plain == 184 && tuned == 171, "config 2: %d -> %d block fetches per XCD", plain, tuned);
         }
     }
 }
@@ -136,10 +180,10 @@ static void check_order(int ns) {
 
 int main() {
     for (int nblk = 1; nblk <= 24; nblk++) check_descs(nblk);
-    const int shapes[][4] = {{256, 96, 11, 25}, {256, 96, 11, 5}, {256, 8, 2, 3}, {256, 3, 1, 1}, {64, 96, 11, 25}, {256, 5, 11, 7},
-                             {304, 96, 11, 25}, {8, 16, 3, 2}, {1, 1, 1, 1}, {256, 192, 11, 50}};
-    for (auto& s : shapes)
-        for (int sk = 0; sk < 3; sk++) check_work(s[0], s[1], s[2], s[3], sk == 1, sk == 2);
+    for (int nblk = 1; nblk <= 40; nblk++) check_frag(nblk);
+    const int shapes[][3] = {{256, 96, 11}, {256, 8, 2}, {256, 3, 1}, {64, 96, 11}, {256, 5, 11}, {304, 96, 11}, {8, 16, 3}, {1, 1, 1},
+                             {256, 192, 11}, {256, 96, 5}, {256, 24, 7}};
+    for (auto& s : shapes) check_work(s[0], s[1], s[2]);
     check_group_order();
     for (int ns : {4, 8, 16, 32, 352}) check_order(ns);
     if (fails) { fprintf(stderr, "%d check(s) failed\n", fails); return 1; }

@@ -410,27 +410,6 @@ def test_reset_drops_partial_integration(gpu):
     x.close()
 
 
-@pytest.mark.parametrize("nstand,nchan,ntime,ngulp,kind", [
-    (32, 8, 32, 3, "full"),          # odd number of 32-sample half-tiles: the last 64-sample K step is half zero
-    (80, 8, 480, 2, "full"),         # the reference gulp length (7.5 K steps per gulp), 3 input blocks
-    (96, 3, 100, 2, "88"),           # ragged gulp, every nibble -8 (code 0b111000): largest magnitudes
-    (176, 2, 64, 1, "full"),
-])
-def test_fp6_route_is_bit_exact(gpu, nstand, nchan, ntime, ngulp, kind):
-    """Opt-in XENG_MFMA=fp6 route: E3M2 codes + block-scaled FP6 MFMA with fp32 accumulation.  Integers
-    -8..7 and their products/sums (< 2^24) are exact, so the visibilities must equal the oracle bit for bit."""
-    os.environ["XENG_MFMA"] = "fp6"
-    try:
-        x = gpu.Xgpu(nstand, nchan, ntime)
-        vin = gpu.synth_voltages(ntime * ngulp, nchan, nstand, kind, seed=nstand)
-        exp = oracle_run(vin, nstand, nchan, ntime)
-        assert np.array_equal(x.run(vin), exp)
-        assert np.array_equal(x.run(vin, use_async=True), exp)
-        x.close()
-    finally:
-        del os.environ["XENG_MFMA"]
-
-
 @pytest.mark.parametrize("nstand,nchan,permute", [(16, 4, False), (48, 7, True), (36, 96, False)])
 def test_packetize_matches_reorder_then_slice(gpu, nstand, nchan, permute):
     """xengXgpuPacketize (device) == bfXgpuReorder followed by the per-baseline slicing of
@@ -461,28 +440,37 @@ def test_packetize_matches_reorder_then_slice(gpu, nstand, nchan, permute):
         b.free()
 
 
-def test_split_k_work_lists_are_bit_exact(gpu):
-    """XENG_SPLITK=1 (experiment): the items left over after dealing whole items to the persistent work-groups
-    are cut along K and handed from slice to slice in order (read-modify-write through one XCD's L2).  Same words."""
-    nstand, nchan, ntime, ngulp = 352, 96, 480, 2          # 1632 items for 256 work-groups: 12 split items per XCD
-    vin = gpu.synth_voltages(ntime * ngulp, nchan, nstand, "random", seed=31)
+@pytest.mark.parametrize("nstand,nchan,ntime,ngulp", [
+    (352, 16, 96, 2),      # 11 blocks: 16 tile groups, 11 Z waves, one wave with a single live cell
+    (288, 8, 96, 1),       # 9 blocks: even number of block pairs, Z(L) takes a cell of a whole bottom tile
+    (416, 8, 96, 1),       # 13 blocks
+    (96, 8, 192, 2),       # 3 blocks: no squares at all
+    (344, 8, 96, 1),       # 688 inputs: 11 blocks, the last one three quarters full (padded fragments, clamped columns)
+])
+def test_fragment_tiling_matches_tile_tiling(gpu, nstand, nchan, ntime, ngulp):
+    """The fragment-level tiling (2x2 waves + Z waves: a diagonal 64x64 tile plus a free cell of an off-diagonal tile)
+    stores the same words as the oracle and as the 64x64-tile tiling it replaces (XENG_TILING=64, the A/B switch)."""
+    vin = gpu.synth_voltages(ntime * ngulp, nchan, nstand, "full", seed=77 + nstand)
     exp = oracle_run(vin, nstand, nchan, ntime)
-    os.environ["XENG_SPLITK"] = "1"
+    x = gpu.Xgpu(nstand, nchan, ntime)
+    assert x.path() == (1, 0)
+    assert np.array_equal(x.run(vin, use_async=True), exp)
+    assert np.array_equal(x.run(vin), exp)
+    x.close()
+    os.environ["XENG_TILING"] = "64"
     try:
         x = gpu.Xgpu(nstand, nchan, ntime)
-        assert x.path() == (1, 0)
-        for _ in range(3):                                  # the hand-over flags count epochs: repeat launches
-            assert np.array_equal(x.run(vin, use_async=True), exp)
+        assert np.array_equal(x.run(vin, use_async=True), exp)
         x.close()
     finally:
-        del os.environ["XENG_SPLITK"]
+        del os.environ["XENG_TILING"]
 
 
 @pytest.mark.parametrize("nstand,nchan,ntime,ngulp,max_gulps,two_accs", [
     (80, 8, 96, 3, 3, True),      # 2.5 blocks: interior, diagonal and padded tiles; two accumulators (dumps may overlap)
     (80, 8, 96, 3, 3, False),     # one accumulator: the dumps are ordered by the library
     (48, 5, 96, 5, 2, True),      # staging depth 2 with 5 gulps: the dump is a read-modify-write flush
-    (352, 8, 96, 1, 1, True),     # 704 inputs: the config-2 tiling (17 tile groups per channel)
+    (352, 8, 96, 1, 1, True),     # 704 inputs: the config-2 tiling (16 tile groups per channel, Z waves)
 ])
 def test_long_accumulation_fused_into_the_dump(gpu, nstand, nchan, ntime, ngulp, max_gulps, two_accs):
     """xengXgpuKernelAsyncAcc = xengXgpuKernelAsync + CorrAcc's "a = b" / "a += b" (corr_acc_block.py:298-306) on the
