@@ -206,7 +206,7 @@ int xengBeamformInitialize(int gpu, int ninput, int nchan, int ntime, int nbeam,
         XENG_HIP(hipMalloc((void**)&x.out_R, ntile * BI_TILE_OUT * 32 * sizeof(float2)));
         XENG_HIP(hipHostMalloc((void**)&x.any_host, sizeof(int)));
         XENG_HIP(hipEventCreateWithFlags(&x.ev_route, hipEventDisableTiming));
-        if (getenv("XENG_BEAM_STAMPS")) {
+        if (diag_env("XENG_BEAM_STAMPS")) {
             const size_t nw = (size_t)((ntime + BI_NT - 1) / BI_NT) * nchan * x.nbtile * 4 * 4;
             XENG_HIP(hipMalloc((void**)&x.stamps, nw * sizeof(unsigned long long)));
             XENG_HIP(hipMemset(x.stamps, 0, nw * sizeof(unsigned long long)));

@@ -750,7 +750,10 @@ __global__ __launch_bounds__(256, 3) void beamform_i8x3_kernel(const uint8_t* __
 // beam power sums (beamformer_sum_test.py:64-77, cublas_beamform.cu:46-79).
 // in cf32[nchan][nbeam][ntime] -> out f32[npair][ntime/ntime_sum][nchan][4]; one wave per
 // (channel, beam pair): lanes stride the time blocks, 8-lane groups sweep one block's samples
-// so global reads are contiguous, then reduce across the group with DPP/shuffles.
+// so global reads are contiguous, then reduce across the group with DPP row shifts.
+// (XENG_EXTERNAL_BEAM_INTEGRATE: the hazard lab, profiles/hazard/, compiles this translation unit with the round-2 form
+// of the kernel in its place; defining the macro without supplying a kernel does not build.)
+#ifndef XENG_EXTERNAL_BEAM_INTEGRATE
 __global__ __launch_bounds__(256) void beam_integrate_kernel(const float2* __restrict__ in, float4* __restrict__ out,
                                                              int nchan, int nbeam, int ntime, int ntime_sum,
                                                              int pair0, int npair_out) {
@@ -765,27 +768,6 @@ __global__ __launch_bounds__(256) void beam_integrate_kernel(const float2* __res
     // latency chain, so more resident waves beat longer loops
     for (int tb = blockIdx.z * 8 + grp; tb < nblk; tb += 8 * gridDim.z) {
         float xx = 0.f, yy = 0.f, xyr = 0.f, xyi = 0.f;
-#if defined(INTEG_DIAG) && INTEG_DIAG == 12      // diagnostic: accumulate with single fp32 FMAs, no packed math
-        for (int t = sub; t < ntime_sum; t += 8) {
-            const float2 a = x[(size_t)tb * ntime_sum + t], b = y[(size_t)tb * ntime_sum + t];
-            asm volatile("v_fmac_f32 %0, %1, %1\n\tv_fmac_f32 %0, %2, %2" : "+v"(xx) : "v"(a.x), "v"(a.y));
-            asm volatile("v_fmac_f32 %0, %1, %1\n\tv_fmac_f32 %0, %2, %2" : "+v"(yy) : "v"(b.x), "v"(b.y));
-            asm volatile("v_fmac_f32 %0, %1, %2\n\tv_fmac_f32 %0, %3, %4" : "+v"(xyr) : "v"(a.x), "v"(b.x), "v"(a.y), "v"(b.y));
-            const float nax = -a.x;
-            asm volatile("v_fmac_f32 %0, %1, %2\n\tv_fmac_f32 %0, %3, %4" : "+v"(xyi) : "v"(a.y), "v"(b.x), "v"(nax), "v"(b.y));
-        }
-#elif defined(INTEG_DIAG) && INTEG_DIAG == 13    // diagnostic: 32-bit element offsets (no 64-bit pointer increments in VGPRs)
-        {
-            const unsigned base = (unsigned)(((size_t)c * nbeam + 2 * (pair0 + bp)) * ntime) + (unsigned)tb * ntime_sum;
-            for (int t = sub; t < ntime_sum; t += 8) {
-                const float2 a = in[base + (unsigned)t], b = in[base + (unsigned)ntime + (unsigned)t];
-                xx += a.x * a.x + a.y * a.y;
-                yy += b.x * b.x + b.y * b.y;
-                xyr += a.x * b.x + a.y * b.y;
-                xyi += a.y * b.x - a.x * b.y;
-            }
-        }
-#else
         for (int t = sub; t < ntime_sum; t += 8) {
             const float2 a = x[(size_t)tb * ntime_sum + t], b = y[(size_t)tb * ntime_sum + t];
             xx += a.x * a.x + a.y * a.y;
@@ -793,32 +775,9 @@ __global__ __launch_bounds__(256) void beam_integrate_kernel(const float2* __res
             xyr += a.x * b.x + a.y * b.y;
             xyi += a.y * b.x - a.x * b.y;
         }
-#endif
-#if defined(INTEG_DIAG)                            // diagnostic builds: the ds_bpermute reduction that failed beside MFMA kernels
-#if INTEG_DIAG == 11
-        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
-#elif INTEG_DIAG == 16
-        asm volatile("s_nop 1" ::: "memory");
-#elif INTEG_DIAG == 17
-        asm volatile("s_nop 7" ::: "memory");
-#elif INTEG_DIAG == 18
-        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-#endif
-#pragma unroll
-        for (int o = 4; o >= 1; o >>= 1) {
-            const float a0 = __shfl_xor(xx, o), a1 = __shfl_xor(yy, o), a2 = __shfl_xor(xyr, o), a3 = __shfl_xor(xyi, o);
-#if INTEG_DIAG == 14
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7" ::: "memory");
-#endif
-            xx += a0; yy += a1; xyr += a2; xyi += a3;
-        }
-        if (sub == 0) out[((size_t)bp * nblk + tb) * nchan + c] = make_float4(xx, yy, xyr, xyi);
-        continue;
-#endif
         // 8-lane sums by DPP row shifts (lane i += lane i+4, i+2, i+1: the total lands in lane sub == 0; same association
-        // as an xor butterfly).  NOT ds_bpermute (__shfl_xor): with this kernel's packed-fp32 accumulators the
-        // bpermute form returned wrong sums in lanes 48-63 whenever an MFMA kernel shared the CU (profiles/soak.py,
-        // DESIGN.md 4.10) -- alone on the GPU it never failed.
+        // as an xor butterfly).  NOT ds_bpermute (__shfl_xor): see DESIGN.md 4.10 and profiles/hazard/ -- no kernel of
+        // this object may contain ds_bpermute / ds_swizzle (tests/test_abi.py checks the ISA).
 #define XENG_DPP_ADD(v, ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, true))
         XENG_DPP_ADD(xx, 0x104); XENG_DPP_ADD(yy, 0x104); XENG_DPP_ADD(xyr, 0x104); XENG_DPP_ADD(xyi, 0x104);
         XENG_DPP_ADD(xx, 0x102); XENG_DPP_ADD(yy, 0x102); XENG_DPP_ADD(xyr, 0x102); XENG_DPP_ADD(xyi, 0x102);
@@ -828,5 +787,6 @@ __global__ __launch_bounds__(256) void beam_integrate_kernel(const float2* __res
     }
     (void)npair_out;
 }
+#endif
 
 }  // namespace xeng

@@ -55,9 +55,9 @@ static int map_i32(void* a, const void* b, size_t nwords, bool add) {
     const int32_t* bt = (const int32_t*)b + n16 * 4;
     // XENG_MAP_VAR = U*10 + NT overrides the defaults measured on config-2 planes (profiles/side_kernels.py map):
     // "a += b" one piece per lane, non-temporal (88.8 us = 6.46 TB/s); "a = b" four pieces, non-temporal (62.6 us = 6.11 TB/s)
-    static const int var_env = getenv("XENG_MAP_VAR") ? atoi(getenv("XENG_MAP_VAR")) : 0;
+    static const int var_env = diag_env("XENG_MAP_VAR") ? atoi(diag_env("XENG_MAP_VAR")) : 0;
     const int var = var_env ? var_env : (add ? 11 : 41);
-    static const int maxb = getenv("XENG_MAP_BLOCKS") ? atoi(getenv("XENG_MAP_BLOCKS")) : 2048;
+    static const int maxb = diag_env("XENG_MAP_BLOCKS") ? atoi(diag_env("XENG_MAP_BLOCKS")) : 2048;
     const int U = var / 10 == 1 ? 1 : var / 10 == 2 ? 2 : var / 10 == 8 ? 8 : 4;
     size_t blocks = (n16 + 256 * (size_t)U - 1) / (256 * (size_t)U);
     if (blocks > (size_t)maxb) blocks = (size_t)maxb;

@@ -382,7 +382,7 @@ static int initialize_locked(int gpu) {
     {
         int ncu = 0;
         XENG_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, x.gpu));
-        const char* e = getenv("XENG_GRID");          // experiment: persistent grid size
+        const char* e = diag_env("XENG_GRID");          // experiment: persistent grid size
         x.ncu = e ? atoi(e) : ncu;
         if (x.ncu < 1) x.ncu = 1;
     }
@@ -445,7 +445,7 @@ static int initialize_locked(int gpu) {
     if (x.raw) {
         // fragment-level tile groups and the persistent work-groups' item lists (the same for every K length)
         const bool tiles64 = getenv("XENG_TILING") && !strcmp(getenv("XENG_TILING"), "64");        // A/B switch: the 64x64 tiling
-        const bool plain_order = getenv("XENG_ITEM_ORDER") && !strcmp(getenv("XENG_ITEM_ORDER"), "plain");   // A/B switch
+        const bool plain_order = diag_env("XENG_ITEM_ORDER") && !strcmp(diag_env("XENG_ITEM_ORDER"), "plain");   // A/B switch
         const std::vector<FragGroup> groups = tiles64 ? frag_groups_from_tiles(x.nblk64) : build_frag_groups(x.nblk64);
         if (check_frag_groups(groups, x.nblk64) != -1) XENG_FAIL(XENG_STATUS_DEVICE_ERROR, "xgpu: the tiling of %d blocks is not an exact cover", x.nblk64);
         x.nfg = (int)groups.size();
@@ -460,7 +460,7 @@ static int initialize_locked(int gpu) {
     XENG_HIP(hipMemcpy(x.descs_dev, descs.data(), descs.size() * sizeof(WgDesc), hipMemcpyHostToDevice));
     int rc = get_stream(STREAM_XGPU, &x.stream);
     if (rc) return rc;
-    if (const char* e = getenv("XENG_MM_STREAMS")) x.nmm = std::max(1, std::min(XgpuContext::NMM, atoi(e)));   // experiment
+    if (const char* e = diag_env("XENG_MM_STREAMS")) x.nmm = std::max(1, std::min(XgpuContext::NMM, atoi(e)));   // experiment
     for (int t = 0; t < x.nmm; t++) {      // (only the streams in use: every stream takes a share of a hardware queue)
         rc = get_stream((StreamId)(STREAM_XGPU_MM + t), &x.stream_mm2[t]);
         if (rc) return rc;
@@ -468,7 +468,7 @@ static int initialize_locked(int gpu) {
     }
     for (int k = 0; k < XgpuContext::NEV; k++) XENG_HIP(hipEventCreateWithFlags(&x.ev_ring[k], hipEventDisableTiming));
     x.stream_mm = x.stream_mm2[0];
-    if (getenv("XENG_DBG_STAMPS")) {
+    if (diag_env("XENG_DBG_STAMPS")) {
         const int ng = std::max(x.nwg, x.nfg);
         XENG_HIP(hipMalloc((void**)&x.stamps, (size_t)x.cfg.nchan * ng * 4 * 8 * sizeof(unsigned long long)));
         XENG_HIP(hipMemset(x.stamps, 0, (size_t)x.cfg.nchan * ng * 4 * 8 * sizeof(unsigned long long)));

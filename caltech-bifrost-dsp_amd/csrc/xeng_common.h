@@ -1,5 +1,6 @@
 // Shared host-side helpers for libxeng (error convention, per-device streams).
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -34,6 +35,17 @@ void set_error(const char* fmt, ...);
 enum StreamId { STREAM_XGPU = 0, STREAM_MAP = 1, STREAM_BEAM = 2, STREAM_COPY = 3, STREAM_XGPU_MM = 4, STREAM_XGPU_MM2 = 5, STREAM_XGPU_MM3 = 6, STREAM_XGPU_MM4 = 7, STREAM_CONSUMER = 8, STREAM_COUNT = 9 };
 int get_stream(StreamId which, hipStream_t* out);   // lazily created per device
 int sync_all_streams();
+
+// Experiment / diagnostic switches (grid sizes, map variants, clock stamps, item order ...) exist only in
+// -DXENG_DIAGNOSTICS builds (profiles/); the shipped library reads XENG_RAW, XENG_BEAM[_F32] and XENG_TILING only.
+inline const char* diag_env(const char* name) {
+#ifdef XENG_DIAGNOSTICS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 // profiling helper: pairs of events accumulated per kind
 struct EventTimer {

@@ -1,0 +1,80 @@
+"""Rules on the ISA of the shipped code objects (CPU test: disassembles the gfx950 code objects inside libxeng.so).
+
+Rule 1 (profiles/hazard/): no packed-fp32 VOP3P instruction (v_pk_mul_f32 / v_pk_add_f32 /
+v_pk_fma_f32) with op_sel:[0,1,...], i.e. whose LOW result takes the low register of src0 and the HIGH register of
+src1.  On MI355X that form returns a wrong low result in lanes 48-63 whenever an MFMA kernel shares the CU (round 2:
+beam_integrate_kernel's cross-power sums; isolated at the instruction level in round 3).  hipcc chooses these forms by
+itself when it packs fp32 arithmetic, so the check runs on what was actually built."""
+import os
+import re
+import shutil
+import struct
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "caltech-bifrost-dsp_amd", "libxeng.so")
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+BAD_PK = re.compile(r"\bv_pk_(mul|add|fma)_f32\b.*\bop_sel:\[0,1[,\]]")
+
+
+def code_objects(lib, tmp):
+    """gfx950 code objects of a HIP shared library: the .hip_fatbin section is a sequence of clang offload bundles."""
+    fat = os.path.join(tmp, "fat.bin")
+    subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, lib])
+    data = open(fat, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    out, pos = [], data.find(magic)
+    while pos >= 0:
+        n, = struct.unpack_from("<Q", data, pos + 24)
+        off = pos + 32
+        for _ in range(n):
+            o, s, tl = struct.unpack_from("<QQQ", data, off)
+            off += 24
+            triple = data[off:off + tl].decode()
+            off += tl
+            if "gfx950" in triple and s:
+                path = os.path.join(tmp, "co_%d.co" % len(out))
+                with open(path, "wb") as fh:
+                    fh.write(data[pos + o:pos + o + s])
+                out.append(path)
+        pos = data.find(magic, pos + 1)
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "llvm-objdump")), reason="llvm-objdump not available")
+def test_no_packed_fp32_with_op_sel_lo_hi(tmp_path):
+    assert os.path.exists(LIB), "build libxeng.so first (__graft_entry__.build())"
+    cos = code_objects(LIB, str(tmp_path))
+    assert len(cos) >= 3, "expected the code objects of xcorr, beamform, corracc, ingest: %d found" % len(cos)
+    npk, bad, kernels = 0, [], 0
+    for co in cos:
+        dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", co], capture_output=True, text=True, check=True).stdout
+        sym = "?"
+        for line in dis.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.+)>:", line)
+            if m:
+                sym = m.group(1)
+                kernels += 1
+                continue
+            if "v_pk_" in line and "_f32" in line:
+                npk += 1
+                if BAD_PK.search(line):
+                    bad.append("%s: %s" % (sym, line.strip()))
+    assert kernels >= 20 and npk > 0, "disassembly looks empty (%d symbols, %d packed-fp32 instructions)" % (kernels, npk)
+    assert not bad, "packed fp32 with op_sel:[0,1] (wrong low result beside MFMA kernels, DESIGN.md 4.10):\n" + "\n".join(bad[:20])
+
+
+def test_rule_matches_the_failing_instruction():
+    """the pattern flags the instruction of the round-2 kernel and its relatives, and not the forms measured clean"""
+    assert BAD_PK.search("v_pk_mul_f32 v[30:31], v[30:31], v[24:25] op_sel:[0,1]")
+    assert BAD_PK.search("v_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7] op_sel:[0,1,0] op_sel_hi:[1,0,1]")
+    assert BAD_PK.search("v_pk_add_f32 v[0:1], v[2:3], v[4:5] op_sel:[0,1] op_sel_hi:[0,1]")
+    for ok in ("v_pk_mul_f32 v[30:31], v[24:25], v[30:31] op_sel:[1,0]",
+               "v_pk_mul_f32 v[28:29], v[20:21], v[22:23] op_sel:[1,1] op_sel_hi:[0,1]",
+               "v_pk_fma_f32 v[22:23], v[22:23], v[24:25], v[30:31] op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]",
+               "v_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7] op_sel:[0,0,1]",
+               "v_pk_add_f32 v[10:11], v[10:11], v[28:29]"):
+        assert not BAD_PK.search(ok), ok

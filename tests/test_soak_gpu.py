@@ -24,7 +24,24 @@ def _load_soak():
     return mod
 
 
-def test_results_do_not_depend_on_concurrency():
+@pytest.mark.parametrize("env,rounds", [
+    ({}, 240),                          # the shipped kernels
+    ({"XENG_BEAM": "bf16x3"}, 60),      # bf16 MFMA beamformer beside the contraction's epilogue
+    ({"XENG_BEAM": "f32"}, 60),         # fp32 MFMA beamformer
+    ({"XENG_TILING": "64"}, 60),        # the 64x64-tile tiling of the fused kernel (17 groups, 7-vs-6 items)
+    ({"XENG_RAW": "0"}, 60),            # two-pass X-engine (corner turn + xcorr_mfma_kernel)
+])
+def test_results_do_not_depend_on_concurrency(env, rounds):
+    for k, v in env.items():
+        os.environ[k] = v
+    try:
+        _soak_once(rounds)
+    finally:
+        for k in env:
+            del os.environ[k]
+
+
+def _soak_once(rounds):
     sk = _load_soak()
     rng = np.random.default_rng(77)
     vin = rng.integers(0, 256, (sk.NTIME_GULP, sk.NCHAN, sk.NSTAND, 2), dtype=np.uint8)
@@ -33,7 +50,7 @@ def test_results_do_not_depend_on_concurrency():
     order = rng.permutation(len(pk))
     slab = b"".join(pk[i] for i in order)
     lines = []
-    res = sk.soak(N=240, packets=(slab, len(pk), len(pk[0]), seq0, vin.reshape(-1)), log=lines.append)
+    res = sk.soak(N=rounds, packets=(slab, len(pk), len(pk[0]), seq0, vin.reshape(-1)), log=lines.append)
     print("\n".join(lines))
     assert len(res) >= 10
     for name, n, bad in res:
