@@ -146,6 +146,74 @@ def corr_block_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=100):
                     "`throughput` stat of its last integration (corr_block.py:453 formula)"}
 
 
+def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=240, nwarm=60, long_len=10):
+    """BASELINE config 5 through the BLOCKS on one GPU: Corr -> CorrAcc and Beamform -> BeamformSumBeams as four Python
+    threads on in-repo rings (gpu-input read in place by Corr and Beamform), fed by a zero-copy replay source.  CorrAcc's
+    long accumulation (`long_len` dumps) is done by the dumps' own epilogue (fused mode, blocks/corr_acc_block.py)."""
+    import json as _json
+    import logging
+    import threading
+    from caltech_bifrost_dsp_amd.blocks import Beamform, BeamformSumBeams, Corr, CorrAcc
+    from caltech_bifrost_dsp_amd.ndarray import XArray
+    from caltech_bifrost_dsp_amd.ring import Ring
+    gulps_per_step = ACC_LEN // NTIME_GULP
+    nbeam, ns = 32, 24
+    r_in = Ring("gpu-input", space="cuda")
+    r_vis, r_slow = Ring("corr-output", space="cuda"), Ring("corr-slow-output", space="cuda_host")
+    r_bf, r_pow = Ring("bf-output", space="cuda"), Ring("bf-pow-output", space="cuda_host")
+    r_in.resize(gulp_bytes, total_span=2 * gulps_per_step * gulp_bytes)
+    log = logging.getLogger("bench-config5")
+    corr = Corr(log, r_in, r_vis, ntime_gulp=NTIME_GULP, nchan=NCHAN, npol=NPOL, nstand=NSTAND, acc_len=ACC_LEN, autostartat=0, gpu=gpu)
+    cacc = CorrAcc(log, r_vis, r_slow, nchan=NCHAN, npol=NPOL, nstand=NSTAND, acc_len=long_len * ACC_LEN, autostartat=0, gpu=gpu)
+    bf = Beamform(log, r_in, r_bf, nchan=NCHAN, nbeam=nbeam, ninput=NINPUT, ntime_gulp=NTIME_GULP, gpu=gpu)
+    sb = BeamformSumBeams(log, r_bf, r_pow, nchan=NCHAN, ntime_gulp=NTIME_GULP, ntime_sum=ns, gpu=gpu)
+    rng = np.random.default_rng(7)
+    bf.gains_cpu[...] = (rng.uniform(-17, 17, bf.gains_cpu.shape) + 1j * rng.uniform(-17, 17, bf.gains_cpu.shape)).astype(np.complex64)
+    spans = [XArray(shape=(gulp_bytes,), dtype=np.uint8, space="cuda", _ptr=ring.ptr + g * gulp_bytes, _base=ring) for g in range(ring_gulps)]
+    hdr = {'nchan': NCHAN, 'chan0': 0, 'bw_hz': NCHAN * 23925.78125, 'fs_hz': 196000000, 'sfreq': 0.0, 'nstand': NSTAND, 'npol': NPOL,
+           'seq0': 0, 'sync_time': 0, 'pipeline_id': 0, 'system_nchan': 32 * NCHAN}
+    stamps, nslow = [], [0]
+
+    def source():
+        import time as _t
+        t0 = _t.time()
+        while len(r_in._readers) < 2 and _t.time() - t0 < 10:
+            _t.sleep(0.002)
+        with r_in.begin_writing() as w:
+            with w.begin_sequence(time_tag=0, header=_json.dumps(hdr), nringlet=1) as oseq:
+                for k in range((nwarm + nint) * gulps_per_step):
+                    oseq.commit_external(spans[k % ring_gulps])
+
+    def drain(rg, gulp, on_span=None):
+        gen = rg.read(guarantee=True)
+
+        def run():
+            for iseq in gen:
+                for ispan in iseq.read(gulp):
+                    if on_span:
+                        on_span()
+        return threading.Thread(target=run, daemon=True)
+
+    def slow_span():
+        nslow[0] += 1
+    ths = [drain(r_vis, corr.ogulp_size, lambda: stamps.append(time.perf_counter())), drain(r_slow, cacc.ogulp_size, slow_span),
+           drain(r_pow, (nbeam // 2) * (NTIME_GULP // ns) * NCHAN * 16)]
+    ths += [threading.Thread(target=f, daemon=True) for f in (corr.main, cacc.main, bf.main, sb.main, source)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(300)
+    n = len(stamps)
+    ok = n > nwarm + 1
+    el = (stamps[-1] - stamps[nwarm]) if ok else 0.0
+    return {"value": round(8 * NINPUT * ACC_LEN * NCHAN * (n - 1 - nwarm) / el / 1e9, 1) if ok else 0.0, "unit": "Gb/s",
+            "ms_per_integration": round(el / max(n - 1 - nwarm, 1) * 1e3, 4) if ok else None, "integrations": n,
+            "long_integrations_published": nslow[0], "corracc_fused_into_dumps": bool(cacc.stats.get('fused')) and cacc.fused_dumps == n,
+            "note": "config 5 through the blocks on one GPU: Corr -> CorrAcc (%d dumps per long integration, accumulated by the "
+                    "dumps' epilogue; published to a pinned-host ring) and Beamform (480-sample gulps) -> BeamformSumBeams, four "
+                    "Python threads on in-repo rings, zero-copy replay source; wall rate between visibility spans at a sink" % long_len}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -722,6 +790,7 @@ def main():
     # user of the block sees, next to the C-ABI rate above
     if rank == 0 and world == 1 and args.beamform and not args.sync_per_call and not args.sync_per_integration:
         res["corr_block"] = corr_block_leg(ffi, ring, gulp_bytes, args.ring_gulps, gpu)
+        res["config5_blocks"] = config5_blocks_leg(ffi, ring, gulp_bytes, args.ring_gulps, gpu)
     # outside the timed region: SURVEY 8d's other device-resident case, one 2400-sample call per integration
     # (xGPU's NTIME = acc_len; needs its own context, so it runs last)
     if args.beamform and rank == 0 and world == 1 and args.ring_gulps >= 2 * gulps_per_step:

@@ -54,6 +54,11 @@ class HipBackend:
         xgpu_sync() (include/xeng.h: xengXgpuKernelAsync).  No reference counterpart."""
         return self._lib.xengXgpuKernelAsync(in_arr.contents.data, out_arr.contents.data, int(do_dump))
 
+    def bfXgpuKernelAsyncAcc(self, in_arr, out_arr, do_dump, acc, acc_mode):
+        """bfXgpuKernelAsync whose dump also assigns (acc_mode 1) / adds (2) every stored word to the long accumulator
+        `acc` -- CorrAcc's "a = b" / "a += b" (corr_acc_block.py:304-306) done by the contraction's epilogue."""
+        return self._lib.xengXgpuKernelAsyncAcc(in_arr.contents.data, out_arr.contents.data, int(do_dump), acc.ptr, int(acc_mode))
+
     def xgpu_sync(self):
         return self._lib.xengXgpuSync()
 

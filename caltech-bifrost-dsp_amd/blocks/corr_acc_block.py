@@ -10,8 +10,24 @@ vectorised int32 kernels (csrc/corracc.hip).
 Input header needs `seq0`, `acc_len` (:214-215); output adds `upstream_acc_len` (:216) and
 rewrites `acc_len` / `seq0`.  `start_time == -1` starts on the current block (:244-245);
 recovery after a new upstream sequence skips 2 integrations (:227).
+
+Fused mode (round 3; no reference counterpart).  When the input ring is the in-repo one and the upstream `Corr` streams
+(blocks/corr_block.py), the "a = b" / "a += b" of every dump is done by the contraction kernel's own epilogue
+(`xengXgpuKernelAsyncAcc`, csrc/xcorr_kernels.h `LACC`): one pass over the accumulator per dump instead of a 574 MB map
+kernel.  The gate below is the same state machine either way; what changes is WHO steps it and WHEN:
+
+  * classic: this block's thread steps it for every span it reads, then runs the map;
+  * fused:   `Corr` steps it (`plan_sequence` / `plan_dump`) right before it enqueues a dump -- the decision (skip, assign,
+             add, first, last, new output sequence) depends on headers, sample counts and commands only, never on data --
+             and this block's thread follows the queue of decisions when the spans arrive: it opens output sequences and,
+             on the last dump of a long integration, adds the two partial accumulators and publishes.
+    Dumps alternate between two accumulators (dumps that name the same accumulator are serialised by the library, two
+    keep consecutive dumps independent), and long integrations alternate between two such pairs, so integration j+1
+    accumulates while j is being published: 4 x 191 MB at config-2 size.
 """
+import collections
 import json
+import threading
 import time
 
 from ..backend import default_backend
@@ -20,6 +36,20 @@ from ..proclog import cpu_affinity
 from ..ring import WriteSpan
 from .block_base import Block
 from .integration import IntegrationGate
+
+
+class _Decision:
+    """What to do with one upstream span."""
+    __slots__ = ("kind", "now", "begin_hdr", "first", "last", "state", "acc_set", "acc_half", "mode", "nhalves")
+
+    def __init__(self, kind, now):
+        self.kind, self.now = kind, now           # kind: 'stop' | 'wait' | 'acc'
+        self.begin_hdr = None                     # header (dict) of an output sequence to open before this span
+        self.first = self.last = False
+        self.state = None
+        self.acc_set = self.acc_half = 0          # fused: which accumulator the dump feeds ...
+        self.mode = 0                             # ... 1 assign, 2 add
+        self.nhalves = 1                          # fused, on `last`: accumulators of the pair that hold data
 
 
 class CorrAcc(Block):
@@ -39,13 +69,151 @@ class CorrAcc(Block):
         self.accdata = XArray(shape=(self.igulp_size // 4,), dtype='i32', space=self._bf.space_in)
         self.define_command_key('start_time', type=int, initial_val=autostartat)
         self.define_command_key('acc_len', type=int, initial_val=acc_len)
+        # gate + header state, stepped by _begin_upstream_sequence / _decide (either thread, never both for one sequence)
+        self._gate = IntegrationGate(recovery_skip=2, round_start_to_acc_len=False)
+        self.update_pending = True                # the first gate step loads the initial command values
+        self._ohdr = None
+        self._upstream_start = 0
+        # fused mode
+        self._plan = collections.deque()          # ('seq', seq0) | _Decision, in upstream order
+        self._plan_cv = threading.Condition()
+        self._plan_now = 0
+        self._plan_step = 0
+        self._fused_accs = None                   # [[XArray, XArray], [XArray, XArray]]
+        self._set_busy = [False, False]           # pair holds a long integration that is not published yet
+        self._long_index = 0                      # long integrations started (fused)
+        self._dump_index = 0                      # dumps inside the current long integration (fused)
+        self._open_set = None                     # pair of the long integration in progress (first seen, last not yet)
+        self._stopping = False
+        self.fused_dumps = 0                      # dumps accumulated by the contraction's epilogue (stat)
+        # the upstream Corr finds its long accumulator through the ring it writes (no change to the pipeline script)
+        if getattr(iring, 'span_memory_outlives_release', False) and hasattr(self._bf, 'bfXgpuKernelAsyncAcc'):
+            iring.long_accumulator = self
 
+    # ------------------------------------------------------------------ the gate, one step per upstream sequence / span
     def _check_compat(self, gate, upstream_acc_len, upstream_start_time):
         if upstream_acc_len and gate.acc_len % upstream_acc_len != 0:
             self.log.error("CORRACC >> Requested acc_len %d incompatible with upstream integration %d" % (gate.acc_len, upstream_acc_len))
         if upstream_acc_len and gate.acc_len != 0 and ((gate.start_time - upstream_start_time) % upstream_acc_len != 0):
             self.log.error("CORRACC >> Requested start_time %d incompatible with upstream integration %d" % (gate.start_time, upstream_acc_len))
 
+    def _begin_upstream_sequence(self, ihdr):
+        """corr_acc_block.py:212-233: header of the output sequences, recovery of a running gate."""
+        gate = self._gate
+        ohdr = dict(ihdr)
+        now, step = ihdr['seq0'], ihdr['acc_len']
+        ohdr['upstream_acc_len'] = step
+        ohdr.pop('fused_corracc', None)
+        self._upstream_start = now
+        self.sequence_proclog.update(ohdr)
+        if gate.recover(now):
+            self.log.info("CORRACC >> Recovering start time set to %d. Accumulating %d samples" % (gate.start_time, gate.acc_len))
+            self._check_compat(gate, step, now)
+            ohdr['acc_len'] = gate.acc_len
+            ohdr['seq0'] = gate.start_time
+        self._ohdr = ohdr
+
+    def _decide(self, now, step):
+        """corr_acc_block.py:237-296 for one upstream span starting at sample `now`."""
+        gate, ohdr = self._gate, self._ohdr
+        if self.update_pending:
+            self.update_command_vals()
+            gate.configure(now, self.command_vals['acc_len'], self.command_vals['start_time'])
+            self.log.info("CORRACC >> New start time at %d. Accumulation: %d samples" % (gate.start_time, gate.acc_len))
+            self._check_compat(gate, step, self._upstream_start)
+            ohdr['acc_len'] = gate.acc_len
+            ohdr['seq0'] = gate.start_time
+        self.stats.update({'curr_sample': now})
+        self.update_stats()
+        if gate.acc_len == 0:                   # stop command (:257-263)
+            gate.running = False
+            d = _Decision('stop', now)
+            d.state = 'stopped'
+            return d
+        begin = None
+        if gate.try_start(now, step):
+            begin = dict(ohdr)
+            self.log.info("CORRACC >> Start time %d reached. Accumulating to %d (upstream accumulation: %d)" % (gate.start_time, gate.last, step))
+        if not gate.running:
+            d = _Decision('wait', now)
+            d.state = 'waiting_start_missed' if now > gate.start_time else 'waiting'
+            return d
+        d = _Decision('acc', now)
+        d.begin_hdr = begin
+        d.state = 'running'
+        d.first, d.last = now == gate.first, now == gate.last
+        if d.last:
+            gate.advance(step)
+        return d
+
+    # ------------------------------------------------------------------ fused mode: called by the upstream Corr's thread
+    def plan_sequence(self, ohdr_upstream):
+        """Corr is about to open an output sequence with this header (and will mark it 'fused_corracc')."""
+        if self._fused_accs is None:
+            n = self.igulp_size // 4
+            self._fused_accs = [[XArray(shape=(n,), dtype='i32', space=self._bf.space_in) for _ in range(2)] for _ in range(2)]
+        with self._plan_cv:
+            self._begin_upstream_sequence(ohdr_upstream)
+            self._abandon_open_set()              # (a long integration cut off by the end of the upstream sequence)
+            self._plan_now = ohdr_upstream['seq0']
+            self._plan_step = ohdr_upstream['acc_len']
+            self._plan.append(('seq', self._plan_now))
+            self._plan_cv.notify_all()
+
+    def _abandon_open_set(self):
+        """under _plan_cv: a long integration that will never see its last dump (new command, stop, upstream sequence
+        ended) is never published: its accumulator pair is free again"""
+        if self._open_set is not None:
+            self._set_busy[self._open_set] = False
+            self._open_set = None
+            self._plan_cv.notify_all()
+
+    def plan_dump(self, timeout=60.0):
+        """Corr is about to enqueue the dump of its next integration: returns (accumulator, mode) for
+        bfXgpuKernelAsyncAcc, or (None, 0) when this dump is not part of a long integration."""
+        with self._plan_cv:
+            d = self._decide(self._plan_now, self._plan_step)
+            self._plan_now += self._plan_step
+            acc = None
+            if d.kind != 'acc' or d.first:
+                self._abandon_open_set()
+            if d.kind == 'acc':
+                if d.first:
+                    self._long_index += 1
+                    self._dump_index = 0
+                    s = self._long_index & 1
+                    t0 = time.time()
+                    while self._set_busy[s] and not self._stopping:     # (never in normal operation: publishing one long
+                        if not self._plan_cv.wait(0.05) and time.time() - t0 > timeout:   # integration takes far less than accumulating one)
+                            raise RuntimeError("CORRACC >> accumulator pair still unpublished after %.0f s" % timeout)
+                    self._set_busy[s] = True
+                    self._open_set = s
+                d.acc_set = self._long_index & 1
+                d.acc_half = self._dump_index & 1
+                d.mode = 1 if self._dump_index < 2 else 2
+                self._dump_index += 1
+                d.nhalves = min(2, self._dump_index)
+                if d.last:
+                    self._open_set = None         # (stays busy until this block's thread has published it)
+                acc = self._fused_accs[d.acc_set][d.acc_half]
+                self.fused_dumps += 1
+            self._plan.append(d)
+            self._plan_cv.notify_all()
+            return acc, d.mode
+
+    def _next_plan(self, want_seq, timeout=60.0):
+        t0 = time.time()
+        with self._plan_cv:
+            while not self._plan:
+                if not self._plan_cv.wait(0.05) and time.time() - t0 > timeout:
+                    raise RuntimeError("CORRACC >> no decision from the upstream Corr for a span that has arrived")
+            e = self._plan.popleft()
+        is_seq = isinstance(e, tuple)
+        if is_seq != want_seq:
+            raise RuntimeError("CORRACC >> decision queue out of step with the input ring (%r)" % (e,))
+        return e
+
+    # ------------------------------------------------------------------ this block's thread
     def main(self):
         cpu_affinity.set_core(self.core)
         if self.gpu != -1:
@@ -54,94 +222,99 @@ class CorrAcc(Block):
 
         self.oring.resize(self.ogulp_size)
         oseq = ospan = None
-        gate = IntegrationGate(recovery_skip=2, round_start_to_acc_len=False)
         process_time = 0
         acquire_time = reserve_time = 0
         time_tag = 1
         self.update_stats({'state': 'starting'})
-        with self.oring.begin_writing() as oring:
-            prev_time = time.time()
-            self.update_pending = True
-            for iseq in self.iring.read(guarantee=self.guarantee):
-                ihdr = json.loads(iseq.header.tostring())
-                ohdr = ihdr.copy()
-                now = ihdr['seq0']
-                step = ihdr['acc_len']                      # upstream integration length
-                ohdr['upstream_acc_len'] = step
-                upstream_start_time = now
-                self.sequence_proclog.update(ohdr)
-                if gate.recover(now):
-                    self.log.info("CORRACC >> Recovering start time set to %d. Accumulating %d samples" % (gate.start_time, gate.acc_len))
-                    self._check_compat(gate, step, upstream_start_time)
-                    ohdr['acc_len'] = gate.acc_len
-                    ohdr['seq0'] = gate.start_time
-                for ispan in iseq.read(self.igulp_size):
-                    if ispan.size < self.igulp_size:
-                        continue
-                    if self.update_pending:
-                        self.update_command_vals()
-                        gate.configure(now, self.command_vals['acc_len'], self.command_vals['start_time'])
-                        self.log.info("CORRACC >> New start time at %d. Accumulation: %d samples" % (gate.start_time, gate.acc_len))
-                        self._check_compat(gate, step, upstream_start_time)
-                        ohdr['acc_len'] = gate.acc_len
-                        ohdr['seq0'] = gate.start_time
-                    self.stats.update({'curr_sample': now})
-                    self.update_stats()
-                    if gate.acc_len == 0:                   # stop command (:257-263)
-                        self.update_stats({'state': 'stopped'})
-                        if oseq:
-                            oseq.end()
-                        oseq = None
-                        gate.running = False
-                        now += step
-                        continue
-                    if gate.try_start(now, step):
-                        if oseq:
-                            oseq.end()
-                        self.sequence_proclog.update(ohdr)
-                        oseq = oring.begin_sequence(time_tag=time_tag, header=json.dumps(ohdr), nringlet=iseq.nringlet)
-                        time_tag += 1
-                        self.log.info("CORRACC >> Start time %d reached. Accumulating to %d (upstream accumulation: %d)" % (gate.start_time, gate.last, step))
-                    if not gate.running:
-                        self.update_stats({'state': 'waiting_start_missed' if now > gate.start_time else 'waiting'})
-                        now += step
-                        continue
-                    self.update_stats({'state': 'running'})
-                    curr_time = time.time()
-                    acquire_time = curr_time - prev_time
-                    prev_time = curr_time
-                    idata = ispan.data_view('i32')
-                    if now == gate.first:
-                        curr_time = time.time()
-                        reserve_time = curr_time - prev_time
-                        prev_time = curr_time
-                        rv = self._bf.map_assign_i32(self.accdata, idata)      # "a = b"
+        try:
+            with self.oring.begin_writing() as oring:
+                prev_time = time.time()
+                # (the command values are loaded by the first gate step, whichever thread makes it: set in __init__, not
+                # here -- in fused mode the upstream Corr may already have planned dumps when this thread starts)
+                for iseq in self.iring.read(guarantee=self.guarantee):
+                    ihdr = json.loads(iseq.header.tostring())
+                    fused = bool(ihdr.get('fused_corracc'))
+                    now, step = ihdr['seq0'], ihdr['acc_len']
+                    if fused:
+                        self._next_plan(want_seq=True)
                     else:
-                        rv = self._bf.map_add_i32(self.accdata, idata)         # "a += b"
-                    if rv != self._bf.BF_STATUS_SUCCESS:
-                        raise RuntimeError("CorrAcc map returned %d: %s" % (rv, self._bf.last_error()))
-                    # the input span is recycled when the loop advances: the map must have read it (this block's
-                    # stream only: the X-engine and beamformer streams keep running)
-                    self._bf.map_sync()
-                    curr_time = time.time()
-                    process_time += curr_time - prev_time
-                    prev_time = curr_time
-                    if now == gate.last:
-                        ospan = WriteSpan(oseq.ring, self.ogulp_size, nonblocking=False)
-                        odata = ospan.data_view('i32').reshape(self.accdata.shape)
-                        copy_array(odata, self.accdata)       # (synchronous: complete before the span is committed)
-                        ospan.close()
-                        ospan = None
+                        self._begin_upstream_sequence(ihdr)
+                    self.update_stats({'fused': fused})
+                    for ispan in iseq.read(self.igulp_size):
+                        if ispan.size < self.igulp_size:
+                            continue
+                        d = self._next_plan(want_seq=False) if fused else self._decide(now, step)
+                        if fused and d.now != now:
+                            raise RuntimeError("CORRACC >> decision for sample %d, span of sample %d" % (d.now, now))
+                        now += step
+                        self.update_stats({'state': d.state})
+                        if d.kind == 'stop':
+                            if oseq:
+                                oseq.end()
+                            oseq = None
+                            continue
+                        if d.kind == 'wait':
+                            continue
+                        if d.begin_hdr is not None:
+                            if oseq:
+                                oseq.end()
+                            self.sequence_proclog.update(d.begin_hdr)
+                            oseq = oring.begin_sequence(time_tag=time_tag, header=json.dumps(d.begin_hdr), nringlet=iseq.nringlet)
+                            time_tag += 1
+                        curr_time = time.time()
+                        acquire_time = curr_time - prev_time
+                        prev_time = curr_time
+                        if d.first:
+                            curr_time = time.time()
+                            reserve_time = curr_time - prev_time
+                            prev_time = curr_time
+                        if not fused:
+                            idata = ispan.data_view('i32')
+                            if d.first:
+                                rv = self._bf.map_assign_i32(self.accdata, idata)      # "a = b"
+                            else:
+                                rv = self._bf.map_add_i32(self.accdata, idata)         # "a += b"
+                            if rv != self._bf.BF_STATUS_SUCCESS:
+                                raise RuntimeError("CorrAcc map returned %d: %s" % (rv, self._bf.last_error()))
+                            # the input span is recycled when the loop advances: the map must have read it (this block's
+                            # stream only: the X-engine and beamformer streams keep running)
+                            self._bf.map_sync()
+                        # (fused: the dump that produced this span has also accumulated it -- Corr commits a span only
+                        # after its dump has completed)
                         curr_time = time.time()
                         process_time += curr_time - prev_time
                         prev_time = curr_time
-                        self.perf_proclog.update({'acquire_time': acquire_time, 'reserve_time': reserve_time,
-                                                  'process_time': process_time})
-                        self.update_stats({'last_end_sample': now})
-                        process_time = 0
-                        gate.advance(step)
-                    now += step
-            if ospan:
-                ospan.close()
-            if oseq:
-                oseq.end()
+                        if d.last:
+                            result = self.accdata
+                            if fused:
+                                pair = self._fused_accs[d.acc_set]
+                                result = pair[0]
+                                if d.nhalves == 2:
+                                    rv = self._bf.map_add_i32(pair[0], pair[1])
+                                    if rv != self._bf.BF_STATUS_SUCCESS:
+                                        raise RuntimeError("CorrAcc map returned %d: %s" % (rv, self._bf.last_error()))
+                                    self._bf.map_sync()
+                            ospan = WriteSpan(oseq.ring, self.ogulp_size, nonblocking=False)
+                            odata = ospan.data_view('i32').reshape(result.shape)
+                            copy_array(odata, result)         # (synchronous: complete before the span is committed)
+                            ospan.close()
+                            ospan = None
+                            if fused:
+                                with self._plan_cv:
+                                    self._set_busy[d.acc_set] = False
+                                    self._plan_cv.notify_all()
+                            curr_time = time.time()
+                            process_time += curr_time - prev_time
+                            prev_time = curr_time
+                            self.perf_proclog.update({'acquire_time': acquire_time, 'reserve_time': reserve_time,
+                                                      'process_time': process_time})
+                            self.update_stats({'last_end_sample': d.now})
+                            process_time = 0
+                if ospan:
+                    ospan.close()
+                if oseq:
+                    oseq.end()
+        finally:
+            with self._plan_cv:                   # a Corr thread waiting for an accumulator pair must not hang
+                self._stopping = True
+                self._plan_cv.notify_all()

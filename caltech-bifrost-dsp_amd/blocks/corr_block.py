@@ -144,6 +144,11 @@ class Corr(Block):
             # (xengXgpuSyncLag(1)), so the GPU never idles between integrations.  `_pending` = (span, held gulps) of
             # the integration whose dump is in flight.
             streaming = in_place and hasattr(self._bf, 'xgpu_sync_lag')
+            # ... and feeds an attached CorrAcc from the dump's own epilogue (blocks/corr_acc_block.py, fused mode): the
+            # CorrAcc that reads this block's output ring registered itself there; it decides, dump by dump, which
+            # accumulator takes the dump and how (assign / add), and publishes when its long integration is complete
+            long_acc = getattr(self.oring, 'long_accumulator', None) if (streaming and hasattr(self._bf, 'bfXgpuKernelAsyncAcc')) else None
+            self.update_stats({'fused_corracc': long_acc is not None})
             self._held = []
             self._pending = None
             for iseq in self.iring.read(guarantee=self.guarantee):
@@ -192,7 +197,12 @@ class Corr(Block):
                         if oseq:
                             oseq.end()
                         self.sequence_proclog.update(ohdr)
-                        oseq = oring.begin_sequence(time_tag=time_tag, header=json.dumps(ohdr), nringlet=iseq.nringlet)
+                        if long_acc is not None:
+                            ohdr_out = dict(ohdr, fused_corracc=1)
+                            long_acc.plan_sequence(ohdr_out)
+                        else:
+                            ohdr_out = ohdr
+                        oseq = oring.begin_sequence(time_tag=time_tag, header=json.dumps(ohdr_out), nringlet=iseq.nringlet)
                         time_tag += 1
                     if not gate.running:
                         self.update_stats({'state': 'waiting'})
@@ -217,7 +227,13 @@ class Corr(Block):
                         test_out += self._test(ispan.data, ihdr['nchan'], ihdr['nstand'], ihdr['npol'])
                     if in_place:
                         self._held.append(ispan.data)      # keeps the gulp's memory alive until the dump has run
-                        rv = self._bf.bfXgpuKernelAsync(ispan.data.as_BFarray(), ospan.data.as_BFarray(), int(now == gate.last))
+                        acc = None
+                        if now == gate.last and long_acc is not None:
+                            acc, acc_mode = long_acc.plan_dump()
+                        if acc is not None:
+                            rv = self._bf.bfXgpuKernelAsyncAcc(ispan.data.as_BFarray(), ospan.data.as_BFarray(), 1, acc, acc_mode)
+                        else:
+                            rv = self._bf.bfXgpuKernelAsync(ispan.data.as_BFarray(), ospan.data.as_BFarray(), int(now == gate.last))
                         if rv == self._bf.BF_STATUS_SUCCESS and now == gate.last:
                             if streaming:
                                 prev, self._pending = self._pending, (ospan, self._held)

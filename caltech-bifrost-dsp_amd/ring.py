@@ -224,7 +224,7 @@ class Ring:
         self._gc_seq = 0           # sequences before this index hold no data any more
         self._pool = {}            # nbytes -> [free allocations] (device / pinned spaces)
         self._pool_bytes = 0
-        self._pool_lock = threading.Lock()
+        self._pool_lock = threading.RLock()     # (re-entrant: a span released by the garbage collector inside _alloc_span puts itself back)
 
     # ------------------------------------------------------------------ span memory
     def _alloc_span(self, nbytes):

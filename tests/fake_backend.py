@@ -70,6 +70,14 @@ class OracleBackend:
         self.async_calls = getattr(self, "async_calls", 0) + 1
         return self.bfXgpuKernel(in_arr, out_arr, do_dump)
 
+    def bfXgpuKernelAsyncAcc(self, in_arr, out_arr, do_dump, acc, acc_mode):
+        rv = self.bfXgpuKernelAsync(in_arr, out_arr, do_dump)
+        if do_dump:
+            self.acc_calls = getattr(self, "acc_calls", []) + [int(acc_mode)]
+            dumped = _np(out_arr, np.int32, acc.numpy().size)
+            orc.map_i32(acc.numpy().reshape(-1), dumped, add=(acc_mode == 2))
+        return rv
+
     def xgpu_sync(self):
         return 0
 

@@ -552,3 +552,80 @@ def test_corr_subsel_then_output_part_packets(golden_dir):
                 assert np.array_equal(data[v, :, 1], gim[it][:, s0, s1, p0, p1].reshape(nco, nsum).sum(1))
     with pytest.raises(NotImplementedError):
         CorrOutputPart(LOG, r2, use_cor_fmt=True)
+
+
+# ---------------------------------------------------------------------------------------------- fused CorrAcc
+def _corr_corracc(seqs, C, S, g, acc, lacc, cacc_start, fused, cacc_cmds=()):
+    """Corr -> CorrAcc on in-repo rings with the oracle backend.  fused: the dumps feed CorrAcc's accumulators themselves
+    (bfXgpuKernelAsyncAcc); classic: CorrAcc maps every span it reads."""
+    r0, r1, r2 = Ring("gpu-input"), Ring("corr-output"), Ring("corr-slow-output")
+    be = OracleBackend()
+    corr = Corr(LOG, r0, r1, ntime_gulp=g, nchan=C, npol=2, nstand=S, acc_len=acc, autostartat=0, backend=be)
+    cacc = CorrAcc(LOG, r1, r2, nchan=C, npol=2, nstand=S, acc_len=lacc, autostartat=cacc_start, backend=be)
+    assert r1.long_accumulator is cacc
+    if not fused:
+        r1.long_accumulator = None
+    for c in cacc_cmds:
+        cacc.process_command_strings(c)
+    fast, slow = Sink(r1, corr.ogulp_size), Sink(r2, cacc.ogulp_size)
+    run_blocks([corr, cacc], Source(r0, seqs), [fast, slow])
+    return corr, cacc, be, fast, slow
+
+
+@pytest.mark.parametrize("cacc_start,lacc", [(0, 12), (8, 12), (-1, 8), (4, 4), (16, 20)])
+def test_fused_corracc_equals_classic_and_oracle(cacc_start, lacc):
+    """The long integration published with the add fused into Corr's dumps equals the classic map path and N x the oracle
+    integration, for aligned starts, a start in the middle of the stream, "now" (-1), one dump per long integration and an
+    odd number (5) of dumps per long integration (the two partial accumulators hold 3 + 2 dumps)."""
+    C, S, g, acc = 2, 8, 2, 4
+    rng = np.random.default_rng(11)
+    vin = rng.integers(0, 256, (64, C, S, 2), dtype=np.uint8)
+    seqs = [(source_header(C, S, 2), vin, g * C * S * 2)]
+    out = {}
+    for fused in (True, False):
+        corr, cacc, be, fast, slow = _corr_corracc(seqs, C, S, g, acc, lacc, cacc_start, fused)
+        assert corr.stats['fused_corracc'] is fused and cacc.stats['fused'] is fused
+        (fh, _, fspans), = fast.sequences
+        assert len(fspans) == 16                                           # the fast stream is untouched
+        for k, sp in enumerate(fspans):
+            assert np.array_equal(sp.view(np.int32), orc.xgpu_correlate(vin[acc * k:acc * (k + 1)], S, C))
+        out[fused] = [(h, [sp.view(np.int32).copy() for sp in spans]) for h, _, spans in slow.sequences]
+        ndumps = getattr(be, "acc_calls", [])
+        if fused:
+            start = 0 if cacc_start == -1 else cacc_start
+            nlong = (64 - start) // lacc
+            assert len(out[True][0][1]) == nlong
+            # every dump of a started long integration went to an accumulator: assign for the first two of each, add after
+            per = lacc // acc
+            want = ([1] * min(2, per) + [2] * max(0, per - 2)) * nlong
+            assert ndumps[:len(want)] == want and cacc.fused_dumps >= len(want)
+            (h, spans), = out[True]
+            assert h['seq0'] == start and h['acc_len'] == lacc and h['upstream_acc_len'] == acc and 'fused_corracc' not in h
+            for k, sp in enumerate(spans):
+                assert np.array_equal(sp, orc.xgpu_correlate(vin[start + lacc * k:start + lacc * (k + 1)], S, C))
+        else:
+            assert ndumps == []
+    assert len(out[True]) == len(out[False])
+    for (h1, s1), (h2, s2) in zip(out[True], out[False]):
+        assert h1 == h2 and len(s1) == len(s2) and all(np.array_equal(a, b) for a, b in zip(s1, s2))
+
+
+def test_fused_corracc_follows_commands_and_new_upstream_sequences():
+    """A start-time command that arrives before the stream, a second upstream sequence (the gate recovers two long
+    integrations later, corr_acc_block.py:221-227) and the long integration cut off by the end of the first sequence:
+    fused and classic publish the same spans under the same headers."""
+    C, S, g, acc, lacc = 2, 4, 2, 4, 8
+    rng = np.random.default_rng(12)
+    d0 = rng.integers(0, 256, (28, C, S, 2), dtype=np.uint8)      # 7 dumps: starts at 8 -> one long integration [8,24), one cut off
+    d1 = rng.integers(0, 256, (80, C, S, 2), dtype=np.uint8)
+    seqs = [(source_header(C, S, 2, seq0=0), d0, g * C * S * 2), (source_header(C, S, 2, seq0=1000), d1, g * C * S * 2)]
+    res = {}
+    for fused in (True, False):
+        corr, cacc, be, fast, slow = _corr_corracc(seqs, C, S, g, acc, lacc, 0, fused, cacc_cmds=[cmd(1, start_time=8)])
+        res[fused] = [(h, tag, [sp.view(np.int32).copy() for sp in spans]) for h, tag, spans in slow.sequences]
+        assert sum(len(sp) for _, _, sp in res[fused]) >= 2
+    assert len(res[True]) == len(res[False])
+    for (h1, t1, s1), (h2, t2, s2) in zip(res[True], res[False]):
+        assert h1 == h2 and t1 == t2 and len(s1) == len(s2) and all(np.array_equal(a, b) for a, b in zip(s1, s2))
+    (h, _, spans) = res[True][0]
+    assert h['seq0'] == 8 and np.array_equal(spans[0], orc.xgpu_correlate(d0[8:16], S, C))

@@ -34,6 +34,51 @@ def test_corr_corracc_on_device_rings():
     assert h2['upstream_acc_len'] == acc and h2['acc_len'] == lacc and len(sp2) == 2
     for k, sp in enumerate(sp2):
         assert np.array_equal(sp.view(np.int32), orc.xgpu_correlate(vin[k * lacc:(k + 1) * lacc], S, C))
+    assert cacc.stats['fused'] is True and cacc.fused_dumps == 4       # accumulated by the dumps' own epilogue
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_corracc_full_size_misaligned_start(fused):
+    """BASELINE config 2 size (704 inputs, 96 channels, acc_len 2400 = 5 x 480): CorrAcc starts in the middle of the
+    stream (start_time = one upstream integration, not 0) with three dumps per long integration -- two in one partial
+    accumulator, one in the other.  Every published slow span equals 3 x the stand-alone integration, bit for bit (the
+    stream repeats one integration, whose visibilities tests/test_xcorr_gpu.py::test_config2_full_size holds to the
+    oracle), with the add fused into the dumps and with the classic map."""
+    import threading
+    from tests.gpu_util import Xgpu
+    C, S, g, acc, nrep = 96, 352, 480, 2400, 8
+    G, gulp_bytes = acc // g, g * C * S * 2
+    rng = np.random.default_rng(2024)
+    vin = rng.integers(0, 256, (acc, C, S, 2), dtype=np.uint8)
+    x = Xgpu(S, C, g, max_gulps=G)
+    ref = x.run(vin, use_async=True).astype(np.int64)
+    x.close()
+    r0, r1, r2 = Ring("gpu-input", space="cuda"), Ring("corr-output", space="cuda"), Ring("corr-slow-output", space="cuda_host")
+    r0.resize(gulp_bytes, total_span=2 * G * gulp_bytes)
+    corr = Corr(LOG, r0, r1, ntime_gulp=g, nchan=C, npol=2, nstand=S, acc_len=acc, autostartat=0, gpu=0)
+    cacc = CorrAcc(LOG, r1, r2, nchan=C, npol=2, nstand=S, acc_len=3 * acc, autostartat=acc, gpu=0)
+    if not fused:
+        r1.long_accumulator = None
+    verdicts, hdrs = [], []
+    want = (3 * ref).astype(np.int32).reshape(-1)
+
+    def slow_sink(gen=r2.read(guarantee=True)):
+        import json
+        for iseq in gen:
+            hdrs.append(json.loads(iseq.header.tostring()))
+            for ispan in iseq.read(cacc.ogulp_size):
+                if ispan.size == cacc.ogulp_size:
+                    verdicts.append(bool(np.array_equal(ispan.data.numpy().view(np.int32).reshape(-1), want)))
+
+    sink = threading.Thread(target=slow_sink, daemon=True)
+    sink.start()
+    data = np.tile(vin.reshape(-1), nrep)
+    run_blocks([corr, cacc], Source(r0, [(source_header(C, S, 2), data, gulp_bytes)], wait_readers=1), [], timeout=240)
+    sink.join(60)
+    assert not sink.is_alive()
+    assert verdicts == [True, True], verdicts                  # [2400, 9600) and [9600, 16800); the third is cut off
+    assert hdrs[0]['seq0'] == acc and hdrs[0]['acc_len'] == 3 * acc and hdrs[0]['upstream_acc_len'] == acc
+    assert cacc.stats['fused'] is fused and (cacc.fused_dumps == 7) is fused
 
 
 def test_beamform_sumbeams_on_device_rings():
