@@ -72,6 +72,8 @@ def cpu_baseline(budget_s=12.0, verify=None):
     el_np = time.time() - t1
     out = {"value": round(8 * NINPUT * units / el / 1e9, 4), "unit": "Gb/s",
            "cores": int(orc.lib().orc_num_threads()), "kind": "port",
+           "kind_detail": "the oracle: scalar C restatement + OpenMP over channels (oracle/xeng_oracle.c); bifrost's own CPU "
+                          "correlator is not in /root/reference (empty submodule), so this is a stated baseline, not the reference's",
            "cmac_per_s": units * CMAC_PER_UNIT / el,
            "sample": "%d gulps of %d samples x %d chan x %d inputs (%.1f s)" % (ngulp, NTIME_GULP, NCHAN, NINPUT, el),
            "reference_numpy_golden_loop": {"cmac_per_s": round(nsp * ncg * NINPUT * NINPUT / el_np, 1), "cores": 1,
@@ -229,6 +231,8 @@ def main():
     ap.add_argument("--lag", type=int, default=1, choices=[1, 2, 3],
                     help="streaming depth: after enqueueing integration n wait for dump n-lag (lag+1 output spans)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sustained", type=int, default=10000,
+                    help="integrations of the untimed `sustained` leg (two runs of this many; 0 = skip)")
     ap.add_argument("--no-h2d", dest="h2d", action="store_false", help="skip the PCIe-inclusive measurement")
     ap.add_argument("--no-beamform", dest="beamform", action="store_false", help="skip the config-4 beamformer leg")
     ap.add_argument("--data", default="random", choices=["random", "zeros", "0x88", "gaussian"],
@@ -277,19 +281,31 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
+    from caltech_bifrost_dsp_amd import sharding as _sh
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     if args.selftest_spawn:
         import torch
-        t = torch.tensor([1e-3 * (rank + 1)], dtype=torch.float64)
+        pin = _sh.pin_rank(local_rank, local_world)          # (no GPU here: every rank takes its share of the allowed CPUs)
+        own = 1e-3 * (rank + 1)
+        t = torch.tensor([own], dtype=torch.float64)
         if dist is not None:
             dist.barrier()
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dist.barrier()
         el = float(t.item())
+        per_rank = [round(v / args.steps * 1e3, 4) for v in _sh.gather_over_ranks(dist, own)]
+        masks = [None] * world
+        if dist is not None:
+            dist.all_gather_object(masks, pin["cpus"])
+        else:
+            masks = [pin["cpus"]]
         if rank == 0:
             units = ACC_LEN * NCHAN * args.steps * world
             print(json.dumps({"metric": "xengine_ingest_gbps_704in_96ch", "value": round(8 * NINPUT * units / el / 1e9, 2),
                               "unit": "Gb/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                              "per_rank_ms": per_rank, "per_rank_ms_min": min(per_rank), "per_rank_ms_max": max(per_rank),
+                              "rank_cpus": masks, "placement": pin["source"],
                               "vs_baseline": None, "data": "selftest (no GPU work; not a result)",
                               "config": {"workload": "selftest", "nchan_total": NCHAN * world}}))
         if dist is not None:
@@ -302,6 +318,9 @@ def main():
     gpu = 0 if args.rehearse_on_gpu0 else local_rank
     ffi.call("xengSetDevice", gpu)
     info = ffi.device_info(gpu)
+    # host placement: this rank (and every thread it starts) on the cores next to its GPU (sharding.pin_rank)
+    host_cpus = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    pin = _sh.pin_rank(local_rank, local_world, ffi.device_pci_bus_id(gpu))
     gulps_per_step = ACC_LEN // NTIME_GULP
     ffi.call("xengXgpuConfigure", NSTAND, NPOL, NCHAN, NTIME_GULP, gulps_per_step)
     ffi.call("xengXgpuInitialize", gpu)
@@ -386,6 +405,45 @@ def main():
             ffi.call("xengXgpuSync")
         ffi.call("xengXgpuGetTimes", iso_tm, iso_cn)
     ffi.call("xengXgpuSetProfiling", 0)
+    # outside the timed region: the same streaming pattern SUSTAINED -- 10 000 integrations (> 2 s) in windows of 1000, on the
+    # replay ring of the timed region and on one of 40 gulps (1.3 GB: past the 256 MB Infinity Cache, so every gulp comes
+    # from HBM whatever the last-level cache holds)
+    sustained = None
+    if rank == 0 and world == 1 and not args.sync_per_call and not args.sync_per_integration and args.sustained > 0:
+        def sustained_run(ring_ptr, ngulps, nsteps, window):
+            k, marks = 0, []
+            ffi.call("xengXgpuSync")
+            for n in range(nsteps + 1):
+                if n % window == 0:
+                    ffi.call("xengXgpuSync") if n == 0 else None
+                    marks.append(time.perf_counter())
+                if n == nsteps:
+                    break
+                out = outs[n % nout]
+                for g in range(gulps_per_step):
+                    rc = kfn(ring_ptr + (k % ngulps) * gulp_bytes, out.ptr, int(g == gulps_per_step - 1))
+                    if rc:
+                        ffi.check(kern, rc)
+                    k += 1
+                rc = L.xengXgpuSyncLag(args.lag)
+                if rc:
+                    ffi.check("xengXgpuSyncLag", rc)
+            ffi.call("xengXgpuSync")
+            total = time.perf_counter() - marks[0]
+            w = sorted((b - a) / window * 1e3 for a, b in zip(marks[:-1], marks[1:]))
+            return {"integrations": nsteps, "seconds": round(total, 3), "ms_per_step": round(total / nsteps * 1e3, 4),
+                    "window": window, "window_ms_min": round(w[0], 4), "window_ms_median": round(w[len(w) // 2], 4),
+                    "window_ms_max": round(w[-1], 4), "gbps": round(8 * NINPUT * units_per_step_c * nsteps / total / 1e9, 1),
+                    "ring_gulps": ngulps, "ring_mb": round(ngulps * gulp_bytes / 1e6, 1)}
+        sustained = {"replay_ring": sustained_run(ring.ptr, args.ring_gulps, args.sustained, 1000)}
+        big = ffi.DeviceBuffer(40 * gulp_bytes)
+        for g in range(40):                       # distinct addresses are what matters here: device copies of the ring's gulps
+            ffi.call("xengMemcpy", big.ptr + g * gulp_bytes, ring.ptr + (g % args.ring_gulps) * gulp_bytes, gulp_bytes)
+        sustained["ring_40_gulps_past_infinity_cache"] = sustained_run(big.ptr, 40, args.sustained, 1000)
+        big.free()
+        sustained["note"] = ("outside the driver's timed region: the timed pattern (enqueue integration n, wait for dump n-%d) held for %d "
+                             "integrations; per-1000-integration windows; the second run reads a 1.3 GB ring, larger than the "
+                             "256 MB Infinity Cache" % (args.lag, args.sustained))
     # outside the timed region: PCIe-inclusive regime (SURVEY 8d "two reporting regimes", ii): gulps start in
     # pinned host memory, are copied H2D (xengMemcpy, the Copy block's copy_array) and then correlated
     verify = None
@@ -673,12 +731,17 @@ def main():
                                    "note": "ntime_blocks = %d: one launch per gulp, power sums in the epilogue (the composed path is "
                                            "run_us + integrate_us above)" % (NT_B // NS)}
         ffi.call("xengBeamformDestroy")
+    per_rank_ms = [round(v / args.steps * 1e3, 4) for v in _sh.gather_over_ranks(dist, el)]
+    placements = [None] * world
     if dist is not None:
         import torch
+        dist.all_gather_object(placements, {"numa_node": pin["numa_node"], "ncpus": len(pin["cpus"]), "source": pin["source"]})
         t = torch.tensor([el], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
         dist.barrier()
+    else:
+        placements = [{"numa_node": pin["numa_node"], "ncpus": len(pin["cpus"]), "source": pin["source"]}]
 
     units_per_step = ACC_LEN * NCHAN
     total_units = units_per_step * args.steps * world
@@ -720,6 +783,9 @@ def main():
                    "nchan_total": NCHAN * world, "sharding": "channels, %d per GPU, no collective" % NCHAN,
                    "call_mode": call_mode,
                    "input": "device-resident replay ring, %d gulps" % args.ring_gulps},
+        "sustained": sustained,
+        "per_rank_ms": per_rank_ms, "per_rank_ms_min": min(per_rank_ms), "per_rank_ms_max": max(per_rank_ms),
+        "rank_placement": placements,
         "cmac_per_s": cmacs,
         "mfma_peak_frac_end_to_end": round(8 * cmacs / (PEAK_INT8_OPS * world), 4),
         "design_rate_x": round(gbps / world / 12.94, 1),
@@ -811,6 +877,8 @@ def main():
                                     "note": "ntime_gulp = acc_len = 2400: one enqueue-only call per integration, same streaming pattern"}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
+            if host_cpus:
+                os.sched_setaffinity(0, host_cpus)      # the CPU baseline runs on all host cores, not on the GPU's share
             res["cpu_baseline"] = cpu_baseline(verify=verify)
             if verify is not None and beam is not None:
                 beam["full_xengine_concurrent"]["verified"] = res["cpu_baseline"].pop("config5_check")

@@ -59,6 +59,14 @@ class HipBackend:
         `acc` -- CorrAcc's "a = b" / "a += b" (corr_acc_block.py:304-306) done by the contraction's epilogue."""
         return self._lib.xengXgpuKernelAsyncAcc(in_arr.contents.data, out_arr.contents.data, int(do_dump), acc.ptr, int(acc_mode))
 
+    def xgpu_fused_acc_supported(self):
+        """True when the live X-engine context runs the default (fused corner turn) contraction kernel, the one whose
+        epilogue can feed a long accumulator; other gulp shapes take the two-pass path and CorrAcc keeps its map."""
+        import ctypes
+        fused, fp6 = ctypes.c_int(), ctypes.c_int()
+        rc = self._lib.xengXgpuGetPath(ctypes.byref(fused), ctypes.byref(fp6))
+        return rc == ffi.STATUS_SUCCESS and fused.value == 1 and fp6.value == 0
+
     def xgpu_sync(self):
         return self._lib.xengXgpuSync()
 

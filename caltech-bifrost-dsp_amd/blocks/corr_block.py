@@ -147,7 +147,8 @@ class Corr(Block):
             # ... and feeds an attached CorrAcc from the dump's own epilogue (blocks/corr_acc_block.py, fused mode): the
             # CorrAcc that reads this block's output ring registered itself there; it decides, dump by dump, which
             # accumulator takes the dump and how (assign / add), and publishes when its long integration is complete
-            long_acc = getattr(self.oring, 'long_accumulator', None) if (streaming and hasattr(self._bf, 'bfXgpuKernelAsyncAcc')) else None
+            long_acc = getattr(self.oring, 'long_accumulator', None) if (streaming and hasattr(self._bf, 'bfXgpuKernelAsyncAcc')
+                                                                         and self._bf.xgpu_fused_acc_supported()) else None
             self.update_stats({'fused_corracc': long_acc is not None})
             self._held = []
             self._pending = None

@@ -141,6 +141,11 @@ int xengGetDeviceInfo(int gpu, int* num_cu, int* clock_khz, size_t* total_mem, c
     }
     return XENG_STATUS_SUCCESS;
 }
+int xengGetDevicePciBusId(int gpu, char* bus_id, int len) {
+    if (!bus_id || len < 16) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "bus id buffer of at least 16 bytes needed");
+    XENG_HIP(hipDeviceGetPCIBusId(bus_id, len, gpu));
+    return XENG_STATUS_SUCCESS;
+}
 int xengMalloc(void** ptr, size_t nbytes, int space) {
     if (!ptr) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "null ptr");
     if (space == XENG_SPACE_CUDA) {

@@ -38,7 +38,7 @@ _pi = ctypes.POINTER(ctypes.c_int)
 _pa = ctypes.POINTER(XENGarray)
 SYMBOLS = {
     "xengGetDeviceCount": [_pi], "xengSetDevice": [_i], "xengGetDevice": [_pi], "xengDeviceSynchronize": [],
-    "xengGetDeviceInfo": [_i, _pi, _pi, ctypes.POINTER(_sz), ctypes.c_char_p, _i],
+    "xengGetDeviceInfo": [_i, _pi, _pi, ctypes.POINTER(_sz), ctypes.c_char_p, _i], "xengGetDevicePciBusId": [_i, ctypes.c_char_p, _i],
     "xengMalloc": [ctypes.POINTER(_vp), _sz, _i], "xengFree": [_vp, _i], "xengMemcpy": [_vp, _vp, _sz],
     "xengMemcpyAsync": [_vp, _vp, _sz], "xengMemset": [_vp, _i, _sz], "xengStreamSynchronize": [],
     "xengXgpuConfigure": [_i, _i, _i, _i, _i], "xengXgpuInitialize": [_i], "xengXgpuDestroy": [],
@@ -142,6 +142,12 @@ def device_count():
     n = ctypes.c_int(0)
     call("xengGetDeviceCount", ctypes.byref(n))
     return n.value
+
+
+def device_pci_bus_id(gpu=0):
+    buf = ctypes.create_string_buffer(32)
+    call("xengGetDevicePciBusId", gpu, buf, 32)
+    return buf.value.decode().lower()
 
 
 def device_info(gpu=0):

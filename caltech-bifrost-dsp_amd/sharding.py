@@ -74,31 +74,112 @@ def free_port():
     return port
 
 
-def spawn_ranks(nranks, argv, env_extra=None, timeout=None):
+def parse_cpulist(text):
+    """'0-3,8,10-11' -> {0,1,2,3,8,10,11} (the format of sysfs cpulist files)."""
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_local_cpus(pci_bus_id, sysfs_root="/sys/bus/pci/devices"):
+    """(numa_node, cpus next to the device) from sysfs, or (None, None) when the platform does not say
+    (no such device directory, numa_node -1, empty list: containers and single-node hosts)."""
+    d = os.path.join(sysfs_root, pci_bus_id or "")
+    try:
+        with open(os.path.join(d, "numa_node")) as fh:
+            node = int(fh.read().strip())
+        with open(os.path.join(d, "local_cpulist")) as fh:
+            cpus = parse_cpulist(fh.read())
+    except (OSError, ValueError):
+        return None, None
+    if node < 0 or not cpus:
+        return None, None
+    return node, cpus
+
+
+def rank_cpu_share(local_rank, local_world, allowed):
+    """Fallback placement: the `local_rank`-th of `local_world` contiguous, disjoint slices of the allowed CPUs."""
+    cpus = sorted(allowed)
+    n = len(cpus)
+    if local_world <= 1 or n < local_world:
+        return set(cpus)
+    lo, hi = (local_rank * n) // local_world, ((local_rank + 1) * n) // local_world
+    return set(cpus[lo:hi])
+
+
+def pin_rank(local_rank, local_world, pci_bus_id=None, sysfs_root="/sys/bus/pci/devices"):
+    """Pin this process (and the block threads it starts) to the host cores next to its GPU -- the reference pins every
+    block thread to a core of the GPU's socket (corr_block.py:336-338, lwa352-pipeline.py `--cores`).  The cores come from
+    the device's sysfs entry (numa_node / local_cpulist); where the platform has none, every rank takes its own contiguous
+    share of the allowed CPUs so that ranks do not migrate over each other.  Returns what was done."""
+    if not hasattr(os, "sched_setaffinity"):
+        return {"source": "unsupported", "cpus": [], "numa_node": None}
+    allowed = os.sched_getaffinity(0)
+    node, cpus = gpu_local_cpus(pci_bus_id, sysfs_root) if pci_bus_id else (None, None)
+    source = "sysfs"
+    if cpus:
+        cpus &= allowed
+    if not cpus:
+        node, cpus, source = None, rank_cpu_share(local_rank, local_world, allowed), "share"
+    try:
+        os.sched_setaffinity(0, cpus)
+    except OSError:
+        return {"source": "failed", "cpus": sorted(allowed), "numa_node": node}
+    return {"source": source, "cpus": sorted(os.sched_getaffinity(0)), "numa_node": node, "pci_bus_id": pci_bus_id}
+
+
+def gather_over_ranks(dist, value):
+    """Every rank's scalar, in rank order, on every rank ([value] without a process group)."""
+    if dist is None:
+        return [float(value)]
+    import torch
+    t = torch.tensor([float(value)], dtype=torch.float64)
+    out = [torch.zeros(1, dtype=torch.float64) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(x.item()) for x in out]
+
+
+def spawn_ranks(nranks, argv, env_extra=None, timeout=1800):
     """Run `python argv...` as `nranks` fresh child processes, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_ADDR / MASTER_PORT set as torch.distributed.run sets them), the way the reference starts one
     pipeline process per channel block (lwa352-start-pipeline.sh:1-8).  The caller must not have touched the
     GPU: the children are new processes (no fork of a HIP context, no exec of a process that holds one).
+    Every rank pins itself to its GPU's cores (pin_rank).  stderr of every rank goes to a temporary file (a pipe
+    that nobody drains would block a chatty rank, and rank 0 with it at the next barrier).
     Returns (exit code, stdout of rank 0, list of per-rank stderr tails); rank 0 prints the job's result."""
+    import tempfile
+    import time
     port = free_port()
-    procs = []
+    procs, errfiles = [], []
     for r in range(nranks):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks), LOCAL_WORLD_SIZE=str(nranks),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.update(env_extra or {})
+        ef = tempfile.TemporaryFile(mode="w+")
+        errfiles.append(ef)
         procs.append(subprocess.Popen([sys.executable] + list(argv), env=env, text=True,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=subprocess.PIPE))
-    rc, out0, errs = 0, "", []
-    for r, pr in enumerate(procs):
-        try:
-            o, e = pr.communicate(timeout=timeout)
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            o, e = pr.communicate()
-            rc = rc or 124
-        if r == 0:
-            out0 = o or ""
-        errs.append((e or "")[-2000:])
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=ef))
+    rc, out0 = 0, ""
+    deadline = None if timeout is None else time.time() + timeout
+    try:
+        out0 = procs[0].communicate(timeout=timeout)[0] or ""       # (the only pipe: drained while waiting)
+        for pr in procs[1:]:
+            pr.wait(timeout=None if deadline is None else max(1.0, deadline - time.time()))
+    except subprocess.TimeoutExpired:
+        rc = 124
+        for q in procs:
+            q.kill()
+        out0 = out0 or (procs[0].communicate()[0] or "")
+        for q in procs:
+            q.wait()
+    errs = []
+    for pr, ef in zip(procs, errfiles):
+        ef.seek(0)
+        errs.append(ef.read()[-2000:])
+        ef.close()
         rc = rc or pr.returncode
     return rc, out0, errs

@@ -72,6 +72,9 @@ int xengSetDevice(int gpu);
 int xengGetDevice(int *gpu);
 int xengDeviceSynchronize(void);
 int xengGetDeviceInfo(int gpu, int *num_cu, int *clock_khz, size_t *total_mem, char *name, int name_len);
+/* "dddd:bb:dd.f" of a device: /sys/bus/pci/devices/<id>/{numa_node,local_cpulist} name the host cores next to it (the
+ * reference pins every block thread, corr_block.py:336; sharding.pin_rank pins a rank to its GPU's NUMA node) */
+int xengGetDevicePciBusId(int gpu, char *bus_id, int len);
 int xengMalloc(void **ptr, size_t nbytes, int space);          /* XENG_SPACE_CUDA or XENG_SPACE_CUDA_HOST */
 int xengFree(void *ptr, int space);
 int xengMemcpy(void *dst, const void *src, size_t nbytes);     /* any direction, synchronous on return */

@@ -5,8 +5,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$1
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/streaming -- python3 $R/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof_streaming.json 2> $OUT/streaming.err
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sync -- python3 $R/bench.py --no-cpu-baseline --no-h2d --no-beamform --sync-per-integration --steps 500 --warmup 50 --prewarm 300 > $OUT/bench_under_rocprof_sync_per_integration.json 2> $OUT/sync.err
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/streaming -- python3 $R/bench.py --no-cpu-baseline --sustained 0 > $OUT/bench_under_rocprof_streaming.json 2> $OUT/streaming.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sync -- python3 $R/bench.py --no-cpu-baseline --no-h2d --no-beamform --sustained 0 --sync-per-integration --steps 500 --warmup 50 --prewarm 300 > $OUT/bench_under_rocprof_sync_per_integration.json 2> $OUT/sync.err
 cp $OUT/streaming/*/*kernel_stats.csv $OUT/kernel_stats_streaming_all_legs.csv
 cp $OUT/sync/*/*kernel_stats.csv $OUT/kernel_stats_sync_per_integration.csv
 rm -rf $OUT/streaming $OUT/sync

@@ -13,6 +13,6 @@ for set in \
   "FETCH_SIZE" \
   "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  timeout -k 10 240 rocprofv3 --pmc $set --output-format csv -d $OUT/pass$i -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline "$@" > $OUT/pass$i.log 2>&1 || echo "pass $i failed" >> $OUT/fail.log
+  timeout -k 10 240 rocprofv3 --pmc $set --output-format csv -d $OUT/pass$i -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --sustained 0 "$@" > $OUT/pass$i.log 2>&1 || echo "pass $i failed" >> $OUT/fail.log
 done
 python3 $R/profiles/pmc_summarize.py "$OUT"

@@ -89,9 +89,14 @@ def soak(N=1500, packets=None, log=print):
         acc_gulp = ffi.DeviceBuffer(gulp_bytes)
         ref_gulp = np.ascontiguousarray(expect, dtype=np.uint8).view(np.uint32)
 
+    import ctypes
+    _fused, _fp6 = ctypes.c_int(), ctypes.c_int()
+    ffi.call("xengXgpuGetPath", ctypes.byref(_fused), ctypes.byref(_fp6))
+    can_fuse = _fused.value == 1 and _fp6.value == 0     # (the two-pass X-engine, XENG_RAW=0, has no fused long accumulation)
+
     def integration(out, acc=None, mode=0):
         for g in range(G):
-            if acc is None:
+            if acc is None or not can_fuse:
                 ffi.check("kernel", L.xengXgpuKernelAsync(ring.ptr + g * gulp_bytes, out.ptr, int(g == G - 1)))
             else:       # CorrAcc's add fused into the dump
                 ffi.check("kernel", L.xengXgpuKernelAsyncAcc(ring.ptr + g * gulp_bytes, out.ptr, int(g == G - 1), acc.ptr, mode))
@@ -150,9 +155,10 @@ def soak(N=1500, packets=None, log=print):
     el = time.perf_counter() - t0
     log("phase 1: %d concurrent rounds in %.2f s (%.3f ms each)" % (N, el, el / N * 1e3))
     report("visibility dumps", acc_vis, ref_vis, N)
-    ffi.check("map", L.xengMapAddI32(acc_fused[0].ptr, acc_fused[1].ptr, 2 * matlen))
-    ffi.call("xengMapSync")
-    report("long accumulation in the dumps", acc_fused[0], ref_vis, N)
+    if can_fuse:
+        ffi.check("map", L.xengMapAddI32(acc_fused[0].ptr, acc_fused[1].ptr, 2 * matlen))
+        ffi.call("xengMapSync")
+        report("long accumulation in the dumps", acc_fused[0], ref_vis, N)
     report("voltage beams", acc_beam, ref_beam, N)
     report("power sums (Integrate)", acc_pow, ref_pow, N)
     report("sub-selections", acc_sub, ref_sub, nsubsel)

@@ -78,6 +78,9 @@ class OracleBackend:
             orc.map_i32(acc.numpy().reshape(-1), dumped, add=(acc_mode == 2))
         return rv
 
+    def xgpu_fused_acc_supported(self):
+        return True
+
     def xgpu_sync(self):
         return 0
 

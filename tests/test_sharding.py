@@ -77,6 +77,13 @@ def test_bench_gpus_n_spawns_n_ranks():
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["config"]["nchan_total"] == 192
     assert abs(res["ms_per_step"] - 0.2) < 1e-9          # max over ranks = rank 1's 2 ms over 10 steps
+    # every rank's own time travels in the line, and every rank was pinned to its own share of the host's cores
+    assert res["per_rank_ms"] == [0.1, 0.2] and res["per_rank_ms_min"] == 0.1 and res["per_rank_ms_max"] == 0.2
+    allowed = sorted(os.sched_getaffinity(0))
+    m0, m1 = res["rank_cpus"]
+    if len(allowed) >= 2:
+        assert m0 and m1 and not (set(m0) & set(m1)) and sorted(m0 + m1) == allowed and res["placement"] == "share"
+        assert max(m0) < min(m1)                         # contiguous slices in rank order
     # the driver's launch line gives the same answer
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "1",
@@ -89,3 +96,36 @@ def test_bench_gpus_n_spawns_n_ranks():
     r3 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-spawn"], cwd=ROOT,
                         env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=120)
     assert r3.returncode != 0
+
+
+def test_pin_rank_follows_sysfs_and_falls_back(tmp_path):
+    """pin_rank takes the cores sysfs names for the GPU's PCI device (numa_node / local_cpulist) and, where the platform
+    says nothing (numa_node -1, no such device), the rank's own share of the allowed CPUs.  Runs in a child process: the
+    affinity mask of the test runner is left alone."""
+    allowed = sorted(os.sched_getaffinity(0))
+    dev = tmp_path / "0000:c1:00.0"
+    dev.mkdir()
+    near = allowed[-2:] if len(allowed) >= 2 else allowed
+    (dev / "numa_node").write_text("1\n")
+    (dev / "local_cpulist").write_text(",".join(str(c) for c in near) + "\n")
+    bad = tmp_path / "0000:05:00.0"
+    bad.mkdir()
+    (bad / "numa_node").write_text("-1\n")
+    (bad / "local_cpulist").write_text("\n")
+    code = ("import json, sys; sys.path.insert(0, %r); import caltech_bifrost_dsp_amd\n"
+            "from caltech_bifrost_dsp_amd import sharding\n"
+            "print(json.dumps(sharding.pin_rank(int(sys.argv[1]), 4, sys.argv[2] or None, %r)))" % (ROOT, str(tmp_path)))
+
+    def run(local_rank, bus):
+        r = subprocess.run([sys.executable, "-c", code, str(local_rank), bus], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    a = run(0, "0000:c1:00.0")
+    assert a["source"] == "sysfs" and a["numa_node"] == 1 and a["cpus"] == near
+    for bus in ("0000:05:00.0", "0000:ff:00.0", ""):
+        b = run(1, bus)
+        assert b["source"] == "share" and b["numa_node"] is None
+        assert set(b["cpus"]) == sharding.rank_cpu_share(1, 4, set(allowed))
+    shares = [sharding.rank_cpu_share(r, 4, set(range(16))) for r in range(4)]
+    assert shares == [set(range(0, 4)), set(range(4, 8)), set(range(8, 12)), set(range(12, 16))]
+    assert sharding.parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}

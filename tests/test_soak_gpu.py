@@ -52,7 +52,7 @@ def _soak_once(rounds):
     lines = []
     res = sk.soak(N=rounds, packets=(slab, len(pk), len(pk[0]), seq0, vin.reshape(-1)), log=lines.append)
     print("\n".join(lines))
-    assert len(res) >= 10
+    assert len(res) >= (9 if os.environ.get("XENG_RAW") == "0" else 10)      # (the two-pass X-engine has no fused long accumulation)
     for name, n, bad in res:
         assert n > 0 and bad == 0, "%s: %d differing words / drops over %d results\n%s" % (name, bad, n, "\n".join(lines))
 
