@@ -38,6 +38,16 @@ class HipBackend:
         """The beamformer's stream: Beamform / BeamformSumBeams (beamform_block.py:450, beamform_sum_beams_block.py:247)."""
         ffi.call("xengBeamformSync")
 
+    def beam_mark(self):
+        """Ticket for everything enqueued on the beamformer's stream so far (beam_wait waits for it)."""
+        import ctypes
+        t = ctypes.c_ulonglong()
+        ffi.call("xengBeamformMark", ctypes.byref(t))
+        return t.value
+
+    def beam_wait(self, ticket):
+        ffi.call("xengBeamformWait", ticket)
+
     # ---- X-engine (corr_block.py:253,331,445)
     def xgpu_configure(self, nstand, npol, nchan, ntime_gulp, max_gulps=0):
         """xGPU's compile-time NSTATION/NFREQUENCY/NTIME (install_xgpu.sh:5) are runtime here."""

@@ -10,6 +10,7 @@ libxeng's fused nibble-decode + fp32-MFMA beamformer (csrc/beamform_kernels.h).
 out[c, b, t] = sum_i gains[c, b, i] * x[t, c, i], cf32 [nchan, nbeam, ntime_gulp]
 (beamformer_test.py:76-84).
 """
+import collections
 import json
 import time
 
@@ -22,6 +23,8 @@ from .block_base import Block, COMMAND_INVALID, COMMAND_OK
 
 
 class Beamform(Block):
+    STREAM_DEPTH = 4        # gulps whose kernels may be in flight behind the one being enqueued (streaming mode)
+
     def __init__(self, log, iring, oring, nchan=256, nbeam=1, ninput=352 * 2, ntime_gulp=2500, ntime_sum=None,
                  guarantee=True, core=-1, gpu=-1, etcd_client=None, backend=None):
         super(Beamform, self).__init__(log, iring, oring, guarantee, core, etcd_client=etcd_client)
@@ -119,6 +122,20 @@ class Beamform(Block):
         igulp_size = self.ntime_gulp * self.nchan * self.ninput           # 4+4 bit
         ogulp_size = self.ntime_blocks * self.nchan * self.nbeam * 8      # complex64
         self.oring.resize(ogulp_size)
+        # Streaming (in-repo rings, which keep a span's memory alive while it is referenced): the kernels of up to
+        # STREAM_DEPTH gulps are in flight; a gulp's output span is committed, and its input released, when ITS kernels
+        # have completed (beam_mark / beam_wait tickets) -- the reference, and the path taken on a circular bifrost ring,
+        # waits for the stream after every gulp (beamform_block.py:450), which leaves the GPU idle between gulps and, beside
+        # the X-engine's persistent kernel, costs one launch boundary of that kernel per gulp.
+        streaming = (getattr(self.iring, 'span_memory_outlives_release', False) and getattr(self.oring, 'span_memory_outlives_release', False)
+                     and hasattr(self._bf, 'beam_mark'))
+        pending = collections.deque()           # (ticket, output span, input data kept alive)
+
+        def retire(keep):
+            while len(pending) > keep:
+                ticket, osp, _ = pending.popleft()
+                self._bf.beam_wait(ticket)
+                osp.close()
         with self.oring.begin_writing() as oring:
             for iseq in self.iring.read(guarantee=self.guarantee):
                 # frequencies may have changed: rebuild and re-upload coefficients on every sequence
@@ -159,13 +176,15 @@ class Beamform(Block):
                             self.stats['last_cmd_proc_time'] = time.time()
                             self.release_control_lock()
                         if copy_pending:
+                            retire(0)           # (kernels in flight may still read the device copy of the weights)
                             self.gains_gpu[...] = self.gains_cpu
                             self._gains_version += 1
                             copy_pending = False
                         curr_time = time.time()
                         acquire_time = curr_time - prev_time
                         prev_time = curr_time
-                        with oseq.reserve(ogulp_size) as ospan:
+                        ospan = oseq.reserve(ogulp_size)
+                        try:
                             curr_time = time.time()
                             reserve_time = curr_time - prev_time
                             prev_time = curr_time
@@ -175,7 +194,15 @@ class Beamform(Block):
                                                         version=self._gains_version)
                             if rv != self._bf.BF_STATUS_SUCCESS:
                                 raise RuntimeError("bfBeamformRun returned %d: %s" % (rv, self._bf.last_error()))
-                            self._bf.beam_sync()              # BFSync() of beamform_block.py:450, this block's stream only
+                            if streaming:
+                                pending.append((self._bf.beam_mark(), ospan, ispan.data))
+                                ospan = None
+                                retire(self.STREAM_DEPTH)
+                            else:
+                                self._bf.beam_sync()          # BFSync() of beamform_block.py:450, this block's stream only
+                        finally:
+                            if ospan is not None:
+                                ospan.close()
                         this_gulp_time += self.ntime_gulp
                         curr_time = time.time()
                         process_time = curr_time - prev_time
@@ -183,3 +210,4 @@ class Beamform(Block):
                         self.perf_proclog.update({'acquire_time': acquire_time, 'reserve_time': reserve_time,
                                                   'process_time': process_time,
                                                   'gbps': 8 * igulp_size / max(process_time, 1e-9) / 1e9})
+                    retire(0)                   # the sequence ends: every gulp in flight is committed first

@@ -6,6 +6,7 @@ samples it emits [XX, YY, Re(XY*), Im(XY*)] per channel, f32 [nbeam/2, ntime/nti
 (:220-222; math beamformer_sum_test.py:64-77).  The beamformer context is the process-global
 one the Beamform block created (:186-187): this block does not initialise it.
 """
+import collections
 import json
 import time
 
@@ -18,6 +19,8 @@ from .block_base import Block
 
 
 class BeamformSumBeams(Block):
+    STREAM_DEPTH = 4        # gulps whose kernel may be in flight behind the one being enqueued (streaming mode)
+
     def __init__(self, log, iring, oring, nchan=256,
                  ntime_gulp=2500, ntime_sum=24, guarantee=True, core=-1, gpu=-1,
                  etcd_client=None, backend=None):
@@ -38,6 +41,18 @@ class BeamformSumBeams(Block):
             self._bf.set_device(self.gpu)
         self.bind_proclog.update({'ncore': 1, 'core0': cpu_affinity.get_core(), 'ngpu': 1,
                                   'gpu0': self._bf.get_device()})
+        # Streaming (in-repo rings): up to STREAM_DEPTH gulps in flight; the kernel writes the power sums straight into the
+        # output span (pinned host memory in the pipeline, lwa352-pipeline.py:155 -- device-visible), and the span is committed
+        # when that kernel has completed.  On a bifrost ring: the reference's Integrate -> wait -> copy (:243-250).
+        streaming = (getattr(self.iring, 'span_memory_outlives_release', False) and getattr(self.oring, 'span_memory_outlives_release', False)
+                     and hasattr(self._bf, 'beam_mark') and self.oring.space in ('cuda', 'cuda_host'))
+        pending = collections.deque()
+
+        def retire(keep):
+            while len(pending) > keep:
+                ticket, osp, _ = pending.popleft()
+                self._bf.beam_wait(ticket)
+                osp.close()
         with self.oring.begin_writing() as oring:
             for iseq in self.iring.read(guarantee=self.guarantee):
                 ihdr = json.loads(iseq.header.tostring())
@@ -64,20 +79,31 @@ class BeamformSumBeams(Block):
                         curr_time = time.time()
                         acquire_time = curr_time - prev_time
                         prev_time = curr_time
-                        with oseq.reserve(ogulp_size) as ospan:
+                        ospan = oseq.reserve(ogulp_size)
+                        try:
                             curr_time = time.time()
                             reserve_time = curr_time - prev_time
                             prev_time = curr_time
                             idata = ispan.data_view(np.float32)
                             odata = ospan.data_view(np.float32).reshape(self.bf_output.shape)
-                            rv = self._bf.bfBeamformIntegrate(idata.as_BFarray(), self.bf_output.as_BFarray(), self.ntime_sum)
+                            target = odata if streaming else self.bf_output
+                            rv = self._bf.bfBeamformIntegrate(idata.as_BFarray(), target.as_BFarray(), self.ntime_sum)
                             if rv != self._bf.BF_STATUS_SUCCESS:
                                 raise RuntimeError("bfBeamformIntegrate returned %d: %s" % (rv, self._bf.last_error()))
-                            self._bf.beam_sync()
-                            odata[...] = self.bf_output           # (synchronous copy)
+                            if streaming:
+                                pending.append((self._bf.beam_mark(), ospan, ispan.data))
+                                ospan = None
+                                retire(self.STREAM_DEPTH)
+                            else:
+                                self._bf.beam_sync()
+                                odata[...] = self.bf_output       # (synchronous copy)
+                        finally:
+                            if ospan is not None:
+                                ospan.close()
                         curr_time = time.time()
                         process_time = curr_time - prev_time
                         prev_time = curr_time
                         self.perf_proclog.update({'acquire_time': acquire_time, 'reserve_time': reserve_time,
                                                   'process_time': process_time,
                                                   'gbps': 8 * igulp_size / max(process_time, 1e-9) / 1e9})
+                    retire(0)

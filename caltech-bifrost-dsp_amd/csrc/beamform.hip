@@ -40,6 +40,10 @@ struct BeamContext {
     unsigned long long* stamps = nullptr;   // diagnostic (XENG_BEAM_STAMPS=1): per wave {entry, first chunk, loop end, exit}
     int nchunk_i8 = 0;
     hipStream_t stream = nullptr;
+    // xengBeamformMark / Wait: completion tickets on the beam stream (a ring of events; ticket n -> marks[n % NMARK])
+    static constexpr int NMARK = 64;
+    hipEvent_t marks[NMARK] = {};
+    unsigned long long nmarks = 0;
     EventTimer timer;
 };
 static std::mutex g_bmu;
@@ -62,6 +66,8 @@ static int beam_destroy_locked() {
     if (g_b.out_R) (void)hipFree(g_b.out_R);
     if (g_b.any_host) (void)hipHostFree(g_b.any_host);
     if (g_b.ev_route) (void)hipEventDestroy(g_b.ev_route);
+    for (int k = 0; k < BeamContext::NMARK; k++)
+        if (g_b.marks[k]) (void)hipEventDestroy(g_b.marks[k]);
     if (g_b.stamps) (void)hipFree(g_b.stamps);
     g_b.timer.destroy();
     g_b = BeamContext();
@@ -107,6 +113,14 @@ static int run_locked(const void* in, float* out, const void* w, long long versi
             x.w_cached = w;
             x.w_version = version;
         } else if (!x.route_known && hipEventQuery(x.ev_route) == hipSuccess) {
+            x.route_known = true;
+            x.need_bf16 = *x.any_host != 0;
+        }
+        if (pow_out && !x.route_known) {
+            // Integrated-power mode: which path forms the power sums (the fused epilogue, or Run -> Integrate) must not
+            // depend on how far the GPU has got -- the two sum in different orders, so the last bits would differ from
+            // call to call.  One wait per weight upload, in this mode only: the routing answer decides, not the clock.
+            XENG_HIP(hipEventSynchronize(x.ev_route));
             x.route_known = true;
             x.need_bf16 = *x.any_host != 0;
         }
@@ -278,6 +292,39 @@ int xengBeamformSync(void) {
     XENG_HIP(hipSetDevice(x.gpu));
     XENG_HIP(hipStreamSynchronize(x.stream));
     x.timer.drain();
+    return XENG_STATUS_SUCCESS;
+}
+
+// Completion tickets, so that a block can keep several gulps in flight and commit each output span when ITS kernels are
+// done (the Beamform and BeamformSumBeams blocks share this stream; xengBeamformSync waits for everything on it).
+int xengBeamformMark(unsigned long long* ticket) {
+    std::lock_guard<std::mutex> lk(g_bmu);
+    BeamContext& x = g_b;
+    if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "Beamform: not initialized");
+    if (!ticket) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Mark: null ticket");
+    XENG_HIP(hipSetDevice(x.gpu));
+    hipEvent_t& ev = x.marks[x.nmarks % BeamContext::NMARK];
+    if (!ev) XENG_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    XENG_HIP(hipEventRecord(ev, x.stream));
+    *ticket = ++x.nmarks;
+    return XENG_STATUS_SUCCESS;
+}
+
+int xengBeamformWait(unsigned long long ticket) {
+    hipEvent_t ev = nullptr;
+    int gpu = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_bmu);
+        BeamContext& x = g_b;
+        if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "Beamform: not initialized");
+        if (ticket == 0 || ticket > x.nmarks) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Wait: unknown ticket %llu", ticket);
+        gpu = x.gpu;
+        // a ticket whose event slot has been re-recorded is NMARK marks old: wait for the newer record of that slot, which
+        // is later on the same stream
+        ev = x.marks[(ticket - 1) % BeamContext::NMARK];
+    }
+    XENG_HIP(hipSetDevice(gpu));
+    XENG_HIP(hipEventSynchronize(ev));          // (outside the lock: the other block keeps enqueueing)
     return XENG_STATUS_SUCCESS;
 }
 

@@ -10,6 +10,8 @@
 //   u64 seq | u32 sync_time (magic) | u16 npol | u16 npol_tot | u16 nchan | u16 nchan_tot |
 //   u32 chan_block_id | u32 chan0 | u32 pol0 ; payload u8[nchan][npol] (4+4 bit, npol = stands*2 in the packet)
 // Destination of payload row c: gulp[seq - seq0][chan0 - chan0_pipeline + c][pol0 .. pol0 + npol).
+#include <chrono>
+#include <cstring>
 #include <mutex>
 
 #include "xeng_common.h"
@@ -29,7 +31,9 @@ __global__ __launch_bounds__(256) void snap2_unpack_kernel(const uint8_t* __rest
                                                            int chan0_pipe, int nchan_tot, int npol_tot, int payload_max,
                                                            int* __restrict__ counter,
                                                            unsigned long long* __restrict__ row_cover,
-                                                           unsigned int* __restrict__ row_geom) {
+                                                           unsigned int* __restrict__ row_geom,
+                                                           unsigned int* __restrict__ done_count,
+                                                           unsigned long long* __restrict__ host_state, unsigned long long call_id) {
     const bool aligned = (((uintptr_t)pkts | (uintptr_t)out | stride) & 15) == 0;
     const bool fast16 = aligned && (npol_tot & 15) == 0;         // 16-byte pieces are possible (wave-uniform)
     const int n_spec = payload_max >> 4;                         // whole 16-byte pieces of a packet's payload area
@@ -129,16 +133,69 @@ __global__ __launch_bounds__(256) void snap2_unpack_kernel(const uint8_t* __rest
     // only drops are counted on the device (rare): thousands of waves adding to one counter serialise in L2
     // (4096 same-address atomics cost ~40 us); placed = npkt - dropped on the host
     if (lane == 0 && ndropped) atomicAdd(counter, ndropped);
+    if (!host_state) return;
+    // Synchronous call: the work-group that finishes LAST reports to the host itself -- it checks the rows' coverage (what
+    // snap2_complete() does on the host), clears the block for the next call, writes {drops, complete} into the pinned
+    // mirror and then raises the call's id in the mirror's first word.  The host polls that word: one launch per call, no
+    // memset before it, no copy and no stream synchronisation behind it.  Every wave first waits for its own atomics to be
+    // acknowledged (vmcnt counts them), so the ticket of a work-group is taken after all its updates.
+    __shared__ int last_wg;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // two-level ticket (thousands of returning atomics on ONE word serialise at ~10 ns each): work-group b counts in
+        // sub-counter b % 16; the last arrival of a sub-counter counts in the top word; the last of those reports
+        const unsigned int k = blockIdx.x & 15u, members = (gridDim.x - k + 15u) >> 4;
+        int last = 0;
+        if (atomicAdd(&done_count[1 + k], 1u) == members - 1) {
+            atomicAnd(&done_count[1 + k], 0u);
+            const unsigned int groups = gridDim.x < 16u ? gridDim.x : 16u;
+            last = atomicAdd(&done_count[0], 1u) == groups - 1;
+        }
+        last_wg = last;
+    }
+    __syncthreads();
+    if (!last_wg) return;
+    // (only atomics and coherent loads ever touch the block: a plain store would leave a dirty line in this XCD's L2 beside
+    // words that the other XCDs update at the memory side)
+    bool ok = true;
+    if (row_cover) {
+        // the check of snap2_complete(), one time row per thread: every cell of the row's packet grid arrived
+        for (int t = threadIdx.x; t < ntime; t += blockDim.x) {
+            const unsigned int g = __hip_atomic_load(&row_geom[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long cv = __hip_atomic_load(&row_cover[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int nchan = (int)(g >> 16), npol = (int)(g & 0xFFFF);
+            bool row_ok = g != 0 && nchan > 0 && npol > 0 && nchan_tot % nchan == 0 && npol_tot % npol == 0;
+            if (row_ok) {
+                const long long cells = (long long)(nchan_tot / nchan) * (npol_tot / npol);
+                row_ok = cells <= 63 && cv == (1ull << cells) - 1;            // (bit 63 = irregular row)
+            }
+            ok = ok && row_ok;
+            atomicAnd(&row_cover[t], 0ull);                                   // cleared for the next call (no-return atomics)
+            atomicAnd(&row_geom[t], 0u);
+        }
+    }
+    const int complete = __syncthreads_and(ok ? 1 : 0);
+    if (threadIdx.x == 0) {
+        const unsigned long long drops = (unsigned long long)(unsigned int)atomicExch(counter, 0);
+        atomicAnd(&done_count[0], 0u);                                        // the next call's kernel is behind this one in stream order
+        __hip_atomic_store(&host_state[1], drops | ((unsigned long long)(complete ? 1 : 0) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence_system();
+        __hip_atomic_store(&host_state[0], call_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // per device: the state block of the running synchronous call (drops + coverage of up to SNAP2_MAX_ROWS time rows) and the
 // drops of the enqueue-only calls since they were last read
 constexpr int SNAP2_MAX_ROWS = 8192;
 struct IngestState {
-    int* counters = nullptr;                 // state block of the synchronous call: [16 B: drops][row_cover][row_geom]
+    int* counters = nullptr;                 // state block of the synchronous call: [8 B: drops][row_cover][row_geom]
+    unsigned int* tickets = nullptr;         // completion tickets of the synchronous call's kernel: [top][16 sub-counters]
     int* async_drops = nullptr;              // ... and, behind it, the drop counter of the enqueue-only calls
-    void* host = nullptr;                    // pinned mirror of the block
+    int* scratch_drops = nullptr;            // drop counter of the second scatter of a lossy slab (already counted)
+    void* host = nullptr;                    // pinned mirror: [8 B: id of the last finished call][the block]
     int* host_async = nullptr;
+    unsigned long long ncalls = 0;
 };
 static IngestState g_ingest[16];
 static std::mutex g_ingest_mu;     // the state of a device is shared by all callers
@@ -149,12 +206,13 @@ using namespace xeng;
 
 static int snap2_launch(hipStream_t s, const void* packets_dev, int npkt, size_t pkt_stride, void* out_dev, uint64_t seq0,
                         int ntime, int chan0_pipeline, int nchan_tot, int npol_tot, int clear, int* counter,
-                        unsigned long long* row_cover, unsigned int* row_geom) {
+                        unsigned long long* row_cover, unsigned int* row_geom, unsigned int* done_count = nullptr,
+                        unsigned long long* host_state = nullptr, unsigned long long call_id = 0) {
     if (clear) XENG_HIP(hipMemsetAsync(out_dev, 0, (size_t)ntime * nchan_tot * npol_tot, s));   // missing packets = blanked samples
     if (npkt > 0) {
         hipLaunchKernelGGL(snap2_unpack_kernel, dim3((npkt + 3) / 4 < 2048 ? (npkt + 3) / 4 : 2048), dim3(256), 0, s, (const uint8_t*)packets_dev, npkt,
                            pkt_stride, (uint8_t*)out_dev, (unsigned long long)seq0, ntime, chan0_pipeline, nchan_tot, npol_tot,
-                           (int)(pkt_stride - 32), counter, row_cover, row_geom);
+                           (int)(pkt_stride - 32), counter, row_cover, row_geom, done_count, host_state, call_id);
         XENG_HIP(hipGetLastError());
     }
     return XENG_STATUS_SUCCESS;
@@ -170,28 +228,19 @@ static int snap2_check(const void* packets_dev, int npkt, size_t pkt_stride, voi
     if (*dev < 0 || *dev >= 16) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "device %d out of range", *dev);
     IngestState& st = g_ingest[*dev];
     if (!st.counters) {
-        const size_t nb = 16 + SNAP2_MAX_ROWS * (sizeof(unsigned long long) + sizeof(unsigned int)) + 16;
+        const size_t nb = 8 + SNAP2_MAX_ROWS * (sizeof(unsigned long long) + sizeof(unsigned int)) + 8 + 16 + 128;
         uint8_t* base = nullptr;
         XENG_HIP(hipMalloc((void**)&base, nb));
         XENG_HIP(hipMemset(base, 0, nb));
-        XENG_HIP(hipHostMalloc(&st.host, nb, hipHostMallocDefault));
-        st.async_drops = (int*)(base + nb - 16);
-        st.host_async = (int*)((uint8_t*)st.host + nb - 16);
+        XENG_HIP(hipHostMalloc(&st.host, nb + 8, hipHostMallocDefault));     // (coherent pinned memory: the kernel writes it)
+        memset(st.host, 0, nb + 8);
+        st.async_drops = (int*)(base + nb - 128 - 16);
+        st.scratch_drops = (int*)(base + nb - 128 - 8);
+        st.tickets = (unsigned int*)(base + nb - 128);
+        st.host_async = (int*)((uint8_t*)st.host + 8 + nb - 128 - 16);
         st.counters = (int*)base;
     }
     return XENG_STATUS_SUCCESS;
-}
-
-// true iff every time row of the window received every cell of its packet grid (no loss; duplicates are harmless)
-static bool snap2_complete(const unsigned long long* cover, const unsigned int* geom, int ntime, int nchan_tot, int npol_tot) {
-    for (int t = 0; t < ntime; t++) {
-        const unsigned int g = geom[t];
-        const int nchan = (int)(g >> 16), npol = (int)(g & 0xFFFF);
-        if (!g || nchan <= 0 || npol <= 0 || nchan_tot % nchan || npol_tot % npol) return false;
-        const long long cells = (long long)(nchan_tot / nchan) * (npol_tot / npol);
-        if (cells > 63 || cover[t] != (1ull << cells) - 1) return false;       // (bit 63 = irregular row)
-    }
-    return true;
 }
 
 extern "C" int xengSnap2Unpack(const void* packets_dev, int npkt, size_t pkt_stride, void* out_dev, uint64_t seq0, int ntime,
@@ -208,27 +257,46 @@ extern "C" int xengSnap2Unpack(const void* packets_dev, int npkt, size_t pkt_str
     // recording which packet cells arrived, and fall back to zero-fill + scatter only when something is missing.  That
     // saves one full write of the gulp (32 MB at config 2) in the normal, loss-free case.
     const bool track = clear && npkt > 0 && ntime <= SNAP2_MAX_ROWS;
-    // the state of this call, packed so that one memset clears it and one copy brings it back:
-    // [16 B: drops | pad][row_cover: ntime x 8 B][row_geom: ntime x 4 B]
-    unsigned long long* cover = (unsigned long long*)((uint8_t*)st.counters + 16);
-    unsigned int* geom = (unsigned int*)((uint8_t*)st.counters + 16 + (size_t)ntime * sizeof(unsigned long long));
-    const size_t track_bytes = track ? (size_t)ntime * (sizeof(unsigned long long) + sizeof(unsigned int)) : 0;
-    XENG_HIP(hipMemsetAsync(st.counters, 0, 16 + track_bytes, s));
-    rc = snap2_launch(s, packets_dev, npkt, pkt_stride, out_dev, seq0, ntime, chan0_pipeline, nchan_tot, npol_tot, clear && !track,
-                      st.counters, track ? cover : nullptr, track ? geom : nullptr);
-    if (rc) return rc;
-    int* hc = (int*)st.host;
-    unsigned long long* hcov = (unsigned long long*)((uint8_t*)st.host + 16);
-    unsigned int* hgeom = (unsigned int*)((uint8_t*)st.host + 16 + (size_t)ntime * sizeof(unsigned long long));
-    XENG_HIP(hipMemcpyAsync(hc, st.counters, 16 + track_bytes, hipMemcpyDeviceToHost, s));
-    XENG_HIP(hipStreamSynchronize(s));
-    const int dropped = hc[0];
-    if (track && !snap2_complete(hcov, hgeom, ntime, nchan_tot, npol_tot)) {
-        // something is missing (or the stream is irregular): blank the gulp and scatter again
-        rc = snap2_launch(s, packets_dev, npkt, pkt_stride, out_dev, seq0, ntime, chan0_pipeline, nchan_tot, npol_tot, 1,
-                          st.counters, nullptr, nullptr);
+    int dropped = 0;
+    if (npkt > 0 && ntime <= SNAP2_MAX_ROWS) {
+        // one launch, and the kernel's last work-group reports to the pinned mirror (see the kernel): state block =
+        // [drops | ticket][row_cover: ntime x 8 B][row_geom: ntime x 4 B], self-clearing
+        unsigned long long* cover = (unsigned long long*)((uint8_t*)st.counters + 8);
+        unsigned int* geom = (unsigned int*)((uint8_t*)st.counters + 8 + (size_t)ntime * sizeof(unsigned long long));
+        unsigned long long* hs = (unsigned long long*)st.host;
+        const unsigned long long id = ++st.ncalls;
+        rc = snap2_launch(s, packets_dev, npkt, pkt_stride, out_dev, seq0, ntime, chan0_pipeline, nchan_tot, npol_tot, clear && !track,
+                          st.counters, track ? cover : nullptr, track ? geom : nullptr, st.tickets, hs, id);
         if (rc) return rc;
+        // poll the mirror's first word (sub-microsecond once the kernel has finished); a kernel that does not report within
+        // 2 s is a fault: fall back to the stream, whose error the HIP call returns
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        while (__atomic_load_n(&hs[0], __ATOMIC_ACQUIRE) != id) {
+            if ((++spins & 0x3FFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+                XENG_HIP(hipStreamSynchronize(s));
+                if (__atomic_load_n(&hs[0], __ATOMIC_ACQUIRE) != id) XENG_FAIL(XENG_STATUS_DEVICE_ERROR, "Snap2Unpack: the scatter kernel did not report");
+                break;
+            }
+        }
+        dropped = (int)(hs[1] & 0xFFFFFFFFull);
+        const bool complete = (hs[1] >> 32) != 0;
+        if (track && !complete) {
+            // something is missing (or the stream is irregular): blank the gulp and scatter again
+            rc = snap2_launch(s, packets_dev, npkt, pkt_stride, out_dev, seq0, ntime, chan0_pipeline, nchan_tot, npol_tot, 1,
+                              st.scratch_drops, nullptr, nullptr);
+            if (rc) return rc;
+            XENG_HIP(hipStreamSynchronize(s));
+        }
+    } else {
+        // no packets, or a window too long for the coverage block: zero-fill (if asked) + scatter, drops by a copy
+        XENG_HIP(hipMemsetAsync(st.scratch_drops, 0, sizeof(int), s));
+        rc = snap2_launch(s, packets_dev, npkt, pkt_stride, out_dev, seq0, ntime, chan0_pipeline, nchan_tot, npol_tot, clear,
+                          st.scratch_drops, nullptr, nullptr);
+        if (rc) return rc;
+        XENG_HIP(hipMemcpyAsync(st.host_async + 2, st.scratch_drops, sizeof(int), hipMemcpyDeviceToHost, s));
         XENG_HIP(hipStreamSynchronize(s));
+        dropped = st.host_async[2];
     }
     if (nplaced) *nplaced = npkt - dropped;
     if (ndropped) *ndropped = dropped;

@@ -121,7 +121,7 @@ static void launch_xcorr(const XcorrParams& p, hipStream_t s, bool raw, int grid
     if (raw) {
         const dim3 grid(grid_size);
 #ifdef XENG_DIAGNOSTICS
-        static const int fabl = getenv("XENG_ABLATE") ? atoi(getenv("XENG_ABLATE")) : 0;
+        const int fabl = getenv("XENG_ABLATE") ? atoi(getenv("XENG_ABLATE")) : 0;     // (diagnostic build: read per launch, so one process can alternate)
         switch (fabl) {
             case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<1>), grid, dim3(256), 0, s, p); return;
             case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<2>), grid, dim3(256), 0, s, p); return;
@@ -132,6 +132,9 @@ static void launch_xcorr(const XcorrParams& p, hipStream_t s, bool raw, int grid
             case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<16>), grid, dim3(256), 0, s, p); return;
             case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<32>), grid, dim3(256), 0, s, p); return;
             case 48: hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<48>), grid, dim3(256), 0, s, p); return;
+            case 5: hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<5>), grid, dim3(256), 0, s, p); return;
+            case 17: hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<17>), grid, dim3(256), 0, s, p); return;
+            case 31: hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<31>), grid, dim3(256), 0, s, p); return;
             default: break;
         }
 #endif
@@ -142,7 +145,7 @@ static void launch_xcorr(const XcorrParams& p, hipStream_t s, bool raw, int grid
 #ifdef XENG_DIAGNOSTICS
     // timing-only ablations of the K loop (results are wrong): build with -DXENG_DIAGNOSTICS, select with
     // XENG_ABLATE = 1 (no LDS-DMA) | 2 (no unpack) | 4 (no LDS reads) | 8 (no barrier); see profiles/r01/README.md
-    static const int abl = getenv("XENG_ABLATE") ? atoi(getenv("XENG_ABLATE")) : 0;
+    const int abl = getenv("XENG_ABLATE") ? atoi(getenv("XENG_ABLATE")) : 0;
     switch (abl) {
         case 1: launch_abl<1>(p, s); return;
         case 2: launch_abl<2>(p, s); return;

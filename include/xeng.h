@@ -223,6 +223,12 @@ int xengBeamformIntegrate(const void *in_dev, void *out_dev, int ntime_sum);
 /* beamform_sum_single_beam_block.py:114: one dual-pol beam -> f32[ntime/ntime_sum][nchan][4]. */
 int xengBeamformIntegrateSingleBeam(const void *in_dev, void *out_dev, int ntime_sum, int beam_id);
 int xengBeamformSync(void);
+/* Completion tickets on the beamformer's stream: Mark returns a ticket for everything enqueued so far (Run, Integrate,
+ * by any thread), Wait blocks until that point has been reached.  They let the Beamform / BeamformSumBeams blocks keep
+ * several gulps in flight and commit each output span when its own kernels are done (no reference counterpart: the
+ * reference waits for the whole stream after every gulp, beamform_block.py:450). */
+int xengBeamformMark(unsigned long long *ticket);
+int xengBeamformWait(unsigned long long ticket);
 int xengBeamformSetProfiling(int enable);
 int xengBeamformGetTimes(double ms[2], int count[2]);   /* [0]=Run, [1]=Integrate */
 /* How the last weight upload was routed (waits for the beam stream): (channel, beam tile) pairs in all, pairs that run on

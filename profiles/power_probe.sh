@@ -3,7 +3,7 @@
 # usage: profiles/power_probe.sh <outfile-under-gpurun_out>
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$1
-python3 $R/bench.py --steps 40000 --warmup 100 --no-cpu-baseline --no-h2d --no-beamform > $OUT.bench.json 2> $OUT.bench.err &
+python3 $R/bench.py --steps 40000 --warmup 100 --no-cpu-baseline --no-h2d --no-beamform --sustained 0 > $OUT.bench.json 2> $OUT.bench.err &
 BP=$!
 sleep 6
 for i in 1 2 3 4 5 6; do

@@ -61,3 +61,24 @@ elif what == "packetize":
     for fmt in (1, 0):
         t = timed(lambda: L.xengXgpuPacketize(vis.ptr, dpay.ptr, dbl.ptr, dcj.ptr, fmt), lambda: None, nrep=30)
         print("packetize fmt %d: %.1f us per synchronous call  %.2f TB/s (read + write %d MB)" % (fmt, t * 1e6, 2 * dpay.nbytes / t / 1e12, 2 * dpay.nbytes >> 20))
+elif what == "unpack":
+    # the synchronous xengSnap2Unpack call at config-2 size: 5280 packets (480 samples x 11 packets of 64 inputs x 96 channels)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import xeng_oracle as orc          # (test infrastructure: builds the packet slab)
+    NT = 480
+    rng = np.random.default_rng(3)
+    vin = rng.integers(0, 256, (NT, NCHAN, NINPUT // 2, 2), dtype=np.uint8)
+    pk = orc.snap2_packets(vin, seq0=10 ** 12, sync_time=3, nchan_blocks=1, nstand_per_pkt=32, chan0_pipeline=0)
+    slab = np.frombuffer(b"".join(pk), dtype=np.uint8)
+    dslab = ffi.DeviceBuffer(slab.nbytes).upload(slab)
+    dg = ffi.DeviceBuffer(vin.nbytes)
+    placed, dropped = ctypes.c_int(), ctypes.c_int()
+    fn = lambda: L.xengSnap2Unpack(dslab.ptr, len(pk), len(pk[0]), dg.ptr, 10 ** 12, NT, 0, NCHAN, NINPUT, 1, ctypes.byref(placed), ctypes.byref(dropped))
+    t = timed(fn, lambda: None, nrep=300, nwarm=20)
+    assert placed.value == len(pk) and dropped.value == 0 and np.array_equal(dg.download(np.uint8), vin.reshape(-1))
+    print("unpack: %.1f us per synchronous call, %d packets of %d B -> %.1f MB gulp (%.2f TB/s read + write)" % (
+        t * 1e6, len(pk), len(pk[0]), vin.nbytes / 1e6, (slab.nbytes + vin.nbytes) / t / 1e12))
+    # a lossy slab takes the second pass (zero-fill + scatter)
+    fn2 = lambda: L.xengSnap2Unpack(dslab.ptr, len(pk) - 7, len(pk[0]), dg.ptr, 10 ** 12, NT, 0, NCHAN, NINPUT, 1, ctypes.byref(placed), ctypes.byref(dropped))
+    t2 = timed(fn2, lambda: None, nrep=100, nwarm=5)
+    print("unpack, 7 packets missing: %.1f us per synchronous call (coverage check on the device, then zero-fill + second scatter)" % (t2 * 1e6))

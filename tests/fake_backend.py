@@ -42,6 +42,13 @@ class OracleBackend:
     def beam_sync(self):
         pass
 
+    def beam_mark(self):
+        self.marks = getattr(self, "marks", 0) + 1
+        return self.marks
+
+    def beam_wait(self, ticket):
+        self.waits = getattr(self, "waits", []) + [ticket]
+
     def last_error(self):
         return ""
 
