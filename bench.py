@@ -527,8 +527,8 @@ def main():
                   "ingest_gbps": round(8 * gulp_bytes / (in_ms * 1e-3) / 1e9, 1),
                   "roofline": {"bound": "hbm", "achieved": round(in_bytes / (in_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": round(in_bytes / (in_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-                  "note": "wall time of the synchronous call: clear of the call state + scatter kernel (device time: profiles/r02 kernel stats) + "
-                          "read-back of the drop counter and packet coverage + host check; no zero-fill pass for a complete slab"}
+                  "note": "wall time of the synchronous call: one launch -- scatter kernel (device time: profiles/r03 kernel stats) whose last work-group checks the coverage and reports to pinned memory + "
+                          "host poll of that word; no memset, copy or stream wait, no zero-fill pass for a complete slab"}
         # packets -> visibilities, device resident (BASELINE: "throughput on synthetic F-engine packets"): every gulp of
         # every integration is first scattered out of its packet slab (enqueue-only, on the X-engine's staging stream),
         # then registered with the X-engine; same streaming pattern as the timed region
@@ -762,7 +762,7 @@ def main():
     traffic = None
     try:
         import hashlib
-        with open(os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r03", "pmc_traffic.json")) as fh:
             pmc = json.load(fh)
         hh = hashlib.sha256()
         for f in pmc.get("xcorr_sources", []):
