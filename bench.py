@@ -231,6 +231,7 @@ def main():
     ap.add_argument("--lag", type=int, default=1, choices=[1, 2, 3],
                     help="streaming depth: after enqueueing integration n wait for dump n-lag (lag+1 output spans)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pin", action="store_true", help="diagnostic: leave the process's CPU affinity alone (default: the cores next to the GPU)")
     ap.add_argument("--sustained", type=int, default=10000,
                     help="integrations of the untimed `sustained` leg (two runs of this many; 0 = skip)")
     ap.add_argument("--no-h2d", dest="h2d", action="store_false", help="skip the PCIe-inclusive measurement")
@@ -320,7 +321,8 @@ def main():
     info = ffi.device_info(gpu)
     # host placement: this rank (and every thread it starts) on the cores next to its GPU (sharding.pin_rank)
     host_cpus = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
-    pin = _sh.pin_rank(local_rank, local_world, ffi.device_pci_bus_id(gpu))
+    pin = (_sh.pin_rank(local_rank, local_world, ffi.device_pci_bus_id(gpu)) if not args.no_pin else
+           {"source": "none (--no-pin)", "cpus": sorted(host_cpus or []), "numa_node": None})
     gulps_per_step = ACC_LEN // NTIME_GULP
     ffi.call("xengXgpuConfigure", NSTAND, NPOL, NCHAN, NTIME_GULP, gulps_per_step)
     ffi.call("xengXgpuInitialize", gpu)

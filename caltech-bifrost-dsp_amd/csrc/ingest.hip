@@ -316,6 +316,7 @@ extern "C" int xengSnap2UnpackAsync(const void* packets_dev, int npkt, size_t pk
     hipStream_t s;
     rc = get_stream(STREAM_XGPU, &s);
     if (rc) return rc;
+    staging_stream_touched();              // (the next contraction waits for this stream)
     return snap2_launch(s, packets_dev, npkt, pkt_stride, out_dev, seq0, ntime, chan0_pipeline, nchan_tot, npol_tot, clear,
                         g_ingest[dev].async_drops, nullptr, nullptr);
 }

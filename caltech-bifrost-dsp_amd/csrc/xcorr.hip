@@ -44,10 +44,11 @@ struct XgpuContext {
     WgDesc* descs_dev = nullptr;
     int nwg = 0;
     hipStream_t stream = nullptr;              // raw copies / corner turns (+ H2D of the host-buffer variant)
-    // MFMA contractions rotate over nmm streams: consecutive launches are independent (unless they touch the
-    // same output span), so the tail of one fills with the next.  Two is the measured optimum (three or
-    // four streams: -5 %, HIP maps them onto the same few hardware queues as the other streams).
-    static constexpr int NMM = 4;
+    // MFMA contractions rotate over nmm streams: consecutive launches are independent (unless they touch the same output
+    // span).  Two.  Round 3 re-measured 1 / 2 / 3 / 4 / 6 / 8 (diagnostic builds, XENG_MM_STREAMS): within +-2 %, and the
+    // sign depends on the harness -- profiles/ab_step.py reads 3+ streams 2 % faster than two, bench.py's own loop in fresh
+    // processes reads two 2 % faster than four (profiles/r03/ab_streams.txt) -- so the smaller number of queues stays.
+    static constexpr int NMM = 8;
     hipStream_t stream_mm2[NMM] = {};
     int nmm = 2;
     unsigned long long nlaunch = 0;
@@ -58,16 +59,19 @@ struct XgpuContext {
     // on and however many launches went to the streams since.
     struct Writer { unsigned long long seq; int stream; };
     std::map<const void*, Writer> writers;
-    static constexpr int NEV = 64;
+    static constexpr int NEV = 256;
+    // ONE event per launch (more records behind a kernel delay the next dispatch on that hardware queue): everything that
+    // has to wait for a launch -- a later launch into the same buffer, a consumer, the refill of a staging area, a dump's
+    // caller -- names the launch by its number.  A slot is re-recorded by launch n + NEV only after launch n has completed
+    // (the enqueuer waits for it if it has not: back-pressure at NEV launches in flight), so a number whose slot has been
+    // taken over needs no wait at all.  (The wait itself happens outside the context lock: wait_for_event_slot.)
     hipEvent_t ev_ring[NEV] = {};              // completion of launch number n: ev_ring[n % NEV]
-    const void* ring_buf[NEV][2] = {};         // ... and the buffers it wrote (forgotten as writers when the slot is reused
-                                               // and the launch has completed)
-    hipEvent_t ev_last[NMM] = {};              // completion of the latest contraction on each stream
-    bool mm_used[NMM] = {};
+    const void* ring_buf[NEV][2] = {};         // ... and the buffers it wrote (forgotten as writers when the slot is reused)
+    unsigned long long last_seq[NMM] = {};     // number of the latest contraction on each stream (0: none)
     hipEvent_t ev_ct = nullptr;                // staged gulps of the area about to be contracted are complete
-    hipEvent_t ev_mm[2] = {nullptr, nullptr};  // the contraction reading staging area b is complete
-    bool area_used[2] = {false, false};
-    hipEvent_t ev_dump[4] = {nullptr, nullptr, nullptr, nullptr};   // completion of the last dumps
+    unsigned long long staging_seen = ~0ull;   // staging_stream_ops() at the last such record
+    unsigned long long area_seq[2] = {0, 0};   // number of the contraction that reads staging area b (0: none)
+    unsigned long long dump_seq[4] = {0, 0, 0, 0};   // numbers of the last dumps
     unsigned long long ndump = 0;
     // integration state
     int nfilled = 0;           // gulps staged since the last flush
@@ -91,17 +95,12 @@ static int destroy_locked() {
     if (x.stream) (void)hipStreamSynchronize(x.stream);
     for (int b = 0; b < XgpuContext::NMM; b++) {
         if (x.stream_mm2[b]) (void)hipStreamSynchronize(x.stream_mm2[b]);
-        if (x.ev_last[b]) (void)hipEventDestroy(x.ev_last[b]);
     }
     for (int k = 0; k < XgpuContext::NEV; k++)
         if (x.ev_ring[k]) (void)hipEventDestroy(x.ev_ring[k]);
-    for (int b = 0; b < 2; b++) {
+    for (int b = 0; b < 2; b++)
         if (x.stash[b]) (void)hipFree(x.stash[b]);
-        if (x.ev_mm[b]) (void)hipEventDestroy(x.ev_mm[b]);
-    }
     if (x.ev_ct) (void)hipEventDestroy(x.ev_ct);
-    for (int k = 0; k < 4; k++)
-        if (x.ev_dump[k]) (void)hipEventDestroy(x.ev_dump[k]);
     if (x.descs_dev) (void)hipFree(x.descs_dev);
     if (x.fgroups_dev) (void)hipFree(x.fgroups_dev);
     if (x.work.dev) (void)hipFree(x.work.dev);
@@ -135,6 +134,7 @@ static void launch_xcorr(const XcorrParams& p, hipStream_t s, bool raw, int grid
             case 5: hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<5>), grid, dim3(256), 0, s, p); return;
             case 17: hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<17>), grid, dim3(256), 0, s, p); return;
             case 31: hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<31>), grid, dim3(256), 0, s, p); return;
+            case 64: hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<64>), grid, dim3(256), 0, s, p); return;
             default: break;
         }
 #endif
@@ -159,14 +159,19 @@ static void launch_xcorr(const XcorrParams& p, hipStream_t s, bool raw, int grid
     launch_abl<0>(p, s);
 }
 
+// completion event of launch number `seq`, or null when that launch is known to have completed (its slot was taken over)
+static hipEvent_t launch_event(unsigned long long seq) {
+    XgpuContext& x = g_ctx;
+    if (seq == 0 || x.nlaunch - seq >= (unsigned long long)XgpuContext::NEV) return nullptr;
+    return x.ev_ring[seq % XgpuContext::NEV];
+}
+
 // under g_mu: make stream `s` (contraction stream `self`, or -1 for a foreign stream) wait for the last enqueued writer of `buf`
 static int order_after_writer(hipStream_t s, int self, const void* buf) {
     XgpuContext& x = g_ctx;
     auto it = x.writers.find(buf);
     if (it == x.writers.end() || it->second.stream == self) return XENG_STATUS_SUCCESS;   // (same stream: stream order)
-    const XgpuContext::Writer& w = it->second;
-    hipEvent_t ev = x.nlaunch - w.seq < (unsigned long long)XgpuContext::NEV ? x.ev_ring[w.seq % XgpuContext::NEV] : x.ev_last[w.stream];
-    XENG_HIP(hipStreamWaitEvent(s, ev, 0));
+    if (hipEvent_t ev = launch_event(it->second.seq)) XENG_HIP(hipStreamWaitEvent(s, ev, 0));
     return XENG_STATUS_SUCCESS;
 }
 
@@ -211,26 +216,28 @@ static int flush_locked(void* out, bool dump, void* acc = nullptr, int acc_mode 
     // the contraction starts when this area's corner turns are done and runs beside the next area's
     const int si = (int)(x.nlaunch++ % x.nmm);
     hipStream_t smm = x.stream_mm2[si];
-    XENG_HIP(hipEventRecord(x.ev_ct, x.stream));
-    XENG_HIP(hipStreamWaitEvent(smm, x.ev_ct, 0));
+    if (const unsigned long long ops = staging_stream_ops(); ops != x.staging_seen) {
+        XENG_HIP(hipEventRecord(x.ev_ct, x.stream));       // (only when something was put on the staging stream since the
+        XENG_HIP(hipStreamWaitEvent(smm, x.ev_ct, 0));     // last contraction: gulps read in place need no barrier packet)
+        x.staging_seen = ops;
+    }
     // contractions that touch the same output (partial sums of one integration, or a caller that
     // reuses one buffer for consecutive integrations) stay ordered; independent ones may overlap
     const unsigned long long seq = x.nlaunch;          // this launch's number (>= 1)
-    if (x.writers.size() > 256) {             // a caller that never reuses a buffer: forget them behind a full join
-        for (int t = 0; t < x.nmm; t++)
-            if (t != si && x.mm_used[t]) XENG_HIP(hipStreamWaitEvent(smm, x.ev_last[t], 0));
-        x.writers.clear();
-    }
     {
-        // this launch takes over the event slot of launch seq - NEV: if that one has completed (the normal case), nobody
-        // needs to wait for it any more; if not (a very deep queue), its buffers fall back to the stream's latest event
+        // this launch takes over the event slot of launch seq - NEV, which must have completed (see XgpuContext): normally
+        // long ago; NEV launches deep in an unsynchronised queue the enqueuer waits here
         const int k = (int)(seq % XgpuContext::NEV);
-        if (seq > (unsigned long long)XgpuContext::NEV && hipEventQuery(x.ev_ring[k]) == hipSuccess)
+        if (seq > (unsigned long long)XgpuContext::NEV) {
+            if (hipEventQuery(x.ev_ring[k]) != hipSuccess) {
+                (void)hipGetLastError();          // (hipErrorNotReady is not an error)
+                XENG_HIP(hipEventSynchronize(x.ev_ring[k]));     // (not reached through the C ABI: its callers have waited, below)
+            }
             for (const void* buf : x.ring_buf[k]) {
                 auto it = buf ? x.writers.find(buf) : x.writers.end();
                 if (it != x.writers.end() && it->second.seq == seq - XgpuContext::NEV) x.writers.erase(it);
             }
-        (void)hipGetLastError();              // (hipErrorNotReady is not an error)
+        }
         x.ring_buf[k][0] = out; x.ring_buf[k][1] = acc;
     }
     for (const void* buf : {(const void*)out, (const void*)acc}) {
@@ -247,13 +254,11 @@ static int flush_locked(void* out, bool dump, void* acc = nullptr, int acc_mode 
     launch_xcorr(p, smm, x.raw, fused_grid(x.cfg.nchan, x.nfg, x.ncu));
     x.timer.end(smm, slot);
     XENG_HIP(hipGetLastError());
-    XENG_HIP(hipEventRecord(x.ev_mm[x.cur], smm));
-    XENG_HIP(hipEventRecord(x.ev_last[si], smm));
     XENG_HIP(hipEventRecord(x.ev_ring[seq % XgpuContext::NEV], smm));
-    x.area_used[x.cur] = true;
-    x.mm_used[si] = true;
+    x.area_seq[x.cur] = seq;
+    x.last_seq[si] = seq;
     if (dump) {
-        XENG_HIP(hipEventRecord(x.ev_dump[x.ndump & 3], smm));
+        x.dump_seq[x.ndump & 3] = seq;
         x.ndump++;
     }
     x.cur ^= 1;
@@ -295,8 +300,8 @@ static int kernel_locked(const void* in_dev, void* out_dev, int doDump, bool syn
     if (((uintptr_t)out_dev & 15) || ((uintptr_t)in_dev & (x.raw ? 15 : 3)))
         XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "xgpu: out must be 16-byte and in %d-byte aligned", x.raw ? 16 : 4);
     XENG_HIP(hipSetDevice(x.gpu));
-    if (x.nfilled == 0 && x.area_used[x.cur])   // this staging area may still be read by an earlier contraction
-        XENG_HIP(hipStreamWaitEvent(x.stream, x.ev_mm[x.cur], 0));
+    if (x.nfilled == 0)                          // this staging area may still be read by an earlier contraction
+        if (hipEvent_t ev = launch_event(x.area_seq[x.cur])) XENG_HIP(hipStreamWaitEvent(x.stream, ev, 0));
     uint8_t* const stash = x.stash[x.cur];
     int slot = -1;
     if (x.raw) {
@@ -333,6 +338,7 @@ static int kernel_locked(const void* in_dev, void* out_dev, int doDump, bool syn
     }
     x.timer.end(x.stream, slot);
     XENG_HIP(hipGetLastError());
+    if (!x.raw || (sync && !doDump)) staging_stream_touched();     // a copy or a corner turn went to the staging stream
     x.nfilled++;
     if (doDump || x.nfilled == x.cap_gulps) {
         int rc = flush_locked(out_dev, doDump != 0, acc, acc_mode);
@@ -344,7 +350,7 @@ static int kernel_locked(const void* in_dev, void* out_dev, int doDump, bool syn
         // input consumed = its copy / corner turn is done; on a dump the output must be complete too
         pw->gpu = x.gpu;
         pw->staging = x.stream;
-        if (doDump) pw->dump = x.ev_dump[(x.ndump - 1) & 3];      // contractions that touch one span are ordered
+        if (doDump) pw->dump = launch_event(x.dump_seq[(x.ndump - 1) & 3]);      // contractions that touch one span are ordered
     }
     return XENG_STATUS_SUCCESS;
 }
@@ -439,10 +445,8 @@ static int initialize_locked(int gpu) {
     for (int b = 0; b < 2; b++) {
         XENG_HIP(hipMalloc((void**)&x.stash[b], x.stash_bytes));
         XENG_HIP(hipMemset(x.stash[b], 0, x.stash_bytes));
-        XENG_HIP(hipEventCreateWithFlags(&x.ev_mm[b], hipEventDisableTiming));
     }
     XENG_HIP(hipEventCreateWithFlags(&x.ev_ct, hipEventDisableTiming));
-    for (int k = 0; k < 4; k++) XENG_HIP(hipEventCreateWithFlags(&x.ev_dump[k], hipEventDisableTiming));
     std::vector<WgDesc> descs = build_wg_descs(x.nblk64);
     x.nwg = (int)descs.size();
     if (x.raw) {
@@ -461,13 +465,20 @@ static int initialize_locked(int gpu) {
     }
     XENG_HIP(hipMalloc((void**)&x.descs_dev, descs.size() * sizeof(WgDesc)));
     XENG_HIP(hipMemcpy(x.descs_dev, descs.data(), descs.size() * sizeof(WgDesc), hipMemcpyHostToDevice));
+    if (const char* o = diag_env("XENG_STREAM_ORDER")) {           // experiment: which library streams exist before the X-engine's
+        hipStream_t tmp;
+        for (const char* c = o; *c; c++) {
+            const StreamId id = *c == 'c' ? STREAM_COPY : *c == 'm' ? STREAM_MAP : *c == 'b' ? STREAM_BEAM : *c == 'k' ? STREAM_CONSUMER : STREAM_XGPU;
+            int rc0 = get_stream(id, &tmp);
+            if (rc0) return rc0;
+        }
+    }
     int rc = get_stream(STREAM_XGPU, &x.stream);
     if (rc) return rc;
     if (const char* e = diag_env("XENG_MM_STREAMS")) x.nmm = std::max(1, std::min(XgpuContext::NMM, atoi(e)));   // experiment
     for (int t = 0; t < x.nmm; t++) {      // (only the streams in use: every stream takes a share of a hardware queue)
-        rc = get_stream((StreamId)(STREAM_XGPU_MM + t), &x.stream_mm2[t]);
+        rc = get_stream(mm_stream_id(t), &x.stream_mm2[t]);
         if (rc) return rc;
-        XENG_HIP(hipEventCreateWithFlags(&x.ev_last[t], hipEventDisableTiming));
     }
     for (int k = 0; k < XgpuContext::NEV; k++) XENG_HIP(hipEventCreateWithFlags(&x.ev_ring[k], hipEventDisableTiming));
     x.stream_mm = x.stream_mm2[0];
@@ -490,8 +501,33 @@ static void drain_timer() {
     if (g_ctx.live) g_ctx.timer.drain();
 }
 
+// Back-pressure of the event ring, outside the context lock: the next launch re-records the slot of launch n - NEV, which
+// must have completed first.  Normally it has, long ago; a caller that is NEV launches ahead of the GPU waits here, and
+// the other blocks' calls (SubSelect, Packetize, ...) go on meanwhile.
+static int wait_for_event_slot() {
+    for (;;) {
+        hipEvent_t ev = nullptr;
+        int gpu = 0;
+        {
+            std::lock_guard<std::mutex> lk(g_mu);
+            XgpuContext& x = g_ctx;
+            if (!x.live) return XENG_STATUS_SUCCESS;             // (the call itself reports it)
+            const unsigned long long next = x.nlaunch + 1;
+            if (next <= (unsigned long long)XgpuContext::NEV) return XENG_STATUS_SUCCESS;
+            ev = x.ev_ring[next % XgpuContext::NEV];
+            gpu = x.gpu;
+            if (hipEventQuery(ev) == hipSuccess) return XENG_STATUS_SUCCESS;
+            (void)hipGetLastError();
+        }
+        XENG_HIP(hipSetDevice(gpu));
+        XENG_HIP(hipEventSynchronize(ev));
+    }
+}
+
 int xengXgpuKernel(const void* in_dev, void* out_dev, int doDump) {
     PendingWait pw;
+    int rc0 = wait_for_event_slot();
+    if (rc0) return rc0;
     {
         std::lock_guard<std::mutex> lk(g_mu);
         int rc = kernel_locked(in_dev, out_dev, doDump, true, &pw);
@@ -504,11 +540,15 @@ int xengXgpuKernel(const void* in_dev, void* out_dev, int doDump) {
 }
 
 int xengXgpuKernelAsync(const void* in_dev, void* out_dev, int doDump) {
+    int rc0 = wait_for_event_slot();
+    if (rc0) return rc0;
     std::lock_guard<std::mutex> lk(g_mu);
     return kernel_locked(in_dev, out_dev, doDump, false, nullptr);
 }
 
 int xengXgpuKernelAsyncAcc(const void* in_dev, void* out_dev, int doDump, void* acc_dev, int acc_mode) {
+    int rc0 = wait_for_event_slot();
+    if (rc0) return rc0;
     std::lock_guard<std::mutex> lk(g_mu);
     return kernel_locked(in_dev, out_dev, doDump, false, nullptr, acc_dev, acc_dev ? acc_mode : 0);
 }
@@ -538,7 +578,7 @@ int xengXgpuSyncLag(int lag) {
         if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized");
         if (lag < 0 || lag > 3) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "SyncLag: lag must be 0..3 (got %d)", lag);
         pw.gpu = x.gpu;
-        if (x.ndump > (unsigned long long)lag) pw.dump = x.ev_dump[(x.ndump - 1 - lag) & 3];
+        if (x.ndump > (unsigned long long)lag) pw.dump = launch_event(x.dump_seq[(x.ndump - 1 - lag) & 3]);
     }
     int rc = wait_unlocked(pw);
     if (rc) return rc;
@@ -588,6 +628,7 @@ int xengXgpuCorrelate(const void* in_host, void* out_host, int doDump) {
         if (!x.in_dev) XENG_HIP(hipMalloc((void**)&x.in_dev, in_bytes));
         if (!x.out_dev) XENG_HIP(hipMalloc((void**)&x.out_dev, out_bytes));
         XENG_HIP(hipMemcpyAsync(x.in_dev, in_host, in_bytes, hipMemcpyHostToDevice, x.stream));
+        staging_stream_touched();
         int rc = kernel_locked(x.in_dev, x.out_dev, doDump, true, &pw);
         if (rc) return rc;
         st = x.stream; out_dev = x.out_dev;

@@ -679,7 +679,8 @@ __device__ __forceinline__ void xcorr_store_cells(const XcorrParams& p, int c, c
 }
 
 // ABL: timing-only ablation bits as for xcorr_mfma_kernel (diagnostic builds; results are wrong unless 0);
-// 16: no epilogue, 32: every channel reads a 1 MB window of gulp 0 that stays in L2.
+// 16: no epilogue, 32: every channel reads a 1 MB window of gulp 0 that stays in L2, 64: half-item skew between the two
+// channels of a round (an experiment: results stay right).
 template <int ABL, bool LACC = false>
 __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
     constexpr int KT_STAGE = XC_KT;
@@ -774,6 +775,13 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
 
     Item it;
     if (!item(0, it)) return;                // (the host never launches work-groups without work)
+    if (ABL & 64) {   // timing only: the second channel of every round (work-groups 16-31 of an XCD) starts half an item late,
+                      // so that the two channels' epilogue bursts do not coincide
+        if ((blockIdx.x >> 3) & 16) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (__builtin_amdgcn_s_memrealtime() - t0 < 1500ull) __builtin_amdgcn_s_sleep(32);     // 15 us at 100 MHz
+        }
+    }
     is_setup(it);
 #pragma unroll
     for (int st = 0; st < DEPTH; st++) {

@@ -32,8 +32,15 @@ void set_error(const char* fmt, ...);
 // Streams owned by the library on the current device: one per block thread of the
 // reference pipeline (Corr, CorrAcc map, Beamform, copies) so they overlap
 // (lwa352-pipeline.py:296-302 runs one thread per block on the same GPU).
-enum StreamId { STREAM_XGPU = 0, STREAM_MAP = 1, STREAM_BEAM = 2, STREAM_COPY = 3, STREAM_XGPU_MM = 4, STREAM_XGPU_MM2 = 5, STREAM_XGPU_MM3 = 6, STREAM_XGPU_MM4 = 7, STREAM_CONSUMER = 8, STREAM_COUNT = 9 };
+enum StreamId { STREAM_XGPU = 0, STREAM_MAP = 1, STREAM_BEAM = 2, STREAM_COPY = 3, STREAM_XGPU_MM = 4, STREAM_XGPU_MM2 = 5, STREAM_XGPU_MM3 = 6, STREAM_XGPU_MM4 = 7, STREAM_CONSUMER = 8,
+                STREAM_XGPU_MM5 = 9, STREAM_XGPU_MM6 = 10, STREAM_XGPU_MM7 = 11, STREAM_XGPU_MM8 = 12, STREAM_COUNT = 13 };
+inline StreamId mm_stream_id(int t) { return (StreamId)(t < 4 ? STREAM_XGPU_MM + t : STREAM_XGPU_MM5 + (t - 4)); }
 int get_stream(StreamId which, hipStream_t* out);   // lazily created per device
+// Work counter of the X-engine's staging stream (STREAM_XGPU: gulp copies, corner turns, enqueue-only ingest scatters):
+// whoever enqueues there bumps it, so that a contraction only waits for that stream when something was put on it since
+// the last contraction (a barrier packet in front of every launch otherwise).
+void staging_stream_touched();
+unsigned long long staging_stream_ops();
 int sync_all_streams();
 
 // Experiment / diagnostic switches (grid sizes, map variants, clock stamps, item order ...) exist only in

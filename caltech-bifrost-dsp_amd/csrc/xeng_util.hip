@@ -1,6 +1,7 @@
 // Device / memory plumbing behind the C ABI (include/xeng.h, "device / memory plumbing").
 // Replaces bifrost.device.set_device / stream_synchronize, BFArray(space='cuda'|'cuda_host')
 // allocation and copy_array for the hot-path blocks.
+#include <atomic>
 #include <mutex>
 #include <utility>
 
@@ -22,6 +23,10 @@ static std::mutex g_stream_mu;
 static hipStream_t g_streams[MAXDEV][STREAM_COUNT];
 static bool g_stream_ok[MAXDEV][STREAM_COUNT];
 
+static std::atomic<unsigned long long> g_staging_ops{0};
+void staging_stream_touched() { g_staging_ops.fetch_add(1, std::memory_order_relaxed); }
+unsigned long long staging_stream_ops() { return g_staging_ops.load(std::memory_order_relaxed); }
+
 int get_stream(StreamId which, hipStream_t* out) {
     int dev = 0;
     XENG_HIP(hipGetDevice(&dev));
@@ -30,12 +35,13 @@ int get_stream(StreamId which, hipStream_t* out) {
     if (!g_stream_ok[dev][which]) {
         // HIP multiplexes its streams onto a few hardware queues per priority class (4 by default); streams that share
         // a hardware queue run in order, so a short kernel of one block would wait behind every queued contraction of
-        // another.  Two classes keep them apart: the long-running X-engine work (staging, contractions, bulk copies)
-        // at normal priority -- at most four such streams exist -- and the short kernels of the other blocks (CorrAcc
-        // map, beamformer, span consumers) at high priority.
+        // another.  Two classes keep them apart: the X-engine's own work (staging stream + four contraction streams) at
+        // normal priority, and everything the other blocks put on the GPU -- CorrAcc map, beamformer, span consumers and the
+        // bulk copies (CorrAcc's 191 MB publish, the Copy block: a multi-millisecond copy at the head of a queue that a
+        // contraction stream shares would stall the X-engine behind it) -- at high priority, one hardware queue each.
         int lo = 0, hi = 0;
         XENG_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));       // numerically lower = higher priority
-        const bool high = which == STREAM_MAP || which == STREAM_BEAM || which == STREAM_CONSUMER;
+        const bool high = which == STREAM_MAP || which == STREAM_BEAM || which == STREAM_CONSUMER || which == STREAM_COPY;
         XENG_HIP(hipStreamCreateWithPriority(&g_streams[dev][which], hipStreamNonBlocking, high ? hi : 0 < lo ? 0 : lo));
         g_stream_ok[dev][which] = true;
     }

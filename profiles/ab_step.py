@@ -65,11 +65,15 @@ def worker(args):
             for _ in range(args.warm):
                 step()
             ffi.call("xengDeviceSynchronize")
+            if args.profiling:
+                ffi.call("xengXgpuSetProfiling", 1)
             t0 = time.perf_counter()
             for _ in range(args.steps):
                 step()
             ffi.call("xengDeviceSynchronize")
             ms = (time.perf_counter() - t0) / args.steps * 1e3
+            if args.profiling:
+                ffi.call("xengXgpuSetProfiling", 0)
             alone = 0.0
             if args.alone:
                 tm = (ctypes.c_double * 2)()
@@ -94,6 +98,7 @@ def main():
     ap.add_argument("--warm", type=int, default=600)
     ap.add_argument("--alone", type=int, default=0, help="also time N stand-alone launches per round")
     ap.add_argument("--ring-gulps", type=int, default=10)
+    ap.add_argument("--profiling", action="store_true", help="HIP-event profiling of every launch on during the streaming loop (as in the timed region of bench.py)")
     ap.add_argument("--worker", action="store_true")
     args = ap.parse_args()
     if args.worker:
@@ -115,7 +120,7 @@ def main():
             if libs.get(name):
                 env["XENG_LIB"] = libs[name]
             cmd = [sys.executable, os.path.abspath(__file__), "--worker", "--rounds", "1", "--steps", str(args.steps), "--warm", str(args.warm),
-                   "--alone", str(args.alone), "--ring-gulps", str(args.ring_gulps)] + [e for _, e in lst]
+                   "--alone", str(args.alone), "--ring-gulps", str(args.ring_gulps)] + (["--profiling"] if args.profiling else []) + [e for _, e in lst]
             out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
             if out.returncode:
                 sys.stderr.write(out.stderr[-2000:])
