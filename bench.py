@@ -148,10 +148,12 @@ def corr_block_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=100):
                     "`throughput` stat of its last integration (corr_block.py:453 formula)"}
 
 
-def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=240, nwarm=60, long_len=10):
+def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=400, long_len=50):
     """BASELINE config 5 through the BLOCKS on one GPU: Corr -> CorrAcc and Beamform -> BeamformSumBeams as four Python
     threads on in-repo rings (gpu-input read in place by Corr and Beamform), fed by a zero-copy replay source.  CorrAcc's
-    long accumulation (`long_len` dumps) is done by the dumps' own epilogue (fused mode, blocks/corr_acc_block.py)."""
+    long accumulation (`long_len` dumps) is done by the dumps' own epilogue (fused mode, blocks/corr_acc_block.py).  The warm-up
+    covers the start of the pipeline: the first long integrations allocate the 383 MB pinned-host spans of the slow ring
+    (hipHostMalloc: ~0.1 s each, device-wide synchronisations), which the ring then recycles."""
     import json as _json
     import logging
     import threading
@@ -201,10 +203,18 @@ def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=240, nwarm=6
     ths = [drain(r_vis, corr.ogulp_size, lambda: stamps.append(time.perf_counter())), drain(r_slow, cacc.ogulp_size, slow_span),
            drain(r_pow, (nbeam // 2) * (NTIME_GULP // ns) * NCHAN * 16)]
     ths += [threading.Thread(target=f, daemon=True) for f in (corr.main, cacc.main, bf.main, sb.main, source)]
-    for t in ths:
-        t.start()
-    for t in ths:
-        t.join(300)
+    # Eight Python threads under one interpreter lock: a thread that comes back from a library call has to wait for the lock,
+    # by default up to 5 ms (sys.getswitchinterval()) while another thread runs bytecode -- 25 integrations' worth.  A
+    # pipeline launcher sets this once; the blocks' own work happens inside the library, lock released.
+    old_switch = sys.getswitchinterval()
+    sys.setswitchinterval(5e-5)
+    try:
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join(300)
+    finally:
+        sys.setswitchinterval(old_switch)
     n = len(stamps)
     ok = n > nwarm + 1
     el = (stamps[-1] - stamps[nwarm]) if ok else 0.0

@@ -10,6 +10,8 @@ memory) and 'cuda_host' (pinned host memory); the latter two go through libxeng.
 """
 import ctypes
 
+import math
+
 import numpy as np
 
 from . import ffi
@@ -65,7 +67,7 @@ class XArray:
     # ------------------------------------------------------------------ geometry
     @property
     def size(self):
-        return int(np.prod(self.shape, dtype=np.int64)) if self.shape else 1
+        return math.prod(int(d) for d in self.shape) if self.shape else 1      # (per-gulp path of every block: no numpy call)
 
     @property
     def nbytes(self):
@@ -82,9 +84,9 @@ class XArray:
         shape = list(shape)
         if -1 in shape:
             k = shape.index(-1)
-            rest = int(np.prod([s for s in shape if s != -1], dtype=np.int64))
+            rest = math.prod(int(s) for s in shape if s != -1)
             shape[k] = self.size // rest
-        assert int(np.prod(shape, dtype=np.int64)) == self.size, (shape, self.shape)
+        assert math.prod(int(s) for s in shape) == self.size, (shape, self.shape)
         return XArray(shape=shape, dtype=self.dtype, space=self.space, _ptr=self.ptr, _base=self)
 
     def byte_slice(self, offset, nbytes):
