@@ -16,3 +16,4 @@ for set in \
   timeout -k 10 240 rocprofv3 --pmc $set --output-format csv -d $OUT/pass$i -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --sustained 0 "$@" > $OUT/pass$i.log 2>&1 || echo "pass $i failed" >> $OUT/fail.log
 done
 python3 $R/profiles/pmc_summarize.py "$OUT"
+rm -rf $OUT/pass1 $OUT/pass2 $OUT/pass3 $OUT/pass4     # (the raw per-dispatch CSVs are tens of MB: the summary and pmc_traffic.json stay)
