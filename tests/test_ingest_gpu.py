@@ -208,3 +208,34 @@ def test_unpack_async_is_ordered_before_the_contraction():
     ffi.call("xengXgpuSync")
     assert np.array_equal(out.download(np.int32), orc.xgpu_correlate(vin, S, C))
     ffi.call("xengXgpuDestroy")
+
+
+def test_unpack_call_state_is_clean_for_the_next_call():
+    """The synchronous call's kernel reports for itself (its last work-group checks the coverage, writes {drops, complete}
+    to pinned memory and clears the device-side state with atomics): sixty calls in a row with changing loss, foreign and
+    window patterns -- including slabs large enough for a multi-level completion ticket -- each give the oracle's gulp and
+    counts, i.e. nothing of one call's coverage, drop count or ticket survives into the next."""
+    T, C, S = 24, 16, 128
+    rng = np.random.default_rng(2025)
+    vin = rng.integers(1, 256, (T, C, S, 2), dtype=np.uint8)
+    pk = orc.snap2_packets(vin, seq0=77, nchan_blocks=2, nstand_per_pkt=32, chan0_pipeline=0)      # 24 x 2 x 4 = 192 packets
+    stride = len(pk[0])
+    foreign = orc.snap2_packets(vin[:2], seq0=10 ** 6, nchan_blocks=2, nstand_per_pkt=32, chan0_pipeline=0)    # outside the window
+    out = ffi.DeviceBuffer(vin.nbytes)
+    for k in range(60):
+        kind = k % 4
+        if kind == 0:
+            sel = list(pk)                                               # complete
+        elif kind == 1:
+            lost = set(rng.choice(len(pk), size=int(rng.integers(1, 9)), replace=False).tolist())
+            sel = [p for i, p in enumerate(pk) if i not in lost]         # loss -> second pass
+        elif kind == 2:
+            sel = list(pk) + foreign[:int(rng.integers(1, 6))]           # complete, plus dropped strangers
+        else:
+            sel = [pk[i] for i in rng.permutation(len(pk))]              # complete, shuffled
+        ffi.call("xengMemset", out.ptr, 0xEE, out.nbytes)
+        exp, ep, ed = orc.snap2_unpack(sel, 77, T, 0, C, S * 2)
+        got, placed, dropped = _unpack(b"".join(sel), len(sel), stride, 77, T, 0, C, S * 2, out=out)
+        assert (placed, dropped) == (ep, ed), (k, kind, placed, dropped, ep, ed)
+        assert np.array_equal(got, exp), (k, kind)
+    out.free()

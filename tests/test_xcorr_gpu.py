@@ -517,3 +517,33 @@ def test_long_accumulation_fused_into_the_dump(gpu, nstand, nchan, ntime, ngulp,
     x.close()
     for b in [outs[1], ref, din] + accs:
         b.free()
+
+
+def test_deep_asynchronous_queue(gpu):
+    """A caller that never waits: 700 dumps enqueued back to back (more than the library's ring of 256 launch events, so the
+    enqueuer meets the back-pressure of the event ring -- outside the context lock -- many times), rotating over three output
+    spans and two long accumulators.  Every span and both accumulators hold the right words at the end."""
+    nstand, nchan, ntime, nint = 32, 8, 96, 700
+    x = gpu.Xgpu(nstand, nchan, ntime)
+    assert x.path() == (1, 0)
+    vin = gpu.synth_voltages(ntime * 3, nchan, nstand, "full", seed=99).reshape(3, -1)
+    din = gpu.ffi.DeviceBuffer(vin.size).upload(vin)
+    outs = [x.out] + [gpu.ffi.DeviceBuffer(x.out.nbytes) for _ in range(2)]
+    accs = [gpu.ffi.DeviceBuffer(x.out.nbytes) for _ in range(2)]
+    L = gpu.ffi.lib()
+    for n in range(nint):
+        rc = L.xengXgpuKernelAsyncAcc(din.ptr + (n % 3) * x.gulp_bytes, outs[n % 3].ptr, 1, accs[n & 1].ptr, 1 if n < 2 else 2)
+        assert rc == 0, gpu.ffi.lib().xengGetLastError()
+    gpu.ffi.call("xengXgpuSync")
+    exp = [oracle_run(vin[k].reshape(ntime, nchan, nstand, 2), nstand, nchan, ntime) for k in range(3)]
+    for k in range(3):
+        assert np.array_equal(outs[k].download(np.int32), exp[k]), k
+    # accumulator a got the dumps n = a, a+2, ...: n % 3 cycles through the three inputs
+    for a in range(2):
+        tot = np.zeros_like(exp[0], dtype=np.int64)
+        for n in range(a, nint, 2):
+            tot += exp[n % 3]
+        assert np.array_equal(accs[a].download(np.int32), tot.astype(np.int32)), a       # (int32 wrap-around is the kernel's arithmetic too)
+    x.close()
+    for b in outs[1:] + accs + [din]:
+        b.free()
