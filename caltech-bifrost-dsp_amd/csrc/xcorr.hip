@@ -414,7 +414,10 @@ static int initialize_locked(int gpu) {
 #endif
         x.gulp_bytes = (size_t)x.cfg.ntime_gulp * x.cfg.nchan * x.ninput;
         x.raw = !(m && !strcmp(m, "fp6")) && !(r && !strcmp(r, "0")) && x.ninput % 16 == 0 &&
-                x.cfg.ntime_gulp % (XC_KT * 32) == 0 && x.gulp_bytes + (size_t)16 * x.cfg.nchan * x.ninput < (1ull << 32);
+                x.cfg.ntime_gulp % (XC_KT * 32) == 0 && x.gulp_bytes + (size_t)16 * x.cfg.nchan * x.ninput < (1ull << 32) &&
+                // (the kernel's per-lane LDS-DMA offsets subtract the instruction's immediate, up to 3072 bytes, from
+                // n * 8 rows: they stay non-negative -- the VGPR offset is unsigned -- only for rows of at least 128 bytes)
+                (size_t)x.cfg.nchan * x.ninput >= 128;
         if (x.raw) cap = std::min(cap, XC_MAX_GULPS);   // gulp pointers travel in the kernel arguments
     }
     x.cap_gulps = cap;

@@ -725,6 +725,7 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
         const uint32_t col = (uint32_t)((chunk >> 2) ? blk1 : blk0) * 64u + (uint32_t)(chunk & 3) * 16u;
         const uint32_t lane_off = (uint32_t)(lane >> 3) * row_stride + (col + 16u <= (uint32_t)p.ninput ? col : 0u);
 #pragma unroll
+        // (never negative: the host takes this kernel only when a row has at least 128 bytes, xengXgpuInitialize)
         for (int n = 0; n < NLOAD; n++) is_voff[n] = lane_off + (uint32_t)n * 8u * row_stride - (uint32_t)((n & 3) * 1024);
         is_g = 0;
         is_sl = 0;

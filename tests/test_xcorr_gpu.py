@@ -125,6 +125,7 @@ def test_golden_64input(gpu, golden_dir):
     (96, 3, 160, 2, "88"),          # every nibble -8: largest magnitudes, exercises the x16 scaling / P-Q split
     (176, 2, 64, 1, "full"),        # 6 blocks: off-diagonal squares
     (208, 1, 100, 3, "full"),       # 7 blocks (odd), ntime not a multiple of 32 (padded K tile per gulp)
+    (8, 2, 96, 1, "full"),          # whole 96-sample stages but rows of 32 bytes: below the fused kernel's 128-byte minimum -> two-pass path
 ])
 def test_parity_vs_oracle(gpu, nstand, nchan, ntime, ngulp, kind):
     x = gpu.Xgpu(nstand, nchan, ntime)
@@ -147,6 +148,9 @@ def test_parity_vs_oracle(gpu, nstand, nchan, ntime, ngulp, kind):
     (224, 1, 96, 1, "full"),         # 7 blocks, a single stage: the pipeline prologue covers all of K
     (80, 8, 480, 2, "full"),         # the reference gulp length; 2.5 blocks
     (512, 8, 96, 1, "random"),       # 1024 inputs = 16 blocks: 136 wave tiles in 34 tile groups, more work-groups than CUs
+    (72, 4, 96, 2, "full"),          # 144 inputs: 3 blocks whose last 32-input fragment is all padding (Z wave on padded fragments)
+    (8, 8, 96, 1, "full"),           # 16 inputs x 8 channels: one block, one live 16-byte chunk, rows of exactly 128 bytes
+    (200, 3, 96, 1, "random"),       # 400 inputs = 6.25 blocks -> 7 blocks, the last one a quarter full
 ])
 def test_parity_fused_corner_turn(gpu, nstand, nchan, ntime, ngulp, kind):
     """Default path when gulps are whole 96-sample stages: the contraction kernel reads the time-major
