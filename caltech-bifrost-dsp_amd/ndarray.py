@@ -37,9 +37,12 @@ class XArray:
         if space not in _SPACE_ID:
             raise ValueError("unknown space %r" % (space,))
         self.space = space
-        if _ptr is not None:                       # window on existing memory
-            self.dtype = to_dtype(dtype)
-            self.shape = tuple(int(s) for s in shape)
+        self._bf = None
+        if _ptr is not None:                       # window on existing memory (the per-gulp path of every block: kept short)
+            self.dtype = dtype if type(dtype) is np.dtype else to_dtype(dtype)
+            self.shape = shape = tuple(int(s) for s in shape)
+            self.size = math.prod(shape) if shape else 1
+            self.nbytes = self.size * self.dtype.itemsize
             self.ptr = int(_ptr)
             self.base = _base
             return
@@ -52,7 +55,8 @@ class XArray:
                 shape = (shape,)
         self.dtype = to_dtype(dtype)
         self.shape = tuple(int(s) for s in shape)
-        nbytes = self.nbytes
+        self.size = math.prod(self.shape) if self.shape else 1      # (shape and dtype are fixed for the life of the array)
+        self.nbytes = nbytes = self.size * self.dtype.itemsize
         if space == "system":
             self.base = np.zeros(max(nbytes, 1), dtype=np.uint8)
             self.ptr = self.base.ctypes.data
@@ -64,15 +68,7 @@ class XArray:
         if src is not None:
             self[...] = src
 
-    # ------------------------------------------------------------------ geometry
-    @property
-    def size(self):
-        return math.prod(int(d) for d in self.shape) if self.shape else 1      # (per-gulp path of every block: no numpy call)
-
-    @property
-    def nbytes(self):
-        return self.size * self.dtype.itemsize
-
+    # ------------------------------------------------------------------ geometry (size, nbytes: set once in __init__)
     def view(self, dtype):
         dtype = to_dtype(dtype)
         assert self.nbytes % dtype.itemsize == 0
@@ -120,7 +116,10 @@ class XArray:
         return out
 
     def as_BFarray(self):
-        """The struct the bf*-named entry points take (include/xeng.h XENGarray = bifrost BFarray)."""
+        """The struct the bf*-named entry points take (include/xeng.h XENGarray = bifrost BFarray).  Built once per
+        array (pointer, shape and dtype never change) and kept alive with it."""
+        if self._bf is not None:
+            return self._bf_ptr
         a = ffi.XENGarray()
         a.data = self.ptr
         a.space = _SPACE_ID[self.space]
@@ -132,7 +131,8 @@ class XArray:
             a.strides[k] = stride
             stride *= self.shape[k]
         self._bf = a                    # keep alive while the callee uses the pointer
-        return ctypes.pointer(a)
+        self._bf_ptr = ctypes.pointer(a)
+        return self._bf_ptr
 
 
 def copy_array(dst, src):

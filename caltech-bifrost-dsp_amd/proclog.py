@@ -12,13 +12,13 @@ _lock = threading.Lock()
 class ProcLog:
     def __init__(self, name):
         self.name = name
+        self._dir = os.environ.get("XENG_PROCLOG_DIR")        # (read once: update() runs per gulp in every block)
         with _lock:
             PROCLOGS.setdefault(name, {})
 
     def update(self, contents, *args, **kwargs):
-        with _lock:
-            PROCLOGS[self.name] = dict(contents)
-        d = os.environ.get("XENG_PROCLOG_DIR")
+        PROCLOGS[self.name] = dict(contents)                  # (one dict store: atomic under the interpreter lock)
+        d = self._dir
         if d:
             path = os.path.join(d, str(os.getpid()), self.name)
             os.makedirs(os.path.dirname(path), exist_ok=True)
