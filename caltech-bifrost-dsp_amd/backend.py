@@ -5,6 +5,8 @@ constructing it without the HIP library or without a GPU raises.  Tests may inje
 object with the same methods (tests/fake_backend.py wraps the CPU oracle) to exercise the block
 state machines without a GPU -- that is test infrastructure, never a fallback.
 """
+import ctypes
+
 from . import ffi
 
 
@@ -14,6 +16,7 @@ class HipBackend:
 
     def __init__(self):
         self._lib = ffi.lib()   # raises ImportError if libxeng.so has not been built
+        self._enq = ffi.enqueue_lib()   # enqueue-only calls, made without giving up the interpreter lock (ffi.ENQUEUE_ONLY)
 
     # ---- device plumbing (bifrost.device.set_device / get_device / stream_synchronize)
     def set_device(self, gpu):
@@ -40,9 +43,8 @@ class HipBackend:
 
     def beam_mark(self):
         """Ticket for everything enqueued on the beamformer's stream so far (beam_wait waits for it)."""
-        import ctypes
         t = ctypes.c_ulonglong()
-        ffi.call("xengBeamformMark", ctypes.byref(t))
+        ffi.check("xengBeamformMark", self._enq.xengBeamformMark(ctypes.byref(t)))
         return t.value
 
     def beam_wait(self, ticket):
@@ -62,12 +64,12 @@ class HipBackend:
     def bfXgpuKernelAsync(self, in_arr, out_arr, do_dump):
         """Enqueue only: the gulp is read in place at dump time, so the caller keeps it alive and unchanged until
         xgpu_sync() (include/xeng.h: xengXgpuKernelAsync).  No reference counterpart."""
-        return self._lib.xengXgpuKernelAsync(in_arr.contents.data, out_arr.contents.data, int(do_dump))
+        return self._enq.xengXgpuKernelAsync(in_arr.contents.data, out_arr.contents.data, int(do_dump))
 
     def bfXgpuKernelAsyncAcc(self, in_arr, out_arr, do_dump, acc, acc_mode):
         """bfXgpuKernelAsync whose dump also assigns (acc_mode 1) / adds (2) every stored word to the long accumulator
         `acc` -- CorrAcc's "a = b" / "a += b" (corr_acc_block.py:304-306) done by the contraction's epilogue."""
-        return self._lib.xengXgpuKernelAsyncAcc(in_arr.contents.data, out_arr.contents.data, int(do_dump), acc.ptr, int(acc_mode))
+        return self._enq.xengXgpuKernelAsyncAcc(in_arr.contents.data, out_arr.contents.data, int(do_dump), acc.ptr, int(acc_mode))
 
     def xgpu_fused_acc_supported(self):
         """True when the live X-engine context runs the default (fused corner turn) contraction kernel, the one whose
@@ -109,10 +111,10 @@ class HipBackend:
 
     # ---- CorrAcc (corr_acc_block.py:304,306: BFMap "a = b" / "a += b")
     def map_assign_i32(self, a, b):
-        return self._lib.xengMapAssignI32(a.ptr, b.ptr, a.nbytes // 4)
+        return self._enq.xengMapAssignI32(a.ptr, b.ptr, a.nbytes // 4)
 
     def map_add_i32(self, a, b):
-        return self._lib.xengMapAddI32(a.ptr, b.ptr, a.nbytes // 4)
+        return self._enq.xengMapAddI32(a.ptr, b.ptr, a.nbytes // 4)
 
     # ---- beamformer (beamform_block.py:251,449; beamform_sum_beams_block.py:245)
     def bfBeamformInitialize(self, gpu, ninput, nchan, ntime, nbeam, ntime_blocks):
@@ -122,12 +124,12 @@ class HipBackend:
         """`version` != 0 lets the library reuse its bf16-split copy of the weights while the caller has
         not changed them (the reference call shape has no such argument: version 0 = always re-split)."""
         if version:
-            return self._lib.xengBeamformRunVersioned(in_arr.contents.data, out_arr.contents.data,
+            return self._enq.xengBeamformRunVersioned(in_arr.contents.data, out_arr.contents.data,
                                                       weights.contents.data, int(version))
-        return self._lib.bfBeamformRun(in_arr, out_arr, weights)
+        return self._enq.bfBeamformRun(in_arr, out_arr, weights)
 
     def bfBeamformIntegrate(self, in_arr, out_arr, ntime_sum):
-        return self._lib.bfBeamformIntegrate(in_arr, out_arr, int(ntime_sum))
+        return self._enq.bfBeamformIntegrate(in_arr, out_arr, int(ntime_sum))
 
     def last_error(self):
         return self._lib.xengGetLastError().decode()

@@ -86,6 +86,31 @@ def lib():
     return _lib
 
 
+# Enqueue-only entry points: a few microseconds of host work, nothing to wait for.  The block threads call them through a
+# second handle on the same library that does NOT release the interpreter lock around the call (ctypes.PyDLL): a thread that
+# gives the lock up for a 3 us call has to win it back afterwards, and with several block threads in one interpreter that
+# costs a sleep and a wake-up -- measured 50 us per call on the GPU box (profiles/r03/blocks_lock_handoff.txt), more than the
+# GPU needs for the gulp.  Calls that wait (Sync, Wait, the synchronous X-engine call, copies) stay on the releasing handle.
+ENQUEUE_ONLY = ["xengXgpuKernelAsync", "xengXgpuKernelAsyncAcc", "xengBeamformRun", "xengBeamformRunVersioned",
+                "xengBeamformIntegrate", "xengBeamformIntegrateSingleBeam", "xengBeamformMark", "xengMapAssignI32",
+                "xengMapAddI32", "xengSnap2UnpackAsync", "bfBeamformRun", "bfBeamformIntegrate", "bfBeamformIntegrateSingleBeam"]
+_enq = None
+
+
+def enqueue_lib():
+    """The same libxeng.so, bound without releasing the interpreter lock; only the ENQUEUE_ONLY symbols are typed."""
+    global _enq
+    if _enq is None:
+        lib()                                   # (raises when the extension is missing)
+        E = ctypes.PyDLL(LIB_PATH)
+        for name in ENQUEUE_ONLY:
+            f = getattr(E, name)
+            f.argtypes = SYMBOLS[name]
+            f.restype = ctypes.c_int
+        _enq = E
+    return _enq
+
+
 def check(name, status):
     if status != STATUS_SUCCESS:
         raise XengError(name, status, lib().xengGetLastError().decode())
