@@ -203,18 +203,14 @@ def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=4
     ths = [drain(r_vis, corr.ogulp_size, lambda: stamps.append(time.perf_counter())), drain(r_slow, cacc.ogulp_size, slow_span),
            drain(r_pow, (nbeam // 2) * (NTIME_GULP // ns) * NCHAN * 16)]
     ths += [threading.Thread(target=f, daemon=True) for f in (corr.main, cacc.main, bf.main, sb.main, source)]
-    # Eight Python threads under one interpreter lock: a thread that comes back from a library call has to wait for the lock,
-    # by default up to 5 ms (sys.getswitchinterval()) while another thread runs bytecode -- 25 integrations' worth.  A
-    # pipeline launcher sets this once; the blocks' own work happens inside the library, lock released.
-    old_switch = sys.getswitchinterval()
-    sys.setswitchinterval(5e-5)
-    try:
-        for t in ths:
-            t.start()
-        for t in ths:
-            t.join(300)
-    finally:
-        sys.setswitchinterval(old_switch)
+    # Eight Python threads under one interpreter lock.  The blocks keep the lock across their enqueue-only library calls and ask
+    # before they wait (ffi.enqueue_lib, backend.beam_wait / xgpu_sync_lag), so a thread gives the lock up only when it really
+    # has to sleep; the interpreter's switch interval stays at its default (a short one, 5e-5 s, measured 0.51-1.25 ms per
+    # integration over six runs against 0.51-0.62 for the default: profiles/r03/blocks_lock_handoff.txt).
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(300)
     n = len(stamps)
     ok = n > nwarm + 1
     el = (stamps[-1] - stamps[nwarm]) if ok else 0.0

@@ -48,7 +48,11 @@ class HipBackend:
         return t.value
 
     def beam_wait(self, ticket):
-        ffi.call("xengBeamformWait", ticket)
+        # ask first, without giving up the interpreter lock; only a ticket the GPU has not reached yet is worth a blocking call
+        done = ctypes.c_int()
+        ffi.check("xengBeamformTicketDone", self._enq.xengBeamformTicketDone(ticket, ctypes.byref(done)))
+        if not done.value:
+            ffi.call("xengBeamformWait", ticket)
 
     # ---- X-engine (corr_block.py:253,331,445)
     def xgpu_configure(self, nstand, npol, nchan, ntime_gulp, max_gulps=0):
@@ -84,6 +88,10 @@ class HipBackend:
 
     def xgpu_sync_lag(self, lag):
         """Wait until the dump issued `lag` dumps before the latest one is complete (lag 0 = the latest)."""
+        done = ctypes.c_int()
+        rc = self._enq.xengXgpuDumpDone(int(lag), ctypes.byref(done))       # (asked without giving up the interpreter lock)
+        if rc != ffi.STATUS_SUCCESS or done.value:
+            return rc
         return self._lib.xengXgpuSyncLag(int(lag))
 
     def bfXgpuGetOrder(self, antpol_to_input, antpol_to_bl, is_conj):

@@ -328,6 +328,19 @@ int xengBeamformWait(unsigned long long ticket) {
     return XENG_STATUS_SUCCESS;
 }
 
+int xengBeamformTicketDone(unsigned long long ticket, int* done) {
+    std::lock_guard<std::mutex> lk(g_bmu);
+    BeamContext& x = g_b;
+    if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "Beamform: not initialized");
+    if (!done || ticket == 0 || ticket > x.nmarks) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "TicketDone: unknown ticket %llu", ticket);
+    XENG_HIP(hipSetDevice(x.gpu));
+    const hipError_t e = hipEventQuery(x.marks[(ticket - 1) % BeamContext::NMARK]);   // (a re-recorded slot: see Wait)
+    if (e != hipSuccess && e != hipErrorNotReady) XENG_HIP(e);
+    if (e == hipErrorNotReady) (void)hipGetLastError();
+    *done = e == hipSuccess;
+    return XENG_STATUS_SUCCESS;
+}
+
 int xengBeamformGetRouteInfo(int* tiles_total, int* tiles_bf16, int* outlier_inputs) {
     std::lock_guard<std::mutex> lk(g_bmu);
     BeamContext& x = g_b;

@@ -589,6 +589,24 @@ int xengXgpuSyncLag(int lag) {
     return XENG_STATUS_SUCCESS;
 }
 
+int xengXgpuDumpDone(int lag, int* done) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    XgpuContext& x = g_ctx;
+    if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized");
+    if (!done || lag < 0 || lag > 3) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "DumpDone: lag must be 0..3 (got %d)", lag);
+    *done = 1;
+    if (x.ndump > (unsigned long long)lag)
+        if (hipEvent_t ev = launch_event(x.dump_seq[(x.ndump - 1 - lag) & 3])) {
+            XENG_HIP(hipSetDevice(x.gpu));
+            const hipError_t e = hipEventQuery(ev);
+            if (e != hipSuccess && e != hipErrorNotReady) XENG_HIP(e);
+            if (e == hipErrorNotReady) (void)hipGetLastError();
+            *done = e == hipSuccess;
+        }
+    if (*done) x.timer.drain();          // (as xengXgpuSyncLag does: finished timing pairs are folded into the profile)
+    return XENG_STATUS_SUCCESS;
+}
+
 // Drops the partial integration.  The state is reset under the lock; the wait for what was already enqueued happens
 // outside it (other blocks' calls must not stall behind a whole contraction).
 int xengXgpuReset(void) {

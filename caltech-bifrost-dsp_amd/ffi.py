@@ -42,7 +42,7 @@ SYMBOLS = {
     "xengMalloc": [ctypes.POINTER(_vp), _sz, _i], "xengFree": [_vp, _i], "xengMemcpy": [_vp, _vp, _sz],
     "xengMemcpyAsync": [_vp, _vp, _sz], "xengMemset": [_vp, _i, _sz], "xengStreamSynchronize": [],
     "xengXgpuConfigure": [_i, _i, _i, _i, _i], "xengXgpuInitialize": [_i], "xengXgpuDestroy": [],
-    "xengXgpuKernel": [_vp, _vp, _i], "xengXgpuKernelAsync": [_vp, _vp, _i], "xengXgpuKernelAsyncAcc": [_vp, _vp, _i, _vp, _i], "xengXgpuSync": [], "xengXgpuSyncLag": [_i], "xengXgpuReset": [],
+    "xengXgpuKernel": [_vp, _vp, _i], "xengXgpuKernelAsync": [_vp, _vp, _i], "xengXgpuKernelAsyncAcc": [_vp, _vp, _i, _vp, _i], "xengXgpuSync": [], "xengXgpuSyncLag": [_i], "xengXgpuDumpDone": [_i, _pi], "xengXgpuReset": [],
     "xengXgpuCorrelate": [_vp, _vp, _i], "xengXgpuGetOrder": [_vp, _vp, _vp],
     "xengXgpuSubSelect": [_vp, _vp, _vp, _vp, _i, _i], "xengXgpuReorder": [_vp, _vp, _vp, _vp],
     "xengXgpuGetInfo": [_pi, _pi, _pi, _pi, ctypes.POINTER(ctypes.c_int64), _pi],
@@ -55,7 +55,7 @@ SYMBOLS = {
     "xengMapAssignI32": [_vp, _vp, _sz], "xengMapAddI32": [_vp, _vp, _sz], "xengMapSync": [],
     "xengBeamformInitialize": [_i, _i, _i, _i, _i, _i], "xengBeamformDestroy": [],
     "xengBeamformRun": [_vp, _vp, _vp], "xengBeamformRunVersioned": [_vp, _vp, _vp, ctypes.c_longlong], "xengBeamformIntegrate": [_vp, _vp, _i],
-    "xengBeamformIntegrateSingleBeam": [_vp, _vp, _i, _i], "xengBeamformMark": [ctypes.POINTER(ctypes.c_ulonglong)], "xengBeamformWait": [ctypes.c_ulonglong], "xengBeamformSync": [],
+    "xengBeamformIntegrateSingleBeam": [_vp, _vp, _i, _i], "xengBeamformMark": [ctypes.POINTER(ctypes.c_ulonglong)], "xengBeamformWait": [ctypes.c_ulonglong], "xengBeamformTicketDone": [ctypes.c_ulonglong, _pi], "xengBeamformSync": [],
     "xengBeamformSetProfiling": [_i], "xengBeamformGetTimes": [ctypes.POINTER(ctypes.c_double), _pi],
     "xengBeamformGetRouteInfo": [_pi, _pi, _pi],
     "bfXgpuInitialize": [_pa, _pa, _i], "bfXgpuKernel": [_pa, _pa, _i], "bfXgpuCorrelate": [_pa, _pa, _i],
@@ -86,14 +86,14 @@ def lib():
     return _lib
 
 
-# Enqueue-only entry points: a few microseconds of host work, nothing to wait for.  The block threads call them through a
+# Enqueue-only entry points (and the two completion queries): a few microseconds of host work, nothing to wait for.  The block threads call them through a
 # second handle on the same library that does NOT release the interpreter lock around the call (ctypes.PyDLL): a thread that
 # gives the lock up for a 3 us call has to win it back afterwards, and with several block threads in one interpreter that
 # costs a sleep and a wake-up -- measured 50 us per call on the GPU box (profiles/r03/blocks_lock_handoff.txt), more than the
 # GPU needs for the gulp.  Calls that wait (Sync, Wait, the synchronous X-engine call, copies) stay on the releasing handle.
 ENQUEUE_ONLY = ["xengXgpuKernelAsync", "xengXgpuKernelAsyncAcc", "xengBeamformRun", "xengBeamformRunVersioned",
                 "xengBeamformIntegrate", "xengBeamformIntegrateSingleBeam", "xengBeamformMark", "xengMapAssignI32",
-                "xengMapAddI32", "xengSnap2UnpackAsync", "bfBeamformRun", "bfBeamformIntegrate", "bfBeamformIntegrateSingleBeam"]
+                "xengMapAddI32", "xengSnap2UnpackAsync", "xengXgpuDumpDone", "xengBeamformTicketDone", "bfBeamformRun", "bfBeamformIntegrate", "bfBeamformIntegrateSingleBeam"]
 _enq = None
 
 

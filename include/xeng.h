@@ -124,6 +124,9 @@ int xengXgpuSync(void);
  * integration n+1 (into a different out_dev) before it waits for integration n, so the contraction of
  * n+1 fills the CUs that the contraction of n vacates.  lag 0 waits for the latest dump. */
 int xengXgpuSyncLag(int lag);
+/* The non-blocking form: *done = 1 when xengXgpuSyncLag(lag) would return without waiting.  (A caller that shares an
+ * interpreter lock with other threads asks first and only gives the lock up for a call that really has to wait.) */
+int xengXgpuDumpDone(int lag, int *done);
 
 /* Drop the gulps staged and the partial sums accumulated since the last dump (an integration that
  * is abandoned, e.g. when a new start_time command interrupts it: corr_block.py:392-404 resets
@@ -229,6 +232,7 @@ int xengBeamformSync(void);
  * reference waits for the whole stream after every gulp, beamform_block.py:450). */
 int xengBeamformMark(unsigned long long *ticket);
 int xengBeamformWait(unsigned long long ticket);
+int xengBeamformTicketDone(unsigned long long ticket, int *done);   /* non-blocking: *done = 1 when Wait would not wait */
 int xengBeamformSetProfiling(int enable);
 int xengBeamformGetTimes(double ms[2], int count[2]);   /* [0]=Run, [1]=Integrate */
 /* How the last weight upload was routed (waits for the beam stream): (channel, beam tile) pairs in all, pairs that run on
