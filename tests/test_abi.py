@@ -47,6 +47,22 @@ def test_no_cpu_fallback_without_device():
         ffi.call("xengXgpuKernel", 16, 16, 1)          # not initialised -> INVALID_STATE, no compute
     with pytest.raises(ffi.XengError):
         ffi.call("xengBeamformRun", 16, 16, 16)
+    done = ctypes.c_int(-1)
+    for name, arg in (("xengBeamformTicketDone", 1), ("xengXgpuDumpDone", 0)):      # the queries do not pretend either
+        with pytest.raises(ffi.XengError):
+            ffi.call(name, arg, ctypes.byref(done))
+    assert done.value == -1
+
+
+def test_enqueue_handle_binds_the_same_library():
+    """ffi.enqueue_lib(): the second handle (interpreter lock kept) names only enqueue-only calls and completion queries
+    -- nothing on it may wait for the GPU -- and they are the library's own symbols."""
+    E = ffi.enqueue_lib()
+    waits = ("Sync", "Wait", "Correlate", "Memcpy", "Memset", "Malloc", "Free", "Initialize", "Destroy")
+    for name in ffi.ENQUEUE_ONLY:
+        assert name in ffi.SYMBOLS and not any(w in name for w in waits), name
+        assert ctypes.cast(getattr(E, name), ctypes.c_void_p).value == ctypes.cast(getattr(ffi.lib(), name), ctypes.c_void_p).value
+    assert "xengXgpuKernel" not in ffi.ENQUEUE_ONLY and "bfXgpuKernel" not in ffi.ENQUEUE_ONLY     # the synchronous call waits
 
 
 def test_argument_validation_needs_no_gpu():

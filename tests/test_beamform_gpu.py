@@ -217,6 +217,55 @@ def test_versioned_weights_are_resplit_only_on_change(gpu):
     gpu.ffi.call("xengBeamformDestroy")
 
 
+def test_completion_tickets_and_their_query(gpu):
+    """xengBeamformMark / Wait / TicketDone: a ticket whose kernels have completed reads done = 1 (and its output is
+    there); unknown tickets are errors; the query never blocks (it is what the blocks call before a blocking Wait)."""
+    import ctypes
+    ntime, nchan, ninput, nbeam = 256, 4, 64, 32
+    rng = np.random.default_rng(11)
+    vin = rng.integers(0, 256, (ntime, nchan, ninput), dtype=np.uint8)
+    w = block_weights(nchan, nbeam, ninput, seed=3)
+    gpu.ffi.call("xengBeamformInitialize", 0, ninput, nchan, ntime, nbeam, 0)
+    di = gpu.ffi.DeviceBuffer(vin.size).upload(vin)
+    dw = gpu.ffi.DeviceBuffer(w.nbytes).upload(w)
+    outs = [gpu.ffi.DeviceBuffer(nchan * nbeam * ntime * 8) for _ in range(6)]
+    tickets, done = [], ctypes.c_int(-1)
+    for o in outs:
+        gpu.ffi.call("xengBeamformRunVersioned", di.ptr, o.ptr, dw.ptr, 1)
+        t = ctypes.c_ulonglong()
+        gpu.ffi.call("xengBeamformMark", ctypes.byref(t))
+        tickets.append(t.value)
+    assert tickets == sorted(set(tickets)) and tickets[0] >= 1
+    gpu.ffi.call("xengBeamformTicketDone", tickets[-1], ctypes.byref(done))      # returns at once, whatever the answer
+    assert done.value in (0, 1)
+    gpu.ffi.call("xengBeamformWait", tickets[2])
+    for t in tickets[:3]:                                                          # stream order: everything before it too
+        gpu.ffi.call("xengBeamformTicketDone", t, ctypes.byref(done))
+        assert done.value == 1
+    expect = orc.beamform(vin, w, ntime, nchan, ninput, nbeam)
+    check_beams(outs[2].download(np.complex64).reshape(nchan, nbeam, ntime), expect)
+    gpu.ffi.call("xengBeamformSync")
+    gpu.ffi.call("xengBeamformTicketDone", tickets[-1], ctypes.byref(done))
+    assert done.value == 1
+    check_beams(outs[-1].download(np.complex64).reshape(nchan, nbeam, ntime), expect)
+    for bad in (0, tickets[-1] + 1):
+        with pytest.raises(gpu.ffi.XengError):
+            gpu.ffi.call("xengBeamformTicketDone", bad, ctypes.byref(done))
+        with pytest.raises(gpu.ffi.XengError):
+            gpu.ffi.call("xengBeamformWait", bad)
+    with pytest.raises(gpu.ffi.XengError):
+        gpu.ffi.call("xengBeamformTicketDone", tickets[0], None)
+    # the backend's beam_wait (query first, blocking call only when needed) through both branches
+    from caltech_bifrost_dsp_amd.backend import HipBackend
+    be = HipBackend()
+    gpu.ffi.call("xengBeamformRunVersioned", di.ptr, outs[0].ptr, dw.ptr, 1)
+    tk = be.beam_mark()
+    be.beam_wait(tk)
+    be.beam_wait(tk)                 # already complete: answered by the query
+    check_beams(outs[0].download(np.complex64).reshape(nchan, nbeam, ntime), expect)
+    gpu.ffi.call("xengBeamformDestroy")
+
+
 @pytest.mark.parametrize("ntime,nchan,ninput,nbeam,kind", [
     (32, 2, 64, 32, "block"),
     (100, 3, 48, 5, "block"),          # ragged: time not /32, inputs not /32, beams not /32

@@ -397,6 +397,26 @@ def test_streaming_lagged_sync_two_outputs(gpu, ntime, fused):
         assert np.array_equal(results[n], oracle_run(vin[n], nstand, nchan, ntime)), n
     with pytest.raises(gpu.ffi.XengError):
         gpu.ffi.call("xengXgpuSyncLag", 4)
+    # the non-blocking form: everything has been waited for, so every lag reads "done"; bad arguments are errors
+    import ctypes
+    done = ctypes.c_int(-1)
+    for lag in range(4):
+        gpu.ffi.call("xengXgpuDumpDone", lag, ctypes.byref(done))
+        assert done.value == 1
+    for g in range(ngulp):           # one more integration in flight: the query answers at once, SyncLag(0) then makes it 1
+        gpu.ffi.call("xengXgpuKernelAsync", din.ptr + g * x.gulp_bytes, outs[0].ptr, int(g == ngulp - 1))
+    gpu.ffi.call("xengXgpuDumpDone", 0, ctypes.byref(done))
+    assert done.value in (0, 1)
+    gpu.ffi.call("xengXgpuDumpDone", 1, ctypes.byref(done))
+    assert done.value == 1           # the dump before it completed long ago
+    gpu.ffi.call("xengXgpuSyncLag", 0)
+    gpu.ffi.call("xengXgpuDumpDone", 0, ctypes.byref(done))
+    assert done.value == 1
+    assert np.array_equal(outs[0].download(np.int32), oracle_run(vin[0], nstand, nchan, ntime))
+    with pytest.raises(gpu.ffi.XengError):
+        gpu.ffi.call("xengXgpuDumpDone", 4, ctypes.byref(done))
+    with pytest.raises(gpu.ffi.XengError):
+        gpu.ffi.call("xengXgpuDumpDone", 0, None)
     x.close()
     outs[1].free()
 
