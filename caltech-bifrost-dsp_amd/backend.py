@@ -10,6 +10,12 @@ import ctypes
 from . import ffi
 
 
+def _dev(a):
+    """Device address behind an `as_BFarray()` reference (or a plain ctypes pointer to an XENGarray)."""
+    d = getattr(a, "data", None)
+    return d if d is not None else a.contents.data
+
+
 class HipBackend:
     BF_STATUS_SUCCESS = ffi.STATUS_SUCCESS
     space_in = "cuda"          # memory space the compute entry points expect
@@ -68,12 +74,12 @@ class HipBackend:
     def bfXgpuKernelAsync(self, in_arr, out_arr, do_dump):
         """Enqueue only: the gulp is read in place at dump time, so the caller keeps it alive and unchanged until
         xgpu_sync() (include/xeng.h: xengXgpuKernelAsync).  No reference counterpart."""
-        return self._enq.xengXgpuKernelAsync(in_arr.contents.data, out_arr.contents.data, int(do_dump))
+        return self._enq.xengXgpuKernelAsync(_dev(in_arr), _dev(out_arr), int(do_dump))
 
     def bfXgpuKernelAsyncAcc(self, in_arr, out_arr, do_dump, acc, acc_mode):
         """bfXgpuKernelAsync whose dump also assigns (acc_mode 1) / adds (2) every stored word to the long accumulator
         `acc` -- CorrAcc's "a = b" / "a += b" (corr_acc_block.py:304-306) done by the contraction's epilogue."""
-        return self._enq.xengXgpuKernelAsyncAcc(in_arr.contents.data, out_arr.contents.data, int(do_dump), acc.ptr, int(acc_mode))
+        return self._enq.xengXgpuKernelAsyncAcc(_dev(in_arr), _dev(out_arr), int(do_dump), acc.ptr, int(acc_mode))
 
     def xgpu_fused_acc_supported(self):
         """True when the live X-engine context runs the default (fused corner turn) contraction kernel, the one whose
@@ -132,8 +138,7 @@ class HipBackend:
         """`version` != 0 lets the library reuse its bf16-split copy of the weights while the caller has
         not changed them (the reference call shape has no such argument: version 0 = always re-split)."""
         if version:
-            return self._enq.xengBeamformRunVersioned(in_arr.contents.data, out_arr.contents.data,
-                                                      weights.contents.data, int(version))
+            return self._enq.xengBeamformRunVersioned(_dev(in_arr), _dev(out_arr), _dev(weights), int(version))
         return self._enq.bfBeamformRun(in_arr, out_arr, weights)
 
     def bfBeamformIntegrate(self, in_arr, out_arr, ntime_sum):

@@ -136,6 +136,19 @@ class Beamform(Block):
                 ticket, osp, _ = pending.popleft()
                 self._bf.beam_wait(ticket)
                 osp.close()
+        try:
+            self._main_loop(igulp_size, ogulp_size, streaming, pending, retire)
+        finally:
+            # An exception must not release spans that kernels in flight still read or write (their memory would go back
+            # to the ring, be handed out again or freed, under a running kernel): wait for the stream first.
+            if pending:
+                try:
+                    self._bf.beam_sync()
+                except Exception:
+                    pass
+                pending.clear()
+
+    def _main_loop(self, igulp_size, ogulp_size, streaming, pending, retire):
         with self.oring.begin_writing() as oring:
             for iseq in self.iring.read(guarantee=self.guarantee):
                 # frequencies may have changed: rebuild and re-upload coefficients on every sequence

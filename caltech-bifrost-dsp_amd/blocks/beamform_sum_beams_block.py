@@ -53,6 +53,18 @@ class BeamformSumBeams(Block):
                 ticket, osp, _ = pending.popleft()
                 self._bf.beam_wait(ticket)
                 osp.close()
+        try:
+            self._main_loop(streaming, pending, retire)
+        finally:
+            # (as in Beamform: spans of kernels in flight are not released by an exception before the stream is idle)
+            if pending:
+                try:
+                    self._bf.beam_sync()
+                except Exception:
+                    pass
+                pending.clear()
+
+    def _main_loop(self, streaming, pending, retire):
         with self.oring.begin_writing() as oring:
             for iseq in self.iring.read(guarantee=self.guarantee):
                 ihdr = json.loads(iseq.header.tostring())

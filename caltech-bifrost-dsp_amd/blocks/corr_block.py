@@ -127,6 +127,22 @@ class Corr(Block):
         time_tag = 1
         gate = IntegrationGate(recovery_skip=10, round_start_to_acc_len=True)
         self.update_stats({'state': 'starting'})
+        self._held = []
+        self._pending = None
+        try:
+            self._main_loop(gate, time_tag)
+        finally:
+            # An exception must not release gulps or an output span that a dump in flight still reads or writes (their
+            # memory would go back to the rings under the running kernel): wait for the X-engine first.
+            if self._pending is not None or self._held:
+                try:
+                    self._bf.xgpu_sync()
+                except Exception:
+                    pass
+                self._pending = None
+                self._held = []
+
+    def _main_loop(self, gate, time_tag):
         with self.oring.begin_writing() as oring:
             prev_time = time.time()
             self.update_pending = True

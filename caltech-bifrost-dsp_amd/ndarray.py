@@ -24,10 +24,20 @@ _DTYPES = {"i8": np.int8, "u8": np.uint8, "i32": np.int32, "i64": np.int64, "f32
            "ci4": np.uint8}
 
 
+_DT_CACHE = {}
+
+
 def to_dtype(dt):
-    if isinstance(dt, str) and dt in _DTYPES:
-        return np.dtype(_DTYPES[dt])
-    return np.dtype(dt)
+    try:
+        return _DT_CACHE[dt]              # (per-gulp path: data_view('i8'), view(np.float32) ...)
+    except (KeyError, TypeError):
+        pass
+    d = np.dtype(_DTYPES[dt]) if isinstance(dt, str) and dt in _DTYPES else np.dtype(dt)
+    try:
+        _DT_CACHE[dt] = d
+    except TypeError:                     # unhashable spec (a list of fields)
+        pass
+    return d
 
 
 class XArray:
@@ -37,7 +47,6 @@ class XArray:
         if space not in _SPACE_ID:
             raise ValueError("unknown space %r" % (space,))
         self.space = space
-        self._bf = None
         if _ptr is not None:                       # window on existing memory (the per-gulp path of every block: kept short)
             self.dtype = dtype if type(dtype) is np.dtype else to_dtype(dtype)
             self.shape = shape = tuple(int(s) for s in shape)
@@ -116,10 +125,14 @@ class XArray:
         return out
 
     def as_BFarray(self):
-        """The struct the bf*-named entry points take (include/xeng.h XENGarray = bifrost BFarray).  Built once per
-        array (pointer, shape and dtype never change) and kept alive with it."""
-        if self._bf is not None:
-            return self._bf_ptr
+        """What the bf*-named entry points take (include/xeng.h XENGarray = bifrost BFarray): a reference that turns into
+        the struct pointer when ctypes passes it to a bf* function, and answers `.contents.data` -- all the raw xeng* calls
+        of the backend need -- without building the struct (two fresh views per gulp in every block)."""
+        # (a fresh reference every time, never stored on the array: array -> reference -> array would be a cycle, and span
+        # memory must return to its ring the moment the last user lets go of it, not when the cycle collector next runs)
+        return _BFRef(self)
+
+    def _xeng_array(self):
         a = ffi.XENGarray()
         a.data = self.ptr
         a.space = _SPACE_ID[self.space]
@@ -130,9 +143,33 @@ class XArray:
             a.shape[k] = self.shape[k]
             a.strides[k] = stride
             stride *= self.shape[k]
-        self._bf = a                    # keep alive while the callee uses the pointer
-        self._bf_ptr = ctypes.pointer(a)
-        return self._bf_ptr
+        return a
+
+
+class _BFRef:
+    """`XArray.as_BFarray()`: quacks like ctypes.pointer(XENGarray) for the uses the backends make of it."""
+    __slots__ = ("arr", "_struct", "_ptr")
+
+    def __init__(self, arr):
+        self.arr = arr
+        self._struct = None
+        self._ptr = None
+
+    @property
+    def contents(self):                   # .contents.data / .contents.shape[...] as on a ctypes pointer
+        if self._struct is None:
+            self._struct = self.arr._xeng_array()
+        return self._struct
+
+    @property
+    def data(self):
+        return self.arr.ptr
+
+    @property
+    def _as_parameter_(self):             # ctypes: passed where POINTER(XENGarray) is expected
+        if self._ptr is None:
+            self._ptr = ctypes.pointer(self.contents)
+        return self._ptr
 
 
 def copy_array(dst, src):

@@ -1,6 +1,6 @@
 """Stand-ins for bifrost.proclog.ProcLog and bifrost.affinity used by the blocks
 (block_base.py:113-119, corr_block.py:336).  ProcLog keeps the latest dict per log name in
-memory (PROCLOGS) and, when XENG_PROCLOG_DIR is set, also writes bifrost-style `key : value`
+memory (PROCLOGS: a reference to the dict the block last passed, so a monitor reads current values) and, when XENG_PROCLOG_DIR is set, also writes bifrost-style `key : value`
 files there so a monitor can poll them like /dev/shm/bifrost."""
 import os
 import threading
@@ -17,7 +17,7 @@ class ProcLog:
             PROCLOGS.setdefault(name, {})
 
     def update(self, contents, *args, **kwargs):
-        PROCLOGS[self.name] = dict(contents)                  # (one dict store: atomic under the interpreter lock)
+        PROCLOGS[self.name] = contents                        # (the caller's live dict, not a copy: update() runs per gulp in every block)
         d = self._dir
         if d:
             path = os.path.join(d, str(os.getpid()), self.name)

@@ -312,21 +312,33 @@ class Ring:
     # ------------------------------------------------------------------ bookkeeping (hold _cond)
     def _gc(self):
         """Free committed spans every registered reader has moved past.  Released chunks leave the head of their
-        sequence's list, so the cost per call is the number of chunks released, not the length of the sequence."""
-        if not self._readers:
+        sequence's list, so the cost per call is the number of chunks released, not the length of the sequence.
+        (Runs once per gulp and reader: kept short.)"""
+        readers = self._readers
+        if not readers:
             return
-        lo_seq = min(r.seq_index for r in self._readers)
-        for seq in self._seqs[self._gc_seq:lo_seq + 1]:
-            lo_off = None
-            if seq.index == lo_seq:
-                lo_off = min(r.offset for r in self._readers if r.seq_index == lo_seq)
-            ch = seq.chunks
-            while ch and (lo_off is None or ch[0].offset + ch[0].nbytes <= lo_off):
+        if len(readers) == 1:
+            lo_seq, lo_off = readers[0].seq_index, readers[0].offset
+        else:
+            lo_seq, lo_off = min([(r.seq_index, r.offset) for r in readers])       # the slowest reader
+        seqs, g, freed = self._seqs, self._gc_seq, 0
+        while g < lo_seq:                              # sequences every reader has left are empty for good
+            ch = seqs[g].chunks
+            while ch:
                 c = ch.popleft()
                 if c.data is not None:
                     c.data = None
-                    self._live_bytes -= c.nbytes
-        self._gc_seq = max(self._gc_seq, lo_seq)      # sequences before the slowest reader are empty for good
+                    freed += c.nbytes
+            g += 1
+        self._gc_seq = g
+        if lo_seq < len(seqs):
+            ch = seqs[lo_seq].chunks
+            while ch and ch[0].offset + ch[0].nbytes <= lo_off:
+                c = ch.popleft()
+                if c.data is not None:
+                    c.data = None
+                    freed += c.nbytes
+        self._live_bytes -= freed
 
     def _drop_oldest(self):
         for seq in self._seqs[self._gc_seq:]:
@@ -341,9 +353,12 @@ class Ring:
     def _assemble(self, seq, offset, nbytes):
         """Bytes [offset, offset+nbytes) of a sequence as one array: a zero-copy window when they
         lie inside one committed span, else a gathered copy in the ring's space."""
-        pieces = []
         if not seq.chunks or seq.chunks[0].offset > offset:
             raise RuntimeError("ring %r: data at %d was overwritten before it was read" % (self.name, offset))
+        c0 = seq.chunks[0]
+        if c0.offset == offset and c0.nbytes == nbytes:       # the usual case: the gulp is the oldest span, whole
+            return c0.data
+        pieces = []
         for ch in seq.chunks:
             if ch.offset >= offset + nbytes:
                 break

@@ -28,3 +28,13 @@ print("entry times us: p10 %.1f median %.1f p90 %.1f max %.1f" % tuple(np.percen
 print("per wave us: entry->first chunk %.2f | chunk loop %.2f (%.3f per chunk) | epilogue %.2f | total %.2f" % (
     np.median(st[:, 1] - st[:, 0]), np.median(st[:, 2] - st[:, 1]), np.median(st[:, 2] - st[:, 1]) / 21, np.median(st[:, 3] - st[:, 2]),
     np.median(st[:, 3] - st[:, 0])))
+
+tot = st[:, 3] - st[:, 0]
+for name, v in (("entry->first chunk", st[:, 1] - st[:, 0]), ("chunk loop", st[:, 2] - st[:, 1]), ("epilogue", st[:, 3] - st[:, 2]), ("total", tot),
+                ("exit time", st[:, 3] - t0)):
+    print("%-20s p1 %.2f p10 %.2f p50 %.2f p90 %.2f p99 %.2f max %.2f" % ((name,) + tuple(np.percentile(v, [1, 10, 50, 90, 99, 100]))))
+wg = st.reshape(-1, 4, 4)                      # [work-group][wave][stamp]
+xcd = np.arange(len(wg)) % 8
+for x in range(8):
+    sel = wg[xcd == x]
+    print("XCD %d: median total %.2f us, last exit %.2f us" % (x, np.median(sel[:, :, 3] - sel[:, :, 0]), (sel[:, :, 3] - t0).max()))

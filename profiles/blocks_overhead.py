@@ -115,9 +115,15 @@ def main():
                     oseq.commit_external(spans[k % len(spans)])
     profs = {}
 
+    cpu = {}
+
     def wrap(name, fn):
         if not a.profile:
-            return fn
+            def run_cpu():
+                t = time.thread_time()
+                fn()
+                cpu[name] = time.thread_time() - t
+            return run_cpu
 
         def run():
             pr = cProfile.Profile()
@@ -135,6 +141,9 @@ def main():
         t.join(60)
     el = time.perf_counter() - t0
     print("%s: %d integrations in %.3f s = %.1f us of interpreter per integration (%d gulps each)" % (a.which, a.nint, el, el / a.nint * 1e6, gps))
+    if cpu:
+        print("    CPU time per integration (thread_time): " + ", ".join("%s %.0f us" % (k, v / a.nint * 1e6) for k, v in cpu.items()) +
+              " | sum %.0f us" % (sum(cpu.values()) / a.nint * 1e6))
     for name, pr in profs.items():
         s = io.StringIO()
         pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(14)

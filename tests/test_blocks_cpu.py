@@ -629,3 +629,60 @@ def test_fused_corracc_follows_commands_and_new_upstream_sequences():
         assert h1 == h2 and t1 == t2 and len(s1) == len(s2) and all(np.array_equal(a, b) for a, b in zip(s1, s2))
     (h, _, spans) = res[True][0]
     assert h['seq0'] == 8 and np.array_equal(spans[0], orc.xgpu_correlate(d0[8:16], S, C))
+
+
+# ---------------------------------------------------------------------------------------------- failures mid-stream
+def test_a_failing_block_waits_for_its_kernels_before_it_lets_go_of_their_spans():
+    """A block thread that dies with gulps in flight (a library call fails mid-stream) must wait for the GPU before its
+    spans are released: their memory goes back to the ring -- to be handed out again or freed -- and a kernel still writing
+    there would be a device memory fault.  Beamform / BeamformSumBeams: beam_sync; Corr: xgpu_sync."""
+    class Failing(OracleBackend):
+        def __init__(self, fail_at):
+            super().__init__()
+            self.fail_at, self.calls, self.order = fail_at, 0, []
+
+        def bfBeamformRun(self, i, o, w, version=0):
+            self.calls += 1
+            if self.calls == self.fail_at:
+                return 3
+            return super().bfBeamformRun(i, o, w, version=version)
+
+        def bfXgpuKernelAsync(self, i, o, d):
+            self.calls += 1
+            if self.calls == self.fail_at:
+                return 3
+            return super().bfXgpuKernelAsync(i, o, d)
+
+        def beam_sync(self):
+            self.order.append("beam_sync")
+
+        def xgpu_sync(self):
+            self.order.append("xgpu_sync")
+            return 0
+
+    nchan, nstand, nbeam, g = 2, 4, 2, 4
+    ninput = nstand * 2
+    rng = np.random.default_rng(5)
+    vin = rng.integers(0, 256, (6 * g, nchan, ninput), dtype=np.uint8)
+    # Beamform: the third Run fails while two gulps are in flight
+    r0, r1 = Ring("gpu-input"), Ring("bf-output")
+    be = Failing(3)
+    bf = Beamform(LOG, r0, r1, nchan=nchan, nbeam=nbeam, ninput=ninput, ntime_gulp=g, backend=be)
+    sink = Sink(r1, g * nchan * nbeam * 8)
+    src = Source(r0, [(source_header(nchan, nstand, 2), vin, g * nchan * ninput)], wait_readers=1)
+    sink.start()
+    src.start()
+    with pytest.raises(RuntimeError, match="bfBeamformRun returned 3"):
+        bf.main()
+    assert be.order == ["beam_sync"]
+    # Corr: the second gulp of the second integration fails while the first integration's dump is in flight
+    r2, r3 = Ring("in"), Ring("out")
+    be = Failing(4)
+    blk = Corr(LOG, r2, r3, ntime_gulp=g, nchan=nchan, npol=2, nstand=nstand, acc_len=2 * g, autostartat=0, backend=be)
+    sink2 = Sink(r3, blk.ogulp_size)
+    src2 = Source(r2, [(source_header(nchan, nstand, 2), vin.reshape(6 * g, nchan, nstand, 2), g * nchan * ninput)], wait_readers=1)
+    sink2.start()
+    src2.start()
+    with pytest.raises(RuntimeError, match="xgpuKernel returned 3"):
+        blk.main()
+    assert be.order and be.order[-1] == "xgpu_sync"

@@ -110,3 +110,26 @@ def test_two_readers_see_everything():
         assert not t.is_alive()
     assert outs[0][-1] == 49 and outs[1][-1] == 49
     assert outs[0] == sorted(outs[0]) and outs[1] == sorted(outs[1])
+
+
+def test_span_memory_is_released_by_reference_counting_alone():
+    """A span's memory goes back to its ring the moment the last user lets go of it: nothing on the per-gulp path (views,
+    as_BFarray references) may form a reference cycle, or the release would wait for the cycle collector -- on the device
+    rings that meant fresh allocations per gulp and frees at arbitrary moments."""
+    import gc
+    import weakref
+    from caltech_bifrost_dsp_amd.ndarray import XArray
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        a = XArray(shape=(64,), dtype=np.uint8, space="system")
+        v = a.view('i8')
+        r = v.as_BFarray()
+        assert r.contents.data == a.ptr and r.data == a.ptr and r._as_parameter_ is not None
+        w = v.reshape(8, 8).byte_slice(0, 16)
+        refs = [weakref.ref(o) for o in (a, v, w)]
+        del a, v, r, w
+        assert all(x() is None for x in refs)
+    finally:
+        if was:
+            gc.enable()
