@@ -46,6 +46,9 @@ class _PooledBuffer:
         try:
             if ring is not None and ring._pool_put(buf):
                 return
+            # really freed (the ring is gone or its free list is full): rare, and never under a kernel -- whoever dropped
+            # the last reference had waited for its own GPU work, but the device is drained first all the same
+            ffi.call("xengDeviceSynchronize")
             buf.free()
         except Exception:          # interpreter shutdown: the process is going away with its allocations
             pass
