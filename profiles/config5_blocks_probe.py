@@ -21,6 +21,24 @@ ring = ffi.DeviceBuffer(ring_gulps * gulp_bytes)
 rs = np.random.RandomState(0xdeadbeef)
 for g in range(ring_gulps):
     ring.upload(rs.randint(0, 255, size=gulp_bytes, dtype=np.uint8), offset=g * gulp_bytes)
+# allocation churn: device / pinned allocations and frees made while the legs run (the rings are meant to recycle)
+counts = {"alloc": 0, "free": 0, "alloc_bytes": 0}
+_init, _free = ffi.DeviceBuffer.__init__, ffi.DeviceBuffer.free
+
+
+def _count_init(self, nbytes, space=ffi.SPACE_CUDA):
+    counts["alloc"] += 1
+    counts["alloc_bytes"] += int(nbytes)
+    _init(self, nbytes, space)
+
+
+def _count_free(self):
+    if self.ptr:
+        counts["free"] += 1
+    _free(self)
+
+
+ffi.DeviceBuffer.__init__, ffi.DeviceBuffer.free = _count_init, _count_free
 real_set = sys.setswitchinterval
 for rep in range(reps):
     for iv in intervals:
@@ -30,4 +48,6 @@ for rep in range(reps):
             r = bench.config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, 0)
         finally:
             sys.setswitchinterval = real_set
-        print("switch interval %.0e s: %.4f ms per integration (%s Gb/s), fused %s" % (iv, r["ms_per_integration"] or -1, r["value"], r["corracc_fused_into_dumps"]), flush=True)
+        print("switch interval %.0e s: %.4f ms per integration (%s Gb/s), fused %s; allocations %d (%.0f MB), frees %d in this leg" % (
+            iv, r["ms_per_integration"] or -1, r["value"], r["corracc_fused_into_dumps"], counts["alloc"], counts["alloc_bytes"] / 1e6, counts["free"]), flush=True)
+        counts.update(alloc=0, free=0, alloc_bytes=0)
