@@ -13,6 +13,13 @@ from tests.pipeline_util import LOG, Sink, Source, run_blocks, source_header  # 
 from tests.test_blocks_cpu import _beam_cmds  # noqa: E402
 
 
+def fused_xengine_expected():
+    """The shipped switch XENG_RAW=0 selects the two-pass X-engine (identical results, no fused long accumulation): the path
+    assertions below follow the switch the suite was started with."""
+    import os
+    return os.environ.get("XENG_RAW") != "0"
+
+
 @pytest.mark.parametrize("g", [32, 96])
 def test_corr_corracc_on_device_rings(g):
     """gpu-input (cuda) -> Corr -> corr-output (cuda) -> CorrAcc -> corr-slow-output (cuda_host),
@@ -37,7 +44,8 @@ def test_corr_corracc_on_device_rings(g):
     assert h2['upstream_acc_len'] == acc and h2['acc_len'] == lacc and len(sp2) == 2
     for k, sp in enumerate(sp2):
         assert np.array_equal(sp.view(np.int32), orc.xgpu_correlate(vin[k * lacc:(k + 1) * lacc], S, C))
-    assert cacc.stats['fused'] is (g == 96) and cacc.fused_dumps == (4 if g == 96 else 0)   # accumulated by the dumps' own epilogue
+    fz = g == 96 and fused_xengine_expected()
+    assert cacc.stats['fused'] is fz and cacc.fused_dumps == (4 if fz else 0)   # accumulated by the dumps' own epilogue
 
 
 @pytest.mark.parametrize("fused", [True, False])
@@ -81,7 +89,8 @@ def test_corracc_full_size_misaligned_start(fused):
     assert not sink.is_alive()
     assert verdicts == [True, True], verdicts                  # [2400, 9600) and [9600, 16800); the third is cut off
     assert hdrs[0]['seq0'] == acc and hdrs[0]['acc_len'] == 3 * acc and hdrs[0]['upstream_acc_len'] == acc
-    assert cacc.stats['fused'] is fused and (cacc.fused_dumps == 7) is fused
+    fz = fused and fused_xengine_expected()
+    assert cacc.stats['fused'] is fz and (cacc.fused_dumps == 7) is fz
 
 
 def test_beamform_sumbeams_on_device_rings():
@@ -191,6 +200,8 @@ def test_corr_reads_gulps_in_place_from_the_in_repo_ring():
     corr = Corr(LOG, r0, r1, ntime_gulp=g, nchan=C, npol=2, nstand=S, acc_len=acc, autostartat=0, gpu=0)
     fused, fp6 = ctypes.c_int(), ctypes.c_int()
     ffi.call("xengXgpuGetPath", ctypes.byref(fused), ctypes.byref(fp6))
+    if not fused_xengine_expected():
+        pytest.skip("XENG_RAW=0: the two-pass X-engine copies its gulps (this test is about the fused kernel reading in place)")
     assert fused.value == 1
     ffi.call("xengXgpuSetProfiling", 1)
     tm, cn = (ctypes.c_double * 2)(), (ctypes.c_int * 2)()
