@@ -142,7 +142,8 @@ class HipBackend:
         return self._enq.bfBeamformRun(in_arr, out_arr, weights)
 
     def bfBeamformIntegrate(self, in_arr, out_arr, ntime_sum):
-        return self._enq.bfBeamformIntegrate(in_arr, out_arr, int(ntime_sum))
+        # (bfBeamformIntegrate reads only the two data pointers from its structs: the raw entry point, no structs built per gulp)
+        return self._enq.xengBeamformIntegrate(_dev(in_arr), _dev(out_arr), int(ntime_sum))
 
     def last_error(self):
         return self._lib.xengGetLastError().decode()

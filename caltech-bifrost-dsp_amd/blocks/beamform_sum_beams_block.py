@@ -96,10 +96,9 @@ class BeamformSumBeams(Block):
                             curr_time = time.time()
                             reserve_time = curr_time - prev_time
                             prev_time = curr_time
-                            idata = ispan.data_view(np.float32)
-                            odata = ospan.data_view(np.float32).reshape(self.bf_output.shape)
-                            target = odata if streaming else self.bf_output
-                            rv = self._bf.bfBeamformIntegrate(idata.as_BFarray(), target.as_BFarray(), self.ntime_sum)
+                            # (streaming: the kernel writes into the span itself; the call only needs addresses, so no typed views)
+                            target = ospan.data if streaming else self.bf_output
+                            rv = self._bf.bfBeamformIntegrate(ispan.data.as_BFarray(), target.as_BFarray(), self.ntime_sum)
                             if rv != self._bf.BF_STATUS_SUCCESS:
                                 raise RuntimeError("bfBeamformIntegrate returned %d: %s" % (rv, self._bf.last_error()))
                             if streaming:
@@ -108,7 +107,7 @@ class BeamformSumBeams(Block):
                                 retire(self.STREAM_DEPTH)
                             else:
                                 self._bf.beam_sync()
-                                odata[...] = self.bf_output       # (synchronous copy)
+                                ospan.data_view(np.float32).reshape(self.bf_output.shape)[...] = self.bf_output       # (synchronous copy)
                         finally:
                             if ospan is not None:
                                 ospan.close()
