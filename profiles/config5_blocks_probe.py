@@ -45,7 +45,7 @@ for rep in range(reps):
         real_set(iv)
         sys.setswitchinterval = lambda v: None          # the leg's own setting is ignored: this probe chooses
         try:
-            r = bench.config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, 0)
+            r = bench.config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, 0, long_len=int(os.environ.get("XENG_PROBE_LONG_LEN", "50")))
         finally:
             sys.setswitchinterval = real_set
         print("switch interval %.0e s: %.4f ms per integration (%s Gb/s), fused %s; allocations %d (%.0f MB), frees %d in this leg" % (
