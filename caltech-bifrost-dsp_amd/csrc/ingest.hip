@@ -23,6 +23,20 @@ __device__ __forceinline__ uint32_t be32(const uint8_t* p) {
 }
 __device__ __forceinline__ uint32_t be16(const uint8_t* p) { return ((uint32_t)p[0] << 8) | p[1]; }
 
+// The gulp is stored THROUGH the caches (system scope: sc0 sc1).  The synchronous call reports completion from inside the
+// kernel (the last work-group raises a word in pinned memory, below) and its caller may hand the gulp to another stream --
+// or read it from the host -- the moment it returns, before the kernel has formally ended: a plain store could still sit
+// dirty in its XCD's L2 then (the eight L2s are only written back by the end-of-kernel release).  With write-through stores a
+// work-group's `s_waitcnt vmcnt(0)` before its ticket means its bytes are in memory, so the report implies the whole gulp is.
+// The scatter streams every byte once: nothing is lost by not keeping it in L2.
+typedef unsigned int snap2_v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_through16(uint8_t* p, snap2_v4u v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_through1(uint8_t* p, uint8_t v) {
+    asm volatile("global_store_byte %0, %1, off sc0 sc1" ::"v"(p), "v"((uint32_t)v) : "memory");
+}
+
 // One wave per packet (four per work-group, grid-stride): the header is fetched with two 16-byte loads (all lanes,
 // same address) and byte-swapped in registers; payload rows move as 16-byte pieces, eight loads in flight per lane
 // before the first store, when the geometry is 16-byte aligned (the deployed 64-byte rows are), else byte by byte.
@@ -89,7 +103,7 @@ __global__ __launch_bounds__(256) void snap2_unpack_kernel(const uint8_t* __rest
                 const int i = lane + u * 64;
                 if (i < n) {
                     const int c = i / per_row, j = i - c * per_row;
-                    *reinterpret_cast<v4u*>(dst + (size_t)c * npol_tot + j * 16) = v[u];
+                    store_through16(dst + (size_t)c * npol_tot + j * 16, v[u]);
                 }
             }
             for (int i0 = lane + 8 * 64; i0 < n; i0 += 8 * 64) {     // payloads beyond 8 KiB
@@ -104,14 +118,14 @@ __global__ __launch_bounds__(256) void snap2_unpack_kernel(const uint8_t* __rest
                     const int i = i0 + u * 64;
                     if (i < n) {
                         const int c = i / per_row, j = i - c * per_row;
-                        *reinterpret_cast<v4u*>(dst + (size_t)c * npol_tot + j * 16) = w[u];
+                        store_through16(dst + (size_t)c * npol_tot + j * 16, w[u]);
                     }
                 }
             }
         } else {
             for (int i = lane; i < nchan * npol; i += 64) {
                 const int c = i / npol, j = i - c * npol;
-                dst[(size_t)c * npol_tot + j] = src[i];
+                store_through1(dst + (size_t)c * npol_tot + j, src[i]);
             }
         }
         if (row_cover && lane == 0) {
