@@ -94,3 +94,23 @@ def test_get_order_and_reorder_are_host_functions():
     ffi.call("xengXgpuReorder", planar.ctypes.data, out.ctypes.data, bl.ctypes.data, cj.ctypes.data)
     assert np.array_equal(out, orc.xgpu_reorder(planar, bl, cj, nchan))
     ffi.call("xengXgpuConfigure", 352, 2, 96, 480, 0)
+
+
+def test_as_bfarray_reference_passes_where_a_struct_pointer_is_expected():
+    """XArray.as_BFarray() returns a light reference: ctypes turns it into the XENGarray pointer when a bf* entry point
+    takes it (here the host-side bfXgpuGetOrder, no GPU needed), and `.contents` / `.data` answer like the pointer would."""
+    import numpy as np
+    from caltech_bifrost_dsp_amd.ndarray import XArray
+    ns = 16
+    ffi.call("xengXgpuConfigure", ns, 2, 4, 8, 0)
+    a2i = np.random.default_rng(1).permutation(ns * 2).astype(np.int32).reshape(ns, 2)
+    xa = XArray(a2i, space="system")
+    bl, cj = XArray(shape=(ns, ns, 2, 2), dtype=np.int32, space="system"), XArray(shape=(ns, ns, 2, 2), dtype=np.int32, space="system")
+    assert ffi.lib().bfXgpuGetOrder(xa.as_BFarray(), bl.as_BFarray(), cj.as_BFarray()) == 0
+    rbl, rcj = np.zeros((ns, ns, 2, 2), np.int32), np.zeros((ns, ns, 2, 2), np.int32)
+    ffi.call("xengXgpuGetOrder", a2i.ctypes.data, rbl.ctypes.data, rcj.ctypes.data)
+    assert np.array_equal(bl.numpy(), rbl) and np.array_equal(cj.numpy(), rcj)
+    r = xa.as_BFarray()
+    assert r.data == xa.ptr and r.contents.data == xa.ptr and r.contents.ndim == 2 and r.contents.shape[0] == ns
+    assert list(r.contents.strides[:2]) == [8, 4]
+    ffi.call("xengXgpuConfigure", 352, 2, 96, 480, 0)
