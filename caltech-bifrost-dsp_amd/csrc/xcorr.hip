@@ -309,7 +309,14 @@ static int kernel_locked(const void* in_dev, void* out_dev, int doDump, bool syn
                                  // waits for the contraction before it returns, so its own gulp is read in place)
             uint8_t* copy = stash + (size_t)x.nfilled * x.gulp_bytes;
             slot = x.timer.begin(x.stream, 0);
-            XENG_HIP(hipMemcpyAsync(copy, in_dev, x.gulp_bytes, hipMemcpyDeviceToDevice, x.stream));
+            if (x.gulp_bytes % 16 == 0) {     // (in_dev and the staging area are 16-byte aligned on this path)
+                const size_t n16 = x.gulp_bytes / 16;
+                const unsigned blocks = (unsigned)std::min<size_t>(2048, (n16 + 1023) / 1024);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(gulp_copy_kernel<4>), dim3(blocks), dim3(256), 0, x.stream, (v4i*)copy, (const v4i*)in_dev, n16);
+                XENG_HIP(hipGetLastError());
+            } else {
+                XENG_HIP(hipMemcpyAsync(copy, in_dev, x.gulp_bytes, hipMemcpyDeviceToDevice, x.stream));
+            }
             x.gulp_ptr[x.nfilled] = copy;
         } else {
             x.gulp_ptr[x.nfilled] = (const uint8_t*)in_dev;

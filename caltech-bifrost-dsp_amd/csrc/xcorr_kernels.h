@@ -947,6 +947,30 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Raw copy of a synchronously handed gulp into the staging area (xengXgpuKernel, reference call semantics: the caller may
+// recycle its buffer on return, corr_block.py:445-452).  HBM-bound: 16 B per lane, U pieces in flight, grid-stride over
+// 2048 work-groups like the CorrAcc map, non-temporal both ways (the source is read once; the copy is read by the contraction
+// tens of microseconds later, through L2 misses either way: 32 MB against 4 MB of L2 per XCD).
+// ---------------------------------------------------------------------------------------
+template <int U>
+__global__ __launch_bounds__(256) void gulp_copy_kernel(v4i* __restrict__ dst, const v4i* __restrict__ src, size_t n16) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x * U;
+    for (size_t k0 = (size_t)blockIdx.x * blockDim.x * U + threadIdx.x; k0 < n16; k0 += stride) {
+        v4i y[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const size_t k = k0 + (size_t)u * blockDim.x;
+            if (k < n16) y[u] = __builtin_nontemporal_load(src + k);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const size_t k = k0 + (size_t)u * blockDim.x;
+            if (k < n16) __builtin_nontemporal_store(y[u], dst + k);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // bfXgpuSubSelect replacement (corr_subsel_block.py:298): gather + channel sum + conjugate
 // ---------------------------------------------------------------------------------------
 __global__ void subselect_kernel(const int32_t* __restrict__ xg, int32_t* __restrict__ out,
