@@ -174,6 +174,8 @@ class Beamform(Block):
                         self.update_stats({'curr_sample': this_gulp_time})
                         if ispan.size < igulp_size:
                             continue
+                        if getattr(ispan, 'skipped', 0):     # gulps overwritten before this reader got to them (ring.py)
+                            this_gulp_time += (ispan.skipped // igulp_size) * self.ntime_gulp
                         if self.update_pending:
                             self.acquire_control_lock()
                             for b in range(self.nbeam):

@@ -86,9 +86,15 @@ class CorrAcc(Block):
         self._open_set = None                     # pair of the long integration in progress (first seen, last not yet)
         self._stopping = False
         self.fused_dumps = 0                      # dumps accumulated by the contraction's epilogue (stat)
-        # the upstream Corr finds its long accumulator through the ring it writes (no change to the pipeline script)
-        if getattr(iring, 'span_memory_outlives_release', False) and hasattr(self._bf, 'bfXgpuKernelAsyncAcc'):
+        # the upstream Corr finds its long accumulator through the ring it writes (no change to the pipeline script).  Only a
+        # guaranteed reader that sees every span from the first can follow Corr's decisions one by one: the reader is
+        # registered here, before anything is written; a second CorrAcc on the same ring, or a reader without the guarantee,
+        # keeps the map path.
+        self._iseqs = None
+        if (getattr(iring, 'span_memory_outlives_release', False) and hasattr(self._bf, 'bfXgpuKernelAsyncAcc') and guarantee
+                and getattr(iring, 'long_accumulator', None) is None):
             iring.long_accumulator = self
+            self._iseqs = iring.read(guarantee=True)
 
     # ------------------------------------------------------------------ the gate, one step per upstream sequence / span
     def _check_compat(self, gate, upstream_acc_len, upstream_start_time):
@@ -168,9 +174,11 @@ class CorrAcc(Block):
             self._open_set = None
             self._plan_cv.notify_all()
 
-    def plan_dump(self, timeout=60.0):
+    def plan_dump(self):
         """Corr is about to enqueue the dump of its next integration: returns (accumulator, mode) for
-        bfXgpuKernelAsyncAcc, or (None, 0) when this dump is not part of a long integration."""
+        bfXgpuKernelAsyncAcc, or (None, 0) when this dump is not part of a long integration.  Waits -- as the classic path
+        and the reference wait on the guaranteed ring -- while the accumulator pair it needs is still being published
+        (downstream back-pressure), for as long as this block is alive."""
         with self._plan_cv:
             d = self._decide(self._plan_now, self._plan_step)
             self._plan_now += self._plan_step
@@ -184,8 +192,9 @@ class CorrAcc(Block):
                     s = self._long_index & 1
                     t0 = time.time()
                     while self._set_busy[s] and not self._stopping:     # (never in normal operation: publishing one long
-                        if not self._plan_cv.wait(0.05) and time.time() - t0 > timeout:   # integration takes far less than accumulating one)
-                            raise RuntimeError("CORRACC >> accumulator pair still unpublished after %.0f s" % timeout)
+                        if not self._plan_cv.wait(0.05) and time.time() - t0 > 10.0:      # integration takes far less than accumulating one)
+                            self.log.warning("CORRACC >> accumulator pair still unpublished (its output ring is full?): the upstream Corr waits")
+                            t0 = time.time()
                     self._set_busy[s] = True
                     self._open_set = s
                 d.acc_set = self._long_index & 1
@@ -201,12 +210,13 @@ class CorrAcc(Block):
             self._plan_cv.notify_all()
             return acc, d.mode
 
-    def _next_plan(self, want_seq, timeout=60.0):
+    def _next_plan(self, want_seq):
         t0 = time.time()
         with self._plan_cv:
-            while not self._plan:
-                if not self._plan_cv.wait(0.05) and time.time() - t0 > timeout:
-                    raise RuntimeError("CORRACC >> no decision from the upstream Corr for a span that has arrived")
+            while not self._plan:          # (Corr queues the decision before it enqueues the dump, long before the span arrives)
+                if not self._plan_cv.wait(0.05) and time.time() - t0 > 10.0:
+                    self.log.warning("CORRACC >> no decision from the upstream Corr yet for a span that has arrived")
+                    t0 = time.time()
             e = self._plan.popleft()
         is_seq = isinstance(e, tuple)
         if is_seq != want_seq:
@@ -231,9 +241,10 @@ class CorrAcc(Block):
                 prev_time = time.time()
                 # (the command values are loaded by the first gate step, whichever thread makes it: set in __init__, not
                 # here -- in fused mode the upstream Corr may already have planned dumps when this thread starts)
-                for iseq in self.iring.read(guarantee=self.guarantee):
+                for iseq in (self._iseqs if self._iseqs is not None else self.iring.read(guarantee=self.guarantee)):
                     ihdr = json.loads(iseq.header.tostring())
-                    fused = bool(ihdr.get('fused_corracc'))
+                    # (fused: Corr planned this sequence with THIS block; any other reader of the ring maps the spans itself)
+                    fused = bool(ihdr.get('fused_corracc')) and getattr(self.iring, 'long_accumulator', None) is self
                     now, step = ihdr['seq0'], ihdr['acc_len']
                     if fused:
                         self._next_plan(want_seq=True)
@@ -243,6 +254,12 @@ class CorrAcc(Block):
                     for ispan in iseq.read(self.igulp_size):
                         if ispan.size < self.igulp_size:
                             continue
+                        if not fused and getattr(ispan, 'skipped', 0):
+                            # spans overwritten before this reader got to them (ring.py): the sample count moves on, and a long
+                            # integration they belonged to is lost -- realigned like a new upstream sequence (:221-236)
+                            now += (ispan.skipped // self.igulp_size) * step
+                            if self._gate.recover(now):
+                                self._ohdr['acc_len'], self._ohdr['seq0'] = self._gate.acc_len, self._gate.start_time
                         d = self._next_plan(want_seq=False) if fused else self._decide(now, step)
                         if fused and d.now != now:
                             raise RuntimeError("CORRACC >> decision for sample %d, span of sample %d" % (d.now, now))

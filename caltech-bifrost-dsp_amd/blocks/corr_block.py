@@ -188,6 +188,17 @@ class Corr(Block):
                     if ispan.size < self.igulp_size:
                         self.log.info("CORR >>> Ignoring final gulp (expected %d bytes but got %d)" % (self.igulp_size, ispan.size))
                         continue
+                    if getattr(ispan, 'skipped', 0):
+                        # gulps this reader never saw (overwritten before it got to them; whole gulps, ring.py): the sample
+                        # count moves on with them, and an integration they belonged to is lost -- realigned like a new
+                        # upstream sequence (:360-371)
+                        now += (ispan.skipped // self.igulp_size) * self.ntime_gulp
+                        self.log.warning("CORR >> %d bytes of input were overwritten before they were read" % ispan.skipped)
+                        if gate.recover(now):
+                            self._abort_integration()
+                            ospan = None
+                            ohdr['acc_len'] = gate.acc_len
+                            ohdr['seq0'] = gate.start_time
                     if self.update_pending:
                         self.update_command_vals()
                         if gate.running:

@@ -86,6 +86,7 @@ static int run_locked(const void* in, float* out, const void* w, long long versi
         hipLaunchKernelGGL(beamform_f32_kernel, grid, dim3(256), 0, x.stream, (const uint8_t*)in, (const float*)w, out,
                            x.ntime, x.nchan, x.ninput, x.nbeam);
         x.timer.end(x.stream, slot);
+    stream_tick(STREAM_BEAM);
         XENG_HIP(hipGetLastError());
         return XENG_STATUS_SUCCESS;
     }
@@ -142,6 +143,7 @@ static int run_locked(const void* in, float* out, const void* w, long long versi
                                x.ntime, x.nchan, x.ninput, x.nbeam, x.nchunk, x.nbtile, x.route);
         }
         x.timer.end(x.stream, slot);
+    stream_tick(STREAM_BEAM);
         XENG_HIP(hipGetLastError());
         return XENG_STATUS_SUCCESS;
     }
@@ -158,6 +160,7 @@ static int run_locked(const void* in, float* out, const void* w, long long versi
     hipLaunchKernelGGL(beamform_bf16x3_kernel, grid, dim3(64 * BF3_NW), 0, x.stream, (const uint8_t*)in, x.wprep, out,
                        x.ntime, x.nchan, x.ninput, x.nbeam, x.nchunk, x.nbtile, (const int*)nullptr);
     x.timer.end(x.stream, slot);
+    stream_tick(STREAM_BEAM);
     XENG_HIP(hipGetLastError());
     return XENG_STATUS_SUCCESS;
 }
@@ -172,6 +175,7 @@ static int integrate_locked(const void* in, void* out, int ntime_sum, int pair0,
     hipLaunchKernelGGL(beam_integrate_kernel, grid, dim3(256), 0, x.stream, (const float2*)in, (float4*)out, x.nchan,
                        x.nbeam, x.ntime, ntime_sum, pair0, npair);
     x.timer.end(x.stream, slot);
+    stream_tick(STREAM_BEAM);
     XENG_HIP(hipGetLastError());
     return XENG_STATUS_SUCCESS;
 }

@@ -79,6 +79,7 @@ static int map_i32(void* a, const void* b, size_t nwords, bool add) {
 #undef XENG_MAP_PICK
 #undef XENG_MAP_LAUNCH
     XENG_HIP(hipGetLastError());
+    stream_tick(STREAM_MAP);
     return XENG_STATUS_SUCCESS;
 }
 

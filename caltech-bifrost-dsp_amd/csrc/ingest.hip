@@ -281,6 +281,7 @@ extern "C" int xengSnap2Unpack(const void* packets_dev, int npkt, size_t pkt_str
         const unsigned long long id = ++st.ncalls;
         rc = snap2_launch(s, packets_dev, npkt, pkt_stride, out_dev, seq0, ntime, chan0_pipeline, nchan_tot, npol_tot, clear && !track,
                           st.counters, track ? cover : nullptr, track ? geom : nullptr, st.tickets, hs, id);
+        stream_tick(STREAM_COPY);
         if (rc) return rc;
         // poll the mirror's first word (sub-microsecond once the kernel has finished); a kernel that does not report within
         // 2 s is a fault: fall back to the stream, whose error the HIP call returns
@@ -299,6 +300,7 @@ extern "C" int xengSnap2Unpack(const void* packets_dev, int npkt, size_t pkt_str
             // something is missing (or the stream is irregular): blank the gulp and scatter again
             rc = snap2_launch(s, packets_dev, npkt, pkt_stride, out_dev, seq0, ntime, chan0_pipeline, nchan_tot, npol_tot, 1,
                               st.scratch_drops, nullptr, nullptr);
+            stream_tick(STREAM_COPY);
             if (rc) return rc;
             XENG_HIP(hipStreamSynchronize(s));
         }
@@ -307,6 +309,7 @@ extern "C" int xengSnap2Unpack(const void* packets_dev, int npkt, size_t pkt_str
         XENG_HIP(hipMemsetAsync(st.scratch_drops, 0, sizeof(int), s));
         rc = snap2_launch(s, packets_dev, npkt, pkt_stride, out_dev, seq0, ntime, chan0_pipeline, nchan_tot, npol_tot, clear,
                           st.scratch_drops, nullptr, nullptr);
+        stream_tick(STREAM_COPY);
         if (rc) return rc;
         XENG_HIP(hipMemcpyAsync(st.host_async + 2, st.scratch_drops, sizeof(int), hipMemcpyDeviceToHost, s));
         XENG_HIP(hipStreamSynchronize(s));
@@ -330,9 +333,10 @@ extern "C" int xengSnap2UnpackAsync(const void* packets_dev, int npkt, size_t pk
     hipStream_t s;
     rc = get_stream(STREAM_XGPU, &s);
     if (rc) return rc;
-    staging_stream_touched();              // (the next contraction waits for this stream)
-    return snap2_launch(s, packets_dev, npkt, pkt_stride, out_dev, seq0, ntime, chan0_pipeline, nchan_tot, npol_tot, clear,
-                        g_ingest[dev].async_drops, nullptr, nullptr);
+    rc = snap2_launch(s, packets_dev, npkt, pkt_stride, out_dev, seq0, ntime, chan0_pipeline, nchan_tot, npol_tot, clear,
+                      g_ingest[dev].async_drops, nullptr, nullptr);
+    staging_stream_touched();              // (the next contraction waits for this stream; ticked after the enqueue: stream clocks)
+    return rc;
 }
 
 // Packets dropped by the enqueue-only calls since the last call of this function; waits for the staging stream.

@@ -87,6 +87,9 @@ struct XgpuContext {
 static std::mutex g_mu;
 static XgpuConfig g_cfg;
 static XgpuContext g_ctx;
+// Bumped whenever registered-but-uncontracted gulps are dropped (Reset, Destroy / re-Initialize): a stamp that waits for the
+// launch that would have read them (xeng_common.h, Stamp::xgpu_seq) is void afterwards.
+static unsigned long long g_epoch = 1;
 
 // frees whatever the context holds -- also the partial state of an Initialize that failed half way (x.live false)
 static int destroy_locked() {
@@ -109,6 +112,7 @@ static int destroy_locked() {
     if (x.out_dev) (void)hipFree(x.out_dev);
     x.timer.destroy();
     x = XgpuContext();
+    g_epoch++;
     return XENG_STATUS_SUCCESS;
 }
 
@@ -192,6 +196,7 @@ static int flush_locked(void* out, bool dump, void* acc = nullptr, int acc_mode 
         if (nhk & 1)   // the last 64-sample K step is half filled: its second half must hold the value 0
             hipLaunchKernelGGL(fp6_zero_half_kernel, dim3(x.cfg.nchan * x.nblk64), dim3(64), 0, x.stream,
                                x.stash[x.cur], x.nblk64, x.cap_kt, nhk >> 1);
+        stream_tick(STREAM_XGPU);
         nkt = (nhk + 1) >> 1;
     }
 #endif
@@ -200,6 +205,7 @@ static int flush_locked(void* out, bool dump, void* acc = nullptr, int acc_mode 
         const int padk = x.kt_stage - rem;
         XENG_HIP(hipMemset2DAsync(x.stash[x.cur] + (size_t)nkt * KT_BYTES, (size_t)x.cap_kt * KT_BYTES, 0,
                                   (size_t)padk * KT_BYTES, (size_t)x.cfg.nchan * x.nblk64, x.stream));
+        stream_tick(STREAM_XGPU);
         nkt += padk;
     }
     XcorrParams p;
@@ -255,6 +261,7 @@ static int flush_locked(void* out, bool dump, void* acc = nullptr, int acc_mode 
     x.timer.end(smm, slot);
     XENG_HIP(hipGetLastError());
     XENG_HIP(hipEventRecord(x.ev_ring[seq % XgpuContext::NEV], smm));
+    stream_tick(mm_stream_id(si));
     x.area_seq[x.cur] = seq;
     x.last_seq[si] = seq;
     if (dump) {
@@ -358,6 +365,41 @@ static int kernel_locked(const void* in_dev, void* out_dev, int doDump, bool syn
         pw->gpu = x.gpu;
         pw->staging = x.stream;
         if (doDump) pw->dump = launch_event(x.dump_seq[(x.ndump - 1) & 3]);      // contractions that touch one span are ordered
+    }
+    return XENG_STATUS_SUCCESS;
+}
+
+// ---- the X-engine's part of a stamp (xeng_common.h): gulps handed over with xengXgpuKernelAsync are read by a launch that
+// does not exist yet; whoever stamps a buffer meanwhile must also wait for that launch
+void xgpu_pending_launch(unsigned long long* seq, unsigned long long* epoch) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    XgpuContext& x = g_ctx;
+    *seq = (x.live && x.nfilled > 0) ? x.nlaunch + 1 : 0;
+    *epoch = g_epoch;
+}
+
+int xgpu_pending_poll(unsigned long long seq, unsigned long long epoch, bool* done, bool* launched, hipEvent_t* ev, int* gpu) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    XgpuContext& x = g_ctx;
+    *done = true;
+    *launched = true;
+    if (ev) *ev = nullptr;
+    if (seq == 0 || !x.live || epoch != g_epoch) return XENG_STATUS_SUCCESS;     // (dropped gulps: Reset / Destroy have waited for the streams)
+    if (x.nlaunch < seq) {
+        *done = false;
+        *launched = false;
+        return XENG_STATUS_SUCCESS;
+    }
+    if (hipEvent_t e = launch_event(seq)) {
+        const hipError_t q = hipEventQuery(e);
+        if (q == hipErrorNotReady) {
+            (void)hipGetLastError();
+            *done = false;
+            if (ev) *ev = e;
+            if (gpu) *gpu = x.gpu;
+        } else if (q != hipSuccess) {
+            XENG_HIP(q);
+        }
     }
     return XENG_STATUS_SUCCESS;
 }
@@ -626,6 +668,7 @@ int xengXgpuReset(void) {
         x.nfilled = 0;
         x.acc_started = false;
         x.acc_out = nullptr;
+        g_epoch++;
         gpu = x.gpu; nmm = x.nmm; st = x.stream;
         for (int t = 0; t < nmm; t++) mm[t] = x.stream_mm2[t];
     }
@@ -665,6 +708,7 @@ int xengXgpuCorrelate(const void* in_host, void* out_host, int doDump) {
     if (rc) return rc;
     if (doDump) {
         XENG_HIP(hipMemcpyAsync(out_host, out_dev, out_bytes, hipMemcpyDeviceToHost, st));
+        stream_tick(STREAM_XGPU);
         XENG_HIP(hipStreamSynchronize(st));
         drain_timer();
     }
@@ -729,6 +773,7 @@ int xengXgpuSubSelect(const void* in_dev, void* out_dev, const int32_t* vismap_d
                            (const int32_t*)in_dev, (int32_t*)out_dev, vismap_dev, conj_dev, nvis, nchan_sum,
                            x.per_chan, x.matlen);
         XENG_HIP(hipGetLastError());
+        stream_tick(STREAM_CONSUMER);
         rc = take_event(&ev);
         if (rc) return rc;
         const hipError_t re = hipEventRecord(ev, s);
@@ -764,6 +809,7 @@ int xengXgpuPacketize(const void* in_dev, void* out_dev, const int32_t* antpol_t
                            (const int32_t*)in_dev, (int2*)out_dev, antpol_to_bl_dev, is_conj_dev, x.cfg.nstand, x.cfg.nchan,
                            x.per_chan, x.matlen, pitch, fmt);
         XENG_HIP(hipGetLastError());
+        stream_tick(STREAM_CONSUMER);
         rc = take_event(&ev);
         if (rc) return rc;
         const hipError_t re = hipEventRecord(ev, s);

@@ -43,6 +43,28 @@ void staging_stream_touched();
 unsigned long long staging_stream_ops();
 int sync_all_streams();
 
+// Stream clocks (round 4): the memory-lifetime mechanism of the span rings (ring.hip).  Every enqueue on a library stream
+// ticks that stream's clock AFTER the enqueue; a stamp is the vector of clock values at one moment ("everything enqueued so
+// far, on every stream").  A stamp is complete when each stream has passed its value -- found out with an event that is
+// recorded on the stream only when somebody asks (no event per launch): an event recorded later on the same stream
+// completes after all the work the stamp counts.  A ring stamps a span buffer when its last user lets go of it and hands
+// it out again only once the stamp is complete, so a buffer released while kernels that were enqueued before the release
+// still run is never reissued (or freed) under them.
+void stream_tick(StreamId which);                                   // call after every enqueue on stream `which` (current device)
+struct Stamp {
+    int dev = -1;                                                   // -1: nothing to wait for
+    unsigned long long clk[STREAM_COUNT] = {};
+    unsigned long long xgpu_seq = 0, xgpu_epoch = 0;                // gulps registered with the X-engine but not contracted yet: the launch that will read them
+};
+int stamp_now(Stamp* s);
+// *done: every clock has passed; *waitable false: it waits for a launch nobody has enqueued yet (only its enqueuer can end that wait)
+int stamp_poll(const Stamp& s, bool* done, bool* waitable);
+int stamp_wait(const Stamp& s);                                     // blocks (event waits happen outside every library lock)
+void stream_clocks_forget(int dev, StreamId which);                 // the stream has been synchronised: everything ticked so far is complete
+// X-engine side of a stamp (xcorr.hip)
+void xgpu_pending_launch(unsigned long long* seq, unsigned long long* epoch);
+int xgpu_pending_poll(unsigned long long seq, unsigned long long epoch, bool* done, bool* launched, hipEvent_t* ev, int* gpu);
+
 // Experiment / diagnostic switches (grid sizes, map variants, clock stamps, item order ...) exist only in
 // -DXENG_DIAGNOSTICS builds (profiles/); the shipped library reads XENG_RAW, XENG_BEAM[_F32] and XENG_TILING only.
 inline const char* diag_env(const char* name) {

@@ -1,6 +1,8 @@
 // Device / memory plumbing behind the C ABI (include/xeng.h, "device / memory plumbing").
 // Replaces bifrost.device.set_device / stream_synchronize, BFArray(space='cuda'|'cuda_host')
 // allocation and copy_array for the hot-path blocks.
+#include <time.h>
+
 #include <atomic>
 #include <mutex>
 #include <utility>
@@ -24,7 +26,10 @@ static hipStream_t g_streams[MAXDEV][STREAM_COUNT];
 static bool g_stream_ok[MAXDEV][STREAM_COUNT];
 
 static std::atomic<unsigned long long> g_staging_ops{0};
-void staging_stream_touched() { g_staging_ops.fetch_add(1, std::memory_order_relaxed); }
+void staging_stream_touched() {
+    g_staging_ops.fetch_add(1, std::memory_order_relaxed);
+    stream_tick(STREAM_XGPU);
+}
 unsigned long long staging_stream_ops() { return g_staging_ops.load(std::memory_order_relaxed); }
 
 int get_stream(StreamId which, hipStream_t* out) {
@@ -46,6 +51,169 @@ int get_stream(StreamId which, hipStream_t* out) {
         g_stream_ok[dev][which] = true;
     }
     *out = g_streams[dev][which];
+    return XENG_STATUS_SUCCESS;
+}
+
+// ---------------------------------------------------------------- stream clocks (xeng_common.h)
+struct StreamClock {
+    std::atomic<unsigned long long> enq{0};     // enqueues so far (ticked after each)
+    std::mutex mu;
+    unsigned long long done = 0;                // everything up to this tick is known to have completed
+    static constexpr int NMARK = 8;
+    struct Mark { unsigned long long upto = 0; hipEvent_t ev = nullptr; bool pending = false; } marks[NMARK];
+};
+static StreamClock g_clock[MAXDEV][STREAM_COUNT];
+
+struct DeviceGuard {            // events are created and recorded with their device current; the caller's device is put back
+    int prev = -1, want;
+    explicit DeviceGuard(int d) : want(d) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != want) (void)hipSetDevice(want);
+    }
+    ~DeviceGuard() {
+        if (prev >= 0 && prev != want) (void)hipSetDevice(prev);
+    }
+};
+
+void stream_tick(StreamId which) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return;
+    g_clock[dev][which].enq.fetch_add(1, std::memory_order_release);
+}
+
+void stream_clocks_forget(int dev, StreamId which) {
+    if (dev < 0 || dev >= MAXDEV) return;
+    StreamClock& c = g_clock[dev][which];
+    std::lock_guard<std::mutex> lk(c.mu);
+    c.done = c.enq.load(std::memory_order_acquire);
+}
+
+// Has stream (dev, which) passed tick t?  If not, *wait_ev is an event to wait for before asking again (recorded now when no
+// pending mark covers t).  Never blocks.
+static int clock_poll(int dev, StreamId which, unsigned long long t, bool* done, hipEvent_t* wait_ev) {
+    *done = true;
+    if (wait_ev) *wait_ev = nullptr;
+    if (t == 0) return XENG_STATUS_SUCCESS;
+    StreamClock& c = g_clock[dev][which];
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (t <= c.done) return XENG_STATUS_SUCCESS;
+    StreamClock::Mark* cover = nullptr;
+    StreamClock::Mark* free_slot = nullptr;
+    StreamClock::Mark* oldest = nullptr;
+    for (auto& m : c.marks) {
+        if (m.pending) {
+            const hipError_t e = hipEventQuery(m.ev);
+            if (e == hipSuccess) {
+                m.pending = false;
+                if (m.upto > c.done) c.done = m.upto;
+            } else if (e == hipErrorNotReady) {
+                (void)hipGetLastError();
+            } else {
+                XENG_HIP(e);
+            }
+        }
+        if (m.pending) {
+            if (m.upto >= t && (!cover || m.upto < cover->upto)) cover = &m;
+            if (!oldest || m.upto < oldest->upto) oldest = &m;
+        } else if (!free_slot) {
+            free_slot = &m;
+        }
+    }
+    if (t <= c.done) return XENG_STATUS_SUCCESS;
+    *done = false;
+    if (!cover && free_slot) {
+        hipStream_t s;
+        {
+            std::lock_guard<std::mutex> slk(g_stream_mu);
+            if (!g_stream_ok[dev][which]) {        // (ticks without a stream cannot happen; nothing to wait for then)
+                *done = true;
+                return XENG_STATUS_SUCCESS;
+            }
+            s = g_streams[dev][which];
+        }
+        DeviceGuard g(dev);
+        const unsigned long long upto = c.enq.load(std::memory_order_acquire);     // (read BEFORE the record: every enqueue counted here precedes it)
+        if (!free_slot->ev) XENG_HIP(hipEventCreateWithFlags(&free_slot->ev, hipEventDisableTiming));
+        XENG_HIP(hipEventRecord(free_slot->ev, s));
+        free_slot->upto = upto;
+        free_slot->pending = true;
+        cover = free_slot;
+        if (hipEventQuery(cover->ev) == hipSuccess) {       // an idle stream: complete at once
+            cover->pending = false;
+            if (upto > c.done) c.done = upto;
+            *done = true;
+            return XENG_STATUS_SUCCESS;
+        }
+        (void)hipGetLastError();
+    }
+    if (wait_ev) *wait_ev = cover ? cover->ev : (oldest ? oldest->ev : nullptr);   // (all slots pending below t: wait for the oldest, ask again)
+    return XENG_STATUS_SUCCESS;
+}
+
+int stamp_now(Stamp* s) {
+    *s = Stamp();
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) {
+        (void)hipGetLastError();
+        return XENG_STATUS_SUCCESS;                // no device: nothing can be in flight
+    }
+    s->dev = dev;
+    for (int k = 0; k < STREAM_COUNT; k++) s->clk[k] = g_clock[dev][k].enq.load(std::memory_order_acquire);
+    xgpu_pending_launch(&s->xgpu_seq, &s->xgpu_epoch);
+    return XENG_STATUS_SUCCESS;
+}
+
+int stamp_poll(const Stamp& s, bool* done, bool* waitable) {
+    *done = true;
+    if (waitable) *waitable = true;
+    if (s.dev < 0) return XENG_STATUS_SUCCESS;
+    for (int k = 0; k < STREAM_COUNT; k++) {
+        bool d = true;
+        int rc = clock_poll(s.dev, (StreamId)k, s.clk[k], &d, nullptr);
+        if (rc) return rc;
+        if (!d) *done = false;
+    }
+    if (s.xgpu_seq) {
+        bool d = true, launched = true;
+        int rc = xgpu_pending_poll(s.xgpu_seq, s.xgpu_epoch, &d, &launched, nullptr, nullptr);
+        if (rc) return rc;
+        if (!d) *done = false;
+        if (!launched && waitable) *waitable = false;
+    }
+    return XENG_STATUS_SUCCESS;
+}
+
+int stamp_wait(const Stamp& s) {
+    if (s.dev < 0) return XENG_STATUS_SUCCESS;
+    for (int k = 0; k < STREAM_COUNT; k++) {
+        for (;;) {
+            bool d = true;
+            hipEvent_t ev = nullptr;
+            int rc = clock_poll(s.dev, (StreamId)k, s.clk[k], &d, &ev);
+            if (rc) return rc;
+            if (d) break;
+            if (ev) XENG_HIP(hipEventSynchronize(ev));          // (outside every lock)
+        }
+    }
+    if (s.xgpu_seq) {
+        for (int spins = 0;; spins++) {
+            bool d = true, launched = true;
+            hipEvent_t ev = nullptr;
+            int gpu = 0;
+            int rc = xgpu_pending_poll(s.xgpu_seq, s.xgpu_epoch, &d, &launched, &ev, &gpu);
+            if (rc) return rc;
+            if (d) break;
+            if (launched && ev) {
+                XENG_HIP(hipEventSynchronize(ev));
+            } else {
+                // registered gulps whose contraction nobody has enqueued yet: only their owner can end this (a dump, or
+                // xengXgpuReset).  Not reached through the rings (they never wait for an unwaitable stamp).
+                if (spins > 40000) XENG_FAIL(XENG_STATUS_INVALID_STATE, "stamp: waiting for an X-engine launch that was never enqueued");
+                struct timespec ts = {0, 50000};
+                nanosleep(&ts, nullptr);
+            }
+        }
+    }
     return XENG_STATUS_SUCCESS;
 }
 
@@ -179,6 +347,7 @@ int xengMemcpy(void* dst, const void* src, size_t nbytes) {
     int rc = get_stream(STREAM_COPY, &s);
     if (rc) return rc;
     XENG_HIP(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDefault, s));
+    stream_tick(STREAM_COPY);
     XENG_HIP(hipStreamSynchronize(s));
     return XENG_STATUS_SUCCESS;
 }
@@ -187,6 +356,7 @@ int xengMemcpyAsync(void* dst, const void* src, size_t nbytes) {
     int rc = get_stream(STREAM_COPY, &s);
     if (rc) return rc;
     XENG_HIP(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDefault, s));
+    stream_tick(STREAM_COPY);
     return XENG_STATUS_SUCCESS;
 }
 int xengMemset(void* dst, int value, size_t nbytes) {
@@ -194,9 +364,52 @@ int xengMemset(void* dst, int value, size_t nbytes) {
     int rc = get_stream(STREAM_COPY, &s);
     if (rc) return rc;
     XENG_HIP(hipMemsetAsync(dst, value, nbytes, s));
+    stream_tick(STREAM_COPY);
     XENG_HIP(hipStreamSynchronize(s));
     return XENG_STATUS_SUCCESS;
 }
 int xengStreamSynchronize(void) { return sync_all_streams(); }
+
+static void stamp_pack(const Stamp& s, xengStamp* o) {
+    o->w[0] = (unsigned long long)(s.dev + 1);
+    for (int k = 0; k < STREAM_COUNT; k++) o->w[1 + k] = s.clk[k];
+    o->w[14] = s.xgpu_seq;
+    o->w[15] = s.xgpu_epoch;
+}
+static void stamp_unpack(const xengStamp* o, Stamp* s) {
+    s->dev = (int)o->w[0] - 1;
+    for (int k = 0; k < STREAM_COUNT; k++) s->clk[k] = o->w[1 + k];
+    s->xgpu_seq = o->w[14];
+    s->xgpu_epoch = o->w[15];
+}
+static_assert(STREAM_COUNT + 3 <= 16, "xengStamp holds one word per library stream");
+
+int xengStampNow(xengStamp* stamp) {
+    if (!stamp) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "StampNow: null stamp");
+    Stamp s;
+    int rc = stamp_now(&s);
+    if (rc) return rc;
+    stamp_pack(s, stamp);
+    return XENG_STATUS_SUCCESS;
+}
+int xengStampDone(const xengStamp* stamp, int* done, int* waitable) {
+    if (!stamp || !done) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "StampDone: null argument");
+    Stamp s;
+    stamp_unpack(stamp, &s);
+    if (s.dev >= MAXDEV) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "StampDone: not a stamp");
+    bool d = true, w = true;
+    int rc = stamp_poll(s, &d, &w);
+    if (rc) return rc;
+    *done = d;
+    if (waitable) *waitable = w;
+    return XENG_STATUS_SUCCESS;
+}
+int xengStampWait(const xengStamp* stamp) {
+    if (!stamp) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "StampWait: null stamp");
+    Stamp s;
+    stamp_unpack(stamp, &s);
+    if (s.dev >= MAXDEV) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "StampWait: not a stamp");
+    return stamp_wait(s);
+}
 
 }  // extern "C"

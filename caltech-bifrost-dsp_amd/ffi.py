@@ -32,11 +32,34 @@ class XENGarray(ctypes.Structure):
                 ("immutable", ctypes.c_int), ("big_endian", ctypes.c_int), ("conjugated", ctypes.c_int)]
 
 
+class XengStamp(ctypes.Structure):
+    """include/xeng.h xengStamp: everything the library has enqueued so far (opaque)."""
+    _fields_ = [("w", ctypes.c_ulonglong * 16)]
+
+
+STATUS_WOULD_BLOCK, STATUS_END_OF_DATA = 6, 7
+# test hooks of the span rings (xengRingSetStampHooks)
+STAMP_NOW_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong))
+STAMP_DONE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong))
+STAMP_WAIT_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong))
+
 # every symbol include/xeng.h declares: name -> argtypes (all return int unless noted)
 _vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
 _pi = ctypes.POINTER(ctypes.c_int)
 _pa = ctypes.POINTER(XENGarray)
+_ll, _pll, _psz, _pvp = ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_void_p)
+_pst = ctypes.POINTER(XengStamp)
 SYMBOLS = {
+    "xengStampNow": [_pst], "xengStampDone": [_pst, _pi, _pi], "xengStampWait": [_pst],
+    "xengRingCreate": [_pvp, ctypes.c_char_p, _i], "xengRingDestroy": [_vp], "xengRingResize": [_vp, _sz, _sz],
+    "xengRingGetInfo": [_vp, _psz, _psz, _psz, _pi, _pll, ctypes.POINTER(ctypes.c_ulonglong)],
+    "xengRingBeginSequence": [_vp, _ll, ctypes.c_char_p, _sz, _i, _pll], "xengRingEndSequence": [_vp, _ll], "xengRingEndWriting": [_vp],
+    "xengRingReserve": [_vp, _ll, _sz, _i, _i, _pvp, _pll], "xengRingCommit": [_vp, _ll, _ll, _sz],
+    "xengRingCommitExternal": [_vp, _ll, _vp, _sz, _i],
+    "xengRingOpenReader": [_vp, _i, _pi], "xengRingCloseReader": [_vp, _i],
+    "xengRingNextSequence": [_vp, _i, _i, _pll, _pll, _pi, _pvp, _psz],
+    "xengRingAcquire": [_vp, _i, _sz, _sz, _i, _pvp, _psz, _pll, _psz], "xengRingSpanRelease": [_ll],
+    "xengRingSetStampHooks": [_vp, STAMP_NOW_FN, STAMP_DONE_FN, STAMP_WAIT_FN, _vp],
     "xengGetDeviceCount": [_pi], "xengSetDevice": [_i], "xengGetDevice": [_pi], "xengDeviceSynchronize": [],
     "xengGetDeviceInfo": [_i, _pi, _pi, ctypes.POINTER(_sz), ctypes.c_char_p, _i], "xengGetDevicePciBusId": [_i, ctypes.c_char_p, _i],
     "xengMalloc": [ctypes.POINTER(_vp), _sz, _i], "xengFree": [_vp, _i], "xengMemcpy": [_vp, _vp, _sz],
@@ -93,7 +116,12 @@ def lib():
 # GPU needs for the gulp.  Calls that wait (Sync, Wait, the synchronous X-engine call, copies) stay on the releasing handle.
 ENQUEUE_ONLY = ["xengXgpuKernelAsync", "xengXgpuKernelAsyncAcc", "xengBeamformRun", "xengBeamformRunVersioned",
                 "xengBeamformIntegrate", "xengBeamformIntegrateSingleBeam", "xengBeamformMark", "xengMapAssignI32",
-                "xengMapAddI32", "xengSnap2UnpackAsync", "xengXgpuDumpDone", "xengBeamformTicketDone", "bfBeamformRun", "bfBeamformIntegrate", "bfBeamformIntegrateSingleBeam"]
+                "xengMapAddI32", "xengSnap2UnpackAsync", "xengXgpuDumpDone", "xengBeamformTicketDone", "bfBeamformRun", "bfBeamformIntegrate", "bfBeamformIntegrateSingleBeam",
+                # the span rings: bookkeeping calls, and the calls that can wait asked with may_block = 0 first
+                "xengRingBeginSequence", "xengRingEndSequence", "xengRingEndWriting", "xengRingReserve", "xengRingCommit",
+                "xengRingCommitExternal", "xengRingNextSequence", "xengRingAcquire", "xengRingSpanRelease", "xengRingGetInfo",
+                "xengRingOpenReader", "xengRingCloseReader", "xengRingResize",
+                "xengStampNow", "xengStampDone"]
 _enq = None
 
 

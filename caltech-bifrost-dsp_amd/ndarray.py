@@ -48,7 +48,7 @@ class XArray:
             raise ValueError("unknown space %r" % (space,))
         self.space = space
         if _ptr is not None:                       # window on existing memory (the per-gulp path of every block: kept short)
-            self.dtype = dtype if type(dtype) is np.dtype else to_dtype(dtype)
+            self.dtype = dtype if isinstance(dtype, np.dtype) else to_dtype(dtype)
             self.shape = shape = tuple(int(s) for s in shape)
             self.size = math.prod(shape) if shape else 1
             self.nbytes = self.size * self.dtype.itemsize

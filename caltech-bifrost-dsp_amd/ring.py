@@ -12,12 +12,26 @@ SURVEY.md section 8b):
     iseq.read(gulp_nbytes) -> ispan.size / ispan.data / ispan.data_view(dtype)
 
 The blocks are duck-typed against this protocol, so they accept a real bifrost Ring or this one.
-This implementation is a single-writer / multi-reader byte stream per sequence, with the data
-held as committed spans in the ring's space ('system' = numpy memory, so config 1 runs with no
-GPU; 'cuda' / 'cuda_host' = HIP allocations through libxeng).  Readers that ask for
-`guarantee=True` apply back-pressure once `total_span` bytes are outstanding.
+This is a single-writer / multi-reader byte stream per sequence, with the data held as committed spans in the ring's space
+('system' = host memory, so config 1 runs with no GPU; 'cuda' / 'cuda_host' = HIP allocations through libxeng).  Readers
+that ask for `guarantee=True` apply back-pressure once `total_span` bytes are outstanding; a reader that registers late, or
+that is not guaranteed and falls behind, skips ahead to the oldest span still in the ring (as a bifrost reader does).
+
+Two implementations of the one protocol (round 4):
+
+  * `NativeRing` (default): the bookkeeping -- committed spans, reader cursors, back-pressure, the free list of span
+    allocations -- lives in libxeng (csrc/ring.hip, include/xeng.h "span rings"), as bifrost's ring is native
+    (lwa352-pipeline.py:147-155); the classes here are thin handles, one foreign call per gulp and side.
+  * `PyRing` (`XENG_RING=python`): the same in Python; kept as the reference implementation of the protocol, and the test
+    suites run on both.
+
+Span memory lifetime, either way: an allocation whose last user has let go is STAMPED with everything the library has enqueued
+so far (include/xeng.h "stamps") and is handed out again -- or really freed -- only when that work has completed.  It is the
+library's completion record that decides, not the moment at which some Python reference happened to be dropped.
 """
 import collections
+import ctypes
+import os
 import threading
 import weakref
 
@@ -26,30 +40,74 @@ import numpy as np
 from . import ffi
 from .ndarray import XArray, copy_array, to_dtype, _SPACE_ID
 
+# which implementation `Ring(...)` builds: 'native' | 'python' (tests switch it per test)
+IMPLEMENTATION = os.environ.get("XENG_RING", "native")
 
-class _PooledBuffer:
-    """Owner of one span allocation in a device / pinned space.  When the last array that references it goes away
-    the allocation returns to its ring's free list instead of hipFree (which synchronises the whole device and
-    would stall the other blocks' streams: Corr alone turns over a 191 MB span per integration)."""
 
-    def __init__(self, ring, buf):
-        self._ring = weakref.ref(ring)
-        self.buf = buf
-        self.ptr = buf.ptr
-        self.nbytes = buf.nbytes
+class LibraryStamps:
+    """Stamps from libxeng's stream clocks (xengStampNow / Done / Wait): the source every device / pinned ring uses."""
+
+    def now(self):
+        s = ffi.XengStamp()
+        ffi.check("xengStampNow", ffi.enqueue_lib().xengStampNow(ctypes.byref(s)))
+        return s
+
+    def done(self, s):
+        """(done, waitable)"""
+        d, w = ctypes.c_int(), ctypes.c_int()
+        ffi.check("xengStampDone", ffi.enqueue_lib().xengStampDone(ctypes.byref(s), ctypes.byref(d), ctypes.byref(w)))
+        return bool(d.value), bool(w.value)
+
+    def wait(self, s):
+        ffi.call("xengStampWait", ctypes.byref(s))
+
+
+class _Allocation:
+    """One span allocation of a PyRing in a device / pinned space: raw address + size, no finaliser of its own (the ring's
+    free list holds these; only `_SpanOwner.__del__` and the ring's teardown ever free one, both behind the stamp)."""
+    __slots__ = ("ptr", "nbytes", "space", "stamp", "keep")
+
+    def __init__(self, ptr, nbytes, space, keep=None):
+        self.ptr, self.nbytes, self.space, self.stamp, self.keep = ptr, nbytes, space, None, keep      # keep: numpy memory behind a system-space allocation
+
+
+def _free_allocation(a, stamps):
+    """Really free a span allocation -- behind its stamp.  An allocation whose stamp can never complete is leaked rather
+    than freed under a kernel that may still use it."""
+    if a.ptr is None:
+        return
+    if stamps is not None and a.stamp is not None:
+        done, waitable = stamps.done(a.stamp)
+        if not done:
+            if not waitable:
+                a.ptr = None
+                return
+            stamps.wait(a.stamp)
+    if a.space == "system":
+        a.ptr = a.keep = None      # (numpy memory)
+        return
+    ffi.call("xengFree", a.ptr, _SPACE_ID[a.space])
+    a.ptr = None
+
+
+class _SpanOwner:
+    """`base` of a PyRing span array: when the last array that references it goes away the allocation is stamped and returns
+    to its ring's free list.  Round 3 kept a `DeviceBuffer` (which frees in its own `__del__`) behind a weak reference to the
+    ring here: when the cycle collector found such a span in a reference cycle it cleared the weak reference first and ran
+    both finalisers, so the allocation was really freed (hipFree / hipHostFree) at collector time instead of being recycled
+    -- the behaviour behind the round-3 churn.  Now the owner is the only finaliser, holds the ring strongly, and frees
+    nothing that its stamp does not allow."""
+    __slots__ = ("ring", "alloc")
+
+    def __init__(self, ring, alloc):
+        self.ring, self.alloc = ring, alloc
 
     def __del__(self):
-        ring = self._ring()
-        buf, self.buf = self.buf, None
-        if buf is None:
+        a, self.alloc = self.alloc, None
+        if a is None:
             return
         try:
-            if ring is not None and ring._pool_put(buf):
-                return
-            # really freed (the ring is gone or its free list is full): rare, and never under a kernel -- whoever dropped
-            # the last reference had waited for its own GPU work, but the device is drained first all the same
-            ffi.call("xengDeviceSynchronize")
-            buf.free()
+            self.ring._pool_put(a)
         except Exception:          # interpreter shutdown: the process is going away with its allocations
             pass
 
@@ -89,7 +147,7 @@ class WriteSequence:
         self.ring = seq.ring      # the blocks pass `oseq.ring` to WriteSpan
 
     def reserve(self, nbytes, nonblocking=False):
-        return WriteSpan(self.ring, nbytes, nonblocking=nonblocking, _seq=self._seq)
+        return PyWriteSpan(self.ring, nbytes, nonblocking=nonblocking, _seq=self._seq)
 
     def commit_external(self, data):
         """Publish an existing array of the ring's space as the next span without copying it (a replay source:
@@ -110,7 +168,13 @@ class WriteSequence:
         return False
 
 
-class WriteSpan:
+class _SpanViews:
+    def data_view(self, dtype=np.uint8, shape=None):
+        v = self.data.view(dtype)
+        return v.reshape(shape) if shape is not None else v
+
+
+class PyWriteSpan(_SpanViews):
     """`WriteSpan(oseq.ring, nbytes, nonblocking=False)` (corr_block.py:435) -- reserved output
     memory in the ring's space; `.close()` (or leaving the `with`) commits all of it."""
 
@@ -123,10 +187,6 @@ class WriteSpan:
         ring._wait_for_room(self.size, nonblocking)
         self.data = ring._alloc_span(self.size)
         self._closed = False
-
-    def data_view(self, dtype=np.uint8, shape=None):
-        v = self.data.view(dtype)
-        return v.reshape(shape) if shape is not None else v
 
     def commit(self, nbytes=None):
         if self._closed:
@@ -147,13 +207,18 @@ class WriteSpan:
         return False
 
 
-class ReadSpan:
-    def __init__(self, data, size):
-        self.data, self.size = data, size
+def WriteSpan(ring, nbytes, nonblocking=False):
+    """`WriteSpan(oseq.ring, nbytes, nonblocking=False)` as the blocks spell it (corr_block.py:435, corr_acc_block.py:313)."""
+    return ring._write_span(nbytes, nonblocking)
 
-    def data_view(self, dtype=np.uint8, shape=None):
-        v = self.data.view(dtype)
-        return v.reshape(shape) if shape is not None else v
+
+class ReadSpan(_SpanViews):
+    """`skipped`: bytes of the sequence this reader never saw immediately before this span (overwritten before it got there:
+    whole gulps; bifrost's `nframe_skipped`).  `offset`: byte offset of the span in its sequence."""
+    __slots__ = ("data", "size", "offset", "skipped")
+
+    def __init__(self, data, size, offset=0, skipped=0):
+        self.data, self.size, self.offset, self.skipped = data, size, offset, skipped
 
 
 class ReadSequence:
@@ -171,14 +236,25 @@ class ReadSequence:
         gulp_nbytes = int(gulp_nbytes)
         while True:
             with ring._cond:
-                while seq.committed - rd.offset < gulp_nbytes and not seq.ended:
+                skipped = 0
+                while True:
+                    # data that was overwritten before this reader got to it (it registered late, or nobody held the data
+                    # for it): skip ahead by whole gulps to the oldest span still there, as a bifrost reader does
+                    lo = seq.chunks[0].offset if seq.chunks else seq.committed
+                    if rd.offset < lo:
+                        sk = -(-(lo - rd.offset) // gulp_nbytes) * gulp_nbytes
+                        rd.offset += sk
+                        skipped += sk
+                    if seq.committed - rd.offset >= gulp_nbytes or seq.ended:
+                        break
                     ring._cond.wait(0.5)
                 avail = seq.committed - rd.offset
                 n = min(avail, gulp_nbytes)
                 if n <= 0:
                     return
                 data = ring._assemble(seq, rd.offset, n)
-            yield ReadSpan(data, n)
+                offset = rd.offset
+            yield ReadSpan(data, n, offset, skipped)
             with ring._cond:
                 rd.offset += n
                 ring._gc()
@@ -209,7 +285,7 @@ class _Writer:
         return False
 
 
-class Ring:
+class PyRing:
     # Every committed span is its own allocation, kept alive by reference counting: a reader that keeps
     # `ispan.data` may go on reading it after the ring has recycled the span (a bifrost ring is one circular
     # buffer and cannot promise that).  Corr uses this to let the X-engine read gulps in place.
@@ -225,36 +301,83 @@ class Ring:
         self._capacity = 0
         self._live_bytes = 0
         self._gc_seq = 0           # sequences before this index hold no data any more
-        self._pool = {}            # nbytes -> [free allocations] (device / pinned spaces)
+        self._pool = {}            # nbytes -> deque of released allocations, oldest first (device / pinned spaces)
         self._pool_bytes = 0
         self._pool_lock = threading.RLock()     # (re-entrant: a span released by the garbage collector inside _alloc_span puts itself back)
+        self._stamps = LibraryStamps() if space != "system" else None
+        self._dead = False
+        self.counters = {"alloc": 0, "free": 0, "reuse": 0, "stamp_wait": 0}
+
+    def set_stamp_source(self, src):
+        """Tests: completion tickets of a fake backend instead of the library's stream clocks -- an object with now() ->
+        stamp, done(stamp) -> (done, waitable), wait(stamp).  Gives a system-space ring a free list too."""
+        self._stamps = src
+
+    def __del__(self):
+        try:
+            with self._pool_lock:
+                self._dead = True
+                pool, self._pool = self._pool, {}
+            for dq in pool.values():
+                for a in dq:
+                    _free_allocation(a, self._stamps)
+        except Exception:
+            pass
 
     # ------------------------------------------------------------------ span memory
-    def _alloc_span(self, nbytes):
-        """Span memory in the ring's space.  'system': fresh zeroed numpy memory.  Device / pinned spaces: recycled
-        from the ring's free list when a span of that size has been released (contents then are whatever the last
-        user left, as in a circular bifrost ring); a first-time allocation is zero-filled."""
-        if self.space == "system":
-            return XArray(shape=(nbytes,), dtype=np.uint8, space="system")
-        with self._pool_lock:
-            lst = self._pool.get(nbytes)
-            buf = lst.pop() if lst else None
-            if buf is not None:
-                self._pool_bytes -= nbytes
-        if buf is None:
-            buf = ffi.DeviceBuffer(max(nbytes, 1), _SPACE_ID[self.space])
-            ffi.call("xengMemset", buf.ptr, 0, max(nbytes, 1))
-        owner = _PooledBuffer(self, buf)
-        return XArray(shape=(nbytes,), dtype=np.uint8, space=self.space, _ptr=buf.ptr, _base=owner)
+    def _write_span(self, nbytes, nonblocking):
+        return PyWriteSpan(self, nbytes, nonblocking)
 
-    def _pool_put(self, buf):
-        """Keep a released allocation for reuse (up to the ring's capacity in bytes); False = caller frees it."""
+    def _alloc_span(self, nbytes):
+        """Span memory in the ring's space.  'system' (without a stamp source): fresh zeroed numpy memory.  Otherwise the
+        OLDEST released allocation of that size whose stamp is complete (contents: whatever its last user left, as in a
+        circular bifrost ring); if every released one is still busy, wait for the oldest; with none released, a fresh
+        zero-filled allocation."""
+        if self._stamps is None:
+            return XArray(shape=(nbytes,), dtype=np.uint8, space="system")
+        a = None
         with self._pool_lock:
-            if self._pool_bytes + buf.nbytes > max(self._capacity, 2 * buf.nbytes):
-                return False
-            self._pool.setdefault(buf.nbytes, []).append(buf)
-            self._pool_bytes += buf.nbytes
-        return True
+            dq = self._pool.get(nbytes)
+            cand = dq.popleft() if dq else None        # the oldest release first: its stamp is the most likely to be complete
+            if cand is not None:
+                self._pool_bytes -= nbytes
+        if cand is not None:
+            done, waitable = self._stamps.done(cand.stamp) if cand.stamp is not None else (True, True)
+            if not done and waitable:
+                self.counters["stamp_wait"] += 1
+                self._stamps.wait(cand.stamp)          # (outside the lock: kernels of other blocks, enqueued before the release)
+                done = True
+            if done:
+                a = cand
+                self.counters["reuse"] += 1
+            else:                                      # waits for a launch nobody has enqueued: try the others first next time
+                with self._pool_lock:
+                    self._pool[nbytes].append(cand)
+                    self._pool_bytes += nbytes
+        if a is None:
+            self.counters["alloc"] += 1
+            if self.space == "system":
+                keep = np.zeros(max(nbytes, 1), dtype=np.uint8)
+                a = _Allocation(keep.ctypes.data, nbytes, "system", keep)
+            else:
+                buf = ffi.DeviceBuffer(max(nbytes, 1), _SPACE_ID[self.space])
+                ffi.call("xengMemset", buf.ptr, 0, max(nbytes, 1))
+                a = _Allocation(buf.ptr, nbytes, self.space)
+                buf.ptr = None                    # (the allocation is the ring's now: DeviceBuffer.__del__ must never free it)
+        return XArray(shape=(nbytes,), dtype=np.uint8, space=self.space, _ptr=a.ptr, _base=_SpanOwner(self, a))
+
+    def _pool_put(self, a):
+        """The last user of a span allocation has let go: stamp it and keep it for reuse (up to the ring's capacity in bytes;
+        beyond that it is really freed, behind its stamp)."""
+        if self._stamps is not None:
+            a.stamp = self._stamps.now()
+        with self._pool_lock:
+            if not self._dead and self._pool_bytes + a.nbytes <= max(self._capacity, 2 * a.nbytes):
+                self._pool.setdefault(a.nbytes, collections.deque()).append(a)
+                self._pool_bytes += a.nbytes
+                return
+        self.counters["free"] += 1
+        _free_allocation(a, self._stamps)
 
     # ------------------------------------------------------------------ writer side
     def resize(self, contig_bytes, total_span=None, nringlet=1):
@@ -356,8 +479,6 @@ class Ring:
     def _assemble(self, seq, offset, nbytes):
         """Bytes [offset, offset+nbytes) of a sequence as one array: a zero-copy window when they
         lie inside one committed span, else a gathered copy in the ring's space."""
-        if not seq.chunks or seq.chunks[0].offset > offset:
-            raise RuntimeError("ring %r: data at %d was overwritten before it was read" % (self.name, offset))
         c0 = seq.chunks[0]
         if c0.offset == offset and c0.nbytes == nbytes:       # the usual case: the gulp is the oldest span, whole
             return c0.data
@@ -380,9 +501,15 @@ class Ring:
     # ------------------------------------------------------------------ reader side
     def read(self, guarantee=True):
         """Iterate over sequences.  The reader is registered when read() is called (not at the first
-        next()), so data written between the call and the first iteration is kept for it."""
+        next()), so data written between the call and the first iteration is kept for it.  A reader that registers late
+        starts at the oldest sequence that still holds data or is still being written -- never at data that is gone."""
         rd = _Reader(guarantee)
         with self._cond:
+            rd.seq_index = len(self._seqs)
+            for seq in self._seqs[self._gc_seq:]:
+                if seq.chunks or not seq.ended:
+                    rd.seq_index = seq.index
+                    break
             self._readers.append(rd)
         return self._read_sequences(rd)
 
@@ -409,4 +536,242 @@ class Ring:
                 self._cond.notify_all()
 
 
-__all__ = ["Ring", "WriteSpan", "to_dtype"]
+# ====================================================================== the native ring: thin handles on csrc/ring.hip
+_WOULD_BLOCK, _END = ffi.STATUS_WOULD_BLOCK, ffi.STATUS_END_OF_DATA
+
+
+class _SpanRef:
+    """One reference on a native span's memory (a handle from xengRingReserve / xengRingAcquire), given back when the last
+    array that uses it goes away.  Holds the ring object, so the native ring outlives every span handle."""
+    __slots__ = ("ring", "handle")
+
+    def __init__(self, ring, handle):
+        self.ring, self.handle = ring, handle
+
+    def __del__(self):
+        h, self.handle = self.handle, 0
+        if h:
+            try:
+                self.ring._enq.xengRingSpanRelease(h)
+            except Exception:
+                pass
+
+
+class _NWriteSpan(_SpanViews):
+    def __init__(self, ring, seq_id, nbytes, nonblocking):
+        self.ring, self._seq_id, self.size = ring, seq_id, int(nbytes)
+        ptr, span = ctypes.c_void_p(), ctypes.c_longlong()
+        rc = ring._enq.xengRingReserve(ring._h, seq_id, self.size, int(bool(nonblocking)), 0, ctypes.byref(ptr), ctypes.byref(span))
+        if rc == _WOULD_BLOCK and not nonblocking:     # has to wait (room, a stamp, a device allocation): give the interpreter lock up
+            rc = ring._lib.xengRingReserve(ring._h, seq_id, self.size, 0, 1, ctypes.byref(ptr), ctypes.byref(span))
+        if rc == _WOULD_BLOCK:
+            raise BlockingIOError("ring %r full" % ring.name)
+        if rc:
+            raise RuntimeError(ring._lib.xengGetLastError().decode())
+        self._span = span.value
+        self.data = XArray(shape=(self.size,), dtype=np.uint8, space=ring.space, _ptr=ptr.value or 0, _base=_SpanRef(ring, span.value))
+        self._closed = False
+
+    def commit(self, nbytes=None):
+        if self._closed:
+            return
+        self._closed = True
+        n = self.size if nbytes is None else int(nbytes)
+        if n > 0:
+            ffi.check("xengRingCommit", self.ring._enq.xengRingCommit(self.ring._h, self._seq_id, self._span, n))
+
+    def close(self):
+        self.commit()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+
+class _NWriteSequence:
+    def __init__(self, ring, seq_id):
+        self.ring, self._seq_id = ring, seq_id
+
+    def reserve(self, nbytes, nonblocking=False):
+        return _NWriteSpan(self.ring, self._seq_id, nbytes, nonblocking)
+
+    def commit_external(self, data):
+        ring = self.ring
+        assert data.space == ring.space, (data.space, ring.space)
+        ring._external[data.ptr] = data          # (the ring hands out windows on the caller's memory: keep it alive with the ring)
+        rc = ring._enq.xengRingCommitExternal(ring._h, self._seq_id, data.ptr, data.nbytes, 0)
+        if rc == _WOULD_BLOCK:
+            rc = ring._lib.xengRingCommitExternal(ring._h, self._seq_id, data.ptr, data.nbytes, 1)
+        ffi.check("xengRingCommitExternal", rc)
+
+    def end(self):
+        self.ring._enq.xengRingEndSequence(self.ring._h, self._seq_id)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.end()
+        return False
+
+
+class _NWriter:
+    def __init__(self, ring):
+        self.ring = ring
+
+    def begin_sequence(self, time_tag=0, header="", nringlet=1, name=None):
+        ring = self.ring
+        hdr = header.encode() if isinstance(header, str) else bytes(header)
+        seq = ctypes.c_longlong()
+        ffi.check("xengRingBeginSequence", ring._enq.xengRingBeginSequence(ring._h, int(time_tag), hdr, len(hdr), int(nringlet), ctypes.byref(seq)))
+        ring._open_seq_id = seq.value
+        return _NWriteSequence(ring, seq.value)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.ring._enq.xengRingEndWriting(self.ring._h)
+        return False
+
+
+class _NReadSequence:
+    def __init__(self, ring, rid, header, time_tag, nringlet):
+        self.ring, self._rid = ring, rid
+        self.header, self.time_tag, self.nringlet = header, time_tag, nringlet
+
+    def read(self, gulp_nbytes):
+        """Full gulps as they become available; a short final gulp once when the sequence ends (corr_block.py:389-391)."""
+        ring, rid = self.ring, self._rid
+        h, enq, space = ring._h, ring._enq.xengRingAcquire, ring.space
+        gulp_nbytes = int(gulp_nbytes)
+        ptr, n, span, skipped = ctypes.c_void_p(), ctypes.c_size_t(), ctypes.c_longlong(), ctypes.c_size_t()
+        refs = (ctypes.byref(ptr), ctypes.byref(n), ctypes.byref(span), ctypes.byref(skipped))
+        advance = offset = 0
+        while True:
+            rc = enq(h, rid, advance, gulp_nbytes, 0, *refs)           # asked first without giving up the interpreter lock
+            sk = skipped.value
+            if rc == _WOULD_BLOCK:
+                rc = ring._lib.xengRingAcquire(h, rid, 0, gulp_nbytes, 1, *refs)      # (the first call has moved the cursor already)
+                sk += skipped.value
+            if rc == _END:
+                return
+            if rc:
+                raise RuntimeError(ring._lib.xengGetLastError().decode())
+            size = n.value
+            offset += advance + sk
+            yield ReadSpan(XArray(shape=(size,), dtype=np.uint8, space=space, _ptr=ptr.value or 0, _base=_SpanRef(ring, span.value)), size, offset, sk)
+            advance = size
+            if size < gulp_nbytes:
+                return
+
+
+class _ReaderCount:
+    def __init__(self, ring):
+        self._ring = ring
+
+    def __len__(self):
+        return self._ring.info()["nreaders"]
+
+
+class NativeRing:
+    span_memory_outlives_release = True
+
+    def __init__(self, name="", space="system", core=None):
+        self.name, self.space = name, space
+        self._lib, self._enq = ffi.lib(), ffi.enqueue_lib()
+        h = ctypes.c_void_p()
+        ffi.call("xengRingCreate", ctypes.byref(h), name.encode(), _SPACE_ID[space])
+        self._h = h.value
+        self._open_seq_id = -1
+        self._external = {}
+        self._hooks = None
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                self._lib.xengRingDestroy(h)
+            except Exception:
+                pass
+
+    @property
+    def _readers(self):
+        return _ReaderCount(self)
+
+    def info(self):
+        cap, live, pool, nrd, nseq = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_int(), ctypes.c_longlong()
+        cnt = (ctypes.c_ulonglong * 5)()
+        ffi.check("xengRingGetInfo", self._enq.xengRingGetInfo(self._h, ctypes.byref(cap), ctypes.byref(live), ctypes.byref(pool), ctypes.byref(nrd),
+                                                               ctypes.byref(nseq), cnt))
+        return {"capacity": cap.value, "live_bytes": live.value, "pool_bytes": pool.value, "nreaders": nrd.value, "nseq": nseq.value,
+                "alloc": cnt[0], "free": cnt[1], "reuse": cnt[2], "stamp_wait": cnt[3], "skipped_bytes": cnt[4]}
+
+    @property
+    def counters(self):
+        return self.info()
+
+    def set_stamp_source(self, src):
+        """Tests: completion tickets of a fake backend instead of the library's stream clocks (see PyRing.set_stamp_source).
+        A stamp of the source must be an integer."""
+        def now(user, out):
+            out[0] = int(src.now())
+
+        def done(user, st):
+            return int(bool(src.done(st[0])[0]))
+
+        def wait(user, st):
+            src.wait(st[0])
+        self._hooks = (ffi.STAMP_NOW_FN(now), ffi.STAMP_DONE_FN(done), ffi.STAMP_WAIT_FN(wait))       # (kept alive with the ring)
+        ffi.call("xengRingSetStampHooks", self._h, self._hooks[0], self._hooks[1], self._hooks[2], None)
+
+    def resize(self, contig_bytes, total_span=None, nringlet=1):
+        ffi.check("xengRingResize", self._enq.xengRingResize(self._h, int(contig_bytes), int(total_span) if total_span else 0))
+
+    def begin_writing(self):
+        return _NWriter(self)
+
+    def _write_span(self, nbytes, nonblocking):
+        return _NWriteSpan(self, -1, nbytes, nonblocking)       # (-1: the open sequence)
+
+    def read(self, guarantee=True):
+        """Iterate over sequences.  The reader is registered when read() is called, so data written between the call and
+        the first iteration is kept for it."""
+        rid = ctypes.c_int()
+        # (registered without giving up the interpreter lock: a reader thread that has just been started is registered before
+        # the thread that started it runs on, as with the Python ring)
+        ffi.check("xengRingOpenReader", self._enq.xengRingOpenReader(self._h, int(bool(guarantee)), ctypes.byref(rid)))
+        return self._read_sequences(rid.value)
+
+    def _read_sequences(self, rid):
+        h = self._h
+        seq, tag, nr = ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_int()
+        hp, hl = ctypes.c_void_p(), ctypes.c_size_t()
+        refs = (ctypes.byref(seq), ctypes.byref(tag), ctypes.byref(nr), ctypes.byref(hp), ctypes.byref(hl))
+        try:
+            while True:
+                rc = self._enq.xengRingNextSequence(h, rid, 0, *refs)
+                if rc == _WOULD_BLOCK:
+                    rc = self._lib.xengRingNextSequence(h, rid, 1, *refs)
+                if rc == _END:
+                    return
+                if rc:
+                    raise RuntimeError(self._lib.xengGetLastError().decode())
+                header = _Header(ctypes.string_at(hp.value, hl.value) if hl.value else b"")
+                yield _NReadSequence(self, rid, header, tag.value, nr.value)
+        finally:
+            if self._h:
+                self._enq.xengRingCloseReader(self._h, rid)
+
+
+def Ring(name="", space="system", core=None):
+    """`Ring(name=, space=)` as lwa352-pipeline.py:147-155 creates them: the native ring unless XENG_RING=python."""
+    if IMPLEMENTATION == "python":
+        return PyRing(name=name, space=space, core=core)
+    return NativeRing(name=name, space=space, core=core)
+
+
+__all__ = ["Ring", "NativeRing", "PyRing", "WriteSpan", "to_dtype"]

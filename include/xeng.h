@@ -40,6 +40,8 @@ extern "C" {
 #define XENG_STATUS_DEVICE_ERROR       3
 #define XENG_STATUS_UNSUPPORTED        4
 #define XENG_STATUS_MEM_ALLOC_FAILED   5
+#define XENG_STATUS_WOULD_BLOCK        6   /* a call that was asked not to wait would have had to */
+#define XENG_STATUS_END_OF_DATA        7   /* ring readers: no more sequences / no more data in this sequence */
 
 /* memory spaces, numbered as bifrost's BFspace [from memory of bifrost/src/bifrost/memory.h] */
 #define XENG_SPACE_AUTO       0
@@ -81,6 +83,67 @@ int xengMemcpy(void *dst, const void *src, size_t nbytes);     /* any direction,
 int xengMemcpyAsync(void *dst, const void *src, size_t nbytes);/* on the library's copy stream */
 int xengMemset(void *dst, int value, size_t nbytes);
 int xengStreamSynchronize(void);                               /* all library streams of the current device */
+
+/* ---------------------------------------------------------------- stamps: what has been enqueued so far
+ * A stamp names everything the library has enqueued on its streams of the current device up to now, by any thread -- including
+ * gulps handed to xengXgpuKernelAsync whose contraction has not been enqueued yet.  It is complete when all of that has run.
+ * Taking one enqueues nothing and costs a few loads; asking about one records an event only on a stream that is still
+ * busy.  The span rings below stamp every allocation at the moment its last user lets go and reissue or free it only once the
+ * stamp is complete: GPU memory lifetime does not rest on who dropped which Python reference when.
+ * No reference counterpart: a bifrost ring is one circular buffer that is never freed while the pipeline runs. */
+typedef struct xengStamp_ { unsigned long long w[16]; } xengStamp;
+int xengStampNow(xengStamp *stamp);
+/* non-blocking: *done = 1 when Wait would not wait; *waitable (may be NULL) = 0 when the stamp waits for an X-engine launch
+ * that nobody has enqueued yet (only the owner of those gulps can end that: a dump, or xengXgpuReset) */
+int xengStampDone(const xengStamp *stamp, int *done, int *waitable);
+int xengStampWait(const xengStamp *stamp);
+
+/* ---------------------------------------------------------------- span rings
+ * The bookkeeping of the ring the blocks sit on -- bifrost.ring.Ring in the reference (lwa352-pipeline.py:147-155; protocol
+ * used by the hot-path blocks: corr_block.py:342-350,388,433-452; corr_acc_block.py:313-318; beamform_block.py:440-450) --
+ * for pipelines that run without bifrost: committed spans, reader cursors, back-pressure and the free list of span
+ * allocations, native.  caltech-bifrost-dsp_amd/ring.py wraps these calls in the reference's Python protocol.
+ * Every span is its own reference-counted allocation in `space` (system / device / pinned): a reader that keeps its span
+ * handle may go on reading the bytes after the ring has moved on.  Calls that can wait take `may_block`: 0 returns
+ * XENG_STATUS_WOULD_BLOCK instead of waiting (a caller that holds an interpreter lock asks first and gives the lock up only
+ * for a call that has to sleep). */
+typedef struct xengRing_ xengRing;
+int xengRingCreate(xengRing **ring, const char *name, int space);
+int xengRingDestroy(xengRing *ring);     /* wakes every waiter; spans still referenced stay valid until released */
+int xengRingResize(xengRing *ring, size_t contig_bytes, size_t total_span);        /* ring.resize(): capacity in bytes (0: 4 x contig) */
+/* counters: allocations made, really freed, reissued from the free list, waits for a stamp at reissue, bytes skipped by readers */
+int xengRingGetInfo(xengRing *ring, size_t *capacity, size_t *live_bytes, size_t *pool_bytes, int *nreaders, long long *nseq,
+                    unsigned long long counters[5]);
+/* writer: one at a time.  BeginSequence ends the sequence that was open. */
+int xengRingBeginSequence(xengRing *ring, long long time_tag, const void *header, size_t header_len, int nringlet, long long *seq);
+int xengRingEndSequence(xengRing *ring, long long seq);
+int xengRingEndWriting(xengRing *ring);
+/* WriteSpan(ring, nbytes, nonblocking) (corr_block.py:435): waits until the ring has room (guaranteed readers apply
+ * back-pressure; without one the oldest span is overwritten, as in bifrost), then hands out span memory -- a released
+ * allocation whose stamp is complete, or a fresh zero-filled one.  nonblocking: XENG_STATUS_WOULD_BLOCK + message when full. */
+int xengRingReserve(xengRing *ring, long long seq, size_t nbytes, int nonblocking, int may_block, void **data, long long *span);
+int xengRingCommit(xengRing *ring, long long seq, long long span, size_t nbytes);       /* the first nbytes of the span become readable */
+/* publish the caller's own memory as the next span without a copy (a replay source: dummy_source_block.py:207-222 re-sends
+ * the same gulps); the caller keeps it valid and unchanged while readers may hold it */
+int xengRingCommitExternal(xengRing *ring, long long seq, void *data, size_t nbytes, int may_block);
+/* readers.  A reader registered late starts at the oldest sequence still in the ring; data overwritten before a reader got
+ * to it is skipped by whole gulps (*skipped bytes), as a bifrost reader skips frames. */
+int xengRingOpenReader(xengRing *ring, int guarantee, int *reader);
+int xengRingCloseReader(xengRing *ring, int reader);
+/* XENG_STATUS_END_OF_DATA once writing has ended and every sequence has been seen; *header stays valid until the next call */
+int xengRingNextSequence(xengRing *ring, int reader, int may_block, long long *seq, long long *time_tag, int *nringlet,
+                         const void **header, size_t *header_len);
+/* iseq.read(gulp_nbytes): first moves the reader `advance` bytes on (the previous gulp), then waits for the next gulp.
+ * *nbytes < gulp_nbytes only for the short tail of an ended sequence; XENG_STATUS_END_OF_DATA when the sequence is over.
+ * *span holds a reference on the memory: xengRingSpanRelease when done with it. */
+int xengRingAcquire(xengRing *ring, int reader, size_t advance, size_t gulp_nbytes, int may_block, void **data, size_t *nbytes,
+                    long long *span, size_t *skipped);
+int xengRingSpanRelease(long long span);      /* a span handle from Reserve or Acquire: the last release stamps the allocation */
+/* tests: tickets of a fake backend instead of the library's stream clocks (and a free list for system-space rings) */
+typedef void (*xengRingStampNowFn)(void *user, unsigned long long stamp[2]);
+typedef int (*xengRingStampDoneFn)(void *user, const unsigned long long stamp[2]);
+typedef void (*xengRingStampWaitFn)(void *user, const unsigned long long stamp[2]);
+int xengRingSetStampHooks(xengRing *ring, xengRingStampNowFn now, xengRingStampDoneFn done, xengRingStampWaitFn wait, void *user);
 
 /* ---------------------------------------------------------------- X-engine (Corr)
  * replaces _bf.bfXgpuInitialize / bfXgpuKernel / bfXgpuCorrelate / bfXgpuGetOrder /

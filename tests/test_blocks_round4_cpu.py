@@ -1,0 +1,130 @@
+"""Round-4 host-logic cases of the blocks (CPU rings, oracle backend; both ring implementations)."""
+import threading
+import time
+
+import numpy as np
+
+import caltech_bifrost_dsp_amd  # noqa: F401
+from caltech_bifrost_dsp_amd.blocks import Corr, CorrAcc
+from caltech_bifrost_dsp_amd.ring import Ring
+from oracle import xeng_oracle as orc
+from tests.fake_backend import OracleBackend
+from tests.pipeline_util import LOG, Sink, Source, run_blocks, source_header
+
+
+def test_fused_registration_needs_a_guaranteed_first_reader():
+    """Only one CorrAcc per ring, and only a guaranteed one, may have the upstream Corr's dumps feed its accumulators: a
+    second CorrAcc (it would overwrite the ring's single slot) and a reader without the guarantee (it may skip spans, and
+    the decision queue would fall out of step) keep the map path."""
+    C, S = 2, 8
+    be = OracleBackend()
+    r1, r2, r3 = Ring("corr-output"), Ring("slow-a"), Ring("slow-b")
+    a = CorrAcc(LOG, r1, r2, nchan=C, npol=2, nstand=S, acc_len=8, backend=be)
+    b = CorrAcc(LOG, r1, r3, nchan=C, npol=2, nstand=S, acc_len=8, backend=be)
+    assert r1.long_accumulator is a and a._iseqs is not None and b._iseqs is None
+    r4 = Ring("corr-output-2")
+    c = CorrAcc(LOG, r4, Ring("slow-c"), nchan=C, npol=2, nstand=S, acc_len=8, backend=be, guarantee=False)
+    assert getattr(r4, 'long_accumulator', None) is None and c._iseqs is None
+    del a, b, c
+
+
+def test_two_corraccs_on_one_ring_one_fused_one_classic():
+    C, S, g, acc, lacc = 2, 8, 2, 4, 8
+    vin = np.random.default_rng(5).integers(0, 256, (32, C, S, 2), dtype=np.uint8)
+    be = OracleBackend()
+    r0, r1, r2, r3 = Ring("gpu-input"), Ring("corr-output"), Ring("slow-a"), Ring("slow-b")
+    corr = Corr(LOG, r0, r1, ntime_gulp=g, nchan=C, npol=2, nstand=S, acc_len=acc, autostartat=0, backend=be)
+    a = CorrAcc(LOG, r1, r2, nchan=C, npol=2, nstand=S, acc_len=lacc, autostartat=0, backend=be)
+    b = CorrAcc(LOG, r1, r3, nchan=C, npol=2, nstand=S, acc_len=lacc, autostartat=0, backend=be)
+    sa, sb = Sink(r2, a.ogulp_size), Sink(r3, b.ogulp_size)
+    run_blocks([corr, a, b], Source(r0, [(source_header(C, S, 2), vin, g * C * S * 2)]), [sa, sb])
+    assert a.stats['fused'] is True and b.stats['fused'] is False         # (the second one maps every span itself)
+    want = [orc.xgpu_correlate(vin[lacc * k:lacc * (k + 1)], S, C) for k in range(4)]
+    for sink in (sa, sb):
+        (_, _, spans), = sink.sequences
+        assert len(spans) == 4
+        for k, sp in enumerate(spans):
+            assert np.array_equal(sp.view(np.int32), want[k])
+
+
+def test_corr_counts_time_across_skipped_gulps():
+    """A Corr that registers after its input ring has overwritten gulps starts on a gulp boundary with the right sample
+    count (round 3: the late reader raised and the block thread died): the integrations it emits are those of the oracle
+    at the sample counts its output headers name."""
+    C, S, g, acc = 2, 8, 2, 4
+    vin = np.random.default_rng(9).integers(0, 256, (48, C, S, 2), dtype=np.uint8)
+    gulp = g * C * S * 2
+    r0, r1 = Ring("gpu-input"), Ring("corr-output")
+    r0.resize(gulp, 4 * gulp)
+    be = OracleBackend()
+    w = r0.begin_writing()
+    import json
+    oseq = w.begin_sequence(time_tag=0, header=json.dumps(source_header(C, S, 2)))
+    raw = vin.reshape(-1)
+    for k in range(8):                        # 8 gulps into a ring of 4, nobody reading: gulps 0..3 are overwritten
+        with oseq.reserve(gulp) as sp:
+            sp.data[...] = raw[k * gulp:(k + 1) * gulp]
+    corr = Corr(LOG, r0, r1, ntime_gulp=g, nchan=C, npol=2, nstand=S, acc_len=acc, autostartat=-1, backend=be)
+    sink = Sink(r1, corr.ogulp_size)
+    sink.start()
+    th = threading.Thread(target=corr.main, daemon=True)
+    th.start()
+    t0 = time.time()
+    while len(r0._readers) < 1 and time.time() - t0 < 10:
+        time.sleep(0.005)
+    for k in range(8, 24):
+        with oseq.reserve(gulp) as sp:
+            sp.data[...] = raw[k * gulp:(k + 1) * gulp]
+    oseq.end()
+    w.__exit__(None, None, None)
+    th.join(20)
+    sink.join(20)
+    assert not th.is_alive() and not sink.is_alive()
+    assert sink.sequences
+    hdr, _, spans = sink.sequences[0]
+    start = hdr['seq0']
+    assert start % acc == 0 and start >= 4 * g and spans          # first sample seen is >= gulp 4; starts on an acc_len boundary
+    for k, sp in enumerate(spans):
+        t = start + k * acc
+        assert np.array_equal(sp.view(np.int32), orc.xgpu_correlate(vin[t:t + acc], S, C)), (k, t)
+
+
+def test_fused_plan_waits_for_a_stalled_consumer_instead_of_failing():
+    """Downstream back-pressure in fused mode: while corr-slow-output is full (its consumer stalls), CorrAcc cannot publish, the
+    accumulator pair stays busy and the upstream Corr waits in plan_dump -- without a deadline, as the classic path and the
+    reference wait on the guaranteed ring.  When the consumer resumes everything is published, nothing lost."""
+    C, S, g, acc, lacc = 2, 8, 2, 2, 4
+    nlong = 8
+    vin = np.random.default_rng(3).integers(0, 256, (nlong * lacc, C, S, 2), dtype=np.uint8)
+    be = OracleBackend()
+    r0, r1, r2 = Ring("gpu-input"), Ring("corr-output"), Ring("corr-slow-output")
+    corr = Corr(LOG, r0, r1, ntime_gulp=g, nchan=C, npol=2, nstand=S, acc_len=acc, autostartat=0, backend=be)
+    cacc = CorrAcc(LOG, r1, r2, nchan=C, npol=2, nstand=S, acc_len=lacc, autostartat=0, backend=be)
+    r2.resize(cacc.ogulp_size, cacc.ogulp_size)              # room for ONE long integration
+    gate = threading.Event()
+    got = []
+    gen = r2.read(guarantee=True)
+
+    def stalled_sink():
+        for iseq in gen:
+            for ispan in iseq.read(cacc.ogulp_size):
+                if not got:
+                    gate.wait(20)                            # the consumer stalls on the first span
+                got.append(ispan.data.numpy().view(np.int32).copy())
+
+    fast = Sink(r1, corr.ogulp_size)
+    ths = [threading.Thread(target=f, daemon=True) for f in (stalled_sink, corr.main, cacc.main)]
+    fast.start()
+    for t in ths:
+        t.start()
+    src = Source(r0, [(source_header(C, S, 2), vin, g * C * S * 2)])
+    src.start()
+    time.sleep(1.0)                                          # everything backs up behind the stalled consumer
+    assert all(t.is_alive() for t in ths[1:]) and len(got) == 0
+    gate.set()
+    for t in [src] + ths + [fast]:
+        t.join(30)
+        assert not t.is_alive()
+    assert len(got) == nlong
+    for k, sp in enumerate(got):
+        assert np.array_equal(sp, orc.xgpu_correlate(vin[lacc * k:lacc * (k + 1)], S, C))
