@@ -23,6 +23,10 @@ class HipBackend:
     def __init__(self):
         self._lib = ffi.lib()   # raises ImportError if libxeng.so has not been built
         self._enq = ffi.enqueue_lib()   # enqueue-only calls, made without giving up the interpreter lock (ffi.ENQUEUE_ONLY)
+        # ... and the ones a block makes per gulp bound directly (csrc/pyext/xfast.cpp): ctypes spends more on converting
+        # their arguments than the library spends on the call
+        from .ring import _xfast
+        self._x = _xfast()
 
     # ---- device plumbing (bifrost.device.set_device / get_device / stream_synchronize)
     def set_device(self, gpu):
@@ -49,15 +53,17 @@ class HipBackend:
 
     def beam_mark(self):
         """Ticket for everything enqueued on the beamformer's stream so far (beam_wait waits for it)."""
-        t = ctypes.c_ulonglong()
-        ffi.check("xengBeamformMark", self._enq.xengBeamformMark(ctypes.byref(t)))
-        return t.value
+        t = self._x.beam_mark()
+        if t < 0:
+            ffi.check("xengBeamformMark", -t)
+        return t
 
     def beam_wait(self, ticket):
         # ask first, without giving up the interpreter lock; only a ticket the GPU has not reached yet is worth a blocking call
-        done = ctypes.c_int()
-        ffi.check("xengBeamformTicketDone", self._enq.xengBeamformTicketDone(ticket, ctypes.byref(done)))
-        if not done.value:
+        d = self._x.beam_ticket_done(ticket)
+        if d < 0:
+            ffi.check("xengBeamformTicketDone", -d)
+        if not d:
             ffi.call("xengBeamformWait", ticket)
 
     # ---- X-engine (corr_block.py:253,331,445)
@@ -74,12 +80,12 @@ class HipBackend:
     def bfXgpuKernelAsync(self, in_arr, out_arr, do_dump):
         """Enqueue only: the gulp is read in place at dump time, so the caller keeps it alive and unchanged until
         xgpu_sync() (include/xeng.h: xengXgpuKernelAsync).  No reference counterpart."""
-        return self._enq.xengXgpuKernelAsync(_dev(in_arr), _dev(out_arr), int(do_dump))
+        return self._x.xgpu_kernel_async(_dev(in_arr), _dev(out_arr), int(do_dump))
 
     def bfXgpuKernelAsyncAcc(self, in_arr, out_arr, do_dump, acc, acc_mode):
         """bfXgpuKernelAsync whose dump also assigns (acc_mode 1) / adds (2) every stored word to the long accumulator
         `acc` -- CorrAcc's "a = b" / "a += b" (corr_acc_block.py:304-306) done by the contraction's epilogue."""
-        return self._enq.xengXgpuKernelAsyncAcc(_dev(in_arr), _dev(out_arr), int(do_dump), acc.ptr, int(acc_mode))
+        return self._x.xgpu_kernel_async_acc(_dev(in_arr), _dev(out_arr), int(do_dump), acc.ptr, int(acc_mode))
 
     def xgpu_fused_acc_supported(self):
         """True when the live X-engine context runs the default (fused corner turn) contraction kernel, the one whose
@@ -94,10 +100,9 @@ class HipBackend:
 
     def xgpu_sync_lag(self, lag):
         """Wait until the dump issued `lag` dumps before the latest one is complete (lag 0 = the latest)."""
-        done = ctypes.c_int()
-        rc = self._enq.xengXgpuDumpDone(int(lag), ctypes.byref(done))       # (asked without giving up the interpreter lock)
-        if rc != ffi.STATUS_SUCCESS or done.value:
-            return rc
+        d = self._x.xgpu_dump_done(int(lag))       # (asked without giving up the interpreter lock)
+        if d:
+            return ffi.STATUS_SUCCESS if d > 0 else -d
         return self._lib.xengXgpuSyncLag(int(lag))
 
     def bfXgpuGetOrder(self, antpol_to_input, antpol_to_bl, is_conj):
@@ -125,10 +130,10 @@ class HipBackend:
 
     # ---- CorrAcc (corr_acc_block.py:304,306: BFMap "a = b" / "a += b")
     def map_assign_i32(self, a, b):
-        return self._enq.xengMapAssignI32(a.ptr, b.ptr, a.nbytes // 4)
+        return self._x.map_i32(a.ptr, b.ptr, a.nbytes // 4, False)
 
     def map_add_i32(self, a, b):
-        return self._enq.xengMapAddI32(a.ptr, b.ptr, a.nbytes // 4)
+        return self._x.map_i32(a.ptr, b.ptr, a.nbytes // 4, True)
 
     # ---- beamformer (beamform_block.py:251,449; beamform_sum_beams_block.py:245)
     def bfBeamformInitialize(self, gpu, ninput, nchan, ntime, nbeam, ntime_blocks):
@@ -138,12 +143,12 @@ class HipBackend:
         """`version` != 0 lets the library reuse its bf16-split copy of the weights while the caller has
         not changed them (the reference call shape has no such argument: version 0 = always re-split)."""
         if version:
-            return self._enq.xengBeamformRunVersioned(_dev(in_arr), _dev(out_arr), _dev(weights), int(version))
-        return self._enq.bfBeamformRun(in_arr, out_arr, weights)
+            return self._x.beam_run(_dev(in_arr), _dev(out_arr), _dev(weights), int(version))
+        return self._lib.bfBeamformRun(in_arr, out_arr, weights)
 
     def bfBeamformIntegrate(self, in_arr, out_arr, ntime_sum):
         # (bfBeamformIntegrate reads only the two data pointers from its structs: the raw entry point, no structs built per gulp)
-        return self._enq.xengBeamformIntegrate(_dev(in_arr), _dev(out_arr), int(ntime_sum))
+        return self._x.beam_integrate(_dev(in_arr), _dev(out_arr), int(ntime_sum))
 
     def last_error(self):
         return self._lib.xengGetLastError().decode()

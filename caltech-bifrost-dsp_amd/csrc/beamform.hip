@@ -77,7 +77,7 @@ static int beam_destroy_locked() {
 // pow_out != nullptr: integrated-power mode, fused into the int8x3 kernel when that is possible (see the kernel); returns
 // *fused = false when the caller has to run the voltage mode into its scratch and integrate separately
 static int run_locked(const void* in, float* out, const void* w, long long version, float* pow_out = nullptr, int ntime_sum = 0,
-                      bool* fused = nullptr) {
+                      bool* fused = nullptr, bool may_wait = true) {
     BeamContext& x = g_b;
     if (fused) *fused = false;
     if (x.use_f32) {
@@ -121,6 +121,11 @@ static int run_locked(const void* in, float* out, const void* w, long long versi
             // Integrated-power mode: which path forms the power sums (the fused epilogue, or Run -> Integrate) must not
             // depend on how far the GPU has got -- the two sum in different orders, so the last bits would differ from
             // call to call.  One wait per weight upload, in this mode only: the routing answer decides, not the clock.
+            if (!may_wait && hipEventQuery(x.ev_route) != hipSuccess) {
+                (void)hipGetLastError();
+                // (the weights are prepared and remembered: the blocking call that follows finds them and only waits)
+                XENG_FAIL(XENG_STATUS_WOULD_BLOCK, "Beamform: the routing answer of a weight upload is not back yet");
+            }
             XENG_HIP(hipEventSynchronize(x.ev_route));
             x.route_known = true;
             x.need_bf16 = *x.any_host != 0;
@@ -255,7 +260,17 @@ int xengBeamformRun(const void* in_dev, void* out_dev, const void* weights_dev) 
     return xengBeamformRunVersioned(in_dev, out_dev, weights_dev, 0);
 }
 
+static int run_versioned(const void* in_dev, void* out_dev, const void* weights_dev, long long weights_version, bool may_wait);
+
 int xengBeamformRunVersioned(const void* in_dev, void* out_dev, const void* weights_dev, long long weights_version) {
+    return run_versioned(in_dev, out_dev, weights_dev, weights_version, true);
+}
+
+int xengBeamformTryRunVersioned(const void* in_dev, void* out_dev, const void* weights_dev, long long weights_version) {
+    return run_versioned(in_dev, out_dev, weights_dev, weights_version, false);
+}
+
+static int run_versioned(const void* in_dev, void* out_dev, const void* weights_dev, long long weights_version, bool may_wait) {
     std::lock_guard<std::mutex> lk(g_bmu);
     BeamContext& x = g_b;
     if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "Beamform: not initialized (call xengBeamformInitialize)");
@@ -265,7 +280,7 @@ int xengBeamformRunVersioned(const void* in_dev, void* out_dev, const void* weig
     XENG_HIP(hipSetDevice(x.gpu));
     if (x.ntime_blocks == 0) return run_locked(in_dev, (float*)out_dev, weights_dev, weights_version);
     bool fused = false;
-    int rc = run_locked(in_dev, x.scratch, weights_dev, weights_version, (float*)out_dev, x.ntime / x.ntime_blocks, &fused);
+    int rc = run_locked(in_dev, x.scratch, weights_dev, weights_version, (float*)out_dev, x.ntime / x.ntime_blocks, &fused, may_wait);
     if (rc || fused) return rc;
     return integrate_locked(x.scratch, out_dev, x.ntime / x.ntime_blocks, 0, x.nbeam / 2);
 }

@@ -88,6 +88,7 @@ struct RingCore {
     xengRingStampDoneFn hook_done = nullptr;
     xengRingStampWaitFn hook_wait = nullptr;
     void* hook_user = nullptr;
+    bool recycle_system = false;     // system space: recycle span memory like the device spaces do (default: fresh zeroed memory per span)
     // statistics
     std::atomic<unsigned long long> n_alloc{0}, n_free{0}, n_reuse{0}, n_stamp_wait{0}, n_skipped{0};
 };
@@ -96,7 +97,7 @@ static void ring_unref(RingCore* r) {
     if (r->refs.fetch_sub(1) == 1) delete r;
 }
 
-static bool pooled_space(const RingCore* r) { return r->space != XENG_SPACE_SYSTEM || r->hook_now; }
+static bool pooled_space(const RingCore* r) { return r->space != XENG_SPACE_SYSTEM || r->hook_now || r->recycle_system; }
 
 static int raw_alloc(int space, size_t nbytes, void** out) {
     const size_t n = nbytes ? nbytes : 1;
@@ -380,6 +381,13 @@ int xengRingSetStampHooks(xengRing* ring, xengRingStampNowFn now, xengRingStampD
     RING_ARG(ring);
     std::lock_guard<std::mutex> lk(r->pool_mu);
     r->hook_now = now; r->hook_done = done; r->hook_wait = wait; r->hook_user = user;
+    return XENG_STATUS_SUCCESS;
+}
+
+int xengRingSetRecycle(xengRing* ring, int on) {
+    RING_ARG(ring);
+    std::lock_guard<std::mutex> lk(r->pool_mu);
+    r->recycle_system = on != 0;
     return XENG_STATUS_SUCCESS;
 }
 

@@ -556,7 +556,7 @@ static void drain_timer() {
 // Back-pressure of the event ring, outside the context lock: the next launch re-records the slot of launch n - NEV, which
 // must have completed first.  Normally it has, long ago; a caller that is NEV launches ahead of the GPU waits here, and
 // the other blocks' calls (SubSelect, Packetize, ...) go on meanwhile.
-static int wait_for_event_slot() {
+static int wait_for_event_slot(bool may_block = true) {
     for (;;) {
         hipEvent_t ev = nullptr;
         int gpu = 0;
@@ -571,6 +571,7 @@ static int wait_for_event_slot() {
             if (hipEventQuery(ev) == hipSuccess) return XENG_STATUS_SUCCESS;
             (void)hipGetLastError();
         }
+        if (!may_block) XENG_FAIL(XENG_STATUS_WOULD_BLOCK, "xgpu: %d launches in flight (xengXgpuWaitLaunchSlot, then retry)", XgpuContext::NEV);
         XENG_HIP(hipSetDevice(gpu));
         XENG_HIP(hipEventSynchronize(ev));
     }
@@ -604,6 +605,15 @@ int xengXgpuKernelAsyncAcc(const void* in_dev, void* out_dev, int doDump, void* 
     std::lock_guard<std::mutex> lk(g_mu);
     return kernel_locked(in_dev, out_dev, doDump, false, nullptr, acc_dev, acc_dev ? acc_mode : 0);
 }
+
+int xengXgpuTryKernelAsyncAcc(const void* in_dev, void* out_dev, int doDump, void* acc_dev, int acc_mode) {
+    int rc0 = wait_for_event_slot(false);
+    if (rc0) return rc0;
+    std::lock_guard<std::mutex> lk(g_mu);
+    return kernel_locked(in_dev, out_dev, doDump, false, nullptr, acc_dev, acc_dev ? acc_mode : 0);
+}
+
+int xengXgpuWaitLaunchSlot(void) { return wait_for_event_slot(true); }
 
 int xengXgpuSync(void) {
     int gpu, nmm;

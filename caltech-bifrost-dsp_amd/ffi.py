@@ -51,7 +51,7 @@ _ll, _pll, _psz, _pvp = ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong), ct
 _pst = ctypes.POINTER(XengStamp)
 SYMBOLS = {
     "xengStampNow": [_pst], "xengStampDone": [_pst, _pi, _pi], "xengStampWait": [_pst],
-    "xengRingCreate": [_pvp, ctypes.c_char_p, _i], "xengRingDestroy": [_vp], "xengRingResize": [_vp, _sz, _sz],
+    "xengRingCreate": [_pvp, ctypes.c_char_p, _i], "xengRingDestroy": [_vp], "xengRingResize": [_vp, _sz, _sz], "xengRingSetRecycle": [_vp, _i],
     "xengRingGetInfo": [_vp, _psz, _psz, _psz, _pi, _pll, ctypes.POINTER(ctypes.c_ulonglong)],
     "xengRingBeginSequence": [_vp, _ll, ctypes.c_char_p, _sz, _i, _pll], "xengRingEndSequence": [_vp, _ll], "xengRingEndWriting": [_vp],
     "xengRingReserve": [_vp, _ll, _sz, _i, _i, _pvp, _pll], "xengRingCommit": [_vp, _ll, _ll, _sz],
@@ -65,7 +65,7 @@ SYMBOLS = {
     "xengMalloc": [ctypes.POINTER(_vp), _sz, _i], "xengFree": [_vp, _i], "xengMemcpy": [_vp, _vp, _sz],
     "xengMemcpyAsync": [_vp, _vp, _sz], "xengMemset": [_vp, _i, _sz], "xengStreamSynchronize": [],
     "xengXgpuConfigure": [_i, _i, _i, _i, _i], "xengXgpuInitialize": [_i], "xengXgpuDestroy": [],
-    "xengXgpuKernel": [_vp, _vp, _i], "xengXgpuKernelAsync": [_vp, _vp, _i], "xengXgpuKernelAsyncAcc": [_vp, _vp, _i, _vp, _i], "xengXgpuSync": [], "xengXgpuSyncLag": [_i], "xengXgpuDumpDone": [_i, _pi], "xengXgpuReset": [],
+    "xengXgpuKernel": [_vp, _vp, _i], "xengXgpuKernelAsync": [_vp, _vp, _i], "xengXgpuKernelAsyncAcc": [_vp, _vp, _i, _vp, _i], "xengXgpuTryKernelAsyncAcc": [_vp, _vp, _i, _vp, _i], "xengXgpuWaitLaunchSlot": [], "xengXgpuSync": [], "xengXgpuSyncLag": [_i], "xengXgpuDumpDone": [_i, _pi], "xengXgpuReset": [],
     "xengXgpuCorrelate": [_vp, _vp, _i], "xengXgpuGetOrder": [_vp, _vp, _vp],
     "xengXgpuSubSelect": [_vp, _vp, _vp, _vp, _i, _i], "xengXgpuReorder": [_vp, _vp, _vp, _vp],
     "xengXgpuGetInfo": [_pi, _pi, _pi, _pi, ctypes.POINTER(ctypes.c_int64), _pi],
@@ -77,7 +77,7 @@ SYMBOLS = {
     "xengXgpuSetProfiling": [_i], "xengXgpuGetTimes": [ctypes.POINTER(ctypes.c_double), _pi],
     "xengMapAssignI32": [_vp, _vp, _sz], "xengMapAddI32": [_vp, _vp, _sz], "xengMapSync": [],
     "xengBeamformInitialize": [_i, _i, _i, _i, _i, _i], "xengBeamformDestroy": [],
-    "xengBeamformRun": [_vp, _vp, _vp], "xengBeamformRunVersioned": [_vp, _vp, _vp, ctypes.c_longlong], "xengBeamformIntegrate": [_vp, _vp, _i],
+    "xengBeamformRun": [_vp, _vp, _vp], "xengBeamformRunVersioned": [_vp, _vp, _vp, ctypes.c_longlong], "xengBeamformTryRunVersioned": [_vp, _vp, _vp, ctypes.c_longlong], "xengBeamformIntegrate": [_vp, _vp, _i],
     "xengBeamformIntegrateSingleBeam": [_vp, _vp, _i, _i], "xengBeamformMark": [ctypes.POINTER(ctypes.c_ulonglong)], "xengBeamformWait": [ctypes.c_ulonglong], "xengBeamformTicketDone": [ctypes.c_ulonglong, _pi], "xengBeamformSync": [],
     "xengBeamformSetProfiling": [_i], "xengBeamformGetTimes": [ctypes.POINTER(ctypes.c_double), _pi],
     "xengBeamformGetRouteInfo": [_pi, _pi, _pi],
@@ -114,9 +114,13 @@ def lib():
 # gives the lock up for a 3 us call has to win it back afterwards, and with several block threads in one interpreter that
 # costs a sleep and a wake-up -- measured 50 us per call on the GPU box (profiles/r03/blocks_lock_handoff.txt), more than the
 # GPU needs for the gulp.  Calls that wait (Sync, Wait, the synchronous X-engine call, copies) stay on the releasing handle.
-ENQUEUE_ONLY = ["xengXgpuKernelAsync", "xengXgpuKernelAsyncAcc", "xengBeamformRun", "xengBeamformRunVersioned",
+# (Round 4: the list holds only calls that cannot wait by construction.  xengXgpuKernelAsync[Acc] wait at 256 launches in
+# flight and xengBeamformRun* waits once after a weight upload in the integrated-power mode: their Try* forms return
+# XENG_STATUS_WOULD_BLOCK instead, and the caller gives the lock up to wait; xengSnap2UnpackAsync shares a mutex with the
+# synchronous call, which polls: it is made on the releasing handle.)
+ENQUEUE_ONLY = ["xengXgpuTryKernelAsyncAcc", "xengBeamformTryRunVersioned",
                 "xengBeamformIntegrate", "xengBeamformIntegrateSingleBeam", "xengBeamformMark", "xengMapAssignI32",
-                "xengMapAddI32", "xengSnap2UnpackAsync", "xengXgpuDumpDone", "xengBeamformTicketDone", "bfBeamformRun", "bfBeamformIntegrate", "bfBeamformIntegrateSingleBeam",
+                "xengMapAddI32", "xengXgpuDumpDone", "xengBeamformTicketDone", "bfBeamformIntegrate", "bfBeamformIntegrateSingleBeam",
                 # the span rings: bookkeeping calls, and the calls that can wait asked with may_block = 0 first
                 "xengRingBeginSequence", "xengRingEndSequence", "xengRingEndWriting", "xengRingReserve", "xengRingCommit",
                 "xengRingCommitExternal", "xengRingNextSequence", "xengRingAcquire", "xengRingSpanRelease", "xengRingGetInfo",

@@ -25,6 +25,7 @@ _DTYPES = {"i8": np.int8, "u8": np.uint8, "i32": np.int32, "i64": np.int64, "f32
 
 
 _DT_CACHE = {}
+_U8 = np.dtype(np.uint8)
 
 
 def to_dtype(dt):
@@ -76,6 +77,14 @@ class XArray:
                 ffi.call("xengMemset", self.ptr, 0, max(nbytes, 1))
         if src is not None:
             self[...] = src
+
+    @classmethod
+    def window(cls, ptr, nbytes, space, base):
+        """A byte window on existing memory -- what a ring hands out per gulp (the general constructor spends as long on its
+        argument handling as the native ring call spends in all)."""
+        a = cls.__new__(cls)
+        a.space, a.dtype, a.shape, a.size, a.nbytes, a.ptr, a.base = space, _U8, (nbytes,), nbytes, nbytes, ptr, base
+        return a
 
     # ------------------------------------------------------------------ geometry (size, nbytes: set once in __init__)
     def view(self, dtype):

@@ -538,38 +538,30 @@ class PyRing:
 
 # ====================================================================== the native ring: thin handles on csrc/ring.hip
 _WOULD_BLOCK, _END = ffi.STATUS_WOULD_BLOCK, ffi.STATUS_END_OF_DATA
+_xf = None
 
 
-class _SpanRef:
-    """One reference on a native span's memory (a handle from xengRingReserve / xengRingAcquire), given back when the last
-    array that uses it goes away.  Holds the ring object, so the native ring outlives every span handle."""
-    __slots__ = ("ring", "handle")
-
-    def __init__(self, ring, handle):
-        self.ring, self.handle = ring, handle
-
-    def __del__(self):
-        h, self.handle = self.handle, 0
-        if h:
-            try:
-                self.ring._enq.xengRingSpanRelease(h)
-            except Exception:
-                pass
+def _xfast():
+    """The CPython extension that binds the per-gulp ring calls directly (csrc/pyext/xfast.cpp): it asks without waiting first
+    and gives the interpreter lock up only for a call that has to sleep."""
+    global _xf
+    if _xf is None:
+        try:
+            from . import _xfast as m
+        except ImportError as e:
+            raise ImportError("the _xfast extension is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(or make -C caltech-bifrost-dsp_amd/csrc): %s" % e)
+        _xf = m
+    return _xf
 
 
 class _NWriteSpan(_SpanViews):
+    __slots__ = ("ring", "_seq_id", "size", "_span", "data", "_closed")
+
     def __init__(self, ring, seq_id, nbytes, nonblocking):
         self.ring, self._seq_id, self.size = ring, seq_id, int(nbytes)
-        ptr, span = ctypes.c_void_p(), ctypes.c_longlong()
-        rc = ring._enq.xengRingReserve(ring._h, seq_id, self.size, int(bool(nonblocking)), 0, ctypes.byref(ptr), ctypes.byref(span))
-        if rc == _WOULD_BLOCK and not nonblocking:     # has to wait (room, a stamp, a device allocation): give the interpreter lock up
-            rc = ring._lib.xengRingReserve(ring._h, seq_id, self.size, 0, 1, ctypes.byref(ptr), ctypes.byref(span))
-        if rc == _WOULD_BLOCK:
-            raise BlockingIOError("ring %r full" % ring.name)
-        if rc:
-            raise RuntimeError(ring._lib.xengGetLastError().decode())
-        self._span = span.value
-        self.data = XArray(shape=(self.size,), dtype=np.uint8, space=ring.space, _ptr=ptr.value or 0, _base=_SpanRef(ring, span.value))
+        ptr, ref, self._span = ring._x.ring_reserve(ring, ring._h, seq_id, self.size, bool(nonblocking))
+        self.data = XArray.window(ptr, self.size, ring.space, ref)
         self._closed = False
 
     def commit(self, nbytes=None):
@@ -578,7 +570,7 @@ class _NWriteSpan(_SpanViews):
         self._closed = True
         n = self.size if nbytes is None else int(nbytes)
         if n > 0:
-            ffi.check("xengRingCommit", self.ring._enq.xengRingCommit(self.ring._h, self._seq_id, self._span, n))
+            self.ring._x.ring_commit(self.ring._h, self._seq_id, self._span, n)
 
     def close(self):
         self.commit()
@@ -601,11 +593,8 @@ class _NWriteSequence:
     def commit_external(self, data):
         ring = self.ring
         assert data.space == ring.space, (data.space, ring.space)
-        ring._external[data.ptr] = data          # (the ring hands out windows on the caller's memory: keep it alive with the ring)
-        rc = ring._enq.xengRingCommitExternal(ring._h, self._seq_id, data.ptr, data.nbytes, 0)
-        if rc == _WOULD_BLOCK:
-            rc = ring._lib.xengRingCommitExternal(ring._h, self._seq_id, data.ptr, data.nbytes, 1)
-        ffi.check("xengRingCommitExternal", rc)
+        ring._external[data.ptr] = data          # (the ring hands out windows on the caller's memory: kept alive with the ring)
+        ring._x.ring_commit_external(ring._h, self._seq_id, data.ptr, data.nbytes)
 
     def end(self):
         self.ring._enq.xengRingEndSequence(self.ring._h, self._seq_id)
@@ -627,7 +616,6 @@ class _NWriter:
         hdr = header.encode() if isinstance(header, str) else bytes(header)
         seq = ctypes.c_longlong()
         ffi.check("xengRingBeginSequence", ring._enq.xengRingBeginSequence(ring._h, int(time_tag), hdr, len(hdr), int(nringlet), ctypes.byref(seq)))
-        ring._open_seq_id = seq.value
         return _NWriteSequence(ring, seq.value)
 
     def __enter__(self):
@@ -646,24 +634,17 @@ class _NReadSequence:
     def read(self, gulp_nbytes):
         """Full gulps as they become available; a short final gulp once when the sequence ends (corr_block.py:389-391)."""
         ring, rid = self.ring, self._rid
-        h, enq, space = ring._h, ring._enq.xengRingAcquire, ring.space
+        h, acquire, space, window = ring._h, ring._x.ring_acquire, ring.space, XArray.window
         gulp_nbytes = int(gulp_nbytes)
-        ptr, n, span, skipped = ctypes.c_void_p(), ctypes.c_size_t(), ctypes.c_longlong(), ctypes.c_size_t()
-        refs = (ctypes.byref(ptr), ctypes.byref(n), ctypes.byref(span), ctypes.byref(skipped))
         advance = offset = 0
         while True:
-            rc = enq(h, rid, advance, gulp_nbytes, 0, *refs)           # asked first without giving up the interpreter lock
-            sk = skipped.value
-            if rc == _WOULD_BLOCK:
-                rc = ring._lib.xengRingAcquire(h, rid, 0, gulp_nbytes, 1, *refs)      # (the first call has moved the cursor already)
-                sk += skipped.value
-            if rc == _END:
+            got = acquire(ring, h, rid, advance, gulp_nbytes)       # (one native call per gulp: moves on, collects, waits)
+            if got is None:
                 return
-            if rc:
-                raise RuntimeError(ring._lib.xengGetLastError().decode())
-            size = n.value
-            offset += advance + sk
-            yield ReadSpan(XArray(shape=(size,), dtype=np.uint8, space=space, _ptr=ptr.value or 0, _base=_SpanRef(ring, span.value)), size, offset, sk)
+            ptr, size, ref, skipped = got
+            offset += advance + skipped
+            yield ReadSpan(window(ptr, size, space, ref), size, offset, skipped)
+            del ref, got
             advance = size
             if size < gulp_nbytes:
                 return
@@ -682,11 +663,10 @@ class NativeRing:
 
     def __init__(self, name="", space="system", core=None):
         self.name, self.space = name, space
-        self._lib, self._enq = ffi.lib(), ffi.enqueue_lib()
+        self._lib, self._enq, self._x = ffi.lib(), ffi.enqueue_lib(), _xfast()
         h = ctypes.c_void_p()
         ffi.call("xengRingCreate", ctypes.byref(h), name.encode(), _SPACE_ID[space])
         self._h = h.value
-        self._open_seq_id = -1
         self._external = {}
         self._hooks = None
 
@@ -728,6 +708,10 @@ class NativeRing:
         self._hooks = (ffi.STAMP_NOW_FN(now), ffi.STAMP_DONE_FN(done), ffi.STAMP_WAIT_FN(wait))       # (kept alive with the ring)
         ffi.call("xengRingSetStampHooks", self._h, self._hooks[0], self._hooks[1], self._hooks[2], None)
 
+    def set_recycle(self, on=True):
+        """System-space ring: recycle released span memory (no zero fill per span), as the device / pinned rings always do."""
+        ffi.call("xengRingSetRecycle", self._h, int(bool(on)))
+
     def resize(self, contig_bytes, total_span=None, nringlet=1):
         ffi.check("xengRingResize", self._enq.xengRingResize(self._h, int(contig_bytes), int(total_span) if total_span else 0))
 
@@ -747,21 +731,13 @@ class NativeRing:
         return self._read_sequences(rid.value)
 
     def _read_sequences(self, rid):
-        h = self._h
-        seq, tag, nr = ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_int()
-        hp, hl = ctypes.c_void_p(), ctypes.c_size_t()
-        refs = (ctypes.byref(seq), ctypes.byref(tag), ctypes.byref(nr), ctypes.byref(hp), ctypes.byref(hl))
+        nxt = self._x.ring_next_sequence
         try:
             while True:
-                rc = self._enq.xengRingNextSequence(h, rid, 0, *refs)
-                if rc == _WOULD_BLOCK:
-                    rc = self._lib.xengRingNextSequence(h, rid, 1, *refs)
-                if rc == _END:
+                got = nxt(self._h, rid)
+                if got is None:
                     return
-                if rc:
-                    raise RuntimeError(self._lib.xengGetLastError().decode())
-                header = _Header(ctypes.string_at(hp.value, hl.value) if hl.value else b"")
-                yield _NReadSequence(self, rid, header, tag.value, nr.value)
+                yield _NReadSequence(self, rid, _Header(got[0]), got[1], got[2])
         finally:
             if self._h:
                 self._enq.xengRingCloseReader(self._h, rid)

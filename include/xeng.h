@@ -111,6 +111,9 @@ typedef struct xengRing_ xengRing;
 int xengRingCreate(xengRing **ring, const char *name, int space);
 int xengRingDestroy(xengRing *ring);     /* wakes every waiter; spans still referenced stay valid until released */
 int xengRingResize(xengRing *ring, size_t contig_bytes, size_t total_span);        /* ring.resize(): capacity in bytes (0: 4 x contig) */
+/* system-space rings hand out fresh zero-filled memory per span by default; on != 0 recycles released spans as the device /
+ * pinned rings always do (contents: whatever the last user left, as in a circular bifrost ring) */
+int xengRingSetRecycle(xengRing *ring, int on);
 /* counters: allocations made, really freed, reissued from the free list, waits for a stamp at reissue, bytes skipped by readers */
 int xengRingGetInfo(xengRing *ring, size_t *capacity, size_t *live_bytes, size_t *pool_bytes, int *nreaders, long long *nseq,
                     unsigned long long counters[5]);
@@ -182,6 +185,11 @@ int xengXgpuKernelAsync(const void *in_dev, void *out_dev, int doDump);
  * caller alternates between two accumulators (and adds them at the end of the long integration).  Readers of acc_dev:
  * xengXgpuSync / xengXgpuSyncLag as for out_dev.  XENG_STATUS_UNSUPPORTED on the non-default contraction paths. */
 int xengXgpuKernelAsyncAcc(const void *in_dev, void *out_dev, int doDump, void *acc_dev, int acc_mode);
+/* The two enqueue-only calls above wait when the caller is 256 launches ahead of the GPU (every launch owns one of 256
+ * completion events).  This form never waits: XENG_STATUS_WOULD_BLOCK then, nothing enqueued; xengXgpuWaitLaunchSlot blocks
+ * until a launch may be enqueued again.  (A caller that holds an interpreter lock tries, and gives the lock up to wait.) */
+int xengXgpuTryKernelAsyncAcc(const void *in_dev, void *out_dev, int doDump, void *acc_dev, int acc_mode);
+int xengXgpuWaitLaunchSlot(void);
 int xengXgpuSync(void);
 /* Wait until all but the last `lag` (0..3) dumps are complete -- lag 1 lets a streaming caller enqueue
  * integration n+1 (into a different out_dev) before it waits for integration n, so the contraction of
@@ -281,6 +289,10 @@ int xengBeamformRun(const void *in_dev, void *out_dev, const void *weights_dev);
  * bf16 terms its MFMA kernel uses only when (weights_dev, weights_version) differs from the last call
  * (version 0 = always re-split, which is what xengBeamformRun / bfBeamformRun do). */
 int xengBeamformRunVersioned(const void *in_dev, void *out_dev, const void *weights_dev, long long weights_version);
+/* Run* is enqueue-only except in the integrated-power mode right after a weight upload, where it waits once for the routing
+ * answer of the new weights.  This form never waits: XENG_STATUS_WOULD_BLOCK then (the weights are prepared and remembered;
+ * call xengBeamformRunVersioned with the same arguments to wait and run). */
+int xengBeamformTryRunVersioned(const void *in_dev, void *out_dev, const void *weights_dev, long long weights_version);
 
 /* beamform_sum_beams_block.py:243-246.  in_dev cf32[nchan][nbeam][ntime];
  * out_dev f32[nbeam/2][ntime/ntime_sum][nchan][4] = [XX, YY, Re XY*, Im XY*]. */

@@ -22,11 +22,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import caltech_bifrost_dsp_amd  # noqa: E402,F401
 from caltech_bifrost_dsp_amd.blocks import Beamform, BeamformSumBeams, Corr, CorrAcc  # noqa: E402
 from caltech_bifrost_dsp_amd.ndarray import XArray  # noqa: E402
-from caltech_bifrost_dsp_amd.ring import Ring  # noqa: E402
+from caltech_bifrost_dsp_amd import ring as ringmod  # noqa: E402
 from fake_backend import OracleBackend  # noqa: E402  (test infrastructure: only its no-compute shell is used here)
 
 
-class Ring(Ring):
+class _PyRingNoFill(ringmod.PyRing):
     """System-space spans without the zero fill (the device rings recycle pooled allocations: no fill there either)."""
     _free = {}
 
@@ -34,7 +34,15 @@ class Ring(Ring):
         buf = self._free.get(nbytes)
         if buf is None:
             buf = self._free[nbytes] = np.empty(nbytes, dtype=np.uint8)
-        return XArray(shape=(nbytes,), dtype=np.uint8, space="system", _ptr=buf.ctypes.data, _base=buf)
+        return XArray(shape=(nbytes,), dtype=np.uint8, space=self.space, _ptr=buf.ctypes.data, _base=buf)
+
+
+def Ring(name, space="system"):
+    if ringmod.IMPLEMENTATION == "python":
+        return _PyRingNoFill(name, space=space)
+    r = ringmod.NativeRing(name, space=space)
+    r.set_recycle(True)
+    return r
 
 
 class NullBackend(OracleBackend):
@@ -55,7 +63,9 @@ def main():
     ap.add_argument("--profile", action="store_true")
     ap.add_argument("--which", default="corr,cacc,bf,sb")
     ap.add_argument("--switch", type=float, default=0.0, help="sys.setswitchinterval (0 = leave the default)")
+    ap.add_argument("--ring", default=ringmod.IMPLEMENTATION, help="native | python: which implementation of the ring protocol")
     a = ap.parse_args()
+    ringmod.IMPLEMENTATION = a.ring
     if a.switch:
         sys.setswitchinterval(a.switch)
     which = a.which.split(",")
@@ -69,6 +79,7 @@ def main():
     r_vis, r_slow = Ring("corr-output", space="system"), Ring("corr-slow-output", space="system")
     r_bf, r_pow = Ring("bf-output", space="system"), Ring("bf-pow-output", space="system")
     r_in.resize(gulp, total_span=2 * gps * gulp)
+    r_pow.space = "cuda_host"      # (a label only -- the memory stays host memory: BeamformSumBeams then takes its streaming path, the one the pipeline runs)
     blocks, sinks, stamps = [], [], []
 
     def drain(rg, g, on=None):
@@ -140,7 +151,7 @@ def main():
     for t in threads:
         t.join(60)
     el = time.perf_counter() - t0
-    print("%s: %d integrations in %.3f s = %.1f us of interpreter per integration (%d gulps each)" % (a.which, a.nint, el, el / a.nint * 1e6, gps))
+    print("ring %s, %s: %d integrations in %.3f s = %.1f us of interpreter per integration (%d gulps each)" % (a.ring, a.which, a.nint, el, el / a.nint * 1e6, gps))
     if cpu:
         print("    CPU time per integration (thread_time): " + ", ".join("%s %.0f us" % (k, v / a.nint * 1e6) for k, v in cpu.items()) +
               " | sum %.0f us" % (sum(cpu.values()) / a.nint * 1e6))

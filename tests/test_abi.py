@@ -54,15 +54,31 @@ def test_no_cpu_fallback_without_device():
     assert done.value == -1
 
 
-def test_enqueue_handle_binds_the_same_library():
-    """ffi.enqueue_lib(): the second handle (interpreter lock kept) names only enqueue-only calls and completion queries
-    -- nothing on it may wait for the GPU -- and they are the library's own symbols."""
+def test_calls_made_with_the_interpreter_lock_kept_cannot_wait():
+    """ffi.enqueue_lib() keeps the interpreter lock across the call, so nothing on it may wait for the GPU or for another
+    thread.  Round 3 held the list to names; three of those names could wait: xengXgpuKernelAsync[Acc] at 256
+    launches in flight, xengBeamformRun* once per weight upload in the integrated-power mode, xengSnap2UnpackAsync behind the
+    synchronous call's mutex.  Now the library has forms that return XENG_STATUS_WOULD_BLOCK instead of waiting, and only those
+    are bound with the lock kept (behaviour on the GPU: tests/test_enqueue_gpu.py).  Here, without a device: the waiting forms
+    are not on the handle, the non-waiting forms are the library's own symbols, and each returns its error at once."""
+    import time
     E = ffi.enqueue_lib()
-    waits = ("Sync", "Wait", "Correlate", "Memcpy", "Memset", "Malloc", "Free", "Initialize", "Destroy")
+    may_wait = ("xengXgpuKernelAsync", "xengXgpuKernelAsyncAcc", "xengXgpuKernel", "bfXgpuKernel", "xengBeamformRun", "xengBeamformRunVersioned",
+                "bfBeamformRun", "xengSnap2UnpackAsync", "xengSnap2Unpack", "xengXgpuWaitLaunchSlot", "xengBeamformWait", "xengStampWait",
+                "xengXgpuSync", "xengXgpuSyncLag", "xengBeamformSync", "xengMapSync", "xengMemcpy", "xengMemset", "xengMalloc", "xengFree")
+    for name in may_wait:
+        assert name in ffi.SYMBOLS and name not in ffi.ENQUEUE_ONLY, name
+    for name in ("xengXgpuTryKernelAsyncAcc", "xengBeamformTryRunVersioned", "xengXgpuDumpDone", "xengBeamformTicketDone", "xengStampDone"):
+        assert name in ffi.ENQUEUE_ONLY, name
     for name in ffi.ENQUEUE_ONLY:
-        assert name in ffi.SYMBOLS and not any(w in name for w in waits), name
         assert ctypes.cast(getattr(E, name), ctypes.c_void_p).value == ctypes.cast(getattr(ffi.lib(), name), ctypes.c_void_p).value
-    assert "xengXgpuKernel" not in ffi.ENQUEUE_ONLY and "bfXgpuKernel" not in ffi.ENQUEUE_ONLY     # the synchronous call waits
+    n = ctypes.c_int(-1)
+    if ffi.lib().xengGetDeviceCount(ctypes.byref(n)) == 0 and n.value > 0:
+        return
+    t0 = time.perf_counter()
+    assert E.xengXgpuTryKernelAsyncAcc(16, 16, 1, None, 0) != 0          # (not initialised: an error status, at once)
+    assert E.xengBeamformTryRunVersioned(16, 16, 16, 1) != 0
+    assert time.perf_counter() - t0 < 0.5
 
 
 def test_argument_validation_needs_no_gpu():

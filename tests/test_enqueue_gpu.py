@@ -1,0 +1,109 @@
+"""The calls the blocks make with the interpreter lock kept never wait (GPU; round-3 ADVICE, review item 6).
+
+`xengXgpuTryKernelAsyncAcc` returns XENG_STATUS_WOULD_BLOCK instead of waiting when the caller is 256 launches ahead of the
+GPU; `_xfast.xgpu_kernel_async` (what the Corr block calls) gives the lock up for that wait, so the other block threads keep
+running; the results are the ones of the waiting calls."""
+import ctypes
+import threading
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import xeng_oracle as orc  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from tests import gpu_util
+    assert gpu_util.ffi.device_count() >= 1
+    return gpu_util
+
+
+def test_try_enqueue_reports_would_block_instead_of_waiting(gpu):
+    ffi = gpu.ffi
+    nstand, nchan, ntime = 352, 96, 480            # one launch per call, 40 us of GPU work each: 300 calls outrun the GPU
+    x = gpu.Xgpu(nstand, nchan, ntime, max_gulps=1)
+    vin = gpu.synth_voltages(ntime, nchan, nstand, "full", seed=3)
+    din = ffi.DeviceBuffer(vin.size).upload(vin)
+    L = ffi.lib()
+    blocked, worst = 0, 0.0
+    for k in range(600):
+        t0 = time.perf_counter()
+        rc = L.xengXgpuTryKernelAsyncAcc(din.ptr, x.out.ptr, 1, None, 0)
+        worst = max(worst, time.perf_counter() - t0)
+        if rc == ffi.STATUS_WOULD_BLOCK:
+            blocked += 1
+            ffi.call("xengXgpuWaitLaunchSlot")
+            ffi.call("xengXgpuTryKernelAsyncAcc", din.ptr, x.out.ptr, 1, None, 0)
+        else:
+            assert rc == 0
+    ffi.call("xengXgpuSync")
+    assert blocked > 0, "600 enqueue-only launches never got 256 ahead of the GPU"
+    assert worst < 5e-3, "a Try call took %.1f ms: it waited" % (worst * 1e3)
+    assert np.array_equal(x.out.download(np.int32), orc.xgpu_correlate(vin, nstand, nchan))
+    din.free()
+    x.close()
+
+
+def test_a_caller_far_ahead_of_the_gpu_does_not_keep_the_interpreter_lock(gpu):
+    """While one Python thread enqueues 800 launches through _xfast (lock kept per call, given up to wait), another keeps
+    running: its longest stall stays far below the time the enqueuer spends waiting for the GPU."""
+    from caltech_bifrost_dsp_amd import _xfast
+    ffi = gpu.ffi
+    nstand, nchan, ntime = 352, 96, 480
+    x = gpu.Xgpu(nstand, nchan, ntime, max_gulps=1)
+    vin = gpu.synth_voltages(ntime, nchan, nstand, "full", seed=4)
+    din = ffi.DeviceBuffer(vin.size).upload(vin)
+    stop, gaps = threading.Event(), []
+
+    def ticker():
+        last = time.perf_counter()
+        while not stop.is_set():
+            time.sleep(0.0002)
+            now = time.perf_counter()
+            gaps.append(now - last)
+            last = now
+
+    th = threading.Thread(target=ticker, daemon=True)
+    th.start()
+    t0 = time.perf_counter()
+    for k in range(800):
+        assert _xfast.xgpu_kernel_async(din.ptr, x.out.ptr, 1) == 0
+    t_enq = time.perf_counter() - t0
+    ffi.call("xengXgpuSync")
+    stop.set()
+    th.join(5)
+    assert np.array_equal(x.out.download(np.int32), orc.xgpu_correlate(vin, nstand, nchan))
+    assert t_enq > 0.01                       # (the enqueuer did have to wait for the GPU: 800 launches > the 256 slots)
+    assert max(gaps) < 0.02, "the other thread stalled for %.1f ms" % (max(gaps) * 1e3)
+    din.free()
+    x.close()
+
+
+def test_try_run_in_integrated_power_mode_never_waits(gpu):
+    ffi = gpu.ffi
+    ninput, nchan, ntime, nbeam, ns = 704, 96, 480, 32, 24
+    rng = np.random.default_rng(2)
+    w = (rng.uniform(-17, 17, (nchan, nbeam, ninput)) + 1j * rng.uniform(-17, 17, (nchan, nbeam, ninput))).astype(np.complex64)
+    vin = rng.integers(0, 256, ntime * nchan * ninput, dtype=np.uint8)
+    ffi.call("xengBeamformInitialize", 0, ninput, nchan, ntime, nbeam, ntime // ns)
+    di, dw = ffi.DeviceBuffer(vin.size).upload(vin), ffi.DeviceBuffer(w.nbytes).upload(w)
+    do = ffi.DeviceBuffer((nbeam // 2) * (ntime // ns) * nchan * 16)
+    L = ffi.lib()
+    t0 = time.perf_counter()
+    rc = L.xengBeamformTryRunVersioned(di.ptr, do.ptr, dw.ptr, 7)      # a fresh weight upload: the routing answer is not back yet
+    dt = time.perf_counter() - t0
+    assert rc in (0, ffi.STATUS_WOULD_BLOCK) and dt < 5e-3
+    ffi.call("xengBeamformRunVersioned", di.ptr, do.ptr, dw.ptr, 7)    # the waiting form: runs
+    ffi.call("xengBeamformSync")
+    assert L.xengBeamformTryRunVersioned(di.ptr, do.ptr, dw.ptr, 7) == 0      # same weights again: nothing to wait for
+    ffi.call("xengBeamformSync")
+    got = do.download(np.float32).reshape(nbeam // 2, ntime // ns, nchan, 4)
+    exp = orc.beamform_integrate(orc.beamform(vin.reshape(ntime, nchan, ninput)[:, :2].copy(), w[:2].copy(), ntime, 2, ninput, nbeam), ns)
+    assert np.allclose(got[:, :, :2], exp, rtol=2e-5, atol=2e-5 * np.abs(exp).max())
+    ffi.call("xengBeamformDestroy")
+    for b in (di, dw, do):
+        b.free()
