@@ -79,22 +79,29 @@ def cpu_baseline(budget_s=12.0, verify=None):
            "reference_numpy_golden_loop": {"cmac_per_s": round(nsp * ncg * NINPUT * NINPUT / el_np, 1), "cores": 1,
                                            "sample": "%d spectra x %d chan, full-square outer products (%.1f s)" % (nsp, ncg, el_np)}}
     if verify is not None:
-        chk = {"visibilities_bit_exact": bool(np.array_equal(verify["vis"], first_int)),
-               "corracc_sum_bit_exact": bool(np.array_equal(verify["corracc"], 3 * first_int.astype(np.int64))),
-               "corracc_fused_in_dump_bit_exact": bool(np.array_equal(verify["corracc_fused"], 3 * first_int.astype(np.int64)))}
-        nt_b, nb = verify["beams"].shape[2], verify["beams"].shape[1]
-        v2 = np.concatenate([gulps[0], gulps[1]]).reshape(nt_b, NCHAN, NINPUT)
-        exp = orc.beamform(v2, verify["weights"].reshape(NCHAN, nb, NINPUT), nt_b, NCHAN, NINPUT, nb)
-        err = float(np.max(np.abs(verify["beams"].astype(np.complex128) - exp)) / np.sqrt(np.mean(np.abs(exp) ** 2)))
-        chk["beams_max_err_over_rms"] = err
-        chk["beams_within_1e-5"] = bool(err <= 1e-5)
-        pexp = orc.beamform_integrate(verify["beams"], verify["ntime_sum"])
-        chk["power_beams_max_err_over_max"] = float(np.max(np.abs(verify["power"] - pexp)) / np.abs(pexp).max())
-        chk["power_beams_ok"] = bool(chk["power_beams_max_err_over_max"] <= 1e-5)
-        chk["ok"] = bool(chk["visibilities_bit_exact"] and chk["corracc_sum_bit_exact"] and chk["corracc_fused_in_dump_bit_exact"] and
-                         chk["beams_within_1e-5"] and chk["power_beams_ok"])
-        out["config5_check"] = chk
+        out["config5_check"] = config5_check(verify, first_int, gulps)
     return out
+
+
+def config5_check(verify, first_int, gulps):
+    """What the config-5 pattern left on the GPU, held to the oracle: `first_int` = the oracle's integration of `gulps`
+    (replay-ring gulps 0..4 of this rank's generator); `verify` = arrays downloaded after three such integrations."""
+    from oracle import xeng_oracle as orc
+    chk = {"visibilities_bit_exact": bool(np.array_equal(verify["vis"], first_int)),
+           "corracc_sum_bit_exact": bool(verify.get("corracc") is None or np.array_equal(verify["corracc"], 3 * first_int.astype(np.int64))),
+           "corracc_fused_in_dump_bit_exact": bool(np.array_equal(verify["corracc_fused"], 3 * first_int.astype(np.int64)))}
+    nt_b, nb = verify["beams"].shape[2], verify["beams"].shape[1]
+    v2 = np.concatenate([gulps[0], gulps[1]]).reshape(nt_b, NCHAN, NINPUT)
+    exp = orc.beamform(v2, verify["weights"].reshape(NCHAN, nb, NINPUT), nt_b, NCHAN, NINPUT, nb)
+    err = float(np.max(np.abs(verify["beams"].astype(np.complex128) - exp)) / np.sqrt(np.mean(np.abs(exp) ** 2)))
+    chk["beams_max_err_over_rms"] = err
+    chk["beams_within_1e-5"] = bool(err <= 1e-5)
+    pexp = orc.beamform_integrate(verify["beams"], verify["ntime_sum"])
+    chk["power_beams_max_err_over_max"] = float(np.max(np.abs(verify["power"] - pexp)) / np.abs(pexp).max())
+    chk["power_beams_ok"] = bool(chk["power_beams_max_err_over_max"] <= 1e-5)
+    chk["ok"] = bool(chk["visibilities_bit_exact"] and chk["corracc_sum_bit_exact"] and chk["corracc_fused_in_dump_bit_exact"] and
+                     chk["beams_within_1e-5"] and chk["power_beams_ok"])
+    return chk
 
 
 def corr_block_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=100):
@@ -222,9 +229,146 @@ def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=4
                     "Python threads on in-repo rings, zero-copy replay source; wall rate between visibility spans at a sink" % long_len}
 
 
+def beam_weights(chan0, seed):
+    """Weights as the Beamform block builds them (beamform_block.py:343-350) from random delays in [0,12) ns, amplitudes in
+    [10,17) and calibration gains as beamformer_test.py:131-139, for the channels of one shard."""
+    NB = 32
+    rng = np.random.default_rng(seed)
+    freqs = 50e6 + (chan0 + np.arange(NCHAN)) * 23925.78125
+    wts = np.zeros((NCHAN, NB, NINPUT), np.complex64)
+    for b_ in range(NB):
+        delays_ns, amps = rng.uniform(0, 12, NINPUT), rng.uniform(10, 17, NINPUT)
+        cal = (rng.uniform(-1, 1, (NCHAN, NINPUT)) + 1j * rng.uniform(-1, 1, (NCHAN, NINPUT))).astype(np.complex64)
+        wts[:, b_, :] = amps * np.exp(1j * 2 * np.pi * freqs[:, None] * delays_ns * 1e-9) * cal
+    return np.ascontiguousarray(wts.reshape(-1))
+
+
+def config5_workload(args, ffi, dist, rank, world, gpu, ring, gulp_bytes, pin, info, sh):
+    """`--workload config5`: BASELINE config 5 as N ranks run it -- "Full X-engine: corner-turn + Corr + CorrAcc long-accum +
+    Beamform concurrent on HIP streams, 704 inputs, 768 chan across 8 GPUs" (lwa352-start-pipeline.sh:1-8: one pipeline
+    process per channel block).  Every rank runs, on its own GPU and its own 96 channels (chan0 = 96 * rank, input seed
+    0xdeadbeef + rank): per 2400-sample integration five gulps registered in place + one fused contraction whose epilogue
+    also feeds CorrAcc's long accumulators (X-engine streams), and 2.5 beamformer gulps of 960 samples + their power sums
+    (beam stream).  No collective: the process group carries the barriers and the max over ranks.  One step = one
+    integration of every rank; value = ingest of all ranks / max-over-ranks time.  Outside the timed region every rank
+    holds one dumped span, the accumulator sum, one beam gulp and its power sums to the oracle."""
+    L = ffi.lib()
+    gulps_per_step = ACC_LEN // NTIME_GULP
+    matlen = NCHAN * 249216
+    NT_B, NB, NS = 960, 32, 24
+    chan0 = NCHAN * rank
+    ffi.call("xengBeamformInitialize", gpu, NINPUT, NCHAN, NT_B, NB, 0)
+    wts = beam_weights(chan0, 0xaabbccdd + rank)
+    dw = ffi.DeviceBuffer(wts.nbytes).upload(wts)
+    dbeam = ffi.DeviceBuffer(NCHAN * NB * NT_B * 8)
+    dpow = ffi.DeviceBuffer((NB // 2) * (NT_B // NS) * NCHAN * 16)
+    outs3 = [ffi.DeviceBuffer(2 * matlen * 4) for _ in range(3)]
+    acc_pair = [ffi.DeviceBuffer(2 * matlen * 4) for _ in range(2)]
+    afn = L.xengXgpuKernelAsyncAcc
+    gi, bi = [0], [0]
+
+    def bstep(i):
+        src = ring.ptr + ((2 * i) % (args.ring_gulps - 1)) * gulp_bytes          # two consecutive 480-sample gulps = one 960-sample beam gulp
+        ffi.check("run", L.xengBeamformRunVersioned(src, dbeam.ptr, dw.ptr, 1))
+        ffi.check("int", L.xengBeamformIntegrate(dbeam.ptr, dpow.ptr, NS))
+
+    def step(n):
+        o = outs3[n % 3]
+        for g in range(gulps_per_step):
+            ffi.check("kernel", afn(ring.ptr + (gi[0] % args.ring_gulps) * gulp_bytes, o.ptr, int(g == gulps_per_step - 1),
+                                    acc_pair[n & 1].ptr, 1 if n < 2 else 2))
+            gi[0] += 1
+        for _ in range(2 + (n & 1)):
+            bstep(bi[0])
+            bi[0] += 1
+        ffi.call("xengXgpuSyncLag", 1)
+
+    def barrier():
+        ffi.call("xengDeviceSynchronize")
+        if dist is not None:
+            dist.barrier()
+
+    n = 0
+    for _ in range(min(args.prewarm, 300) + args.warmup):
+        step(n)
+        n += 1
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(n)
+        n += 1
+    ffi.call("xengDeviceSynchronize")
+    el = time.perf_counter() - t0
+    # ---- outside the timed region: the same pattern on known inputs, held to the oracle on every rank
+    ok = None
+    if not args.no_cpu_baseline:
+        from oracle import xeng_oracle as orc
+        orc.build()
+        rs5 = np.random.RandomState(0xdeadbeef + rank)
+        gulps = [rs5.randint(0, 255, size=gulp_bytes, dtype=np.uint8) for _ in range(gulps_per_step)]
+        for g in range(gulps_per_step):
+            ring.upload(gulps[g], offset=g * gulp_bytes)
+        ffi.call("xengXgpuSync")
+        for k in range(3):
+            for g in range(gulps_per_step):
+                ffi.check("kernel", afn(ring.ptr + g * gulp_bytes, outs3[k].ptr, int(g == gulps_per_step - 1), acc_pair[k & 1].ptr, 1 if k < 2 else 2))
+            ffi.check("run", L.xengBeamformRunVersioned(ring.ptr, dbeam.ptr, dw.ptr, 1))
+            ffi.check("int", L.xengBeamformIntegrate(dbeam.ptr, dpow.ptr, NS))
+            ffi.call("xengXgpuSyncLag", 1)
+        ffi.call("xengXgpuSync")
+        ffi.call("xengBeamformSync")
+        verify = {"vis": outs3[2].download(np.int32), "corracc": None,
+                  "corracc_fused": acc_pair[0].download(np.int32).astype(np.int64) + acc_pair[1].download(np.int32).astype(np.int64),
+                  "beams": dbeam.download(np.complex64).reshape(NCHAN, NB, NT_B), "weights": wts, "ntime_sum": NS,
+                  "power": dpow.download(np.float32).reshape(NB // 2, NT_B // NS, NCHAN, 4)}
+        g4 = [g.reshape(NTIME_GULP, NCHAN, NSTAND, NPOL) for g in gulps]
+        acc = None
+        for g in g4:
+            acc = orc.xgpu_correlate(g, NSTAND, NCHAN, acc)
+        ok = config5_check(verify, acc, g4)
+    per_rank_ms = [round(v / args.steps * 1e3, 4) for v in sh.gather_over_ranks(dist, el)]
+    oks = [ok]
+    if dist is not None:
+        import torch
+        oks = [None] * world
+        dist.all_gather_object(oks, ok)
+        t = torch.tensor([el], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+        dist.barrier()
+    ffi.call("xengBeamformDestroy")
+    units = ACC_LEN * NCHAN * args.steps * world
+    gbps = 8 * NINPUT * units / el / 1e9
+    return {
+        "metric": "xengine_ingest_gbps_704in_96ch", "value": round(gbps, 2), "unit": "Gb/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "int8 (4+4-bit samples) -> int32; beams fp32", "data": "synthetic",
+        "config": {"workload": "config 5, full X-engine per GPU: Corr (5 x 480-sample gulps, fused corner turn) + CorrAcc fused into the dumps "
+                               "+ Beamform (32 beams, 960-sample gulps) + power beams, concurrent on HIP streams; 704 inputs, %d chan/GPU" % NCHAN,
+                   "nchan_total": NCHAN * world, "chan0_per_rank": [NCHAN * r for r in range(world)],
+                   "sharding": "channels, %d per GPU, no collective" % NCHAN,
+                   "input": "device-resident replay ring, %d gulps, seed 0xdeadbeef + rank" % args.ring_gulps},
+        "per_rank_ms": per_rank_ms, "per_rank_ms_min": min(per_rank_ms), "per_rank_ms_max": max(per_rank_ms),
+        "cmac_per_s": CMAC_PER_UNIT * units / el,
+        "mfma_peak_frac_end_to_end": round(8 * CMAC_PER_UNIT * units / el / (PEAK_INT8_OPS * world), 4),
+        "design_rate_x": round(gbps / world / 12.94, 1),
+        "roofline": {"kernel": "xcorr_fused_kernel", "bound": "mfma", "unit": "TFLOP/s",
+                     "achieved": round(OPS_PER_UNIT * ACC_LEN * NCHAN / (el / args.steps) / 1e12, 1), "peak": round(PEAK_INT8_OPS / 1e12, 1),
+                     "frac": round(OPS_PER_UNIT * ACC_LEN * NCHAN / (el / args.steps) / PEAK_INT8_OPS, 4), "traffic": None,
+                     "note": "the contraction's algorithmic int8 ops per integration / time per integration of the slowest rank, while the "
+                             "beamformer, the power sums and the fused CorrAcc share the GPU (config 5: not the contraction alone)"},
+        "verified": {"ok": all(bool(o and o["ok"]) for o in oks) if oks[0] is not None else None, "per_rank": oks},
+        "rank_placement": {"numa_node": pin["numa_node"], "ncpus": len(pin["cpus"]), "source": pin["source"]},
+        "device": info,
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--workload", default="correlator", choices=["correlator", "config5"],
+                    help="correlator: BASELINE config 2 / 3 (the headline: one contraction per step); config5: the full X-engine per "
+                         "GPU (Corr + fused CorrAcc + Beamform + power beams concurrently), sharded like config 3")
     # steady state of the streaming pipeline is reached after a few hundred integrations (clock / power ramp of a
     # cold GPU, launch overlap pattern): see --prewarm.  The defaults time 2000 integrations (0.43 s)
     ap.add_argument("--steps", type=int, default=2000)
@@ -314,7 +458,8 @@ def main():
                               "per_rank_ms": per_rank, "per_rank_ms_min": min(per_rank), "per_rank_ms_max": max(per_rank),
                               "rank_cpus": masks, "placement": pin["source"],
                               "vs_baseline": None, "data": "selftest (no GPU work; not a result)",
-                              "config": {"workload": "selftest", "nchan_total": NCHAN * world}}))
+                              "config": {"workload": "selftest:%s" % args.workload, "nchan_total": NCHAN * world,
+                                         "chan0_per_rank": [NCHAN * r for r in range(world)]}}))
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -348,6 +493,14 @@ def main():
         else:
             blk = np.full(gulp_bytes, 0 if args.data == "zeros" else 0x88, dtype=np.uint8)
         ring.upload(blk, offset=g * gulp_bytes)
+    if args.workload == "config5":
+        res = config5_workload(args, ffi, dist, rank, world, gpu, ring, gulp_bytes, pin, info, _sh)
+        if rank == 0:
+            print(json.dumps(res))
+        ffi.call("xengXgpuDestroy")
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     nout = args.lag + 1
     outs = [ffi.DeviceBuffer(2 * matlen * 4) for _ in range(max(2, nout))]     # output spans rotate, as ring spans do
     kern = "xengXgpuKernel" if args.sync_per_call else "xengXgpuKernelAsync"
@@ -574,14 +727,7 @@ def main():
         ffi.call("xengBeamformInitialize", gpu, NINPUT, NCHAN, NT_B, NB, 0)
         # weights as the Beamform block builds them (beamform_block.py:343-350) from random delays in [0,12) ns, amplitudes in
         # [10,17) and calibration gains as beamformer_test.py:131-139
-        rng = np.random.default_rng(0xaabbccdd)
-        freqs = 50e6 + np.arange(NCHAN) * 23925.78125
-        wts = np.zeros((NCHAN, NB, NINPUT), np.complex64)
-        for b_ in range(NB):
-            delays_ns, amps = rng.uniform(0, 12, NINPUT), rng.uniform(10, 17, NINPUT)
-            cal = (rng.uniform(-1, 1, (NCHAN, NINPUT)) + 1j * rng.uniform(-1, 1, (NCHAN, NINPUT))).astype(np.complex64)
-            wts[:, b_, :] = amps * np.exp(1j * 2 * np.pi * freqs[:, None] * delays_ns * 1e-9) * cal
-        wts = np.ascontiguousarray(wts.reshape(-1))
+        wts = beam_weights(0, 0xaabbccdd)
         dw = ffi.DeviceBuffer(wts.nbytes).upload(wts)
         dbeam = ffi.DeviceBuffer(NCHAN * NB * NT_B * 8)
         dpow = ffi.DeviceBuffer((NB // 2) * (NT_B // NS) * NCHAN * 16)
