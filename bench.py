@@ -224,6 +224,9 @@ def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=4
     return {"value": round(8 * NINPUT * ACC_LEN * NCHAN * (n - 1 - nwarm) / el / 1e9, 1) if ok else 0.0, "unit": "Gb/s",
             "ms_per_integration": round(el / max(n - 1 - nwarm, 1) * 1e3, 4) if ok else None, "integrations": n,
             "long_integrations_published": nslow[0], "corracc_fused_into_dumps": bool(cacc.stats.get('fused')) and cacc.fused_dumps == n,
+            # span allocations per ring over the whole leg: made, really freed, reissued from the free list, waits for a stamp at reissue
+            "ring_allocations": {r.name: {k: int(v) for k, v in dict(r.counters).items() if k in ("alloc", "free", "reuse", "stamp_wait")}
+                                 for r in (r_vis, r_slow, r_bf, r_pow)},
             "note": "config 5 through the blocks on one GPU: Corr -> CorrAcc (%d dumps per long integration, accumulated by the "
                     "dumps' epilogue; published to a pinned-host ring) and Beamform (480-sample gulps) -> BeamformSumBeams, four "
                     "Python threads on in-repo rings, zero-copy replay source; wall rate between visibility spans at a sink" % long_len}

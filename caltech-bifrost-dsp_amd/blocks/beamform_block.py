@@ -19,7 +19,7 @@ import numpy as np
 from ..backend import default_backend
 from ..ndarray import XArray
 from ..proclog import cpu_affinity
-from .block_base import Block, COMMAND_INVALID, COMMAND_OK
+from .block_base import Block, COMMAND_INVALID, COMMAND_OK, declare_streams
 
 
 class Beamform(Block):
@@ -32,6 +32,8 @@ class Beamform(Block):
         self.ntime_gulp = ntime_gulp
         self.gpu = gpu
         self.ntime_sum = ntime_sum
+        declare_streams(iring, 'beam')          # (both rings' spans are touched by the beamformer's stream only)
+        declare_streams(oring, 'beam')
         if ntime_sum is not None:
             assert ntime_gulp % ntime_sum == 0
             self.ntime_blocks = ntime_gulp // ntime_sum

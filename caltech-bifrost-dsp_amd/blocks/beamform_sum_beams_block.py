@@ -15,7 +15,7 @@ import numpy as np
 from ..backend import default_backend
 from ..ndarray import XArray
 from ..proclog import cpu_affinity
-from .block_base import Block
+from .block_base import Block, declare_streams
 
 
 class BeamformSumBeams(Block):
@@ -29,6 +29,8 @@ class BeamformSumBeams(Block):
         self.ntime_gulp = ntime_gulp
         self.gpu = gpu
         self.ntime_sum = ntime_sum
+        declare_streams(iring, 'beam')
+        declare_streams(oring, 'beam', 'copy')  # (the kernel writes the span itself, or a copy does on the non-streaming path)
         assert ntime_gulp % ntime_sum == 0
         self.ntime_blocks = ntime_gulp // ntime_sum
         self.nchan = nchan

@@ -27,6 +27,14 @@ class _WatchResponse:
         self.events = [_Event(c) for c in cmds]
 
 
+def declare_streams(ring, *classes):
+    """Tell an in-repo ring which of the library's streams touch its spans (ring.py declare_streams; a bifrost ring has no
+    such method: nothing to do)."""
+    f = getattr(ring, 'declare_streams', None)
+    if f is not None:
+        f(*classes)
+
+
 class Block(object):
     pipeline_id = 0
     _instance_count = -1

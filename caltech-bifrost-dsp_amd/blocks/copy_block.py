@@ -18,6 +18,9 @@ class Copy(Block):
                  guarantee=True, core=-1, nbyte_per_time=184 * 352 * 2, gpu=-1,
                  buf_size_gbytes=None, backend=None):
         super(Copy, self).__init__(log, iring, oring, guarantee, core, etcd_client=None)
+        from .block_base import declare_streams
+        declare_streams(iring, 'copy')
+        declare_streams(oring, 'copy')
         cpu_affinity.set_core(self.core)
         self.ntime_gulp = ntime_gulp
         self.gpu = gpu

@@ -34,7 +34,7 @@ from ..backend import default_backend
 from ..ndarray import XArray, copy_array
 from ..proclog import cpu_affinity
 from ..ring import WriteSpan
-from .block_base import Block
+from .block_base import Block, declare_streams
 from .integration import IntegrationGate
 
 
@@ -59,6 +59,8 @@ class CorrAcc(Block):
         super(CorrAcc, self).__init__(log, iring, oring, guarantee, core, etcd_client=etcd_client)
         self._bf = backend if backend is not None else default_backend()
         self.nchan, self.npol, self.nstand = nchan, npol, nstand
+        declare_streams(iring, 'map')           # (the map kernels read the input spans; the publish is a copy into the output span)
+        declare_streams(oring, 'copy')
         self.matlen = nchan * (nstand // 2 + 1) * (nstand // 4) * npol * npol * 4
         self.gpu = gpu
         if self.gpu != -1:

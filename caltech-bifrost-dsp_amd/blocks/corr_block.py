@@ -20,7 +20,7 @@ from ..backend import default_backend
 from ..ndarray import XArray
 from ..proclog import cpu_affinity
 from ..ring import WriteSpan
-from .block_base import Block
+from .block_base import Block, declare_streams
 from .integration import IntegrationGate
 
 
@@ -48,6 +48,8 @@ class Corr(Block):
         self._bf = backend if backend is not None else default_backend()
         self.ntime_gulp = ntime_gulp
         self.nchan, self.npol, self.nstand = nchan, npol, nstand
+        declare_streams(iring, 'xgpu')          # (spans of these rings are read / written by the X-engine's streams)
+        declare_streams(oring, 'xgpu')
         self.matlen = nchan * (nstand // 2 + 1) * (nstand // 4) * npol * npol * 4
         self.gpu = gpu
         self.test = test

@@ -44,6 +44,8 @@ class CorrOutputFull(Block):
                  checkfile=None, checkfile_acc_len=1, antpol_to_bl=None, bl_is_conj=None, use_cor_fmt=True,
                  nchan_sum=1, pipeline_idx=1, npipeline=1, gpu=-1, backend=None, sink=None):
         super(CorrOutputFull, self).__init__(log, iring, None, guarantee, core, etcd_client=etcd_client)
+        from .block_base import declare_streams
+        declare_streams(iring, 'consumer', 'copy')
         self._bf = backend if backend is not None else default_backend()
         self.nchan_sum = nchan_sum
         self.pipeline_idx = pipeline_idx

@@ -25,6 +25,9 @@ class CorrSubsel(Block):
                  nchan=192, npol=2, nstand=352, nchan_sum=4, gpu=-1,
                  antpol_to_bl=None, bl_is_conj=None, backend=None, nvis_out=None):
         super(CorrSubsel, self).__init__(log, iring, oring, guarantee, core, etcd_client=etcd_client)
+        from .block_base import declare_streams
+        declare_streams(iring, 'consumer')      # (the gather kernel runs on the span consumers' stream)
+        declare_streams(oring, 'consumer', 'copy')
         self._bf = backend if backend is not None else default_backend()
         if nvis_out is not None:
             self.nvis_out = nvis_out            # (the reference fixes 4704; smaller values ease testing)

@@ -32,6 +32,9 @@ class Snap2Ingest(Block):
                  fs_hz=196000000, chan_bw_hz=23925.78125, system_nchan=184 * 16,
                  guarantee=True, core=-1, gpu=-1, buffer_multiplier=4, backend=None):
         super(Snap2Ingest, self).__init__(log, iring, oring, guarantee, core, etcd_client=None)
+        from .block_base import declare_streams
+        declare_streams(iring, 'copy', 'xgpu')  # (the scatter runs on the copy stream, or enqueue-only on the X-engine's staging stream)
+        declare_streams(oring, 'copy', 'xgpu')
         self._bf = backend if backend is not None else default_backend()
         self.ntime_gulp, self.nchan, self.nstand, self.npol = ntime_gulp, nchan, nstand, npol
         self.fs_hz, self.chan_bw_hz, self.system_nchan = fs_hz, chan_bw_hz, system_nchan

@@ -53,6 +53,7 @@ static int beam_destroy_locked() {
     if (!g_b.live) return XENG_STATUS_SUCCESS;
     (void)hipSetDevice(g_b.gpu);
     if (g_b.stream) (void)hipStreamSynchronize(g_b.stream);
+    stream_clocks_forget(g_b.gpu, STREAM_BEAM);          // (everything on the stream has completed; the mark events go away below)
     if (g_b.scratch) (void)hipFree(g_b.scratch);
     if (g_b.wprep) (void)hipFree(g_b.wprep);
     if (g_b.wq) (void)hipFree(g_b.wq);
@@ -324,7 +325,9 @@ int xengBeamformMark(unsigned long long* ticket) {
     XENG_HIP(hipSetDevice(x.gpu));
     hipEvent_t& ev = x.marks[x.nmarks % BeamContext::NMARK];
     if (!ev) XENG_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    const unsigned long long upto = stream_clock_now(STREAM_BEAM);      // (read BEFORE the record: everything counted precedes it)
     XENG_HIP(hipEventRecord(ev, x.stream));
+    stream_clock_external_mark(STREAM_BEAM, ev, upto);                  // stamps of released spans find this event: none of their own on this stream
     *ticket = ++x.nmarks;
     return XENG_STATUS_SUCCESS;
 }

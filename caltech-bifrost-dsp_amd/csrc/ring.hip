@@ -89,6 +89,8 @@ struct RingCore {
     xengRingStampWaitFn hook_wait = nullptr;
     void* hook_user = nullptr;
     bool recycle_system = false;     // system space: recycle span memory like the device spaces do (default: fresh zeroed memory per span)
+    unsigned stream_mask = 0;        // stream classes the ring's blocks have declared (0: none declared -> a stamp waits for all)
+    std::atomic<size_t> owned_bytes{0};      // span allocations the ring owns, in the free list or out
     // statistics
     std::atomic<unsigned long long> n_alloc{0}, n_free{0}, n_reuse{0}, n_stamp_wait{0}, n_skipped{0};
 };
@@ -124,7 +126,10 @@ static void raw_free(int space, void* p) {
 static void buf_stamp(Buf* b) {
     RingCore* r = b->ring;
     if (r->hook_now) r->hook_now(r->hook_user, b->hook_stamp);
-    else if (b->space != XENG_SPACE_SYSTEM) (void)stamp_now(&b->stamp);
+    else if (b->space != XENG_SPACE_SYSTEM) {
+        (void)stamp_now(&b->stamp);
+        if (r->stream_mask) b->stamp.mask = r->stream_mask;
+    }
 }
 
 // done / waitable of a released allocation's stamp; never blocks
@@ -160,6 +165,7 @@ static void buf_destroy(Buf* b, bool may_wait) {
             r->n_free++;
         }
         // (not done and not waitable: the allocation is leaked rather than freed under a kernel that may still use it)
+        r->owned_bytes -= b->nbytes;
     }
     delete b;
     ring_unref(r);
@@ -169,12 +175,12 @@ static void buf_release(Buf* b) {
     if (b->refs.fetch_sub(1) != 1) return;
     RingCore* r = b->ring;
     if (!b->owned) { delete b; ring_unref(r); return; }
-    if (!pooled_space(r)) { raw_free(b->space, b->ptr); r->n_free++; delete b; ring_unref(r); return; }
+    if (!pooled_space(r)) { raw_free(b->space, b->ptr); r->n_free++; r->owned_bytes -= b->nbytes; delete b; ring_unref(r); return; }
     buf_stamp(b);
     {
         std::lock_guard<std::mutex> lk(r->pool_mu);
         if (!r->destroyed) {
-            const size_t limit = std::max(r->capacity, 2 * b->nbytes);
+            const size_t limit = 2 * std::max(r->capacity, 2 * b->nbytes);
             if (r->pool_bytes + b->nbytes > limit) {
                 r->graveyard.push_back(b);      // freed by a later call that may block (hipFree synchronises the device)
             } else {
@@ -216,7 +222,10 @@ static int buf_obtain(RingCore* r, size_t nbytes, int may_block, Buf** out) {
         if (cand) {
             bool done, waitable;
             buf_poll(cand, &done, &waitable);
-            if (!done && waitable && may_block) done = buf_wait(cand) == XENG_STATUS_SUCCESS;     // (kernels of other blocks, enqueued before the release)
+            // still busy: a fresh allocation while the ring owns little (a deeper free list costs memory once; a wait costs
+            // every gulp), else wait for it (kernels of other blocks, enqueued before the release)
+            const bool grow = !done && r->owned_bytes.load() + nbytes <= 4 * std::max(r->capacity, 2 * nbytes) && !r->hook_now;
+            if (!done && waitable && may_block && !grow) done = buf_wait(cand) == XENG_STATUS_SUCCESS;
             if (done) {
                 *out = cand;
             } else {
@@ -224,7 +233,7 @@ static int buf_obtain(RingCore* r, size_t nbytes, int may_block, Buf** out) {
                 if (waitable) r->pool[nbytes].push_front(cand);       // still the next one to be reissued
                 else r->pool[nbytes].push_back(cand);                 // waits for a launch nobody has enqueued: try the others first
                 r->pool_bytes += nbytes;
-                if (waitable && !may_block) return XENG_STATUS_WOULD_BLOCK;
+                if (waitable && !may_block && !grow) return XENG_STATUS_WOULD_BLOCK;
             }
         }
         if (*out) {
@@ -241,6 +250,7 @@ static int buf_obtain(RingCore* r, size_t nbytes, int may_block, Buf** out) {
     b->ptr = p; b->nbytes = nbytes; b->space = r->space; b->ring = r;
     r->refs.fetch_add(1);
     r->n_alloc++;
+    r->owned_bytes += nbytes;
     *out = b;
     return XENG_STATUS_SUCCESS;
 }
@@ -381,6 +391,13 @@ int xengRingSetStampHooks(xengRing* ring, xengRingStampNowFn now, xengRingStampD
     RING_ARG(ring);
     std::lock_guard<std::mutex> lk(r->pool_mu);
     r->hook_now = now; r->hook_done = done; r->hook_wait = wait; r->hook_user = user;
+    return XENG_STATUS_SUCCESS;
+}
+
+int xengRingDeclareStreams(xengRing* ring, unsigned classes) {
+    RING_ARG(ring);
+    std::lock_guard<std::mutex> lk(r->pool_mu);
+    r->stream_mask |= classes & STAMP_ALL;
     return XENG_STATUS_SUCCESS;
 }
 

@@ -90,6 +90,7 @@ static XgpuContext g_ctx;
 // Bumped whenever registered-but-uncontracted gulps are dropped (Reset, Destroy / re-Initialize): a stamp that waits for the
 // launch that would have read them (xeng_common.h, Stamp::xgpu_seq) is void afterwards.
 static unsigned long long g_epoch = 1;
+static unsigned long long g_ctx_gen = 1;         // bumped when the context is destroyed (its streams have been waited for)
 
 // frees whatever the context holds -- also the partial state of an Initialize that failed half way (x.live false)
 static int destroy_locked() {
@@ -113,6 +114,7 @@ static int destroy_locked() {
     x.timer.destroy();
     x = XgpuContext();
     g_epoch++;
+    g_ctx_gen++;
     return XENG_STATUS_SUCCESS;
 }
 
@@ -139,6 +141,9 @@ static void launch_xcorr(const XcorrParams& p, hipStream_t s, bool raw, int grid
             case 17: hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<17>), grid, dim3(256), 0, s, p); return;
             case 31: hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<31>), grid, dim3(256), 0, s, p); return;
             case 64: hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<64>), grid, dim3(256), 0, s, p); return;
+            case 128: hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<128>), grid, dim3(256), 0, s, p); return;   // diagonal cells at 3/4 of their MFMAs
+            case 256: hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<256>), grid, dim3(256), 0, s, p); return;   // offset-binary operands
+            case 384: hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<384>), grid, dim3(256), 0, s, p); return;
             default: break;
         }
 #endif
@@ -261,7 +266,6 @@ static int flush_locked(void* out, bool dump, void* acc = nullptr, int acc_mode 
     x.timer.end(smm, slot);
     XENG_HIP(hipGetLastError());
     XENG_HIP(hipEventRecord(x.ev_ring[seq % XgpuContext::NEV], smm));
-    stream_tick(mm_stream_id(si));
     x.area_seq[x.cur] = seq;
     x.last_seq[si] = seq;
     if (dump) {
@@ -371,11 +375,36 @@ static int kernel_locked(const void* in_dev, void* out_dev, int doDump, bool syn
 
 // ---- the X-engine's part of a stamp (xeng_common.h): gulps handed over with xengXgpuKernelAsync are read by a launch that
 // does not exist yet; whoever stamps a buffer meanwhile must also wait for that launch
-void xgpu_pending_launch(unsigned long long* seq, unsigned long long* epoch) {
+void xgpu_pending_launch(unsigned long long* seq, unsigned long long* epoch, unsigned long long* nlaunch, unsigned long long* ctx) {
     std::lock_guard<std::mutex> lk(g_mu);
     XgpuContext& x = g_ctx;
     *seq = (x.live && x.nfilled > 0) ? x.nlaunch + 1 : 0;
     *epoch = g_epoch;
+    *nlaunch = x.live ? x.nlaunch : 0;
+    *ctx = g_ctx_gen;
+}
+
+// have all contractions up to launch number `upto` of context generation `ctx` completed?  Every launch owns a completion
+// event (ev_ring) and the streams take the launches in rotation, so the last nmm launches cover every stream: nothing is recorded.
+int xgpu_launches_poll(unsigned long long upto, unsigned long long ctx, bool* done, hipEvent_t* ev) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    XgpuContext& x = g_ctx;
+    *done = true;
+    if (ev) *ev = nullptr;
+    if (upto == 0 || !x.live || ctx != g_ctx_gen) return XENG_STATUS_SUCCESS;      // (a destroyed context has waited for its streams)
+    for (int k = 0; k < x.nmm && (unsigned long long)k < upto; k++) {
+        if (hipEvent_t e = launch_event(upto - k)) {
+            const hipError_t q = hipEventQuery(e);
+            if (q == hipErrorNotReady) {
+                (void)hipGetLastError();
+                *done = false;
+                if (ev && !*ev) *ev = e;
+            } else if (q != hipSuccess) {
+                XENG_HIP(q);
+            }
+        }
+    }
+    return XENG_STATUS_SUCCESS;
 }
 
 int xgpu_pending_poll(unsigned long long seq, unsigned long long epoch, bool* done, bool* launched, hipEvent_t* ev, int* gpu) {

@@ -222,6 +222,23 @@ __device__ __forceinline__ Frags unpack_frags(const RawFrags& r) {
     return u;
 }
 
+// A/B (diagnostic builds, ABL & 256; results are wrong): operands as an offset-binary decode would supply them -- x ^ 0x88 read as
+// unsigned nibbles 0..15, same two VALU ops per operand dword -- to measure what smaller, sign-free operands are worth at the
+// power cap before anybody builds the row-sum corrections they would need (round-3 review, item 3)
+__device__ __forceinline__ Frags unpack_frags_offset_binary(const RawFrags& r) {
+    const v4i M = (v4i)(0x0F0F0F0F), X = (v4i)(0x88888888u);
+    Frags u;
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+        const v4i a = r.a[m] ^ X, b = r.b[m] ^ X;     // (one more VALU op than the real thing would need: the XOR could be folded into the ingest)
+        u.ar[m] = (a >> 4) & M;
+        u.ai[m] = a & M;
+        u.br[m] = (b >> 4) & M;
+        u.bi[m] = b & M;
+    }
+    return u;
+}
+
 constexpr int XC_KT = 3;      // K-tiles (32 samples each) per LDS stage
 constexpr int XC_RING = 4;    // LDS ring depth (stages), two-pass kernel
 #ifndef XF_NO_RELAX
@@ -553,9 +570,12 @@ __global__ __launch_bounds__(256, 1) void xcorr_mfma_kernel(XcorrParams p) {
 // the 16 (12 when cell 1 is dead) int8 MFMAs of one K-tile: for every cell R += xr*yr + xi*yi, P += xi*yr, Q += xr*yi.
 // Operands: u.a = fragments 0, 1; u.b = fragments 2, 3 of the wave (FragGroup).  Unpacked fragments are the same thing
 // whether they enter as A or B operand, so the Z wiring multiplies a diagonal fragment with itself.
+// skipdiag (diagnostic builds, ABL & 128; results are wrong): the two diagonal cells of a Z wave sit this K-tile out.  Done on every
+// fourth K-tile it takes away a quarter of their MFMA work -- what 16x16x64 MFMAs on the three needed sub-cells would save --
+// without building that data path: an upper bound of the lever (round-3 review, item 3).
 template <bool Z>
 __device__ __forceinline__ void xcorr_mfma_cells(const Frags& u, bool skip1, v16i (&accR)[2][2], v16i (&accP)[2][2],
-                                                 v16i (&accQ)[2][2]) {
+                                                 v16i (&accQ)[2][2], bool skipdiag = false) {
     auto cell = [&](int m, int n, const v4i& xr, const v4i& xi, const v4i& yr, const v4i& yi) {
         accR[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xr, yr, accR[m][n], 0, 0, 0);
         accP[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xi, yr, accP[m][n], 0, 0, 0);
@@ -563,10 +583,10 @@ __device__ __forceinline__ void xcorr_mfma_cells(const Frags& u, bool skip1, v16
         accR[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xi, yi, accR[m][n], 0, 0, 0);
     };
     if (Z) {
-        cell(0, 0, u.ar[0], u.ai[0], u.ar[0], u.ai[0]);                 // (d0, d0)
+        if (!skipdiag) cell(0, 0, u.ar[0], u.ai[0], u.ar[0], u.ai[0]);  // (d0, d0)
         if (!skip1) cell(0, 1, u.br[0], u.bi[0], u.br[1], u.bi[1]);     // the free cell (r, c)
         cell(1, 0, u.ar[1], u.ai[1], u.ar[0], u.ai[0]);                 // (d1, d0)
-        cell(1, 1, u.ar[1], u.ai[1], u.ar[1], u.ai[1]);                 // (d1, d1)
+        if (!skipdiag) cell(1, 1, u.ar[1], u.ai[1], u.ar[1], u.ai[1]);  // (d1, d1)
     } else {
         cell(0, 0, u.ar[0], u.ai[0], u.br[0], u.bi[0]);
         if (!skip1) cell(0, 1, u.ar[0], u.ai[0], u.br[1], u.bi[1]);
@@ -887,8 +907,10 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
                         issue_piece(rf, 2 * j);
                         issue_piece(rf, 2 * j + 1);
                     }
-                    xcorr_mfma_cells<Z>(cur, skip1, accR, accP, accQ);
-                    if (ABL & 2) {
+                    xcorr_mfma_cells<Z>(cur, skip1, accR, accP, accQ, (ABL & 128) && Z && ((s * KT_STAGE + j) & 3) == 3);
+                    if (ABL & 256) {
+                        cur = unpack_frags_offset_binary(raw);
+                    } else if (ABL & 2) {
 #pragma unroll
                         for (int m = 0; m < 2; m++) { cur.ar[m] = raw.a[m]; cur.ai[m] = raw.a[m]; cur.br[m] = raw.b[m]; cur.bi[m] = raw.b[m]; }
                     } else {

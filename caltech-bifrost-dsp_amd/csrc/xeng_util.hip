@@ -60,7 +60,7 @@ struct StreamClock {
     std::mutex mu;
     unsigned long long done = 0;                // everything up to this tick is known to have completed
     static constexpr int NMARK = 8;
-    struct Mark { unsigned long long upto = 0; hipEvent_t ev = nullptr; bool pending = false; } marks[NMARK];
+    struct Mark { unsigned long long upto = 0; hipEvent_t ev = nullptr; bool pending = false; hipEvent_t own = nullptr; } marks[NMARK];   // own: the slot's own event (ev may be a borrowed one)
 };
 static StreamClock g_clock[MAXDEV][STREAM_COUNT];
 
@@ -86,6 +86,34 @@ void stream_clocks_forget(int dev, StreamId which) {
     StreamClock& c = g_clock[dev][which];
     std::lock_guard<std::mutex> lk(c.mu);
     c.done = c.enq.load(std::memory_order_acquire);
+    for (auto& m : c.marks) m.pending = false;          // (borrowed events may be destroyed by their owner after this)
+}
+
+unsigned long long stream_clock_now(StreamId which) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return 0;
+    return g_clock[dev][which].enq.load(std::memory_order_acquire);
+}
+
+void stream_clock_external_mark(StreamId which, hipEvent_t ev, unsigned long long upto) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return;
+    StreamClock& c = g_clock[dev][which];
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (upto <= c.done) return;
+    StreamClock::Mark* slot = nullptr;
+    for (auto& m : c.marks) {
+        if (m.pending && m.ev == ev) { slot = &m; break; }      // the owner re-recorded this event: it now covers more
+        if (!m.pending && !slot) slot = &m;
+    }
+    if (!slot) {                                         // all slots pending: the oldest borrowed one gives way (a later mark covers it)
+        for (auto& m : c.marks)
+            if (m.ev != m.own && (!slot || m.upto < slot->upto)) slot = &m;
+        if (!slot) return;
+    }
+    slot->ev = ev;
+    slot->upto = upto;
+    slot->pending = true;
 }
 
 // Has stream (dev, which) passed tick t?  If not, *wait_ev is an event to wait for before asking again (recorded now when no
@@ -133,7 +161,8 @@ static int clock_poll(int dev, StreamId which, unsigned long long t, bool* done,
         }
         DeviceGuard g(dev);
         const unsigned long long upto = c.enq.load(std::memory_order_acquire);     // (read BEFORE the record: every enqueue counted here precedes it)
-        if (!free_slot->ev) XENG_HIP(hipEventCreateWithFlags(&free_slot->ev, hipEventDisableTiming));
+        if (!free_slot->own) XENG_HIP(hipEventCreateWithFlags(&free_slot->own, hipEventDisableTiming));
+        free_slot->ev = free_slot->own;
         XENG_HIP(hipEventRecord(free_slot->ev, s));
         free_slot->upto = upto;
         free_slot->pending = true;
@@ -150,6 +179,17 @@ static int clock_poll(int dev, StreamId which, unsigned long long t, bool* done,
     return XENG_STATUS_SUCCESS;
 }
 
+static unsigned class_of(int stream) {
+    switch (stream) {
+        case STREAM_XGPU: return STAMP_XGPU;
+        case STREAM_MAP: return STAMP_MAP;
+        case STREAM_BEAM: return STAMP_BEAM;
+        case STREAM_COPY: return STAMP_COPY;
+        case STREAM_CONSUMER: return STAMP_CONSUMER;
+        default: return 0;            // the contraction streams: by launch number (Stamp::xgpu_launch), never by a recorded event
+    }
+}
+
 int stamp_now(Stamp* s) {
     *s = Stamp();
     int dev = 0;
@@ -159,62 +199,70 @@ int stamp_now(Stamp* s) {
     }
     s->dev = dev;
     for (int k = 0; k < STREAM_COUNT; k++) s->clk[k] = g_clock[dev][k].enq.load(std::memory_order_acquire);
-    xgpu_pending_launch(&s->xgpu_seq, &s->xgpu_epoch);
+    xgpu_pending_launch(&s->xgpu_seq, &s->xgpu_epoch, &s->xgpu_launch, &s->xgpu_ctx);
     return XENG_STATUS_SUCCESS;
 }
 
-int stamp_poll(const Stamp& s, bool* done, bool* waitable) {
+// one pass over what the stamp waits for; *wait_ev: something to wait for before asking again (may be null: ask again later)
+static int stamp_pass(const Stamp& s, bool* done, bool* waitable, hipEvent_t* wait_ev) {
     *done = true;
     if (waitable) *waitable = true;
+    if (wait_ev) *wait_ev = nullptr;
     if (s.dev < 0) return XENG_STATUS_SUCCESS;
     for (int k = 0; k < STREAM_COUNT; k++) {
+        if (!(class_of(k) & s.mask)) continue;
         bool d = true;
-        int rc = clock_poll(s.dev, (StreamId)k, s.clk[k], &d, nullptr);
+        hipEvent_t ev = nullptr;
+        int rc = clock_poll(s.dev, (StreamId)k, s.clk[k], &d, wait_ev ? &ev : nullptr);
         if (rc) return rc;
-        if (!d) *done = false;
+        if (!d) {
+            *done = false;
+            if (wait_ev && !*wait_ev) *wait_ev = ev;
+        }
     }
-    if (s.xgpu_seq) {
-        bool d = true, launched = true;
-        int rc = xgpu_pending_poll(s.xgpu_seq, s.xgpu_epoch, &d, &launched, nullptr, nullptr);
+    if (s.mask & STAMP_XGPU) {
+        bool d = true;
+        hipEvent_t ev = nullptr;
+        int rc = xgpu_launches_poll(s.xgpu_launch, s.xgpu_ctx, &d, &ev);
         if (rc) return rc;
-        if (!d) *done = false;
-        if (!launched && waitable) *waitable = false;
+        if (!d) {
+            *done = false;
+            if (wait_ev && !*wait_ev) *wait_ev = ev;
+        }
+        if (s.xgpu_seq) {
+            bool launched = true;
+            ev = nullptr;
+            rc = xgpu_pending_poll(s.xgpu_seq, s.xgpu_epoch, &d, &launched, &ev, nullptr);
+            if (rc) return rc;
+            if (!d) {
+                *done = false;
+                if (wait_ev && !*wait_ev) *wait_ev = ev;
+            }
+            if (!launched && waitable) *waitable = false;
+        }
     }
     return XENG_STATUS_SUCCESS;
 }
 
+int stamp_poll(const Stamp& s, bool* done, bool* waitable) { return stamp_pass(s, done, waitable, nullptr); }
+
 int stamp_wait(const Stamp& s) {
-    if (s.dev < 0) return XENG_STATUS_SUCCESS;
-    for (int k = 0; k < STREAM_COUNT; k++) {
-        for (;;) {
-            bool d = true;
-            hipEvent_t ev = nullptr;
-            int rc = clock_poll(s.dev, (StreamId)k, s.clk[k], &d, &ev);
-            if (rc) return rc;
-            if (d) break;
-            if (ev) XENG_HIP(hipEventSynchronize(ev));          // (outside every lock)
+    for (int spins = 0;; spins++) {
+        bool done = true, waitable = true;
+        hipEvent_t ev = nullptr;
+        int rc = stamp_pass(s, &done, &waitable, &ev);
+        if (rc) return rc;
+        if (done) return XENG_STATUS_SUCCESS;
+        if (ev) {
+            XENG_HIP(hipEventSynchronize(ev));          // (outside every lock)
+            continue;
         }
+        // registered gulps whose contraction nobody has enqueued yet: only their owner can end this (a dump, or xengXgpuReset).
+        // Not reached through the rings (they never wait for an unwaitable stamp).
+        if (!waitable && spins > 40000) XENG_FAIL(XENG_STATUS_INVALID_STATE, "stamp: waiting for an X-engine launch that was never enqueued");
+        struct timespec ts = {0, 50000};
+        nanosleep(&ts, nullptr);
     }
-    if (s.xgpu_seq) {
-        for (int spins = 0;; spins++) {
-            bool d = true, launched = true;
-            hipEvent_t ev = nullptr;
-            int gpu = 0;
-            int rc = xgpu_pending_poll(s.xgpu_seq, s.xgpu_epoch, &d, &launched, &ev, &gpu);
-            if (rc) return rc;
-            if (d) break;
-            if (launched && ev) {
-                XENG_HIP(hipEventSynchronize(ev));
-            } else {
-                // registered gulps whose contraction nobody has enqueued yet: only their owner can end this (a dump, or
-                // xengXgpuReset).  Not reached through the rings (they never wait for an unwaitable stamp).
-                if (spins > 40000) XENG_FAIL(XENG_STATUS_INVALID_STATE, "stamp: waiting for an X-engine launch that was never enqueued");
-                struct timespec ts = {0, 50000};
-                nanosleep(&ts, nullptr);
-            }
-        }
-    }
-    return XENG_STATUS_SUCCESS;
 }
 
 int sync_all_streams() {
@@ -370,19 +418,21 @@ int xengMemset(void* dst, int value, size_t nbytes) {
 }
 int xengStreamSynchronize(void) { return sync_all_streams(); }
 
+// words: 0 = device + 1 | class mask << 32; 1..5 the five non-contraction stream clocks; 6/7 pending launch + epoch; 8/9 launches + context
+static const int PACKED_STREAMS[5] = {STREAM_XGPU, STREAM_MAP, STREAM_BEAM, STREAM_COPY, STREAM_CONSUMER};
 static void stamp_pack(const Stamp& s, xengStamp* o) {
-    o->w[0] = (unsigned long long)(s.dev + 1);
-    for (int k = 0; k < STREAM_COUNT; k++) o->w[1 + k] = s.clk[k];
-    o->w[14] = s.xgpu_seq;
-    o->w[15] = s.xgpu_epoch;
+    memset(o, 0, sizeof(*o));
+    o->w[0] = (unsigned long long)(s.dev + 1) | ((unsigned long long)s.mask << 32);
+    for (int k = 0; k < 5; k++) o->w[1 + k] = s.clk[PACKED_STREAMS[k]];
+    o->w[6] = s.xgpu_seq; o->w[7] = s.xgpu_epoch; o->w[8] = s.xgpu_launch; o->w[9] = s.xgpu_ctx;
 }
 static void stamp_unpack(const xengStamp* o, Stamp* s) {
-    s->dev = (int)o->w[0] - 1;
-    for (int k = 0; k < STREAM_COUNT; k++) s->clk[k] = o->w[1 + k];
-    s->xgpu_seq = o->w[14];
-    s->xgpu_epoch = o->w[15];
+    *s = Stamp();
+    s->dev = (int)(o->w[0] & 0xFFFFFFFFull) - 1;
+    s->mask = (unsigned)(o->w[0] >> 32) & STAMP_ALL;
+    for (int k = 0; k < 5; k++) s->clk[PACKED_STREAMS[k]] = o->w[1 + k];
+    s->xgpu_seq = o->w[6]; s->xgpu_epoch = o->w[7]; s->xgpu_launch = o->w[8]; s->xgpu_ctx = o->w[9];
 }
-static_assert(STREAM_COUNT + 3 <= 16, "xengStamp holds one word per library stream");
 
 int xengStampNow(xengStamp* stamp) {
     if (!stamp) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "StampNow: null stamp");

@@ -44,12 +44,23 @@ from .ndarray import XArray, copy_array, to_dtype, _SPACE_ID
 IMPLEMENTATION = os.environ.get("XENG_RING", "native")
 
 
+def _stream_mask(classes):
+    m = 0
+    for c in classes:
+        m |= ffi.STREAMS[c]
+    return m
+
+
 class LibraryStamps:
-    """Stamps from libxeng's stream clocks (xengStampNow / Done / Wait): the source every device / pinned ring uses."""
+    """Stamps from libxeng's stream clocks (xengStampNow / Done / Wait): the source every device / pinned ring uses.
+    `mask`: the stream classes the ring's blocks have declared (0: none yet -> wait for all)."""
+    mask = 0
 
     def now(self):
         s = ffi.XengStamp()
         ffi.check("xengStampNow", ffi.enqueue_lib().xengStampNow(ctypes.byref(s)))
+        if self.mask:
+            s.w[0] = (s.w[0] & 0xFFFFFFFF) | (self.mask << 32)
         return s
 
     def done(self, s):
@@ -306,12 +317,19 @@ class PyRing:
         self._pool_lock = threading.RLock()     # (re-entrant: a span released by the garbage collector inside _alloc_span puts itself back)
         self._stamps = LibraryStamps() if space != "system" else None
         self._dead = False
+        self._owned_bytes = 0
         self.counters = {"alloc": 0, "free": 0, "reuse": 0, "stamp_wait": 0}
 
     def set_stamp_source(self, src):
         """Tests: completion tickets of a fake backend instead of the library's stream clocks -- an object with now() ->
         stamp, done(stamp) -> (done, waitable), wait(stamp).  Gives a system-space ring a free list too."""
         self._stamps = src
+
+    def declare_streams(self, *classes):
+        """The blocks on this ring name the library streams that touch its spans ('xgpu', 'map', 'beam', 'copy', 'consumer';
+        calls accumulate): a released span then waits for those only (include/xeng.h xengRingDeclareStreams)."""
+        if isinstance(self._stamps, LibraryStamps):
+            self._stamps.mask |= _stream_mask(classes)
 
     def __del__(self):
         try:
@@ -343,19 +361,27 @@ class PyRing:
                 self._pool_bytes -= nbytes
         if cand is not None:
             done, waitable = self._stamps.done(cand.stamp) if cand.stamp is not None else (True, True)
-            if not done and waitable:
+            # still busy: a fresh allocation while the ring owns little (a deeper free list costs memory once, a wait costs
+            # every gulp), else wait for it (outside the lock: kernels of other blocks, enqueued before the release)
+            grow = (not done and isinstance(self._stamps, LibraryStamps)
+                    and self._owned_bytes + nbytes <= 4 * max(self._capacity, 2 * nbytes))
+            if not done and waitable and not grow:
                 self.counters["stamp_wait"] += 1
-                self._stamps.wait(cand.stamp)          # (outside the lock: kernels of other blocks, enqueued before the release)
+                self._stamps.wait(cand.stamp)
                 done = True
             if done:
                 a = cand
                 self.counters["reuse"] += 1
-            else:                                      # waits for a launch nobody has enqueued: try the others first next time
+            else:
                 with self._pool_lock:
-                    self._pool[nbytes].append(cand)
+                    if waitable:
+                        self._pool[nbytes].appendleft(cand)        # still the next one to be reissued
+                    else:
+                        self._pool[nbytes].append(cand)            # waits for a launch nobody has enqueued: try the others first
                     self._pool_bytes += nbytes
         if a is None:
             self.counters["alloc"] += 1
+            self._owned_bytes += nbytes
             if self.space == "system":
                 keep = np.zeros(max(nbytes, 1), dtype=np.uint8)
                 a = _Allocation(keep.ctypes.data, nbytes, "system", keep)
@@ -372,11 +398,12 @@ class PyRing:
         if self._stamps is not None:
             a.stamp = self._stamps.now()
         with self._pool_lock:
-            if not self._dead and self._pool_bytes + a.nbytes <= max(self._capacity, 2 * a.nbytes):
+            if not self._dead and self._pool_bytes + a.nbytes <= 2 * max(self._capacity, 2 * a.nbytes):
                 self._pool.setdefault(a.nbytes, collections.deque()).append(a)
                 self._pool_bytes += a.nbytes
                 return
         self.counters["free"] += 1
+        self._owned_bytes -= a.nbytes
         _free_allocation(a, self._stamps)
 
     # ------------------------------------------------------------------ writer side
@@ -707,6 +734,11 @@ class NativeRing:
             src.wait(st[0])
         self._hooks = (ffi.STAMP_NOW_FN(now), ffi.STAMP_DONE_FN(done), ffi.STAMP_WAIT_FN(wait))       # (kept alive with the ring)
         ffi.call("xengRingSetStampHooks", self._h, self._hooks[0], self._hooks[1], self._hooks[2], None)
+
+    def declare_streams(self, *classes):
+        """The blocks on this ring name the library streams that touch its spans ('xgpu', 'map', 'beam', 'copy', 'consumer';
+        calls accumulate): a released span then waits for those only (include/xeng.h xengRingDeclareStreams)."""
+        ffi.call("xengRingDeclareStreams", self._h, _stream_mask(classes))
 
     def set_recycle(self, on=True):
         """System-space ring: recycle released span memory (no zero fill per span), as the device / pinned rings always do."""

@@ -92,6 +92,14 @@ int xengStreamSynchronize(void);                               /* all library st
  * stamp is complete: GPU memory lifetime does not rest on who dropped which Python reference when.
  * No reference counterpart: a bifrost ring is one circular buffer that is never freed while the pipeline runs. */
 typedef struct xengStamp_ { unsigned long long w[16]; } xengStamp;
+/* stream classes a stamp waits for (bits 32..36 of w[0]; xengStampNow sets all): the X-engine (staging stream, contractions,
+ * registered gulps), the CorrAcc map stream, the beamformer stream, the copy stream, the span consumers' stream */
+#define XENG_STREAMS_XGPU      1u
+#define XENG_STREAMS_MAP       2u
+#define XENG_STREAMS_BEAM      4u
+#define XENG_STREAMS_COPY      8u
+#define XENG_STREAMS_CONSUMER 16u
+#define XENG_STREAMS_ALL      31u
 int xengStampNow(xengStamp *stamp);
 /* non-blocking: *done = 1 when Wait would not wait; *waitable (may be NULL) = 0 when the stamp waits for an X-engine launch
  * that nobody has enqueued yet (only the owner of those gulps can end that: a dump, or xengXgpuReset) */
@@ -111,6 +119,11 @@ typedef struct xengRing_ xengRing;
 int xengRingCreate(xengRing **ring, const char *name, int space);
 int xengRingDestroy(xengRing *ring);     /* wakes every waiter; spans still referenced stay valid until released */
 int xengRingResize(xengRing *ring, size_t contig_bytes, size_t total_span);        /* ring.resize(): capacity in bytes (0: 4 x contig) */
+/* Which of the library's streams touch this ring's spans (XENG_STREAMS_*; calls accumulate).  Until somebody declares, a
+ * released span waits for everything the library had enqueued; the blocks declare what they use -- the beamformer's rings
+ * XENG_STREAMS_BEAM, Corr's XENG_STREAMS_XGPU ... -- so that a beam span is not held back by the 200 us contraction that
+ * happened to be enqueued before its release. */
+int xengRingDeclareStreams(xengRing *ring, unsigned classes);
 /* system-space rings hand out fresh zero-filled memory per span by default; on != 0 recycles released spans as the device /
  * pinned rings always do (contents: whatever the last user left, as in a circular bifrost ring) */
 int xengRingSetRecycle(xengRing *ring, int on);

@@ -48,8 +48,9 @@ def worker(args):
                 ffi.call("xengXgpuConfigure", NSTAND, NPOL, NCHAN, NTIME_GULP, gps)
                 ffi.call("xengXgpuInitialize", 0)
             finally:
-                for k in env:
-                    del os.environ[k]
+                if not args.keep_env:
+                    for k in env:
+                        del os.environ[k]
             gi = 0
 
             def step(sync_all=False):
@@ -86,6 +87,9 @@ def worker(args):
                 ffi.call("xengXgpuSetProfiling", 0)
                 alone = tm[1] / max(cn[1], 1) * 1e3
             ffi.call("xengXgpuDestroy")
+            if args.keep_env:
+                for k in env:
+                    del os.environ[k]
             print("R %d %.4f %.1f" % (vi, ms, alone), flush=True)
 
 
@@ -99,6 +103,7 @@ def main():
     ap.add_argument("--alone", type=int, default=0, help="also time N stand-alone launches per round")
     ap.add_argument("--ring-gulps", type=int, default=10)
     ap.add_argument("--profiling", action="store_true", help="HIP-event profiling of every launch on during the streaming loop (as in the timed region of bench.py)")
+    ap.add_argument("--keep-env", action="store_true", help="keep a variant's environment set while it runs (switches read per launch: XENG_ABLATE of the diagnostic build)")
     ap.add_argument("--worker", action="store_true")
     args = ap.parse_args()
     if args.worker:
@@ -120,7 +125,7 @@ def main():
             if libs.get(name):
                 env["XENG_LIB"] = libs[name]
             cmd = [sys.executable, os.path.abspath(__file__), "--worker", "--rounds", "1", "--steps", str(args.steps), "--warm", str(args.warm),
-                   "--alone", str(args.alone), "--ring-gulps", str(args.ring_gulps)] + (["--profiling"] if args.profiling else []) + [e for _, e in lst]
+                   "--alone", str(args.alone), "--ring-gulps", str(args.ring_gulps)] + (["--profiling"] if args.profiling else []) + (["--keep-env"] if args.keep_env else []) + [e for _, e in lst]
             out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
             if out.returncode:
                 sys.stderr.write(out.stderr[-2000:])

@@ -191,6 +191,72 @@ static void launch_sweep(int m, int nblocks, hipStream_t s, int iters, const flo
     if constexpr (M > 0) launch_sweep<OP, M - 1>(m, nblocks, s, iters, tab, dev);
 }
 
+// mode 200 + 16*cls + m (round 4): is the fault a property of the OPERAND SELECT or of the packed-fp32 opcodes?  The same sweep of
+// the two swept sources' selects (m as above) for the other VOP3P classes gfx950 has:
+//   cls 0: v_pk_mov_b32    (64-bit register pairs, like packed fp32; which source register lands in which half of the result is
+//                           calibrated on an idle GPU first -- no semantics assumed: the inputs are four distinct tags per lane)
+//   cls 1: v_pk_add_u16    (32-bit registers; op_sel picks the 16-bit half that feeds the LOW result)
+//   cls 2: v_pk_fma_f16    (the same with a third source taken straight; small integers: exact in fp16)
+template <int CLS, int M>
+__global__ __launch_bounds__(256) void pk_class_kernel(int iters, const float* __restrict__ tab, unsigned long long* __restrict__ out,
+                                                       int map_lo, int map_hi, int calibrate) {
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gw = blockIdx.x * 4 + wave;
+    constexpr int s0 = M & 1, s1 = (M >> 1) & 1, h0 = (M >> 2) & 1, h1 = (M >> 3) & 1;
+    unsigned nerr = 0, nlo = 0, nq[4] = {0, 0, 0, 0};
+    unsigned long long first = 0;
+    for (int it = 0; it < iters; it++) {
+        const int base = ((gw * 131 + it * 17) & 1023) * 64;
+        // small integers from memory, as in the kernel the fault was found in
+        const int ia = (int)tab[2 * ((base + lane) & 65535)], ib = (int)tab[2 * ((base + lane + 7) & 65535) + 1];
+        const int ic = (int)tab[2 * ((base + lane + 19) & 65535)];
+        unsigned wlo = 0, whi = 0, glo = 0, ghi = 0;
+        if (CLS == 0) {
+            const unsigned t = (unsigned)(base + lane) * 8u;
+            const v2u a = {t + 1u, t + 2u}, b = {t + 3u, t + 4u};
+            v2u d;
+            asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[%c3,%c4] op_sel_hi:[%c5,%c6]" : "=&v"(d) : "v"(a), "v"(b), "n"(s0), "n"(s1), "n"(h0), "n"(h1));
+            glo = d.x - t; ghi = d.y - t;                       // 1..4: which source register it is
+            if (calibrate) { wlo = glo; whi = ghi; if (gw == 0 && lane == 0 && it == 0) out[7] = (unsigned long long)glo | ((unsigned long long)ghi << 8); }
+            else { wlo = (unsigned)map_lo; whi = (unsigned)map_hi; }
+        } else if (CLS == 1) {
+            const unsigned a = ((unsigned)(ia + 16) & 0xFFFFu) | ((unsigned)(ib + 300) << 16), b = ((unsigned)(ic + 16) & 0xFFFFu) | ((unsigned)(ia + 700) << 16);
+            unsigned d;
+            asm volatile("v_pk_add_u16 %0, %1, %2 op_sel:[%c3,%c4] op_sel_hi:[%c5,%c6]" : "=&v"(d) : "v"(a), "v"(b), "n"(s0), "n"(s1), "n"(h0), "n"(h1));
+            const unsigned ah[2] = {a & 0xFFFFu, a >> 16}, bh[2] = {b & 0xFFFFu, b >> 16};
+            wlo = (ah[s0] + bh[s1]) & 0xFFFFu; whi = (ah[h0] + bh[h1]) & 0xFFFFu;
+            glo = d & 0xFFFFu; ghi = d >> 16;
+        } else {
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            const float af[2] = {(float)(ia & 3) - 2.f, (float)(ib & 3) + 1.f}, bf[2] = {(float)(ic & 3) - 1.f, (float)(ia & 7) - 3.f};
+            const float cf[2] = {(float)(ib & 7), (float)(ic & 7) - 4.f};
+            const h2 a = {(_Float16)af[0], (_Float16)af[1]}, b = {(_Float16)bf[0], (_Float16)bf[1]}, c = {(_Float16)cf[0], (_Float16)cf[1]};
+            h2 d;
+            asm volatile("v_pk_fma_f16 %0, %1, %2, %3 op_sel:[%c4,%c5,0] op_sel_hi:[%c6,%c7,1]" : "=&v"(d) : "v"(a), "v"(b), "v"(c), "n"(s0), "n"(s1), "n"(h0), "n"(h1));
+            const h2 w = {(_Float16)(af[s0] * bf[s1] + cf[0]), (_Float16)(af[h0] * bf[h1] + cf[1])};
+            wlo = __builtin_bit_cast(unsigned short, w.x); whi = __builtin_bit_cast(unsigned short, w.y);
+            glo = __builtin_bit_cast(unsigned short, d.x); ghi = __builtin_bit_cast(unsigned short, d.y);
+        }
+        const bool blo = glo != wlo, bhi = ghi != whi;
+        if (blo || bhi) {
+            nerr++; nlo += blo; nq[lane >> 4]++;
+            if (!first) first = ((unsigned long long)(blo ? glo : ghi) << 32) | (blo ? wlo : whi);
+        }
+    }
+    if (nerr) {
+        atomicAdd(&out[0], (unsigned long long)nerr);
+        for (int k = 0; k < 4; k++) atomicAdd(&out[1 + k], (unsigned long long)nq[k]);
+        atomicAdd(&out[5], (unsigned long long)nlo);
+        atomicCAS(&out[6], 0ull, first);
+    }
+}
+template <int CLS, int M>
+static void launch_class(int m, int nblocks, hipStream_t s, int iters, const float* tab, unsigned long long* dev, int ml, int mh, int cal) {
+    if (m == M) hipLaunchKernelGGL(HIP_KERNEL_NAME(pk_class_kernel<CLS, M>), dim3(nblocks), dim3(256), 0, s, iters, tab, dev, ml, mh, cal);
+    if constexpr (M > 0) launch_class<CLS, M - 1>(m, nblocks, s, iters, tab, dev, ml, mh, cal);
+}
+
 }  // namespace xeng
 
 extern "C" int xengDiagBpermProbe(int mode, int iters, int nblocks, unsigned long long* host8) {
@@ -224,6 +290,13 @@ extern "C" int xengDiagBpermProbe(int mode, int iters, int nblocks, unsigned lon
         else if (op == 1) xeng::launch_sweep<1, 15>(m, nblocks, s, iters, tab, dev);
         else if (op == 2) xeng::launch_sweep<2, 15>(m, nblocks, s, iters, tab, dev);
         else xeng::launch_sweep<3, 15>(m, nblocks, s, iters, tab, dev);
+    } else if (mode >= 200 && mode < 248) {
+        // host8[0] on entry: (map_lo | map_hi << 8 | calibrate << 16) for the v_pk_mov_b32 class
+        const int cls = (mode - 200) >> 4, m = (mode - 200) & 15;
+        const int ml = (int)(host8[0] & 0xFF), mh = (int)((host8[0] >> 8) & 0xFF), cal = (int)((host8[0] >> 16) & 1);
+        if (cls == 0) xeng::launch_class<0, 15>(m, nblocks, s, iters, tab, dev, ml, mh, cal);
+        else if (cls == 1) xeng::launch_class<1, 15>(m, nblocks, s, iters, tab, dev, ml, mh, cal);
+        else xeng::launch_class<2, 15>(m, nblocks, s, iters, tab, dev, ml, mh, cal);
     } else XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "probe: unknown mode %d", mode);
     XENG_HIP(hipGetLastError());
     XENG_HIP(hipMemcpyAsync(host8, dev, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));

@@ -28,11 +28,16 @@ ring.upload(np.random.RandomState(1).randint(0, 255, size=5 * gb, dtype=np.uint8
 outs = [ffi.DeviceBuffer(2 * matlen * 4) for _ in range(2)]
 
 
+CAL = {}
+
+
 def run_probe(mode, label, nrep):
     tot = np.zeros(8, dtype=np.uint64)
     first = 0
     for _ in range(nrep):
         h = np.zeros(8, dtype=np.uint64)
+        if 200 <= mode < 216:                      # v_pk_mov_b32: expected source registers, calibrated on the idle GPU
+            h[0] = CAL[mode]
         ffi.check("probe", probe(mode, 3000 if mode < 2 else 600, 1024, h.ctypes.data))
         tot[:6] += h[:6]
         first = first or int(h[6])
@@ -69,11 +74,20 @@ MODES = ((0, "ds_bpermute_b32"), (1, "DPP row_shl/row_shr"), (2, "packed-fp32 su
 OPS = ("v_pk_mul_f32 D, A, B", "v_pk_add_f32 D, A, B", "v_pk_fma_f32 D, A, B, C (selects on A, B)", "v_pk_fma_f32 D, A, B, C (selects on B, C)")
 SWEEP = tuple((100 + 16 * op + m, "%s op_sel:[%d,%d] op_sel_hi:[%d,%d]" % (OPS[op], m & 1, (m >> 1) & 1, (m >> 2) & 1, (m >> 3) & 1))
               for op in range(4) for m in range(16))
+CLS = ("v_pk_mov_b32 D, A, B", "v_pk_add_u16 D, A, B", "v_pk_fma_f16 D, A, B, C (selects on A, B)")
+CLASSES = tuple((200 + 16 * c + m, "%s op_sel:[%d,%d] op_sel_hi:[%d,%d]" % (CLS[c], m & 1, (m >> 1) & 1, (m >> 2) & 1, (m >> 3) & 1))
+                for c in range(3) for m in range(16))
 lo = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 hi = int(sys.argv[2]) if len(sys.argv) > 2 else 7
-for mode, name in [mn for mn in MODES + SWEEP if lo <= mn[0] <= hi]:
-    if mode < 100:
-        run_probe(mode, name + ", GPU otherwise idle:", 2)
+for mode, name in [mn for mn in MODES + SWEEP + CLASSES if lo <= mn[0] <= hi]:
+    if 200 <= mode < 216:                          # which source register lands where: read off an idle GPU, one lane
+        h = np.zeros(8, dtype=np.uint64)
+        h[0] = 1 << 16
+        ffi.check("probe", probe(mode, 1, 1, h.ctypes.data))
+        CAL[mode] = int(h[7]) & 0xFFFF
+        name += " (idle: low = reg %d, high = reg %d of a.x a.y b.x b.y)" % (CAL[mode] & 0xFF, CAL[mode] >> 8)
+    if mode < 100 or mode >= 200:
+        run_probe(mode, name + ", GPU otherwise idle:", 1 if mode >= 200 else 2)
     stop.clear()
     th = threading.Thread(target=feeder)
     th.start()
