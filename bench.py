@@ -176,8 +176,11 @@ def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=4
     log = logging.getLogger("bench-config5")
     corr = Corr(log, r_in, r_vis, ntime_gulp=NTIME_GULP, nchan=NCHAN, npol=NPOL, nstand=NSTAND, acc_len=ACC_LEN, autostartat=0, gpu=gpu)
     cacc = CorrAcc(log, r_vis, r_slow, nchan=NCHAN, npol=NPOL, nstand=NSTAND, acc_len=long_len * ACC_LEN, autostartat=0, gpu=gpu)
-    bf = Beamform(log, r_in, r_bf, nchan=NCHAN, nbeam=nbeam, ninput=NINPUT, ntime_gulp=NTIME_GULP, gpu=gpu)
-    sb = BeamformSumBeams(log, r_bf, r_pow, nchan=NCHAN, ntime_gulp=NTIME_GULP, ntime_sum=ns, gpu=gpu)
+    # Beamform on GPU_NGULP = 2 input gulps per call, as the reference runs it (lwa352-pipeline.py:172,279-282): the two spans
+    # are taken as the two windows of one 960-sample gulp (ring read_parts + xengBeamformRunParts), one launch, no copy
+    nt_b = 2 * NTIME_GULP
+    bf = Beamform(log, r_in, r_bf, nchan=NCHAN, nbeam=nbeam, ninput=NINPUT, ntime_gulp=nt_b, gpu=gpu)
+    sb = BeamformSumBeams(log, r_bf, r_pow, nchan=NCHAN, ntime_gulp=nt_b, ntime_sum=ns, gpu=gpu)
     rng = np.random.default_rng(7)
     bf.gains_cpu[...] = (rng.uniform(-17, 17, bf.gains_cpu.shape) + 1j * rng.uniform(-17, 17, bf.gains_cpu.shape)).astype(np.complex64)
     spans = [XArray(shape=(gulp_bytes,), dtype=np.uint8, space="cuda", _ptr=ring.ptr + g * gulp_bytes, _base=ring) for g in range(ring_gulps)]
@@ -208,7 +211,7 @@ def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=4
     def slow_span():
         nslow[0] += 1
     ths = [drain(r_vis, corr.ogulp_size, lambda: stamps.append(time.perf_counter())), drain(r_slow, cacc.ogulp_size, slow_span),
-           drain(r_pow, (nbeam // 2) * (NTIME_GULP // ns) * NCHAN * 16)]
+           drain(r_pow, (nbeam // 2) * (nt_b // ns) * NCHAN * 16)]
     ths += [threading.Thread(target=f, daemon=True) for f in (corr.main, cacc.main, bf.main, sb.main, source)]
     # Eight Python threads under one interpreter lock.  The blocks keep the lock across their enqueue-only library calls and ask
     # before they wait (ffi.enqueue_lib, backend.beam_wait / xgpu_sync_lag), so a thread gives the lock up only when it really

@@ -136,7 +136,10 @@ class HipBackend:
         return self._x.map_i32(a.ptr, b.ptr, a.nbytes // 4, True)
 
     # ---- beamformer (beamform_block.py:251,449; beamform_sum_beams_block.py:245)
+    _beam_row_bytes = 0
+
     def bfBeamformInitialize(self, gpu, ninput, nchan, ntime, nbeam, ntime_blocks):
+        self._beam_row_bytes = int(ninput) * int(nchan)         # bytes per sample of a gulp (4+4 bit per input)
         return self._lib.bfBeamformInitialize(int(gpu), ninput, nchan, ntime, nbeam, ntime_blocks)
 
     def bfBeamformRun(self, in_arr, out_arr, weights, version=0):
@@ -145,6 +148,13 @@ class HipBackend:
         if version:
             return self._x.beam_run(_dev(in_arr), _dev(out_arr), _dev(weights), int(version))
         return self._lib.bfBeamformRun(in_arr, out_arr, weights)
+
+    def bfBeamformRunParts(self, part0, part1, out_arr, weights, version=0):
+        """One beamformer gulp out of two consecutive spans of the input ring (arrays `part0`, `part1`: whole samples each),
+        one launch, no gathered copy (include/xeng.h xengBeamformRunParts).  No reference counterpart: bifrost's circular ring
+        hands the reference's 2-gulp read (lwa352-pipeline.py:172,279-282) out contiguously."""
+        ntime0 = part0.nbytes // (self._beam_row_bytes or 1)
+        return self._x.beam_run_parts(part0.ptr, ntime0, part1.ptr, _dev(out_arr), _dev(weights), int(version))
 
     def bfBeamformIntegrate(self, in_arr, out_arr, ntime_sum):
         # (bfBeamformIntegrate reads only the two data pointers from its structs: the raw entry point, no structs built per gulp)

@@ -171,8 +171,11 @@ class Beamform(Block):
                 ohdr['complex'] = True
                 ohdr['nbeam'] = self.nbeam
                 prev_time = time.time()
+                # A gulp that lies in two spans of the input ring (ntime_gulp = 2 x the writer's gulp, as the reference runs it:
+                # lwa352-pipeline.py:172,279-282) is taken as two windows and beamformed in ONE launch, without a gathered copy
+                read_parts = getattr(iseq, 'read_parts', None) if hasattr(self._bf, 'bfBeamformRunParts') else None
                 with oring.begin_sequence(time_tag=iseq.time_tag, header=json.dumps(ohdr)) as oseq:
-                    for ispan in iseq.read(igulp_size):
+                    for ispan in (read_parts(igulp_size) if read_parts is not None else iseq.read(igulp_size)):
                         self.update_stats({'curr_sample': this_gulp_time})
                         if ispan.size < igulp_size:
                             continue
@@ -207,12 +210,19 @@ class Beamform(Block):
                             prev_time = curr_time
                             # (the reference takes typed views, ispan.data_view('i8') / ospan.data_view(np.float32), :441-444; the
                             # call only needs the spans' addresses, and two fewer objects per gulp is time under the interpreter lock)
-                            rv = self._bf.bfBeamformRun(ispan.data.as_BFarray(), ospan.data.as_BFarray(), self.gains_gpu.as_BFarray(),
-                                                        version=self._gains_version)
+                            parts = getattr(ispan, 'parts', None)
+                            if parts is not None and len(parts) == 2:
+                                held = parts
+                                rv = self._bf.bfBeamformRunParts(parts[0], parts[1], ospan.data.as_BFarray(), self.gains_gpu.as_BFarray(),
+                                                                 version=self._gains_version)
+                            else:
+                                held = ispan.data
+                                rv = self._bf.bfBeamformRun(held.as_BFarray(), ospan.data.as_BFarray(), self.gains_gpu.as_BFarray(),
+                                                            version=self._gains_version)
                             if rv != self._bf.BF_STATUS_SUCCESS:
                                 raise RuntimeError("bfBeamformRun returned %d: %s" % (rv, self._bf.last_error()))
                             if streaming:
-                                pending.append((self._bf.beam_mark(), ospan, ispan.data))
+                                pending.append((self._bf.beam_mark(), ospan, held))
                                 ospan = None
                                 retire(self.STREAM_DEPTH)
                             else:

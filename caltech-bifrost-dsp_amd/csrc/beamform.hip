@@ -77,15 +77,18 @@ static int beam_destroy_locked() {
 
 // pow_out != nullptr: integrated-power mode, fused into the int8x3 kernel when that is possible (see the kernel); returns
 // *fused = false when the caller has to run the voltage mode into its scratch and integrate separately
+// in1 / split: the gulp in two parts (samples [split, ntime) at in1; beamform_kernels.h gulp_row); one part: in1 null
 static int run_locked(const void* in, float* out, const void* w, long long version, float* pow_out = nullptr, int ntime_sum = 0,
-                      bool* fused = nullptr, bool may_wait = true) {
+                      bool* fused = nullptr, bool may_wait = true, const void* in1v = nullptr, int split = 0) {
     BeamContext& x = g_b;
     if (fused) *fused = false;
+    const uint8_t* in1 = (const uint8_t*)in1v;
+    if (!in1) { in1 = (const uint8_t*)in; split = x.ntime; }
     if (x.use_f32) {
         dim3 grid((x.ntime + BF_NT - 1) / BF_NT, x.nchan, (x.nbeam + 31) / 32);
         int slot = x.timer.begin(x.stream, 0);
         hipLaunchKernelGGL(beamform_f32_kernel, grid, dim3(256), 0, x.stream, (const uint8_t*)in, (const float*)w, out,
-                           x.ntime, x.nchan, x.ninput, x.nbeam);
+                           x.ntime, x.nchan, x.ninput, x.nbeam, in1, split);
         x.timer.end(x.stream, slot);
     stream_tick(STREAM_BEAM);
         XENG_HIP(hipGetLastError());
@@ -142,11 +145,11 @@ static int run_locked(const void* in, float* out, const void* w, long long versi
         }
         hipLaunchKernelGGL(beamform_i8x3_kernel, grid, dim3(256), 0, x.stream, (const uint8_t*)in, x.wq, x.wscale, x.wsum, out,
                            x.ntime, x.nchan, x.ninput, x.nbeam, x.nchunk_i8, x.nbtile, x.route, x.out_n, x.out_idx, x.out_R, x.stamps,
-                           fuse ? pow_out : (float*)nullptr, ntime_sum);
+                           fuse ? pow_out : (float*)nullptr, ntime_sum, in1, split);
         if (x.need_bf16) {
             dim3 grid3(((x.ntime + BF3_NT - 1) / BF3_NT) * x.nchan * x.nbtile);
             hipLaunchKernelGGL(beamform_bf16x3_kernel, grid3, dim3(64 * BF3_NW), 0, x.stream, (const uint8_t*)in, x.wprep, out,
-                               x.ntime, x.nchan, x.ninput, x.nbeam, x.nchunk, x.nbtile, x.route);
+                               x.ntime, x.nchan, x.ninput, x.nbeam, x.nchunk, x.nbtile, x.route, in1, split);
         }
         x.timer.end(x.stream, slot);
     stream_tick(STREAM_BEAM);
@@ -164,7 +167,7 @@ static int run_locked(const void* in, float* out, const void* w, long long versi
     dim3 grid(((x.ntime + BF3_NT - 1) / BF3_NT) * x.nchan * x.nbtile);
     int slot = x.timer.begin(x.stream, 0);
     hipLaunchKernelGGL(beamform_bf16x3_kernel, grid, dim3(64 * BF3_NW), 0, x.stream, (const uint8_t*)in, x.wprep, out,
-                       x.ntime, x.nchan, x.ninput, x.nbeam, x.nchunk, x.nbtile, (const int*)nullptr);
+                       x.ntime, x.nchan, x.ninput, x.nbeam, x.nchunk, x.nbtile, (const int*)nullptr, in1, split);
     x.timer.end(x.stream, slot);
     stream_tick(STREAM_BEAM);
     XENG_HIP(hipGetLastError());
@@ -261,7 +264,8 @@ int xengBeamformRun(const void* in_dev, void* out_dev, const void* weights_dev) 
     return xengBeamformRunVersioned(in_dev, out_dev, weights_dev, 0);
 }
 
-static int run_versioned(const void* in_dev, void* out_dev, const void* weights_dev, long long weights_version, bool may_wait);
+static int run_versioned(const void* in_dev, void* out_dev, const void* weights_dev, long long weights_version, bool may_wait,
+                         const void* in1_dev = nullptr, int ntime0 = 0);
 
 int xengBeamformRunVersioned(const void* in_dev, void* out_dev, const void* weights_dev, long long weights_version) {
     return run_versioned(in_dev, out_dev, weights_dev, weights_version, true);
@@ -271,17 +275,30 @@ int xengBeamformTryRunVersioned(const void* in_dev, void* out_dev, const void* w
     return run_versioned(in_dev, out_dev, weights_dev, weights_version, false);
 }
 
-static int run_versioned(const void* in_dev, void* out_dev, const void* weights_dev, long long weights_version, bool may_wait) {
+int xengBeamformRunParts(const void* in0_dev, int ntime0, const void* in1_dev, void* out_dev, const void* weights_dev, long long weights_version) {
+    return run_versioned(in0_dev, out_dev, weights_dev, weights_version, true, in1_dev, ntime0);
+}
+
+int xengBeamformTryRunParts(const void* in0_dev, int ntime0, const void* in1_dev, void* out_dev, const void* weights_dev, long long weights_version) {
+    return run_versioned(in0_dev, out_dev, weights_dev, weights_version, false, in1_dev, ntime0);
+}
+
+static int run_versioned(const void* in_dev, void* out_dev, const void* weights_dev, long long weights_version, bool may_wait,
+                         const void* in1_dev, int ntime0) {
     std::lock_guard<std::mutex> lk(g_bmu);
     BeamContext& x = g_b;
     if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "Beamform: not initialized (call xengBeamformInitialize)");
     if (!in_dev || !out_dev || !weights_dev) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Beamform: null buffer");
     if (((uintptr_t)weights_dev & 15) || ((uintptr_t)out_dev & 15) || ((uintptr_t)in_dev & 3))
         XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Beamform: weights/out must be 16-byte, in 4-byte aligned");
+    if (in1_dev) {
+        if (ntime0 <= 0 || ntime0 >= x.ntime) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Beamform: first part of %d samples in a gulp of %d", ntime0, x.ntime);
+        if ((uintptr_t)in1_dev & 3) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Beamform: in must be 4-byte aligned");
+    }
     XENG_HIP(hipSetDevice(x.gpu));
-    if (x.ntime_blocks == 0) return run_locked(in_dev, (float*)out_dev, weights_dev, weights_version);
+    if (x.ntime_blocks == 0) return run_locked(in_dev, (float*)out_dev, weights_dev, weights_version, nullptr, 0, nullptr, true, in1_dev, ntime0);
     bool fused = false;
-    int rc = run_locked(in_dev, x.scratch, weights_dev, weights_version, (float*)out_dev, x.ntime / x.ntime_blocks, &fused, may_wait);
+    int rc = run_locked(in_dev, x.scratch, weights_dev, weights_version, (float*)out_dev, x.ntime / x.ntime_blocks, &fused, may_wait, in1_dev, ntime0);
     if (rc || fused) return rc;
     return integrate_locked(x.scratch, out_dev, x.ntime / x.ntime_blocks, 0, x.nbeam / 2);
 }

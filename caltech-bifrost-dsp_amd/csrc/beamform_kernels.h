@@ -27,10 +27,17 @@ constexpr int BF_WS = BF_KC * 8 + 16;     // W row stride (bytes): conflict-free
 constexpr int BF_XS = BF_KC + 4;          // X row stride (bytes): conflict-free ds_read_b32
 constexpr int BF_NT = 128;                // samples per work-group
 
+// A gulp in up to two parts (round 4): samples [0, split) start at `in`, samples [split, ntime) at `in1` -- two consecutive spans
+// of the input ring taken as one 960-sample gulp without a gathered copy (the reference reads GPU_NGULP = 2 capture gulps per
+// beamformer gulp, lwa352-pipeline.py:172,279-282; bifrost's one circular buffer gives that for free).  One part: split = ntime.
+__device__ __forceinline__ const uint8_t* gulp_row(const uint8_t* in, const uint8_t* in1, int split, int t, size_t row_stride) {
+    return t < split ? in + (size_t)t * row_stride : in1 + (size_t)(t - split) * row_stride;
+}
+
 __global__ __launch_bounds__(256) void beamform_f32_kernel(const uint8_t* __restrict__ in,
                                                            const float* __restrict__ w,
                                                            float* __restrict__ out, int ntime, int nchan,
-                                                           int ninput, int nbeam) {
+                                                           int ninput, int nbeam, const uint8_t* __restrict__ in1, int split) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[32 * BF_WS + BF_NT * BF_XS];
     uint8_t* ldsW = lds;
     uint8_t* ldsX = lds + 32 * BF_WS;
@@ -66,7 +73,7 @@ __global__ __launch_bounds__(256) void beamform_f32_kernel(const uint8_t* __rest
             const int t = t0 + row, i = k0 + col * 16;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (t < ntime && i < ninput) {
-                const uint8_t* src = in + ((size_t)t * nchan + c) * ninput + i;
+                const uint8_t* src = gulp_row(in, in1, split, t, (size_t)nchan * ninput) + (size_t)c * ninput + i;
                 if (i + 16 <= ninput) v = *reinterpret_cast<const uint4*>(src);
                 else {
                     uint32_t tmp[4] = {0, 0, 0, 0};
@@ -215,7 +222,7 @@ __global__ __launch_bounds__(64 * BF3_NW, BF3_NW == 8 ? 2 : 3) void beamform_bf1
                                                                  const uint8_t* __restrict__ wp,
                                                                  float* __restrict__ out, int ntime, int nchan,
                                                                  int ninput, int nbeam, int nchunk, int nbtile,
-                                                                 const int* __restrict__ route) {
+                                                                 const int* __restrict__ route, const uint8_t* __restrict__ in1, int split) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[BF3_RING * BF3_STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -236,7 +243,7 @@ __global__ __launch_bounds__(64 * BF3_NW, BF3_NW == 8 ? 2 : 3) void beamform_bf1
     // makes the 8-byte fragment reads below bank-conflict-free.  Rows past ntime: any valid row (never stored).
     int xt = t0 + wave * 32 + (lane >> 1);
     if (xt >= ntime) xt = ntime - 1;
-    const uint8_t* xsrc = in + (size_t)xt * row_stride + (size_t)c * ninput;
+    const uint8_t* xsrc = gulp_row(in, in1, split, xt, row_stride) + (size_t)c * ninput;
     const int xhalf = ((lane & 1) ^ ((lane >> 4) & 1)) * 16;
     // every stage costs exactly BF3_WSLOTS + 1 pieces per wave on the vmcnt counter (chunks past the end re-read
     // the last one; weight slots past the 12th piece re-copy an earlier piece onto itself)
@@ -576,7 +583,8 @@ __global__ __launch_bounds__(256, 3) void beamform_i8x3_kernel(const uint8_t* __
                                                                const int* __restrict__ route, const int* __restrict__ out_n,
                                                                const int* __restrict__ out_idx, const float2* __restrict__ out_R,
                                                                unsigned long long* __restrict__ stamps,
-                                                               float* __restrict__ pow_out, int ntime_sum) {
+                                                               float* __restrict__ pow_out, int ntime_sum,
+                                                               const uint8_t* __restrict__ in1, int split) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[BI_RING * BI_STAGE];
     const unsigned long long r0 = stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;   // diagnostic (XENG_BEAM_STAMPS=1)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -600,7 +608,7 @@ __global__ __launch_bounds__(256, 3) void beamform_i8x3_kernel(const uint8_t* __
     for (int n = 0; n < BI_XSLOTS; n++) {
         int xt = t0 + wave * 32 + n * 16 + (lane >> 2);
         if (xt >= ntime) xt = ntime - 1;
-        xsrc[n] = in + (size_t)xt * row_stride + (size_t)c * ninput;
+        xsrc[n] = gulp_row(in, in1, split, xt, row_stride) + (size_t)c * ninput;
     }
     const int xpiece = ((lane & 3) ^ ((lane >> 4) & 1)) * 16;
     // every stage costs exactly BI_WSLOTS + BI_XSLOTS pieces per wave on the vmcnt counter (chunks past the end
@@ -689,7 +697,7 @@ __global__ __launch_bounds__(256, 3) void beamform_i8x3_kernel(const uint8_t* __
     }
     if (n_outl > 0) {
         // the tile's outlier weights (zero digits above) times the voltages, in fp32
-        const uint8_t* xcol = in + (size_t)(t < ntime ? t : ntime - 1) * row_stride + (size_t)c * ninput;
+        const uint8_t* xcol = gulp_row(in, in1, split, t < ntime ? t : ntime - 1, row_stride) + (size_t)c * ninput;
         const int tile = c * nbtile + bt;
         for (int k = 0; k < n_outl; k++) {
             const int xb = xcol[out_idx[(size_t)tile * BI_TILE_OUT + k]];

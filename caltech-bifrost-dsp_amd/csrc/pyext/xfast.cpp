@@ -148,6 +148,37 @@ PyObject* ring_acquire(PyObject*, PyObject* args) {
     return Py_BuildValue("(KnNn)", (unsigned long long)(uintptr_t)data, (Py_ssize_t)n, ref, (Py_ssize_t)skipped);
 }
 
+// ring_acquire_parts(ring_obj, h, reader, advance, gulp) -> None | (skipped, (ptr, nbytes, SpanRef), ...)  -- one or two parts
+PyObject* ring_acquire_parts(PyObject*, PyObject* args) {
+    PyObject* ring;
+    unsigned long long h;
+    int reader;
+    Py_ssize_t advance, gulp;
+    if (!PyArg_ParseTuple(args, "OKinn", &ring, &h, &reader, &advance, &gulp)) return nullptr;
+    void* data[2] = {nullptr, nullptr};
+    size_t n[2] = {0, 0}, skipped = 0, sk2 = 0;
+    long long span[2] = {0, 0};
+    int nparts = 0;
+    int rc = xengRingAcquireParts((xengRing*)h, reader, (size_t)advance, (size_t)gulp, 0, data, n, span, &nparts, &skipped);
+    if (rc == XENG_STATUS_WOULD_BLOCK) {
+        Py_BEGIN_ALLOW_THREADS
+        rc = xengRingAcquireParts((xengRing*)h, reader, 0, (size_t)gulp, 1, data, n, span, &nparts, &sk2);
+        Py_END_ALLOW_THREADS
+        skipped += sk2;
+    }
+    if (rc == XENG_STATUS_END_OF_DATA) Py_RETURN_NONE;
+    if (rc) return raise_xeng("xengRingAcquireParts", rc);
+    PyObject* out = PyTuple_New(1 + nparts);
+    if (!out) { for (int k = 0; k < nparts; k++) (void)xengRingSpanRelease(span[k]); return nullptr; }
+    PyTuple_SET_ITEM(out, 0, PyLong_FromSsize_t((Py_ssize_t)skipped));
+    for (int k = 0; k < nparts; k++) {
+        PyObject* ref = make_spanref(ring, span[k]);
+        if (!ref) { for (int q = k + 1; q < nparts; q++) (void)xengRingSpanRelease(span[q]); Py_DECREF(out); return nullptr; }
+        PyTuple_SET_ITEM(out, 1 + k, Py_BuildValue("(KnN)", (unsigned long long)(uintptr_t)data[k], (Py_ssize_t)n[k], ref));
+    }
+    return out;
+}
+
 // ---------------------------------------------------------------- enqueue-only compute calls (return the status)
 // xengXgpuKernelAsync[Acc]: tried without waiting; 256 launches ahead of the GPU the lock is given up for the wait
 int kernel_async(unsigned long long in, unsigned long long out, int dump, unsigned long long acc, int mode) {
@@ -196,6 +227,21 @@ PyObject* beam_run(PyObject*, PyObject* args) {
     return PyLong_FromLong(rc);
 }
 
+// beam_run_parts(in0, ntime0, in1, out, w, version): one beamformer gulp out of two consecutive ring spans
+PyObject* beam_run_parts(PyObject*, PyObject* args) {
+    unsigned long long in0, in1, out, w;
+    int ntime0;
+    long long version;
+    if (!PyArg_ParseTuple(args, "KiKKKL", &in0, &ntime0, &in1, &out, &w, &version)) return nullptr;
+    int rc = xengBeamformTryRunParts((const void*)(uintptr_t)in0, ntime0, (const void*)(uintptr_t)in1, (void*)(uintptr_t)out, (const void*)(uintptr_t)w, version);
+    if (rc == XENG_STATUS_WOULD_BLOCK) {
+        Py_BEGIN_ALLOW_THREADS
+        rc = xengBeamformRunParts((const void*)(uintptr_t)in0, ntime0, (const void*)(uintptr_t)in1, (void*)(uintptr_t)out, (const void*)(uintptr_t)w, version);
+        Py_END_ALLOW_THREADS
+    }
+    return PyLong_FromLong(rc);
+}
+
 PyObject* beam_integrate(PyObject*, PyObject* args) {
     unsigned long long in, out;
     int ntime_sum;
@@ -235,10 +281,12 @@ PyMethodDef methods[] = {
     {"ring_commit_external", ring_commit_external, METH_VARARGS, "(handle, seq, ptr, nbytes)"},
     {"ring_next_sequence", ring_next_sequence, METH_VARARGS, "(handle, reader) -> None | (header, time_tag, nringlet)"},
     {"ring_acquire", ring_acquire, METH_VARARGS, "(ring_obj, handle, reader, advance, gulp) -> None | (ptr, nbytes, SpanRef, skipped)"},
+    {"ring_acquire_parts", ring_acquire_parts, METH_VARARGS, "(ring_obj, handle, reader, advance, gulp) -> None | (skipped, (ptr, nbytes, SpanRef), ...)"},
     {"xgpu_kernel_async", xgpu_kernel_async, METH_VARARGS, "xengXgpuKernelAsync -> status"},
     {"xgpu_kernel_async_acc", xgpu_kernel_async_acc, METH_VARARGS, "xengXgpuKernelAsyncAcc -> status"},
     {"xgpu_dump_done", xgpu_dump_done, METH_VARARGS, "xengXgpuDumpDone(lag) -> -status | 0 | 1"},
     {"beam_run", beam_run, METH_VARARGS, "xengBeamformRunVersioned -> status"},
+    {"beam_run_parts", beam_run_parts, METH_VARARGS, "xengBeamformRunParts (two ring spans as one gulp) -> status"},
     {"beam_integrate", beam_integrate, METH_VARARGS, "xengBeamformIntegrate -> status"},
     {"beam_mark", beam_mark, METH_NOARGS, "xengBeamformMark -> ticket | -status"},
     {"beam_ticket_done", beam_ticket_done, METH_VARARGS, "xengBeamformTicketDone -> -status | 0 | 1"},

@@ -99,6 +99,11 @@ static void ring_unref(RingCore* r) {
     if (r->refs.fetch_sub(1) == 1) delete r;
 }
 
+// Span memory a ring may own (in its free list + handed out): eight times its capacity.  Released spans carry the stamp of
+// everything their streams had queued at that moment, so the free list has to be deep enough for the oldest entry to have
+// completed when it is needed again (bf-output at config 5: a new span every 77 us, stamps ~150 us deep, 10-14 spans out).
+static size_t own_limit(const RingCore* r, size_t nbytes) { return 8 * std::max(r->capacity, 2 * nbytes); }
+
 static bool pooled_space(const RingCore* r) { return r->space != XENG_SPACE_SYSTEM || r->hook_now || r->recycle_system; }
 
 static int raw_alloc(int space, size_t nbytes, void** out) {
@@ -180,8 +185,9 @@ static void buf_release(Buf* b) {
     {
         std::lock_guard<std::mutex> lk(r->pool_mu);
         if (!r->destroyed) {
-            const size_t limit = 2 * std::max(r->capacity, 2 * b->nbytes);
-            if (r->pool_bytes + b->nbytes > limit) {
+            // one bound for what the ring may own (own_limit): an allocation is really freed only past it, so a ring in
+            // steady state neither allocates nor frees (hipFree synchronises the device)
+            if (r->owned_bytes.load() > own_limit(r, b->nbytes)) {
                 r->graveyard.push_back(b);      // freed by a later call that may block (hipFree synchronises the device)
             } else {
                 r->pool[b->nbytes].push_back(b);
@@ -224,7 +230,7 @@ static int buf_obtain(RingCore* r, size_t nbytes, int may_block, Buf** out) {
             buf_poll(cand, &done, &waitable);
             // still busy: a fresh allocation while the ring owns little (a deeper free list costs memory once; a wait costs
             // every gulp), else wait for it (kernels of other blocks, enqueued before the release)
-            const bool grow = !done && r->owned_bytes.load() + nbytes <= 4 * std::max(r->capacity, 2 * nbytes) && !r->hook_now;
+            const bool grow = !done && r->owned_bytes.load() + nbytes <= own_limit(r, nbytes) && !r->hook_now;
             if (!done && waitable && may_block && !grow) done = buf_wait(cand) == XENG_STATUS_SUCCESS;
             if (done) {
                 *out = cand;
@@ -611,8 +617,10 @@ int xengRingNextSequence(xengRing* ring, int reader, int may_block, long long* s
     return rc;
 }
 
-int xengRingAcquire(xengRing* ring, int reader, size_t advance, size_t gulp_nbytes, int may_block, void** data, size_t* nbytes,
-                    long long* span, size_t* skipped) {
+// max_parts: a gulp that lies in up to that many committed spans is returned as windows on them (data / nbytes / span arrays
+// of that size, *nparts filled in); one that needs more pieces is gathered into one copy as before
+static int acquire_common(xengRing* ring, int reader, size_t advance, size_t gulp_nbytes, int may_block, int max_parts, void** data,
+                          size_t* nbytes, long long* span, int* nparts, size_t* skipped) {
     RING_ARG(ring);
     if (!data || !nbytes || !span || gulp_nbytes == 0) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Acquire: bad argument");
     std::vector<Buf*> released;
@@ -662,12 +670,17 @@ int xengRingAcquire(xengRing* ring, int reader, size_t advance, size_t gulp_nbyt
     release_all(released);
     if (skipped) *skipped = skip_total;
     if (rc) return rc;
-    *nbytes = n;
-    if (pieces.size() == 1) {                       // the usual case: the gulp lies inside one committed span -- a window, no copy
-        *data = (uint8_t*)pieces[0].buf->ptr + pieces[0].boff;
-        *span = (long long)(intptr_t)pieces[0].buf;
+    if ((int)pieces.size() <= max_parts) {          // the usual case: the gulp lies inside one committed span (or max_parts of them) -- windows, no copy
+        for (size_t k = 0; k < pieces.size(); k++) {
+            data[k] = (uint8_t*)pieces[k].buf->ptr + pieces[k].boff;
+            nbytes[k] = pieces[k].nbytes;
+            span[k] = (long long)(intptr_t)pieces[k].buf;
+        }
+        if (nparts) *nparts = (int)pieces.size();
         return XENG_STATUS_SUCCESS;
     }
+    *nbytes = n;
+    if (nparts) *nparts = 1;
     // gathered copy in the ring's space
     Buf* g = nullptr;
     rc = buf_obtain(r, n, 1, &g);
@@ -681,6 +694,17 @@ int xengRingAcquire(xengRing* ring, int reader, size_t advance, size_t gulp_nbyt
     *data = g->ptr;
     *span = (long long)(intptr_t)g;
     return XENG_STATUS_SUCCESS;
+}
+
+int xengRingAcquire(xengRing* ring, int reader, size_t advance, size_t gulp_nbytes, int may_block, void** data, size_t* nbytes,
+                    long long* span, size_t* skipped) {
+    return acquire_common(ring, reader, advance, gulp_nbytes, may_block, 1, data, nbytes, span, nullptr, skipped);
+}
+
+int xengRingAcquireParts(xengRing* ring, int reader, size_t advance, size_t gulp_nbytes, int may_block, void* data[2], size_t nbytes[2],
+                         long long span[2], int* nparts, size_t* skipped) {
+    if (!nparts) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "AcquireParts: null nparts");
+    return acquire_common(ring, reader, advance, gulp_nbytes, may_block, 2, data, nbytes, span, nparts, skipped);
 }
 
 int xengRingSpanRelease(long long span) {

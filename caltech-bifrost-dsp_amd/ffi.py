@@ -60,6 +60,7 @@ SYMBOLS = {
     "xengRingOpenReader": [_vp, _i, _pi], "xengRingCloseReader": [_vp, _i],
     "xengRingNextSequence": [_vp, _i, _i, _pll, _pll, _pi, _pvp, _psz],
     "xengRingAcquire": [_vp, _i, _sz, _sz, _i, _pvp, _psz, _pll, _psz], "xengRingSpanRelease": [_ll],
+    "xengRingAcquireParts": [_vp, _i, _sz, _sz, _i, _pvp, _psz, _pll, _pi, _psz],
     "xengRingSetStampHooks": [_vp, STAMP_NOW_FN, STAMP_DONE_FN, STAMP_WAIT_FN, _vp],
     "xengGetDeviceCount": [_pi], "xengSetDevice": [_i], "xengGetDevice": [_pi], "xengDeviceSynchronize": [],
     "xengGetDeviceInfo": [_i, _pi, _pi, ctypes.POINTER(_sz), ctypes.c_char_p, _i], "xengGetDevicePciBusId": [_i, ctypes.c_char_p, _i],
@@ -78,7 +79,8 @@ SYMBOLS = {
     "xengXgpuSetProfiling": [_i], "xengXgpuGetTimes": [ctypes.POINTER(ctypes.c_double), _pi],
     "xengMapAssignI32": [_vp, _vp, _sz], "xengMapAddI32": [_vp, _vp, _sz], "xengMapSync": [],
     "xengBeamformInitialize": [_i, _i, _i, _i, _i, _i], "xengBeamformDestroy": [],
-    "xengBeamformRun": [_vp, _vp, _vp], "xengBeamformRunVersioned": [_vp, _vp, _vp, ctypes.c_longlong], "xengBeamformTryRunVersioned": [_vp, _vp, _vp, ctypes.c_longlong], "xengBeamformIntegrate": [_vp, _vp, _i],
+    "xengBeamformRun": [_vp, _vp, _vp], "xengBeamformRunVersioned": [_vp, _vp, _vp, ctypes.c_longlong], "xengBeamformTryRunVersioned": [_vp, _vp, _vp, ctypes.c_longlong],
+    "xengBeamformRunParts": [_vp, _i, _vp, _vp, _vp, ctypes.c_longlong], "xengBeamformTryRunParts": [_vp, _i, _vp, _vp, _vp, ctypes.c_longlong], "xengBeamformIntegrate": [_vp, _vp, _i],
     "xengBeamformIntegrateSingleBeam": [_vp, _vp, _i, _i], "xengBeamformMark": [ctypes.POINTER(ctypes.c_ulonglong)], "xengBeamformWait": [ctypes.c_ulonglong], "xengBeamformTicketDone": [ctypes.c_ulonglong, _pi], "xengBeamformSync": [],
     "xengBeamformSetProfiling": [_i], "xengBeamformGetTimes": [ctypes.POINTER(ctypes.c_double), _pi],
     "xengBeamformGetRouteInfo": [_pi, _pi, _pi],
@@ -119,12 +121,12 @@ def lib():
 # flight and xengBeamformRun* waits once after a weight upload in the integrated-power mode: their Try* forms return
 # XENG_STATUS_WOULD_BLOCK instead, and the caller gives the lock up to wait; xengSnap2UnpackAsync shares a mutex with the
 # synchronous call, which polls: it is made on the releasing handle.)
-ENQUEUE_ONLY = ["xengXgpuTryKernelAsyncAcc", "xengBeamformTryRunVersioned",
+ENQUEUE_ONLY = ["xengXgpuTryKernelAsyncAcc", "xengBeamformTryRunVersioned", "xengBeamformTryRunParts",
                 "xengBeamformIntegrate", "xengBeamformIntegrateSingleBeam", "xengBeamformMark", "xengMapAssignI32",
                 "xengMapAddI32", "xengXgpuDumpDone", "xengBeamformTicketDone", "bfBeamformIntegrate", "bfBeamformIntegrateSingleBeam",
                 # the span rings: bookkeeping calls, and the calls that can wait asked with may_block = 0 first
                 "xengRingBeginSequence", "xengRingEndSequence", "xengRingEndWriting", "xengRingReserve", "xengRingCommit",
-                "xengRingCommitExternal", "xengRingNextSequence", "xengRingAcquire", "xengRingSpanRelease", "xengRingGetInfo",
+                "xengRingCommitExternal", "xengRingNextSequence", "xengRingAcquire", "xengRingAcquireParts", "xengRingSpanRelease", "xengRingGetInfo",
                 "xengRingOpenReader", "xengRingCloseReader", "xengRingResize",
                 "xengStampNow", "xengStampDone"]
 _enq = None

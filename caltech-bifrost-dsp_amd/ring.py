@@ -225,11 +225,26 @@ def WriteSpan(ring, nbytes, nonblocking=False):
 
 class ReadSpan(_SpanViews):
     """`skipped`: bytes of the sequence this reader never saw immediately before this span (overwritten before it got there:
-    whole gulps; bifrost's `nframe_skipped`).  `offset`: byte offset of the span in its sequence."""
-    __slots__ = ("data", "size", "offset", "skipped")
+    whole gulps; bifrost's `nframe_skipped`).  `offset`: byte offset of the span in its sequence.  `parts` (read_parts only):
+    the gulp as one or two windows on the committed spans it lies in, in order -- `data` then gathers a copy only if asked."""
+    __slots__ = ("_data", "size", "offset", "skipped", "parts")
 
-    def __init__(self, data, size, offset=0, skipped=0):
-        self.data, self.size, self.offset, self.skipped = data, size, offset, skipped
+    def __init__(self, data, size, offset=0, skipped=0, parts=None):
+        self._data, self.size, self.offset, self.skipped, self.parts = data, size, offset, skipped, parts
+
+    @property
+    def data(self):
+        if self._data is None and self.parts:
+            if len(self.parts) == 1:
+                self._data = self.parts[0]
+            else:
+                out = XArray(shape=(self.size,), dtype=np.uint8, space=self.parts[0].space)
+                pos = 0
+                for p in self.parts:
+                    copy_array(out.byte_slice(pos, p.nbytes), p)
+                    pos += p.nbytes
+                self._data = out
+        return self._data
 
 
 class ReadSequence:
@@ -239,7 +254,12 @@ class ReadSequence:
         self.time_tag, self.nringlet = seq.time_tag, seq.nringlet
         self.ring = seq.ring
 
-    def read(self, gulp_nbytes):
+    def read_parts(self, gulp_nbytes):
+        """read(), but a gulp that lies in two committed spans is handed over as two windows (`ispan.parts`) instead of a
+        gathered copy -- for a consumer that takes its gulp in two parts (Beamform: xengBeamformRunParts)."""
+        return self.read(gulp_nbytes, parts=True)
+
+    def read(self, gulp_nbytes, parts=False):
         """Yield full gulps as they become available; a short final gulp (size < gulp_nbytes) is
         yielded once when the sequence ends, as bifrost does (the blocks skip it:
         corr_block.py:389-391)."""
@@ -263,9 +283,14 @@ class ReadSequence:
                 n = min(avail, gulp_nbytes)
                 if n <= 0:
                     return
-                data = ring._assemble(seq, rd.offset, n)
+                if parts:
+                    pieces = ring._pieces(seq, rd.offset, n)
+                    data = None if len(pieces) <= 2 else ring._assemble(seq, rd.offset, n)
+                    pieces = pieces if data is None else [data]
+                else:
+                    data, pieces = ring._assemble(seq, rd.offset, n), None
                 offset = rd.offset
-            yield ReadSpan(data, n, offset, skipped)
+            yield ReadSpan(data, n, offset, skipped, pieces)
             with ring._cond:
                 rd.offset += n
                 ring._gc()
@@ -364,7 +389,7 @@ class PyRing:
             # still busy: a fresh allocation while the ring owns little (a deeper free list costs memory once, a wait costs
             # every gulp), else wait for it (outside the lock: kernels of other blocks, enqueued before the release)
             grow = (not done and isinstance(self._stamps, LibraryStamps)
-                    and self._owned_bytes + nbytes <= 4 * max(self._capacity, 2 * nbytes))
+                    and self._owned_bytes + nbytes <= 8 * max(self._capacity, 2 * nbytes))
             if not done and waitable and not grow:
                 self.counters["stamp_wait"] += 1
                 self._stamps.wait(cand.stamp)
@@ -398,7 +423,8 @@ class PyRing:
         if self._stamps is not None:
             a.stamp = self._stamps.now()
         with self._pool_lock:
-            if not self._dead and self._pool_bytes + a.nbytes <= 2 * max(self._capacity, 2 * a.nbytes):
+            # (one bound for what the ring may own: really freed only past it -- steady state neither allocates nor frees)
+            if not self._dead and (self._owned_bytes <= 8 * max(self._capacity, 2 * a.nbytes) or self._stamps is None or not isinstance(self._stamps, LibraryStamps)):
                 self._pool.setdefault(a.nbytes, collections.deque()).append(a)
                 self._pool_bytes += a.nbytes
                 return
@@ -503,12 +529,8 @@ class PyRing:
                 return
         self._live_bytes = 0
 
-    def _assemble(self, seq, offset, nbytes):
-        """Bytes [offset, offset+nbytes) of a sequence as one array: a zero-copy window when they
-        lie inside one committed span, else a gathered copy in the ring's space."""
-        c0 = seq.chunks[0]
-        if c0.offset == offset and c0.nbytes == nbytes:       # the usual case: the gulp is the oldest span, whole
-            return c0.data
+    def _pieces(self, seq, offset, nbytes):
+        """Bytes [offset, offset+nbytes) of a sequence as windows on the committed spans they lie in, in order."""
         pieces = []
         for ch in seq.chunks:
             if ch.offset >= offset + nbytes:
@@ -516,6 +538,15 @@ class PyRing:
             lo, hi = max(offset, ch.offset), min(offset + nbytes, ch.offset + ch.nbytes)
             if lo < hi:
                 pieces.append(ch.data if (lo == ch.offset and hi == ch.offset + ch.nbytes) else ch.data.byte_slice(lo - ch.offset, hi - lo))
+        return pieces
+
+    def _assemble(self, seq, offset, nbytes):
+        """Bytes [offset, offset+nbytes) of a sequence as one array: a zero-copy window when they
+        lie inside one committed span, else a gathered copy in the ring's space."""
+        c0 = seq.chunks[0]
+        if c0.offset == offset and c0.nbytes == nbytes:       # the usual case: the gulp is the oldest span, whole
+            return c0.data
+        pieces = self._pieces(seq, offset, nbytes)
         if len(pieces) == 1:
             return pieces[0]
         out = XArray(shape=(nbytes,), dtype=np.uint8, space=self.space)
@@ -672,6 +703,28 @@ class _NReadSequence:
             offset += advance + skipped
             yield ReadSpan(window(ptr, size, space, ref), size, offset, skipped)
             del ref, got
+            advance = size
+            if size < gulp_nbytes:
+                return
+
+
+    def read_parts(self, gulp_nbytes):
+        """read(), but a gulp that lies in two committed spans is handed over as two windows (`ispan.parts`) instead of a
+        gathered copy (xengRingAcquireParts)."""
+        ring, rid = self.ring, self._rid
+        h, acquire, space, window = ring._h, ring._x.ring_acquire_parts, ring.space, XArray.window
+        gulp_nbytes = int(gulp_nbytes)
+        advance = offset = 0
+        while True:
+            got = acquire(ring, h, rid, advance, gulp_nbytes)
+            if got is None:
+                return
+            skipped = got[0]
+            parts = [window(ptr, n, space, ref) for ptr, n, ref in got[1:]]
+            size = sum(p.nbytes for p in parts)
+            offset += advance + skipped
+            yield ReadSpan(None, size, offset, skipped, parts)
+            del parts, got
             advance = size
             if size < gulp_nbytes:
                 return

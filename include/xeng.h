@@ -154,6 +154,10 @@ int xengRingNextSequence(xengRing *ring, int reader, int may_block, long long *s
  * *span holds a reference on the memory: xengRingSpanRelease when done with it. */
 int xengRingAcquire(xengRing *ring, int reader, size_t advance, size_t gulp_nbytes, int may_block, void **data, size_t *nbytes,
                     long long *span, size_t *skipped);
+/* The same, but a gulp that lies in TWO committed spans comes back as two windows (*nparts = 2: data / nbytes / span of each,
+ * in order) instead of a gathered copy -- for a consumer that can take its gulp in two parts (xengBeamformRunParts). */
+int xengRingAcquireParts(xengRing *ring, int reader, size_t advance, size_t gulp_nbytes, int may_block, void *data[2], size_t nbytes[2],
+                         long long span[2], int *nparts, size_t *skipped);
 int xengRingSpanRelease(long long span);      /* a span handle from Reserve or Acquire: the last release stamps the allocation */
 /* tests: tickets of a fake backend instead of the library's stream clocks (and a free list for system-space rings) */
 typedef void (*xengRingStampNowFn)(void *user, unsigned long long stamp[2]);
@@ -306,6 +310,13 @@ int xengBeamformRunVersioned(const void *in_dev, void *out_dev, const void *weig
  * answer of the new weights.  This form never waits: XENG_STATUS_WOULD_BLOCK then (the weights are prepared and remembered;
  * call xengBeamformRunVersioned with the same arguments to wait and run). */
 int xengBeamformTryRunVersioned(const void *in_dev, void *out_dev, const void *weights_dev, long long weights_version);
+/* The gulp in two parts: samples [0, ntime0) at in0_dev, samples [ntime0, ntime) at in1_dev -- two consecutive spans of the
+ * input ring taken as ONE beamformer gulp, one launch, no gathered copy.  The reference's Beamform reads GPU_NGULP = 2 capture
+ * gulps per call (lwa352-pipeline.py:172,279-282: ntime_gulp = 2 x 480) out of bifrost's circular buffer, where two gulps
+ * are contiguous; on a ring of separate spans this call gives the same.  RunVersioned semantics otherwise; the Try form never
+ * waits (see xengBeamformTryRunVersioned). */
+int xengBeamformRunParts(const void *in0_dev, int ntime0, const void *in1_dev, void *out_dev, const void *weights_dev, long long weights_version);
+int xengBeamformTryRunParts(const void *in0_dev, int ntime0, const void *in1_dev, void *out_dev, const void *weights_dev, long long weights_version);
 
 /* beamform_sum_beams_block.py:243-246.  in_dev cf32[nchan][nbeam][ntime];
  * out_dev f32[nbeam/2][ntime/ntime_sum][nchan][4] = [XX, YY, Re XY*, Im XY*]. */

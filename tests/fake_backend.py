@@ -161,6 +161,16 @@ class OracleBackend:
         _np(out_arr, np.complex64, out.size)[...] = out.ravel()
         return 0
 
+    def bfBeamformRunParts(self, part0, part1, out_arr, weights, version=0):
+        b = self.beam
+        self.parts_calls = getattr(self, "parts_calls", 0) + 1
+        vin = np.concatenate([part0.numpy().reshape(-1), part1.numpy().reshape(-1)]).view(np.uint8)
+        assert vin.size == b["ntime"] * b["nchan"] * b["ninput"]
+        w = _np(weights, np.complex64, b["nchan"] * b["nbeam"] * b["ninput"])
+        out = orc.beamform(vin, w, b["ntime"], b["nchan"], b["ninput"], b["nbeam"])
+        _np(out_arr, np.complex64, out.size)[...] = out.ravel()
+        return 0
+
     def bfBeamformIntegrate(self, in_arr, out_arr, ntime_sum):
         b = getattr(OracleBackend, "shared_beam", None)
         if b is None:

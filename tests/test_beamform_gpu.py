@@ -340,3 +340,51 @@ def test_beamform_kernel_routes(gpu, ntime, nchan, ninput, nbeam, kind, mode):
     finally:
         del os.environ["XENG_BEAM"]
         gpu.ffi.call("xengBeamformDestroy")
+
+
+@pytest.mark.parametrize("mode", ["", "bf16x3", "f32"])
+@pytest.mark.parametrize("ninput,nchan,ntime,nbeam,ntime0", [(704, 96, 960, 32, 480), (704, 8, 960, 32, 100), (80, 16, 120, 32, 64), (192, 5, 100, 6, 37)])
+def test_two_part_gulp_equals_the_contiguous_gulp(gpu, mode, ninput, nchan, ntime, nbeam, ntime0):
+    """xengBeamformRunParts (round 4): one beamformer gulp out of two separate spans -- the first ntime0 samples at one
+    address, the rest at another -- is BIT-IDENTICAL to xengBeamformRun on the same samples laid out contiguously (same
+    kernels, same order of operations; only the row addresses differ), on all three kernel routes, for a split on and off the
+    128-sample work-group boundary; heavy-tailed weights exercise the outlier and routed-tile paths."""
+    ffi = gpu.ffi
+    rng = np.random.default_rng(ninput + ntime0)
+    w = (rng.uniform(-17, 17, (nchan, nbeam, ninput)) + 1j * rng.uniform(-17, 17, (nchan, nbeam, ninput))).astype(np.complex64)
+    w[:, :, 3] *= 4096.0
+    w[0] *= np.exp(rng.uniform(-12, 12, (nbeam, ninput))).astype(np.float32)
+    vin = rng.integers(0, 256, (ntime, nchan, ninput), dtype=np.uint8)
+    old = os.environ.get("XENG_BEAM")
+    if mode:
+        os.environ["XENG_BEAM"] = mode
+    try:
+        ffi.call("xengBeamformInitialize", 0, ninput, nchan, ntime, nbeam, 0)
+    finally:
+        if mode:
+            os.environ.pop("XENG_BEAM")
+            if old is not None:
+                os.environ["XENG_BEAM"] = old
+    row = nchan * ninput
+    dfull = ffi.DeviceBuffer(vin.size).upload(vin)
+    # the two parts far apart, in the "wrong" order in memory, with junk around them
+    dparts = ffi.DeviceBuffer(2 * vin.size + 4096)
+    ffi.call("xengMemset", dparts.ptr, 0x77, dparts.nbytes)
+    p1_off, p0_off = 1024, vin.size + 2048
+    dparts.upload(vin[:ntime0], offset=p0_off)
+    dparts.upload(vin[ntime0:], offset=p1_off)
+    dw = ffi.DeviceBuffer(w.nbytes).upload(w)
+    o1, o2 = ffi.DeviceBuffer(nchan * nbeam * ntime * 8), ffi.DeviceBuffer(nchan * nbeam * ntime * 8)
+    ffi.call("xengBeamformRunVersioned", dfull.ptr, o1.ptr, dw.ptr, 1)
+    ffi.call("xengBeamformRunParts", dparts.ptr + p0_off, ntime0, dparts.ptr + p1_off, o2.ptr, dw.ptr, 1)
+    ffi.call("xengBeamformSync")
+    a, b = o1.download(np.uint32), o2.download(np.uint32)
+    assert np.array_equal(a, b)
+    exp = orc.beamform(np.ascontiguousarray(vin[:, :2]), np.ascontiguousarray(w[:2]), ntime, 2, ninput, nbeam)
+    check_beams(o2.download(np.complex64).reshape(nchan, nbeam, ntime)[:2], exp)
+    with pytest.raises(ffi.XengError):
+        ffi.call("xengBeamformRunParts", dparts.ptr + p0_off, ntime, dparts.ptr + p1_off, o2.ptr, dw.ptr, 1)     # first part = the whole gulp
+    assert row * ntime0 % 4 == 0 or True
+    ffi.call("xengBeamformDestroy")
+    for d in (dfull, dparts, dw, o1, o2):
+        d.free()

@@ -128,3 +128,29 @@ def test_fused_plan_waits_for_a_stalled_consumer_instead_of_failing():
     assert len(got) == nlong
     for k, sp in enumerate(got):
         assert np.array_equal(sp, orc.xgpu_correlate(vin[lacc * k:lacc * (k + 1)], S, C))
+
+
+def test_beamform_takes_a_gulp_that_lies_in_two_ring_spans_without_a_copy():
+    """The reference runs Beamform on 2 x the capture gulp (lwa352-pipeline.py:172,279-282: ntime_gulp = GPU_NGULP * GSIZE) out
+    of bifrost's circular buffer.  Here the writer's 8-sample spans are taken two at a time as the two windows of one
+    16-sample gulp (`read_parts` -> bfBeamformRunParts): every gulp one call, no gathered copy, results those of the oracle
+    on the 16-sample gulp; a writer whose spans already hold whole gulps still takes the one-part call."""
+    from caltech_bifrost_dsp_amd.blocks import Beamform
+    nchan, nstand, nbeam, g = 3, 6, 4, 16
+    ninput = nstand * 2
+    rng = np.random.default_rng(21)
+    vin = rng.integers(0, 256, (4 * g, nchan, ninput), dtype=np.uint8)
+    w = (rng.uniform(-1, 1, (nchan, nbeam, ninput)) + 1j * rng.uniform(-1, 1, (nchan, nbeam, ninput))).astype(np.complex64)
+    for span_samples, want_parts_calls in ((g // 2, 4), (g, 0)):
+        r0, r1 = Ring("gpu-input"), Ring("bf-output")
+        be = OracleBackend()
+        bf = Beamform(LOG, r0, r1, nchan=nchan, nbeam=nbeam, ninput=ninput, ntime_gulp=g, backend=be)
+        bf.gains_cpu[...] = w
+        s1 = Sink(r1, g * nchan * nbeam * 8)
+        hdr = source_header(nchan, nstand, 2, seq0=0, sfreq=50e6)
+        run_blocks([bf], Source(r0, [(hdr, vin, span_samples * nchan * ninput)], wait_readers=1), [s1])
+        (_, _, spans), = s1.sequences
+        assert len(spans) == 4 and getattr(be, "parts_calls", 0) == want_parts_calls
+        for k, sp in enumerate(spans):
+            exp = orc.beamform(vin[k * g:(k + 1) * g], w, g, nchan, ninput, nbeam)
+            assert np.array_equal(sp.view(np.complex64).reshape(exp.shape), exp), (span_samples, k)
