@@ -231,7 +231,7 @@ def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=4
             "ring_allocations": {r.name: {k: int(v) for k, v in dict(r.counters).items() if k in ("alloc", "free", "reuse", "stamp_wait")}
                                  for r in (r_vis, r_slow, r_bf, r_pow)},
             "note": "config 5 through the blocks on one GPU: Corr -> CorrAcc (%d dumps per long integration, accumulated by the "
-                    "dumps' epilogue; published to a pinned-host ring) and Beamform (480-sample gulps) -> BeamformSumBeams, four "
+                    "dumps' epilogue; published to a pinned-host ring) and Beamform (960-sample gulps = two input spans per call) -> BeamformSumBeams, four "
                     "Python threads on in-repo rings, zero-copy replay source; wall rate between visibility spans at a sink" % long_len}
 
 

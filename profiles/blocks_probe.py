@@ -112,9 +112,10 @@ def main():
         run.ring.upload(rs.randint(0, 255, size=gulp_bytes, dtype=np.uint8), offset=g * gulp_bytes)
     for which in (["corr"], ["corr", "cacc"], ["corr", "cacc", "classic"], ["corr"], ["corr", "cacc"], ["bf"], ["bf", "sb"], ["corr", "bf"], ["corr", "bf", "sb"], ["corr", "cacc", "bf", "sb"]):
         run(which, nint)
-    run(["corr", "cacc", "bf", "sb"], nint, beam_gulp=960)
-    run(["corr", "cacc", "bf", "sb"], nint, depth=8)
-    run(["corr", "cacc", "bf", "sb"], nint, depth=1)
+    for which in (["bf", "sb"], ["corr", "bf", "sb"], ["corr", "cacc", "bf", "sb"], ["corr", "cacc", "bf", "sb"]):
+        run(which, nint, beam_gulp=960)
+    run(["corr", "cacc", "bf", "sb"], nint, beam_gulp=960, depth=8)
+    run(["corr", "cacc", "bf", "sb"], nint, beam_gulp=960, depth=2)
 
 
 if __name__ == "__main__":

@@ -34,6 +34,12 @@ def timed(owner, name, label):
 
 
 timed(threading.Condition, "wait", "ring wait")
+# the native ring (round 4): its calls wait inside the extension
+from caltech_bifrost_dsp_amd import _xfast  # noqa: E402
+for n in ("ring_acquire", "ring_acquire_parts", "ring_reserve", "ring_next_sequence", "ring_commit_external", "ring_commit"):
+    timed(_xfast, n, "ring call (work + wait): " + n)
+for n in ("beam_run", "beam_run_parts", "beam_integrate", "beam_mark", "beam_ticket_done", "xgpu_kernel_async", "xgpu_kernel_async_acc", "xgpu_dump_done"):
+    timed(_xfast, n, "enqueue / query: " + n)
 for n in ("beam_wait", "xgpu_sync_lag", "map_sync", "stream_synchronize", "beam_sync", "xgpu_sync"):
     timed(backend.HipBackend, n, "library wait: " + n)
 for n in ("bfBeamformRun", "bfBeamformIntegrate", "beam_mark", "bfXgpuKernelAsync", "bfXgpuKernelAsyncAcc", "map_add_i32", "map_assign_i32"):
@@ -60,9 +66,10 @@ def main():
     rs = np.random.RandomState(0xdeadbeef)
     for g in range(10):
         bp.run.ring.upload(rs.randint(0, 255, size=gulp_bytes, dtype=np.uint8), offset=g * gulp_bytes)
-    bp.run(["corr", "cacc", "bf", "sb"], 400)          # warm-up: the pinned spans of the slow ring exist afterwards
+    bg = int(os.environ.get("XENG_PROBE_BEAM_GULP", "960"))
+    bp.run(["corr", "cacc", "bf", "sb"], 400, beam_gulp=bg)          # warm-up: the pinned spans of the slow ring exist afterwards
     acc.clear(); born.clear()
-    bp.run(["corr", "cacc", "bf", "sb"], nint)
+    bp.run(["corr", "cacc", "bf", "sb"], nint, beam_gulp=bg)
     for th in sorted(born):
         tot = born[th]
         waits = sum(v[0] for v in acc[th].values())
