@@ -238,6 +238,37 @@ class CorrAcc(Block):
         acquire_time = reserve_time = 0
         time_tag = 1
         self.update_stats({'state': 'starting'})
+        # Fused mode publishes without stopping: the copy of a finished long integration into the (pinned-host) output span --
+        # 383 MB over PCIe, 7 ms, twenty short integrations' worth -- is only enqueued; a short-lived helper thread waits for
+        # it (interpreter lock released), commits the span and hands the accumulator pair back to Corr, while this thread
+        # goes on following the upstream spans: corr-output never backs up into Corr and the X-engine keeps running.  (The
+        # other pair accumulates the next long integration; one publish in flight at a time.)
+        self._publishing = None                   # (helper thread, copy stamp, [exception])
+        async_publish = hasattr(self._bf, 'copy_async')
+
+        def start_publish(osp, acc_set, stamp):
+            err = []
+
+            def complete():
+                try:
+                    self._bf.copy_wait(stamp)
+                    osp.close()
+                except Exception as e:            # (re-raised by the block's thread at the next join)
+                    err.append(e)
+                finally:
+                    with self._plan_cv:
+                        self._set_busy[acc_set] = False
+                        self._plan_cv.notify_all()
+            th = threading.Thread(target=complete, name="corracc-publish", daemon=True)
+            self._publishing = (th, stamp, err)
+            th.start()
+
+        def finish_publish():
+            pub, self._publishing = self._publishing, None
+            if pub is not None:
+                pub[0].join()
+                if pub[2]:
+                    raise pub[2][0]
         try:
             with self.oring.begin_writing() as oring:
                 prev_time = time.time()
@@ -268,6 +299,7 @@ class CorrAcc(Block):
                         now += step
                         self.update_stats({'state': d.state})
                         if d.kind == 'stop':
+                            finish_publish()
                             if oseq:
                                 oseq.end()
                             oseq = None
@@ -275,6 +307,7 @@ class CorrAcc(Block):
                         if d.kind == 'wait':
                             continue
                         if d.begin_hdr is not None:
+                            finish_publish()            # (its span belongs to the sequence that ends here)
                             if oseq:
                                 oseq.end()
                             self.sequence_proclog.update(d.begin_hdr)
@@ -313,15 +346,20 @@ class CorrAcc(Block):
                                     if rv != self._bf.BF_STATUS_SUCCESS:
                                         raise RuntimeError("CorrAcc map returned %d: %s" % (rv, self._bf.last_error()))
                                     self._bf.map_sync()
+                            finish_publish()            # (one copy in flight at a time: the previous one is long done)
                             ospan = WriteSpan(oseq.ring, self.ogulp_size, nonblocking=False)
                             odata = ospan.data_view('i32').reshape(result.shape)
-                            copy_array(odata, result)         # (synchronous: complete before the span is committed)
-                            ospan.close()
-                            ospan = None
-                            if fused:
-                                with self._plan_cv:
-                                    self._set_busy[d.acc_set] = False
-                                    self._plan_cv.notify_all()
+                            if fused and async_publish:
+                                start_publish(ospan, d.acc_set, self._bf.copy_async(odata, result))
+                                ospan = None
+                            else:
+                                copy_array(odata, result)     # (synchronous: complete before the span is committed)
+                                ospan.close()
+                                ospan = None
+                                if fused:
+                                    with self._plan_cv:
+                                        self._set_busy[d.acc_set] = False
+                                        self._plan_cv.notify_all()
                             curr_time = time.time()
                             process_time += curr_time - prev_time
                             prev_time = curr_time
@@ -329,11 +367,15 @@ class CorrAcc(Block):
                                                       'process_time': process_time})
                             self.update_stats({'last_end_sample': d.now})
                             process_time = 0
+                finish_publish()
                 if ospan:
                     ospan.close()
                 if oseq:
                     oseq.end()
         finally:
+            if self._publishing is not None:      # (an exception: the copy in flight still writes its span -- wait before it is let go)
+                self._publishing[0].join()
+                self._publishing = None
             with self._plan_cv:                   # a Corr thread waiting for an accumulator pair must not hang
                 self._stopping = True
                 self._plan_cv.notify_all()

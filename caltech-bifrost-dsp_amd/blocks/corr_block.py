@@ -48,8 +48,8 @@ class Corr(Block):
         self._bf = backend if backend is not None else default_backend()
         self.ntime_gulp = ntime_gulp
         self.nchan, self.npol, self.nstand = nchan, npol, nstand
-        declare_streams(iring, 'xgpu')          # (spans of these rings are read / written by the X-engine's streams)
-        declare_streams(oring, 'xgpu')
+        declare_streams(iring, 'xgpu')          # (gulps: read by whichever contraction they were registered for)
+        declare_streams(oring, 'xgpu_out')      # (visibility spans: written by their own dump and by nothing else on those streams)
         self.matlen = nchan * (nstand // 2 + 1) * (nstand // 4) * npol * npol * 4
         self.gpu = gpu
         self.test = test

@@ -132,8 +132,7 @@ static void buf_stamp(Buf* b) {
     RingCore* r = b->ring;
     if (r->hook_now) r->hook_now(r->hook_user, b->hook_stamp);
     else if (b->space != XENG_SPACE_SYSTEM) {
-        (void)stamp_now(&b->stamp);
-        if (r->stream_mask) b->stamp.mask = r->stream_mask;
+        (void)stamp_now(&b->stamp, b->ptr, r->stream_mask ? r->stream_mask : (unsigned)STAMP_ALL);
     }
 }
 
@@ -403,7 +402,7 @@ int xengRingSetStampHooks(xengRing* ring, xengRingStampNowFn now, xengRingStampD
 int xengRingDeclareStreams(xengRing* ring, unsigned classes) {
     RING_ARG(ring);
     std::lock_guard<std::mutex> lk(r->pool_mu);
-    r->stream_mask |= classes & STAMP_ALL;
+    r->stream_mask |= classes & (STAMP_ALL | STAMP_XGPU_OUT);
     return XENG_STATUS_SUCCESS;
 }
 

@@ -386,13 +386,21 @@ void xgpu_pending_launch(unsigned long long* seq, unsigned long long* epoch, uns
 
 // have all contractions up to launch number `upto` of context generation `ctx` completed?  Every launch owns a completion
 // event (ev_ring) and the streams take the launches in rotation, so the last nmm launches cover every stream: nothing is recorded.
-int xgpu_launches_poll(unsigned long long upto, unsigned long long ctx, bool* done, hipEvent_t* ev) {
+unsigned long long xgpu_last_writer(const void* buf) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    XgpuContext& x = g_ctx;
+    if (!x.live || !buf) return 0;
+    auto it = x.writers.find(buf);
+    return it == x.writers.end() ? 0 : it->second.seq;
+}
+
+int xgpu_launches_poll(unsigned long long upto, unsigned long long ctx, bool* done, hipEvent_t* ev, bool exact) {
     std::lock_guard<std::mutex> lk(g_mu);
     XgpuContext& x = g_ctx;
     *done = true;
     if (ev) *ev = nullptr;
     if (upto == 0 || !x.live || ctx != g_ctx_gen) return XENG_STATUS_SUCCESS;      // (a destroyed context has waited for its streams)
-    for (int k = 0; k < x.nmm && (unsigned long long)k < upto; k++) {
+    for (int k = 0; k < (exact ? 1 : x.nmm) && (unsigned long long)k < upto; k++) {
         if (hipEvent_t e = launch_event(upto - k)) {
             const hipError_t q = hipEventQuery(e);
             if (q == hipErrorNotReady) {

@@ -54,15 +54,18 @@ void stream_tick(StreamId which);                                   // call afte
 // Which streams can have touched a buffer (a ring's blocks declare it: xengRingDeclareStreams; default: all of them).  A stamp
 // waits only for those: a span of the beamformer's output ring does not wait for the 200 us contraction that happened to be
 // enqueued before its release.
-enum StampClass { STAMP_XGPU = 1, STAMP_MAP = 2, STAMP_BEAM = 4, STAMP_COPY = 8, STAMP_CONSUMER = 16, STAMP_ALL = 31 };
+// STAMP_XGPU_OUT: spans that contractions only WRITE (a visibility span, a long accumulator): the stamp then names the last
+// launch enqueued into that very buffer (the X-engine keeps that per buffer anyway) instead of every launch enqueued so far.
+enum StampClass { STAMP_XGPU = 1, STAMP_MAP = 2, STAMP_BEAM = 4, STAMP_COPY = 8, STAMP_CONSUMER = 16, STAMP_ALL = 31, STAMP_XGPU_OUT = 32 };
 struct Stamp {
     int dev = -1;                                                   // -1: nothing to wait for
     unsigned mask = STAMP_ALL;
     unsigned long long clk[STREAM_COUNT] = {};                      // (the contraction streams' entries are unused: xgpu_launch)
     unsigned long long xgpu_seq = 0, xgpu_epoch = 0;                // gulps registered with the X-engine but not contracted yet: the launch that will read them
     unsigned long long xgpu_launch = 0, xgpu_ctx = 0;               // contractions enqueued so far (each owns a completion event: none is recorded for a stamp)
+    bool xgpu_exact = false;                                        // xgpu_launch is the one launch that writes the buffer (STAMP_XGPU_OUT)
 };
-int stamp_now(Stamp* s);
+int stamp_now(Stamp* s, const void* buf = nullptr, unsigned mask = STAMP_ALL);
 // *done: every clock has passed; *waitable false: it waits for a launch nobody has enqueued yet (only its enqueuer can end that wait)
 int stamp_poll(const Stamp& s, bool* done, bool* waitable);
 int stamp_wait(const Stamp& s);                                     // blocks (event waits happen outside every library lock)
@@ -73,7 +76,8 @@ void stream_clock_external_mark(StreamId which, hipEvent_t ev, unsigned long lon
 // X-engine side of a stamp (xcorr.hip)
 void xgpu_pending_launch(unsigned long long* seq, unsigned long long* epoch, unsigned long long* nlaunch, unsigned long long* ctx);
 int xgpu_pending_poll(unsigned long long seq, unsigned long long epoch, bool* done, bool* launched, hipEvent_t* ev, int* gpu);
-int xgpu_launches_poll(unsigned long long upto, unsigned long long ctx, bool* done, hipEvent_t* ev);
+int xgpu_launches_poll(unsigned long long upto, unsigned long long ctx, bool* done, hipEvent_t* ev, bool exact = false);
+unsigned long long xgpu_last_writer(const void* buf);               // number of the last enqueued launch that writes buf (0: none on record = long done)
 
 // Experiment / diagnostic switches (grid sizes, map variants, clock stamps, item order ...) exist only in
 // -DXENG_DIAGNOSTICS builds (profiles/); the shipped library reads XENG_RAW, XENG_BEAM[_F32] and XENG_TILING only.

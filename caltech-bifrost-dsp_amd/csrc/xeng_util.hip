@@ -190,8 +190,9 @@ static unsigned class_of(int stream) {
     }
 }
 
-int stamp_now(Stamp* s) {
+int stamp_now(Stamp* s, const void* buf, unsigned mask) {
     *s = Stamp();
+    s->mask = mask;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) {
         (void)hipGetLastError();
@@ -200,6 +201,11 @@ int stamp_now(Stamp* s) {
     s->dev = dev;
     for (int k = 0; k < STREAM_COUNT; k++) s->clk[k] = g_clock[dev][k].enq.load(std::memory_order_acquire);
     xgpu_pending_launch(&s->xgpu_seq, &s->xgpu_epoch, &s->xgpu_launch, &s->xgpu_ctx);
+    if ((mask & STAMP_XGPU_OUT) && !(mask & STAMP_XGPU) && buf) {       // a span contractions only write: its own last launch
+        s->xgpu_launch = xgpu_last_writer(buf);
+        s->xgpu_exact = true;
+        s->xgpu_seq = 0;
+    }
     return XENG_STATUS_SUCCESS;
 }
 
@@ -220,10 +226,10 @@ static int stamp_pass(const Stamp& s, bool* done, bool* waitable, hipEvent_t* wa
             if (wait_ev && !*wait_ev) *wait_ev = ev;
         }
     }
-    if (s.mask & STAMP_XGPU) {
+    if (s.mask & (STAMP_XGPU | STAMP_XGPU_OUT)) {
         bool d = true;
         hipEvent_t ev = nullptr;
-        int rc = xgpu_launches_poll(s.xgpu_launch, s.xgpu_ctx, &d, &ev);
+        int rc = xgpu_launches_poll(s.xgpu_launch, s.xgpu_ctx, &d, &ev, s.xgpu_exact);
         if (rc) return rc;
         if (!d) {
             *done = false;
@@ -424,12 +430,13 @@ static void stamp_pack(const Stamp& s, xengStamp* o) {
     memset(o, 0, sizeof(*o));
     o->w[0] = (unsigned long long)(s.dev + 1) | ((unsigned long long)s.mask << 32);
     for (int k = 0; k < 5; k++) o->w[1 + k] = s.clk[PACKED_STREAMS[k]];
-    o->w[6] = s.xgpu_seq; o->w[7] = s.xgpu_epoch; o->w[8] = s.xgpu_launch; o->w[9] = s.xgpu_ctx;
+    o->w[6] = s.xgpu_seq; o->w[7] = s.xgpu_epoch; o->w[8] = s.xgpu_launch; o->w[9] = s.xgpu_ctx; o->w[10] = s.xgpu_exact ? 1 : 0;
 }
 static void stamp_unpack(const xengStamp* o, Stamp* s) {
     *s = Stamp();
     s->dev = (int)(o->w[0] & 0xFFFFFFFFull) - 1;
-    s->mask = (unsigned)(o->w[0] >> 32) & STAMP_ALL;
+    s->mask = (unsigned)(o->w[0] >> 32) & (STAMP_ALL | STAMP_XGPU_OUT);
+    s->xgpu_exact = o->w[10] != 0;
     for (int k = 0; k < 5; k++) s->clk[PACKED_STREAMS[k]] = o->w[1 + k];
     s->xgpu_seq = o->w[6]; s->xgpu_epoch = o->w[7]; s->xgpu_launch = o->w[8]; s->xgpu_ctx = o->w[9];
 }
@@ -438,6 +445,14 @@ int xengStampNow(xengStamp* stamp) {
     if (!stamp) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "StampNow: null stamp");
     Stamp s;
     int rc = stamp_now(&s);
+    if (rc) return rc;
+    stamp_pack(s, stamp);
+    return XENG_STATUS_SUCCESS;
+}
+int xengStampNowFor(xengStamp* stamp, const void* buf, unsigned classes) {
+    if (!stamp) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "StampNowFor: null stamp");
+    Stamp s;
+    int rc = stamp_now(&s, buf, classes ? (classes & (STAMP_ALL | STAMP_XGPU_OUT)) : (unsigned)STAMP_ALL);
     if (rc) return rc;
     stamp_pack(s, stamp);
     return XENG_STATUS_SUCCESS;

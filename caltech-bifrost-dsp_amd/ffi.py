@@ -38,7 +38,7 @@ class XengStamp(ctypes.Structure):
 
 
 STATUS_WOULD_BLOCK, STATUS_END_OF_DATA = 6, 7
-STREAMS = {"xgpu": 1, "map": 2, "beam": 4, "copy": 8, "consumer": 16}       # include/xeng.h XENG_STREAMS_*
+STREAMS = {"xgpu": 1, "map": 2, "beam": 4, "copy": 8, "consumer": 16, "xgpu_out": 32}       # include/xeng.h XENG_STREAMS_*
 # test hooks of the span rings (xengRingSetStampHooks)
 STAMP_NOW_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong))
 STAMP_DONE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong))
@@ -51,7 +51,7 @@ _pa = ctypes.POINTER(XENGarray)
 _ll, _pll, _psz, _pvp = ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_void_p)
 _pst = ctypes.POINTER(XengStamp)
 SYMBOLS = {
-    "xengStampNow": [_pst], "xengStampDone": [_pst, _pi, _pi], "xengStampWait": [_pst],
+    "xengStampNow": [_pst], "xengStampNowFor": [_pst, _vp, ctypes.c_uint], "xengStampDone": [_pst, _pi, _pi], "xengStampWait": [_pst],
     "xengRingCreate": [_pvp, ctypes.c_char_p, _i], "xengRingDestroy": [_vp], "xengRingResize": [_vp, _sz, _sz], "xengRingSetRecycle": [_vp, _i], "xengRingDeclareStreams": [_vp, ctypes.c_uint],
     "xengRingGetInfo": [_vp, _psz, _psz, _psz, _pi, _pll, ctypes.POINTER(ctypes.c_ulonglong)],
     "xengRingBeginSequence": [_vp, _ll, ctypes.c_char_p, _sz, _i, _pll], "xengRingEndSequence": [_vp, _ll], "xengRingEndWriting": [_vp],
@@ -128,7 +128,7 @@ ENQUEUE_ONLY = ["xengXgpuTryKernelAsyncAcc", "xengBeamformTryRunVersioned", "xen
                 "xengRingBeginSequence", "xengRingEndSequence", "xengRingEndWriting", "xengRingReserve", "xengRingCommit",
                 "xengRingCommitExternal", "xengRingNextSequence", "xengRingAcquire", "xengRingAcquireParts", "xengRingSpanRelease", "xengRingGetInfo",
                 "xengRingOpenReader", "xengRingCloseReader", "xengRingResize",
-                "xengStampNow", "xengStampDone"]
+                "xengStampNow", "xengStampNowFor", "xengStampDone"]
 _enq = None
 
 

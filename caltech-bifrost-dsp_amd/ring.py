@@ -56,11 +56,9 @@ class LibraryStamps:
     `mask`: the stream classes the ring's blocks have declared (0: none yet -> wait for all)."""
     mask = 0
 
-    def now(self):
+    def now(self, ptr=None):
         s = ffi.XengStamp()
-        ffi.check("xengStampNow", ffi.enqueue_lib().xengStampNow(ctypes.byref(s)))
-        if self.mask:
-            s.w[0] = (s.w[0] & 0xFFFFFFFF) | (self.mask << 32)
+        ffi.check("xengStampNowFor", ffi.enqueue_lib().xengStampNowFor(ctypes.byref(s), ptr, self.mask))
         return s
 
     def done(self, s):
@@ -421,7 +419,7 @@ class PyRing:
         """The last user of a span allocation has let go: stamp it and keep it for reuse (up to the ring's capacity in bytes;
         beyond that it is really freed, behind its stamp)."""
         if self._stamps is not None:
-            a.stamp = self._stamps.now()
+            a.stamp = self._stamps.now(a.ptr) if isinstance(self._stamps, LibraryStamps) else self._stamps.now()
         with self._pool_lock:
             # (one bound for what the ring may own: really freed only past it -- steady state neither allocates nor frees)
             if not self._dead and (self._owned_bytes <= 8 * max(self._capacity, 2 * a.nbytes) or self._stamps is None or not isinstance(self._stamps, LibraryStamps)):

@@ -100,7 +100,11 @@ typedef struct xengStamp_ { unsigned long long w[16]; } xengStamp;
 #define XENG_STREAMS_COPY      8u
 #define XENG_STREAMS_CONSUMER 16u
 #define XENG_STREAMS_ALL      31u
+/* a buffer that contractions only WRITE (a visibility span, a long accumulator; never handed over as a gulp): its stamp names
+ * the last launch enqueued into that very buffer instead of every launch enqueued so far */
+#define XENG_STREAMS_XGPU_OUT 32u
 int xengStampNow(xengStamp *stamp);
+int xengStampNowFor(xengStamp *stamp, const void *buf, unsigned classes);   /* the stamp of one buffer whose users are `classes` (0: all) */
 /* non-blocking: *done = 1 when Wait would not wait; *waitable (may be NULL) = 0 when the stamp waits for an X-engine launch
  * that nobody has enqueued yet (only the owner of those gulps can end that: a dump, or xengXgpuReset) */
 int xengStampDone(const xengStamp *stamp, int *done, int *waitable);

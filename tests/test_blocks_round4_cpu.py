@@ -154,3 +154,50 @@ def test_beamform_takes_a_gulp_that_lies_in_two_ring_spans_without_a_copy():
         for k, sp in enumerate(spans):
             exp = orc.beamform(vin[k * g:(k + 1) * g], w, g, nchan, ninput, nbeam)
             assert np.array_equal(sp.view(np.complex64).reshape(exp.shape), exp), (span_samples, k)
+
+
+class _AsyncCopyBackend(OracleBackend):
+    """the oracle backend with an enqueue-only copy that completes a few polls later (the HIP backend's copy_async /
+    copy_done / copy_wait: CorrAcc's publish of a long integration)"""
+
+    def __init__(self):
+        super().__init__()
+        self.copies = []
+
+    def copy_async(self, dst, src):
+        stamp = {"dst": dst, "src": src, "done": False}
+        self.copies.append(stamp)
+        return stamp
+
+    def _complete(self, stamp):
+        if not stamp["done"]:
+            stamp["dst"].numpy().reshape(-1)[...] = stamp["src"].numpy().reshape(-1)      # (the copy lands only now)
+            stamp["done"] = True
+
+    def copy_done(self, stamp):
+        return stamp["done"]
+
+    def copy_wait(self, stamp):
+        time.sleep(0.02)                   # (the copy takes a while: the block's thread must not sit here)
+        self._complete(stamp)
+
+
+def test_fused_corracc_publishes_without_stopping():
+    """Fused mode: the copy of a finished long integration is only enqueued; a helper waits for it (20 ms here), commits the
+    span and hands the accumulator pair back, while CorrAcc goes on following the upstream spans -- also when Corr needs the
+    pair again before anything else arrives (three dumps per long integration: the pair of long integration j is wanted
+    again two long integrations later).  Every long integration arrives complete and in order, equal to N x the oracle's."""
+    C, S, g, acc, lacc = 2, 8, 2, 2, 6
+    nlong = 7
+    vin = np.random.default_rng(13).integers(0, 256, (nlong * lacc + 2, C, S, 2), dtype=np.uint8)
+    be = _AsyncCopyBackend()
+    r0, r1, r2 = Ring("gpu-input"), Ring("corr-output"), Ring("corr-slow-output")
+    corr = Corr(LOG, r0, r1, ntime_gulp=g, nchan=C, npol=2, nstand=S, acc_len=acc, autostartat=0, backend=be)
+    cacc = CorrAcc(LOG, r1, r2, nchan=C, npol=2, nstand=S, acc_len=lacc, autostartat=0, backend=be)
+    fast, slow = Sink(r1, corr.ogulp_size), Sink(r2, cacc.ogulp_size)
+    run_blocks([corr, cacc], Source(r0, [(source_header(C, S, 2), vin, g * C * S * 2)]), [fast, slow])
+    assert cacc.stats['fused'] is True and len(be.copies) == nlong and all(c["done"] for c in be.copies)
+    (_, _, spans), = slow.sequences
+    assert len(spans) == nlong
+    for k, sp in enumerate(spans):
+        assert np.array_equal(sp.view(np.int32), orc.xgpu_correlate(vin[lacc * k:lacc * (k + 1)], S, C)), k
