@@ -172,7 +172,10 @@ def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=4
     r_in = Ring("gpu-input", space="cuda")
     r_vis, r_slow = Ring("corr-output", space="cuda"), Ring("corr-slow-output", space="cuda_host")
     r_bf, r_pow = Ring("bf-output", space="cuda"), Ring("bf-pow-output", space="cuda_host")
-    r_in.resize(gulp_bytes, total_span=2 * gulps_per_step * gulp_bytes)
+    # (input ring of four integrations: Beamform alone keeps up to five 960-sample gulps = ten input spans referenced while their
+    # kernels are in flight, which was the whole of round 3's two-integration ring -- Corr then waited for gulps, not for the GPU;
+    # the spans are windows on the replay buffer, the depth costs no memory)
+    r_in.resize(gulp_bytes, total_span=4 * gulps_per_step * gulp_bytes)
     log = logging.getLogger("bench-config5")
     corr = Corr(log, r_in, r_vis, ntime_gulp=NTIME_GULP, nchan=NCHAN, npol=NPOL, nstand=NSTAND, acc_len=ACC_LEN, autostartat=0, gpu=gpu)
     cacc = CorrAcc(log, r_vis, r_slow, nchan=NCHAN, npol=NPOL, nstand=NSTAND, acc_len=long_len * ACC_LEN, autostartat=0, gpu=gpu)

@@ -23,7 +23,7 @@ NSTAND, NPOL, NCHAN, NTIME_GULP, ACC_LEN = 352, 2, 96, 480, 2400
 NINPUT = NSTAND * NPOL
 
 
-def run(which, nint, beam_gulp=480, depth=4, ring_gulps=10):
+def run(which, nint, beam_gulp=480, depth=4, ring_gulps=10, in_span=2):
     gps = ACC_LEN // NTIME_GULP
     gulp_bytes = NTIME_GULP * NCHAN * NINPUT
     ring = run.ring
@@ -31,7 +31,7 @@ def run(which, nint, beam_gulp=480, depth=4, ring_gulps=10):
     r_in = Ring("gpu-input", space="cuda")
     r_vis, r_slow = Ring("corr-output", space="cuda"), Ring("corr-slow-output", space="cuda_host")
     r_bf, r_pow = Ring("bf-output", space="cuda"), Ring("bf-pow-output", space="cuda_host")
-    r_in.resize(gulp_bytes, total_span=2 * gps * gulp_bytes)
+    r_in.resize(gulp_bytes, total_span=in_span * gps * gulp_bytes)
     log = logging.getLogger("probe")
     blocks, sinks = [], []
     stamps = []
@@ -99,7 +99,7 @@ def run(which, nint, beam_gulp=480, depth=4, ring_gulps=10):
         per = (bstamps[-1] - bstamps[k]) / (len(bstamps) - 1 - k) * (ACC_LEN / beam_gulp) * 1e3
     else:
         per = el / nint * 1e3
-    print("%-22s beam gulp %4d depth %d: %.4f ms per integration" % ("+".join(which), beam_gulp, depth, per), flush=True)
+    print("%-22s beam gulp %4d depth %d input ring %d integrations: %.4f ms per integration" % ("+".join(which), beam_gulp, depth, in_span, per), flush=True)
 
 
 def main():
@@ -116,6 +116,9 @@ def main():
         run(which, nint, beam_gulp=960)
     run(["corr", "cacc", "bf", "sb"], nint, beam_gulp=960, depth=8)
     run(["corr", "cacc", "bf", "sb"], nint, beam_gulp=960, depth=2)
+    for k in (4, 8, 4):
+        run(["corr", "cacc", "bf", "sb"], 2 * nint, beam_gulp=960, in_span=k)
+    run(["corr", "cacc", "bf", "sb"], 2 * nint, beam_gulp=960, depth=2, in_span=4)
 
 
 if __name__ == "__main__":

@@ -67,9 +67,10 @@ def main():
     for g in range(10):
         bp.run.ring.upload(rs.randint(0, 255, size=gulp_bytes, dtype=np.uint8), offset=g * gulp_bytes)
     bg = int(os.environ.get("XENG_PROBE_BEAM_GULP", "960"))
-    bp.run(["corr", "cacc", "bf", "sb"], 400, beam_gulp=bg)          # warm-up: the pinned spans of the slow ring exist afterwards
+    isp = int(os.environ.get("XENG_PROBE_IN_SPAN", "4"))
+    bp.run(["corr", "cacc", "bf", "sb"], 400, beam_gulp=bg, in_span=isp)          # warm-up: the pinned spans of the slow ring exist afterwards
     acc.clear(); born.clear()
-    bp.run(["corr", "cacc", "bf", "sb"], nint, beam_gulp=bg)
+    bp.run(["corr", "cacc", "bf", "sb"], nint, beam_gulp=bg, in_span=isp)
     for th in sorted(born):
         tot = born[th]
         waits = sum(v[0] for v in acc[th].values())
