@@ -923,18 +923,20 @@ def main():
     # (PMC counters cannot be collected inside this run; the committed figure counts only while the X-engine sources it was
     # taken from are the ones this library was built from, else traffic is null)
     traffic = None
-    try:
-        import hashlib
-        with open(os.path.join(ROOT, "profiles", "r03", "pmc_traffic.json")) as fh:
-            pmc = json.load(fh)
-        hh = hashlib.sha256()
-        for f in pmc.get("xcorr_sources", []):
-            with open(os.path.join(ROOT, "caltech-bifrost-dsp_amd", "csrc", f), "rb") as fh:
-                hh.update(fh.read())
-        if hh.hexdigest() == pmc.get("xcorr_sources_sha256"):
-            traffic = pmc.get(kname + "_bytes_per_launch")
-    except (OSError, ValueError):
-        pass
+    import hashlib
+    for rnd in ("r04", "r03"):                     # (the latest PMC pass whose X-engine sources are the ones this library was built from)
+        try:
+            with open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")) as fh:
+                pmc = json.load(fh)
+            hh = hashlib.sha256()
+            for f in pmc.get("xcorr_sources", []):
+                with open(os.path.join(ROOT, "caltech-bifrost-dsp_amd", "csrc", f), "rb") as fh:
+                    hh.update(fh.read())
+            if hh.hexdigest() == pmc.get("xcorr_sources_sha256"):
+                traffic = pmc.get(kname + "_bytes_per_launch")
+                break
+        except (OSError, ValueError):
+            pass
     res = {
         "metric": "xengine_ingest_gbps_704in_96ch", "value": round(gbps, 2), "unit": "Gb/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_steps": args.prewarm,
