@@ -23,7 +23,7 @@ from .block_base import Block, COMMAND_INVALID, COMMAND_OK, declare_streams
 
 
 class Beamform(Block):
-    STREAM_DEPTH = 4        # gulps whose kernels may be in flight behind the one being enqueued (streaming mode)
+    STREAM_DEPTH = 8        # gulps whose kernels may be in flight behind the one being enqueued (streaming mode; 4 -> 8: -2.4 %, profiles/r04/blocks_depth_sweep.txt)
 
     def __init__(self, log, iring, oring, nchan=256, nbeam=1, ninput=352 * 2, ntime_gulp=2500, ntime_sum=None,
                  guarantee=True, core=-1, gpu=-1, etcd_client=None, backend=None):

@@ -19,7 +19,7 @@ from .block_base import Block, declare_streams
 
 
 class BeamformSumBeams(Block):
-    STREAM_DEPTH = 4        # gulps whose kernel may be in flight behind the one being enqueued (streaming mode)
+    STREAM_DEPTH = 8        # gulps whose kernel may be in flight behind the one being enqueued (streaming mode)
 
     def __init__(self, log, iring, oring, nchan=256,
                  ntime_gulp=2500, ntime_sum=24, guarantee=True, core=-1, gpu=-1,
