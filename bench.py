@@ -705,25 +705,46 @@ def main():
         slabs = [dslab] + [ffi.DeviceBuffer(slab.nbytes) for _ in range(2 * gulps_per_step - 1)]
         for k in range(1, len(slabs)):
             ffi.call("xengMemcpy", slabs[k].ptr, dslab.ptr, slab.nbytes)
-        nrep, nwarm, kk = 300, 100, 0
-        for it in range(nwarm + nrep):
-            if it == nwarm:
-                ffi.call("xengXgpuSync")
-                t1 = time.perf_counter()
-            for g in range(gulps_per_step):
-                slot = kk % (2 * gulps_per_step)
-                dst = ring.ptr + slot * gulp_bytes
-                ffi.check("unpack", L.xengSnap2UnpackAsync(slabs[slot].ptr, npk, stride, dst, 0, NTIME_GULP, 0, NCHAN, NINPUT, 1))
-                ffi.check(kern, L.xengXgpuKernelAsync(dst, outs[it & 1].ptr, int(g == gulps_per_step - 1)))
-                kk += 1
-            ffi.call("xengXgpuSyncLag", 1)
-        ffi.call("xengXgpuSync")
-        el4 = time.perf_counter() - t1
-        ingest["packets_to_visibilities"] = {
+        def packets_leg(direct):
+            nrep, nwarm, kk = 300, 100, 0
+            for it in range(nwarm + nrep):
+                if it == nwarm:
+                    ffi.call("xengXgpuSync")
+                    t1 = time.perf_counter()
+                for g in range(gulps_per_step):
+                    slot = kk % (2 * gulps_per_step)
+                    if direct:      # the slab IS the gulp: verified on the device, read in place by the contraction (no scatter pass)
+                        ffi.check("slab", L.xengXgpuKernelAsyncSlab(slabs[slot].ptr, npk, stride, 0, 0, outs[it & 1].ptr, int(g == gulps_per_step - 1), None, 0))
+                    else:
+                        dst = ring.ptr + slot * gulp_bytes
+                        ffi.check("unpack", L.xengSnap2UnpackAsync(slabs[slot].ptr, npk, stride, dst, 0, NTIME_GULP, 0, NCHAN, NINPUT, 1))
+                        ffi.check(kern, L.xengXgpuKernelAsync(dst, outs[it & 1].ptr, int(g == gulps_per_step - 1)))
+                    kk += 1
+                ffi.call("xengXgpuSyncLag", 1)
+            ffi.call("xengXgpuSync")
+            return time.perf_counter() - t1, nrep
+        el4, nrep = packets_leg(False)
+        ingest["packets_to_visibilities_scatter"] = {
             "value": round(8 * NINPUT * units_per_step_c * nrep / el4 / 1e9, 1), "unit": "Gb/s",
             "ms_per_step": round(el4 / nrep * 1e3, 4),
             "note": "device-resident packet slabs (5280 packets per gulp) -> xengSnap2UnpackAsync -> xengXgpuKernelAsync, "
-                    "%d integrations" % nrep}
+                    "%d integrations (the path of rounds 2-3)" % nrep}
+        el4, nrep = packets_leg(True)
+        nfb = ctypes.c_int(-1)
+        ffi.call("xengXgpuGetSlabFallbacks", ctypes.byref(nfb))
+        slab_vis = outs[(300 + 100 - 1) & 1].download(np.int32)
+        ingest["packets_to_visibilities"] = {
+            "value": round(8 * NINPUT * units_per_step_c * nrep / el4 / 1e9, 1), "unit": "Gb/s",
+            "ms_per_step": round(el4 / nrep * 1e3, 4), "gulps_scattered_after_all": int(nfb.value),
+            "note": "device-resident packet slabs -> xengXgpuKernelAsyncSlab: every slab is verified on the device and, being "
+                    "regular, read by the contraction where it lies (no scatter pass); %d integrations" % nrep}
+        # (same slabs both ways: the two paths must agree word for word)
+        for g in range(gulps_per_step):
+            dst = ring.ptr + g * gulp_bytes
+            ffi.check("unpack", L.xengSnap2UnpackAsync(slabs[(4 * gulps_per_step + g) % (2 * gulps_per_step)].ptr, npk, stride, dst, 0, NTIME_GULP, 0, NCHAN, NINPUT, 1))
+            ffi.check(kern, L.xengXgpuKernelAsync(dst, outs[0].ptr, int(g == gulps_per_step - 1)))
+        ffi.call("xengXgpuSync")
+        ingest["packets_to_visibilities"]["equals_scatter_path"] = bool(np.array_equal(slab_vis, outs[0].download(np.int32)))
         for b in slabs:
             b.free()
         dgulp.free()

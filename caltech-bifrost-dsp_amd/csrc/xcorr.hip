@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "xcorr_kernels.h"
+#include "slab_kernels.h"
 #include "xeng_common.h"
 
 namespace xeng {
@@ -81,6 +82,10 @@ struct XgpuContext {
     uint8_t* in_dev = nullptr;
     int32_t* out_dev = nullptr;
     unsigned long long* stamps = nullptr;   // diagnostic (XENG_DBG_STAMPS=1)
+    // packet slabs as gulps (xengXgpuKernelAsyncSlab): per staging area one descriptor per gulp, written on the staging stream
+    GulpDesc* gdesc_dev[2] = {nullptr, nullptr};
+    int* slab_bad_dev = nullptr;            // [0]: verify counter (re-armed by the describe kernel), [1]: gulps that took the scratch path
+    bool slab_mode = false;                 // the gulps staged since the last flush are slabs (no mixing inside one flush)
     EventTimer timer;
 };
 
@@ -111,6 +116,9 @@ static int destroy_locked() {
     if (x.in_dev) (void)hipFree(x.in_dev);
     if (x.stamps) (void)hipFree(x.stamps);
     if (x.out_dev) (void)hipFree(x.out_dev);
+    for (int b = 0; b < 2; b++)
+        if (x.gdesc_dev[b]) (void)hipFree(x.gdesc_dev[b]);
+    if (x.slab_bad_dev) (void)hipFree(x.slab_bad_dev);
     x.timer.destroy();
     x = XgpuContext();
     g_epoch++;
@@ -147,6 +155,11 @@ static void launch_xcorr(const XcorrParams& p, hipStream_t s, bool raw, int grid
             default: break;
         }
 #endif
+        if (p.gdesc) {          // gulps by descriptor (packet slabs)
+            if (p.acc2_mode) hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<0, true, true>), grid, dim3(256), 0, s, p);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<0, false, true>), grid, dim3(256), 0, s, p);
+            return;
+        }
         if (p.acc2_mode) hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<0, true>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<0>), grid, dim3(256), 0, s, p);
         return;
@@ -223,6 +236,7 @@ static int flush_locked(void* out, bool dump, void* acc = nullptr, int acc_mode 
     p.ninput = x.ninput;
     p.fgroups = x.fgroups_dev; p.work = x.work.dev; p.maxi = x.work.maxi; p.nstage = nkt / XC_KT;
     p.acc2 = (int32_t*)acc; p.acc2_mode = acc ? acc_mode : 0;
+    p.gdesc = x.slab_mode ? x.gdesc_dev[x.cur] : nullptr;
     for (int g = 0; g < XC_MAX_GULPS; g++) p.gulps[g] = g < x.nfilled ? x.gulp_ptr[g] : nullptr;
     // the contraction starts when this area's corner turns are done and runs beside the next area's
     const int si = (int)(x.nlaunch++ % x.nmm);
@@ -274,6 +288,7 @@ static int flush_locked(void* out, bool dump, void* acc = nullptr, int acc_mode 
     }
     x.cur ^= 1;
     x.nfilled = 0;
+    x.slab_mode = false;
     x.acc_started = !dump;
     x.acc_out = dump ? nullptr : out;
     return XENG_STATUS_SUCCESS;
@@ -311,6 +326,8 @@ static int kernel_locked(const void* in_dev, void* out_dev, int doDump, bool syn
     if (((uintptr_t)out_dev & 15) || ((uintptr_t)in_dev & (x.raw ? 15 : 3)))
         XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "xgpu: out must be 16-byte and in %d-byte aligned", x.raw ? 16 : 4);
     XENG_HIP(hipSetDevice(x.gpu));
+    if (x.nfilled > 0 && x.slab_mode)
+        XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: packet slabs and plain gulps cannot be mixed between two flushes");
     if (x.nfilled == 0)                          // this staging area may still be read by an earlier contraction
         if (hipEvent_t ev = launch_event(x.area_seq[x.cur])) XENG_HIP(hipStreamWaitEvent(x.stream, ev, 0));
     uint8_t* const stash = x.stash[x.cur];
@@ -536,6 +553,14 @@ static int initialize_locked(int gpu) {
         XENG_HIP(hipMemset(x.stash[b], 0, x.stash_bytes));
     }
     XENG_HIP(hipEventCreateWithFlags(&x.ev_ct, hipEventDisableTiming));
+    if (x.raw) {
+        for (int b = 0; b < 2; b++) {
+            XENG_HIP(hipMalloc((void**)&x.gdesc_dev[b], XC_MAX_GULPS * sizeof(GulpDesc)));
+            XENG_HIP(hipMemset(x.gdesc_dev[b], 0, XC_MAX_GULPS * sizeof(GulpDesc)));
+        }
+        XENG_HIP(hipMalloc((void**)&x.slab_bad_dev, 2 * sizeof(int)));
+        XENG_HIP(hipMemset(x.slab_bad_dev, 0, 2 * sizeof(int)));
+    }
     std::vector<WgDesc> descs = build_wg_descs(x.nblk64);
     x.nwg = (int)descs.size();
     if (x.raw) {
@@ -652,6 +677,69 @@ int xengXgpuTryKernelAsyncAcc(const void* in_dev, void* out_dev, int doDump, voi
 
 int xengXgpuWaitLaunchSlot(void) { return wait_for_event_slot(true); }
 
+// A gulp handed over as the slab of packets it arrived in (slab_kernels.h): verified on the device; read in place by the
+// contraction when it is regular, scattered into the library's staging area (and read from there) when it is not.
+int xengXgpuKernelAsyncSlab(const void* packets_dev, int npkt, size_t pkt_stride, uint64_t seq0, int chan0_pipeline, void* out_dev,
+                            int doDump, void* acc_dev, int acc_mode) {
+    int rc0 = wait_for_event_slot();
+    if (rc0) return rc0;
+    std::lock_guard<std::mutex> lk(g_mu);
+    XgpuContext& x = g_ctx;
+    if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized (call xengXgpuInitialize)");
+    if (!x.raw) XENG_FAIL(XENG_STATUS_UNSUPPORTED, "xgpu: packet slabs need the default contraction kernel (unpack with xengSnap2UnpackAsync instead)");
+    if (!packets_dev || !out_dev || npkt < 0 || pkt_stride < 32 || pkt_stride > 0x7FFFFFFFu)
+        XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "xgpu: bad slab (npkt %d, stride %zu)", npkt, pkt_stride);
+    if (acc_dev) {
+        if (acc_mode != 1 && acc_mode != 2) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "xgpu: acc_mode must be 1 (assign) or 2 (add)");
+        if (((uintptr_t)acc_dev & 15) || acc_dev == out_dev) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "xgpu: accumulator must be 16-byte aligned and distinct from out");
+    }
+    if ((uintptr_t)out_dev & 15) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "xgpu: out must be 16-byte aligned");
+    if (x.nfilled > 0 && !x.slab_mode)
+        XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: packet slabs and plain gulps cannot be mixed between two flushes");
+    if (x.acc_started && x.acc_out != out_dev) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: output buffer changed inside one integration");
+    XENG_HIP(hipSetDevice(x.gpu));
+    if (x.nfilled == 0)                          // this staging area (scratch gulps, descriptors) may still be read by an earlier contraction
+        if (hipEvent_t ev = launch_event(x.area_seq[x.cur])) XENG_HIP(hipStreamWaitEvent(x.stream, ev, 0));
+    const int k = x.nfilled;
+    SlabArgs a;
+    a.pkts = (const uint8_t*)packets_dev; a.npkt = npkt; a.stride = (uint32_t)pkt_stride; a.seq0 = seq0;
+    a.ntime = x.cfg.ntime_gulp; a.chan0 = chan0_pipeline; a.nchan = x.cfg.nchan; a.ninput = x.ninput; a.nblk = x.ninput / 64;
+    // regular at all?  whole 64-input blocks, one packet per (sample, block), payload rows of 64 bytes, 16-byte pieces, and the
+    // kernel's 32-bit per-lane offsets must hold 48 rows
+    const bool maybe = x.ninput % 64 == 0 && npkt == x.cfg.ntime_gulp * a.nblk && pkt_stride >= 32 + (size_t)x.cfg.nchan * 64 &&
+                       pkt_stride % 16 == 0 && ((uintptr_t)packets_dev & 15) == 0 && (uint64_t)a.nblk * pkt_stride * 48 < (1ull << 31);
+    uint8_t* scratch = x.stash[x.cur] + (size_t)k * x.gulp_bytes;
+    GulpDesc* desc = x.gdesc_dev[x.cur] + k;
+    if (maybe && npkt > 0) hipLaunchKernelGGL(slab_verify_kernel, dim3((npkt + 255) / 256), dim3(256), 0, x.stream, a, x.slab_bad_dev);
+    hipLaunchKernelGGL(slab_describe_kernel, dim3(1), dim3(64), 0, x.stream, a, x.slab_bad_dev, desc, scratch, maybe ? 0 : 1, x.slab_bad_dev + 1);
+    hipLaunchKernelGGL(slab_clear_kernel, dim3(1024), dim3(256), 0, x.stream, desc, (uint4*)scratch, x.gulp_bytes / 16);
+    if (npkt > 0) hipLaunchKernelGGL(slab_scatter_kernel, dim3(std::min(2048, (npkt + 3) / 4)), dim3(256), 0, x.stream, desc, a, scratch);
+    XENG_HIP(hipGetLastError());
+    staging_stream_touched();
+    x.gulp_ptr[k] = nullptr;
+    x.slab_mode = true;
+    x.nfilled++;
+    if (doDump || x.nfilled == x.cap_gulps) return flush_locked(out_dev, doDump != 0, acc_dev, acc_dev ? acc_mode : 0);
+    return XENG_STATUS_SUCCESS;
+}
+
+// gulps handed over as slabs that took the scratch path (lost / reordered / foreign packets) since the last call; waits for the
+// staging stream
+int xengXgpuGetSlabFallbacks(int* nfallback) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    XgpuContext& x = g_ctx;
+    if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized");
+    if (!nfallback) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "GetSlabFallbacks: null pointer");
+    *nfallback = 0;
+    if (!x.slab_bad_dev) return XENG_STATUS_SUCCESS;
+    XENG_HIP(hipSetDevice(x.gpu));
+    XENG_HIP(hipMemcpyAsync(nfallback, x.slab_bad_dev + 1, sizeof(int), hipMemcpyDeviceToHost, x.stream));
+    XENG_HIP(hipMemsetAsync(x.slab_bad_dev + 1, 0, sizeof(int), x.stream));
+    stream_tick(STREAM_XGPU);
+    XENG_HIP(hipStreamSynchronize(x.stream));
+    return XENG_STATUS_SUCCESS;
+}
+
 int xengXgpuSync(void) {
     int gpu, nmm;
     hipStream_t st, mm[XgpuContext::NMM];
@@ -713,6 +801,7 @@ int xengXgpuReset(void) {
         XgpuContext& x = g_ctx;
         if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized");
         x.nfilled = 0;
+        x.slab_mode = false;
         x.acc_started = false;
         x.acc_out = nullptr;
         g_epoch++;

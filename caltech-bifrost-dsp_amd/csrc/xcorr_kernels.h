@@ -200,7 +200,22 @@ struct XcorrParams {
     // values this launch stores): acc2 = planar int32 buffer like `out`; acc2_mode 0 none, 1 assign, 2 add
     int32_t* acc2;
     int acc2_mode;
+    // DESC instantiation (round 4): the gulps of this launch are described in DEVICE memory, one GulpDesc each, written on the
+    // staging stream before the launch -- a gulp may then be a slab of F-engine packets read where it lies (xengXgpuKernelAsyncSlab)
+    const struct GulpDesc* gdesc;
 };
+
+// Where the bytes of one gulp lie: sample t, channel c, 64-input block b, byte j of the block at
+//   base + t * t_stride + c * c_stride + b * b_stride + j.
+// A time-major gulp u8[t][c][input]: (nchan * ninput, ninput, 64).  A regular slab of SNAP2 packets -- packet (t, b) at index
+// t * nblocks + b, 32-byte header + payload [nchan][64 inputs] (test_tx_vectors.py:38-48,103-108) --: base = slab + 32,
+// (nblocks * pkt_stride, 64, pkt_stride): the contraction reads the packets where they lie, no scatter pass.
+struct GulpDesc {
+    const uint8_t* base;
+    uint32_t t_stride, c_stride, b_stride, pad;
+    uint64_t pad2;
+};
+static_assert(sizeof(GulpDesc) == 32, "GulpDesc is read as eight aligned dwords");
 
 struct Frags {   // the 8 unpacked int8 operand fragments of one 64x64 wave tile and one K-tile
     v4i ar[2], ai[2], br[2], bi[2];
@@ -701,7 +716,9 @@ __device__ __forceinline__ void xcorr_store_cells(const XcorrParams& p, int c, c
 // ABL: timing-only ablation bits as for xcorr_mfma_kernel (diagnostic builds; results are wrong unless 0);
 // 16: no epilogue, 32: every channel reads a 1 MB window of gulp 0 that stays in L2, 64: half-item skew between the two
 // channels of a round (an experiment: results stay right).
-template <int ABL, bool LACC = false>
+// DESC: gulps by descriptor (GulpDesc above) instead of by pointer: strides are per gulp and read with scalar loads; the default
+// instantiation is untouched.
+template <int ABL, bool LACC = false, bool DESC = false>
 __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
     constexpr int KT_STAGE = XC_KT;
     constexpr int SLOT_BYTES = KT_STAGE * KT_BYTES;
@@ -736,17 +753,38 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
     int is_k = 0, is_c = 0, is_g = 0, is_sl = 0, is_issued = 0;
     uint32_t is_voff[NLOAD] = {};
     const uint8_t* is_stage = nullptr;
+    // DESC: this lane's 64-input block and byte position inside it (per item), the current gulp's layout (per gulp)
+    uint32_t is_blk = 0, is_sub = 0, d_t = row_stride, d_c = (uint32_t)p.ninput;
+    const uint8_t* d_base = nullptr;
+    const DescPtr gdesc = (DescPtr)(uintptr_t)p.gdesc;
+    auto load_desc = [&](int g) {          // gulp g's layout (scalar loads) -> this lane's six piece offsets
+        const uint32_t lo = gdesc[g * 8], hi = gdesc[g * 8 + 1];
+        d_base = (const uint8_t*)(((uint64_t)hi << 32) | lo);
+        d_t = gdesc[g * 8 + 2];
+        d_c = gdesc[g * 8 + 3];
+        const uint32_t d_b = gdesc[g * 8 + 4];
+        const uint32_t lane_off = (uint32_t)(lane >> 3) * d_t + is_blk * d_b + is_sub;
+#pragma unroll
+        for (int n = 0; n < NLOAD; n++) is_voff[n] = lane_off + (uint32_t)n * 8u * d_t - (uint32_t)((n & 3) * 1024);
+    };
     auto is_setup = [&](const Item& it) {
         is_c = it.c;
         // (columns past ninput in the last block: any valid bytes of the row; their products are never stored)
         const uint32_t slots = groups[it.wg * 8];                         // slot_blk[0..3]
         const int chunk = (lane & 7) ^ (((lane >> 4) & 3) << 1);          // source chunk 0..7 of the 128-byte pair row
         const int blk0 = (slots >> (8 * (wave & 2))) & 0xFF, blk1 = (slots >> (8 * (wave & 2) + 8)) & 0xFF;
+        if (DESC) {
+            is_blk = (uint32_t)((chunk >> 2) ? blk1 : blk0);
+            is_sub = (uint32_t)(chunk & 3) * 16u;
+            if (is_blk * 64u + is_sub + 16u > (uint32_t)p.ninput) { is_blk = 0; is_sub = 0; }
+            load_desc(0);
+        } else {
         const uint32_t col = (uint32_t)((chunk >> 2) ? blk1 : blk0) * 64u + (uint32_t)(chunk & 3) * 16u;
         const uint32_t lane_off = (uint32_t)(lane >> 3) * row_stride + (col + 16u <= (uint32_t)p.ninput ? col : 0u);
 #pragma unroll
         // (never negative: the host takes this kernel only when a row has at least 128 bytes, xengXgpuInitialize)
         for (int n = 0; n < NLOAD; n++) is_voff[n] = lane_off + (uint32_t)n * 8u * row_stride - (uint32_t)((n & 3) * 1024);
+        }
         is_g = 0;
         is_sl = 0;
         is_issued = 0;
@@ -758,12 +796,18 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
             is_k++;
             is_setup(nx);
         }
-        if (ABL & 32)   // timing only: every channel reads channel (c & 7)'s first stage of gulp 0 (a 1 MB window that stays in L2)
+        if (DESC)
+            is_stage = d_base + (size_t)(is_sl * (KT_STAGE * 32)) * d_t + (size_t)is_c * d_c;
+        else if (ABL & 32)   // timing only: every channel reads channel (c & 7)'s first stage of gulp 0 (a 1 MB window that stays in L2)
             is_stage = p.gulps[0] + (size_t)(is_c & 7) * (size_t)p.ninput;
         else
         is_stage = p.gulps[is_g] + ((size_t)(is_sl * (KT_STAGE * 32)) * p.nchan + is_c) * (size_t)p.ninput;
         is_issued++;
-        if (++is_sl == p.spg) { is_sl = 0; is_g++; }
+        if (++is_sl == p.spg) {
+            is_sl = 0;
+            is_g++;
+            if (DESC && is_issued < p.nstage) load_desc(is_g);       // (the next gulp may be laid out differently)
+        }
     };
     // one 1 KiB piece (8 rows x 128 B) of the stage last returned by next_stage() into ring buffer S % XC_RING.
     // Issued from asm: hipcc cannot prove that the transposing reads do not alias a pending builtin LDS-DMA
@@ -777,7 +821,7 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
     // twice per stage (pieces 0-3: imm 0..3072, pieces 4-5: M0 + 4096, imm 0, 1024) instead of once per piece.
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(const __attribute__((address_space(3))) void*)lds);
     auto issue_piece = [&](int ring_slot, int n) {
-        const uint8_t* sb = is_stage + (size_t)(48 * (wave & 1)) * row_stride;                  // scalar base of this wave's rows
+        const uint8_t* sb = is_stage + (size_t)(48 * (wave & 1)) * (DESC ? d_t : row_stride);   // scalar base of this wave's rows
         const uint32_t la = lds_base + ring_slot * STAGE_BYTES + wave * SLOT_BYTES + (n < 4 ? 0 : 4096);
         const uint32_t vo = is_voff[n];
         if (n == 0) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(vo), "s"(sb), "s"(la) : "memory");

@@ -67,7 +67,8 @@ SYMBOLS = {
     "xengMalloc": [ctypes.POINTER(_vp), _sz, _i], "xengFree": [_vp, _i], "xengMemcpy": [_vp, _vp, _sz],
     "xengMemcpyAsync": [_vp, _vp, _sz], "xengMemset": [_vp, _i, _sz], "xengStreamSynchronize": [],
     "xengXgpuConfigure": [_i, _i, _i, _i, _i], "xengXgpuInitialize": [_i], "xengXgpuDestroy": [],
-    "xengXgpuKernel": [_vp, _vp, _i], "xengXgpuKernelAsync": [_vp, _vp, _i], "xengXgpuKernelAsyncAcc": [_vp, _vp, _i, _vp, _i], "xengXgpuTryKernelAsyncAcc": [_vp, _vp, _i, _vp, _i], "xengXgpuWaitLaunchSlot": [], "xengXgpuSync": [], "xengXgpuSyncLag": [_i], "xengXgpuDumpDone": [_i, _pi], "xengXgpuReset": [],
+    "xengXgpuKernel": [_vp, _vp, _i], "xengXgpuKernelAsync": [_vp, _vp, _i], "xengXgpuKernelAsyncAcc": [_vp, _vp, _i, _vp, _i], "xengXgpuTryKernelAsyncAcc": [_vp, _vp, _i, _vp, _i], "xengXgpuWaitLaunchSlot": [],
+    "xengXgpuKernelAsyncSlab": [_vp, _i, _sz, ctypes.c_uint64, _i, _vp, _i, _vp, _i], "xengXgpuGetSlabFallbacks": [_pi], "xengXgpuSync": [], "xengXgpuSyncLag": [_i], "xengXgpuDumpDone": [_i, _pi], "xengXgpuReset": [],
     "xengXgpuCorrelate": [_vp, _vp, _i], "xengXgpuGetOrder": [_vp, _vp, _vp],
     "xengXgpuSubSelect": [_vp, _vp, _vp, _vp, _i, _i], "xengXgpuReorder": [_vp, _vp, _vp, _vp],
     "xengXgpuGetInfo": [_pi, _pi, _pi, _pi, ctypes.POINTER(ctypes.c_int64), _pi],
