@@ -796,18 +796,18 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
             is_k++;
             is_setup(nx);
         }
-        if (DESC)
+        if (DESC) {
+            // (a new gulp may be laid out differently: its descriptor is loaded here, when its first stage is set up -- not when
+            // the previous gulp's last stage was, whose pieces are still to be issued with the old offsets)
+            if (is_sl == 0 && is_g > 0) load_desc(is_g);
             is_stage = d_base + (size_t)(is_sl * (KT_STAGE * 32)) * d_t + (size_t)is_c * d_c;
+        }
         else if (ABL & 32)   // timing only: every channel reads channel (c & 7)'s first stage of gulp 0 (a 1 MB window that stays in L2)
             is_stage = p.gulps[0] + (size_t)(is_c & 7) * (size_t)p.ninput;
         else
         is_stage = p.gulps[is_g] + ((size_t)(is_sl * (KT_STAGE * 32)) * p.nchan + is_c) * (size_t)p.ninput;
         is_issued++;
-        if (++is_sl == p.spg) {
-            is_sl = 0;
-            is_g++;
-            if (DESC && is_issued < p.nstage) load_desc(is_g);       // (the next gulp may be laid out differently)
-        }
+        if (++is_sl == p.spg) { is_sl = 0; is_g++; }
     };
     // one 1 KiB piece (8 rows x 128 B) of the stage last returned by next_stage() into ring buffer S % XC_RING.
     // Issued from asm: hipcc cannot prove that the transposing reads do not alias a pending builtin LDS-DMA
