@@ -32,6 +32,7 @@ struct XgpuContext {
     FragGroup* fgroups_dev = nullptr;          // fused kernel: fragment-level tile groups (xcorr_tiling.h) ...
     int nfg = 0;
     WorkList work;                             // ... and the persistent work-groups' item lists
+    WorkList work_pairs;                       // the same items with neighbouring channels per XCD and round (packet-slab launches: xcorr_tiling.h build_work)
     size_t gulp_bytes = 0;
     const uint8_t* gulp_ptr[XC_MAX_GULPS] = {};
     bool fp6 = false;          // -DXENG_EXPERIMENTS builds, XENG_MFMA=fp6: E3M2 codes + block-scaled FP6 MFMA (exact)
@@ -113,6 +114,7 @@ static int destroy_locked() {
     if (x.descs_dev) (void)hipFree(x.descs_dev);
     if (x.fgroups_dev) (void)hipFree(x.fgroups_dev);
     if (x.work.dev) (void)hipFree(x.work.dev);
+    if (x.work_pairs.dev) (void)hipFree(x.work_pairs.dev);
     if (x.in_dev) (void)hipFree(x.in_dev);
     if (x.stamps) (void)hipFree(x.stamps);
     if (x.out_dev) (void)hipFree(x.out_dev);
@@ -237,6 +239,7 @@ static int flush_locked(void* out, bool dump, void* acc = nullptr, int acc_mode 
     p.fgroups = x.fgroups_dev; p.work = x.work.dev; p.maxi = x.work.maxi; p.nstage = nkt / XC_KT;
     p.acc2 = (int32_t*)acc; p.acc2_mode = acc ? acc_mode : 0;
     p.gdesc = x.slab_mode ? x.gdesc_dev[x.cur] : nullptr;
+    if (x.slab_mode && !diag_env("XENG_SLAB_PLAIN_ORDER")) { p.work = x.work_pairs.dev; p.maxi = x.work_pairs.maxi; }    // (diagnostic builds: A/B switch)
     for (int g = 0; g < XC_MAX_GULPS; g++) p.gulps[g] = g < x.nfilled ? x.gulp_ptr[g] : nullptr;
     // the contraction starts when this area's corner turns are done and runs beside the next area's
     const int si = (int)(x.nlaunch++ % x.nmm);
@@ -576,6 +579,9 @@ static int initialize_locked(int gpu) {
         x.work = build_work(fused_grid(x.cfg.nchan, x.nfg, x.ncu), x.cfg.nchan, x.nfg, plain_order ? nullptr : &masks);
         XENG_HIP(hipMalloc((void**)&x.work.dev, x.work.entries.size() * sizeof(WorkEntry)));
         XENG_HIP(hipMemcpy(x.work.dev, x.work.entries.data(), x.work.entries.size() * sizeof(WorkEntry), hipMemcpyHostToDevice));
+        x.work_pairs = build_work(fused_grid(x.cfg.nchan, x.nfg, x.ncu), x.cfg.nchan, x.nfg, plain_order ? nullptr : &masks, true);
+        XENG_HIP(hipMalloc((void**)&x.work_pairs.dev, x.work_pairs.entries.size() * sizeof(WorkEntry)));
+        XENG_HIP(hipMemcpy(x.work_pairs.dev, x.work_pairs.entries.data(), x.work_pairs.entries.size() * sizeof(WorkEntry), hipMemcpyHostToDevice));
     }
     XENG_HIP(hipMalloc((void**)&x.descs_dev, descs.size() * sizeof(WgDesc)));
     XENG_HIP(hipMemcpy(x.descs_dev, descs.data(), descs.size() * sizeof(WgDesc), hipMemcpyHostToDevice));

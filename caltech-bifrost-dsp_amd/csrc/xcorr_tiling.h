@@ -352,7 +352,10 @@ inline std::vector<uint64_t> group_block_masks(const std::vector<FragGroup>& gs)
 }
 
 // masks: per tile group the blocks it stages (null: groups in their natural order)
-inline WorkList build_work(int grid, int nchan, int nwg, const std::vector<uint64_t>* masks = nullptr) {
+// pair_channels (packet slabs, round 4): the q-th channel of XCD x is 16 (q / 2) + 2 x + (q & 1) instead of x + 8 q, so that the two
+// channels an XCD contracts in one round are NEIGHBOURS: in a packet the 64 bytes of channel c and of channel c + 1 share a
+// 128-byte line, and a line should pass through one L2, once (needs nchan % 16 == 0)
+inline WorkList build_work(int grid, int nchan, int nwg, const std::vector<uint64_t>* masks = nullptr, bool pair_channels = false) {
     WorkList wl;
     const bool xcd_map = (nchan & 7) == 0 && (grid & 7) == 0;
     const int ngroup = xcd_map ? 8 : 1;
@@ -368,7 +371,7 @@ inline WorkList build_work(int grid, int nchan, int nwg, const std::vector<uint6
     auto put = [&](int b, int k, int x, int idx) {
         const int q = idx / nwg;
         const int wg = gorder.empty() ? idx - q * nwg : gorder[q][idx - q * nwg];
-        const int c = xcd_map ? x + 8 * q : q;
+        const int c = !xcd_map ? q : (pair_channels && (nchan & 15) == 0) ? 16 * (q >> 1) + 2 * x + (q & 1) : x + 8 * q;
         wl.entries[(size_t)b * wl.maxi + k] = (uint32_t)c | ((uint32_t)wg << 16) | WORK_VALID;
     };
     for (int x = 0; x < ngroup; x++) {

@@ -81,6 +81,29 @@ static void check_work(int ncu, int nchan, int nblk) {
     const int grid = fused_grid(nchan, nwg, ncu);
     CHECK(grid >= 1 && grid <= std::max(ncu, 1) && grid <= nchan * nwg, "grid %d (ncu %d, items %d)", grid, ncu, nchan * nwg);
     const std::vector<uint64_t> masks = group_block_masks(gs);
+    // ... and the channel-pair order of the packet-slab launches: the same exact cover, neighbouring channels per XCD and round
+    if ((nchan & 15) == 0 && (grid & 7) == 0) {
+        const WorkList wp = build_work(grid, nchan, nwg, &masks, true);
+        std::map<std::pair<int, int>, int> seen;
+        for (int b = 0; b < grid; b++)
+            for (int k = 0; k < wp.maxi; k++) {
+                const WorkEntry e = wp.entries[(size_t)b * wp.maxi + k];
+                if (!(e & WORK_VALID)) continue;
+                const int c = e & 0xFFFF, wg = (e >> 16) & 0x7FFF;
+                CHECK(c < nchan && wg < nwg, "pair order: entry (%d,%d)", c, wg);
+                CHECK(((c >> 1) & 7) == (b & 7), "pair order: channel %d on work-group %d: wrong XCD class", c, b);
+                seen[{c, wg}]++;
+            }
+        CHECK((int)seen.size() == nchan * nwg, "pair order: %zu items of %d", seen.size(), nchan * nwg);
+        for (auto& kv : seen) CHECK(kv.second == 1, "pair order: item (%d,%d) %d times", kv.first.first, kv.first.second, kv.second);
+        if (ncu == 256 && nchan == 96 && nblk == 11)
+            for (int x = 0; x < 8; x++)
+                for (int k = 0; k < 6; k++) {
+                    std::set<int> chans;
+                    for (int j = 0; j < 32; j++) chans.insert(wp.entries[(size_t)(j * 8 + x) * wp.maxi + k] & 0xFFFF);
+                    CHECK(chans.size() == 2 && (*chans.begin() ^ 1) == *chans.rbegin(), "config 2, pair order: round %d of XCD %d does not hold two neighbouring channels", k, x);
+                }
+    }
     const WorkList wl = build_work(grid, nchan, nwg, &masks);
     CHECK((int)wl.entries.size() == grid * wl.maxi, "entries");
     std::map<std::pair<int, int>, int> items;
