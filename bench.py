@@ -705,6 +705,16 @@ def main():
         slabs = [dslab] + [ffi.DeviceBuffer(slab.nbytes) for _ in range(2 * gulps_per_step - 1)]
         for k in range(1, len(slabs)):
             ffi.call("xengMemcpy", slabs[k].ptr, dslab.ptr, slab.nbytes)
+        # the same packets as a receiver that chooses where each packet lands can place them: payloads on 128-byte lines
+        # (49 lines per packet; the header in the last 32 bytes of the line before)
+        stride_a, lead_a = 49 * 128, 96
+        slab_a = np.zeros(lead_a + npk * stride_a, dtype=np.uint8)
+        slab_a[lead_a:].reshape(npk, stride_a)[:, :stride] = slab
+        slabs_a = [ffi.DeviceBuffer(slab_a.nbytes).upload(slab_a)]
+        for k in range(1, len(slabs)):
+            slabs_a.append(ffi.DeviceBuffer(slab_a.nbytes))
+            ffi.call("xengMemcpy", slabs_a[k].ptr, slabs_a[0].ptr, slab_a.nbytes)
+
         def packets_leg(direct):
             nrep, nwarm, kk = 300, 100, 0
             for it in range(nwarm + nrep):
@@ -713,7 +723,9 @@ def main():
                     t1 = time.perf_counter()
                 for g in range(gulps_per_step):
                     slot = kk % (2 * gulps_per_step)
-                    if direct:      # the slab IS the gulp: verified on the device, read in place by the contraction (no scatter pass)
+                    if direct == 2:
+                        ffi.check("slab", L.xengXgpuKernelAsyncSlab(slabs_a[slot].ptr + lead_a, npk, stride_a, 0, 0, outs[it & 1].ptr, int(g == gulps_per_step - 1), None, 0))
+                    elif direct:    # the slab IS the gulp: verified on the device, read in place by the contraction (no scatter pass)
                         ffi.check("slab", L.xengXgpuKernelAsyncSlab(slabs[slot].ptr, npk, stride, 0, 0, outs[it & 1].ptr, int(g == gulps_per_step - 1), None, 0))
                     else:
                         dst = ring.ptr + slot * gulp_bytes
@@ -729,7 +741,16 @@ def main():
             "ms_per_step": round(el4 / nrep * 1e3, 4),
             "note": "device-resident packet slabs (5280 packets per gulp) -> xengSnap2UnpackAsync -> xengXgpuKernelAsync, "
                     "%d integrations (the path of rounds 2-3)" % nrep}
-        el4, nrep = packets_leg(True)
+        el4, nrep = packets_leg(2)
+        nfb = ctypes.c_int(-1)
+        ffi.call("xengXgpuGetSlabFallbacks", ctypes.byref(nfb))
+        slab_a_vis = outs[(300 + 100 - 1) & 1].download(np.int32)
+        ingest["packets_to_visibilities_payloads_on_cache_lines"] = {
+            "value": round(8 * NINPUT * units_per_step_c * nrep / el4 / 1e9, 1), "unit": "Gb/s",
+            "ms_per_step": round(el4 / nrep * 1e3, 4), "gulps_scattered_after_all": int(nfb.value), "packet_stride": stride_a,
+            "note": "as packets_to_visibilities with every packet placed so that its payload starts on a 128-byte line (stride 6272, "
+                    "the slab handed over at +96): in the packed slab half of the 64-byte rows straddle a 64-byte boundary"}
+        el4, nrep = packets_leg(1)
         nfb = ctypes.c_int(-1)
         ffi.call("xengXgpuGetSlabFallbacks", ctypes.byref(nfb))
         slab_vis = outs[(300 + 100 - 1) & 1].download(np.int32)
@@ -744,8 +765,10 @@ def main():
             ffi.check("unpack", L.xengSnap2UnpackAsync(slabs[(4 * gulps_per_step + g) % (2 * gulps_per_step)].ptr, npk, stride, dst, 0, NTIME_GULP, 0, NCHAN, NINPUT, 1))
             ffi.check(kern, L.xengXgpuKernelAsync(dst, outs[0].ptr, int(g == gulps_per_step - 1)))
         ffi.call("xengXgpuSync")
-        ingest["packets_to_visibilities"]["equals_scatter_path"] = bool(np.array_equal(slab_vis, outs[0].download(np.int32)))
-        for b in slabs:
+        want_vis = outs[0].download(np.int32)
+        ingest["packets_to_visibilities"]["equals_scatter_path"] = bool(np.array_equal(slab_vis, want_vis))
+        ingest["packets_to_visibilities_payloads_on_cache_lines"]["equals_scatter_path"] = bool(np.array_equal(slab_a_vis, want_vis))
+        for b in slabs + slabs_a:
             b.free()
         dgulp.free()
     # outside the timed region: BASELINE config 4 -- Beamform (32 beams, 96 chan, 960 samples, fp32 weights)

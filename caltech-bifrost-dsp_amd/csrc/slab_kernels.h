@@ -7,11 +7,11 @@
 // bytes: sample t, channel c, input block b at  slab + 32 + (t * nblk + b) * stride + c * 64  -- and the contraction kernel can
 // read it there (GulpDesc, xcorr_kernels.h) instead of reading a copy that a scatter pass made.  These kernels decide that on
 // the device, without a host round trip:
-//   slab_verify_kernel    one thread per packet: is packet p the packet (p / nblk, p % nblk) of this gulp?   -> *bad
-//   slab_describe_kernel  one thread: writes the gulp's descriptor -- the slab itself, or (any packet out of place, lost,
-//                         foreign, duplicated) the scratch gulp below -- and re-arms the counter
-//   slab_clear_kernel, slab_scatter_kernel   only when the descriptor says "scratch": zero-fill + scatter with the validation
-//                         rules of snap2_unpack_kernel (ingest.hip); otherwise they return at once
+//   slab_prepare_kernel   one thread per packet: is packet p the packet (p / nblk, p % nblk) of this gulp?  The last group to
+//                         finish writes the gulp's descriptor -- the slab itself, or (any packet out of place, lost, foreign,
+//                         duplicated) the scratch gulp below
+//   slab_clear_kernel, slab_scatter_kernel   once per integration, for the gulps whose descriptor says "scratch": zero-fill +
+//                         scatter with the validation rules of snap2_unpack_kernel (ingest.hip); otherwise they return at once
 #pragma once
 #include <stdint.h>
 
@@ -41,20 +41,32 @@ __device__ __forceinline__ SlabHeader slab_header(const uint8_t* h, int chan0_pi
     return r;
 }
 
-__global__ __launch_bounds__(256) void slab_verify_kernel(SlabArgs a, int* __restrict__ bad) {
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= a.npkt) return;
-    const SlabHeader h = slab_header(a.pkts + (size_t)p * a.stride, a.chan0);
-    const int t = p / a.nblk, b = p % a.nblk;
-    const bool ok = h.seq == a.seq0 + (unsigned long long)t && h.pol0 == (long long)b * 64 && h.npol == 64 && h.nchan == a.nchan && h.chan0 == 0;
-    if (!ok) atomicAdd(bad, 1);
-}
-
-// force_scratch: the host already knows the slab cannot be regular (packet count, stride, alignment)
-__global__ void slab_describe_kernel(SlabArgs a, int* __restrict__ bad, GulpDesc* __restrict__ desc, uint8_t* scratch, int force_scratch,
-                                     int* __restrict__ fallbacks) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const bool fb = force_scratch || *bad != 0;
+// verify + describe in one launch.  Every wave checks its 64 packets and adds ONE word to the tally: (packets out of place) << 32
+// | 1.  The wave that reads back "all other waves have added theirs" has, in the same word, the gulp's total: it writes the
+// descriptor and re-arms the tally.  One returning atomic per wave carries both the count and the ticket, so nothing has to be
+// ordered and the kernel needs NO fence: an agent-scope fence on this part is an L2 write-back + invalidate on every XCD, and
+// beside a running contraction (which lives on L2 hits of the gulps) that cost 7 % of the streaming rate (measured:
+// profiles/r04/slab_paths.txt).  No LDS either.
+// tally: the 64-bit word; fallbacks: gulps that took the scratch path (read by xengXgpuGetSlabFallbacks).
+// force_scratch: the host already knows the slab cannot be regular (packet count, stride, alignment); then one wave, no check.
+__global__ __launch_bounds__(256) void slab_prepare_kernel(SlabArgs a, unsigned long long* __restrict__ tally, int* __restrict__ fallbacks,
+                                                           GulpDesc* __restrict__ desc, SlabArgs* __restrict__ args_out, uint8_t* scratch,
+                                                           int force_scratch) {
+    bool ok = true;
+    if (!force_scratch) {
+        const int p = blockIdx.x * 256 + threadIdx.x;
+        if (p < a.npkt) {
+            const SlabHeader h = slab_header(a.pkts + (size_t)p * a.stride, a.chan0);
+            const int t = p / a.nblk, b = p % a.nblk;
+            ok = h.seq == a.seq0 + (unsigned long long)t && h.pol0 == (long long)b * 64 && h.npol == 64 && h.nchan == a.nchan && h.chan0 == 0;
+        }
+    }
+    const unsigned long long nbad = (unsigned long long)__popcll(__ballot(!ok));
+    if ((threadIdx.x & 63) != 0) return;
+    const unsigned long long nwaves = (unsigned long long)gridDim.x * (blockDim.x >> 6);
+    const unsigned long long before = atomicAdd(tally, (nbad << 32) | 1ull);
+    if ((before & 0xFFFFFFFFull) != nwaves - 1) return;
+    const bool fb = force_scratch || ((before >> 32) + nbad) != 0;
     GulpDesc d;
     if (fb) {
         d.base = scratch; d.t_stride = (uint32_t)a.nchan * (uint32_t)a.ninput; d.c_stride = (uint32_t)a.ninput; d.b_stride = 64;
@@ -65,17 +77,25 @@ __global__ void slab_describe_kernel(SlabArgs a, int* __restrict__ bad, GulpDesc
     d.pad = fb ? 1u : 0u;
     d.pad2 = 0;
     *desc = d;
-    *bad = 0;                 // (re-armed for the next gulp that uses this counter)
+    *args_out = a;            // (for the scatter at flush time, should this gulp need it)
+    *tally = 0;               // (re-armed for the next gulp: launches on one stream, in order)
 }
 
-__global__ __launch_bounds__(256) void slab_clear_kernel(const GulpDesc* __restrict__ desc, uint4* __restrict__ scratch, size_t n16) {
-    if (!desc->pad) return;
+// Once per integration, behind the prepare kernels of its gulps (grid.y = gulp): zero-fill and scatter of the gulps whose
+// descriptor says "scratch"; the groups of every other gulp return at once.
+__global__ __launch_bounds__(256) void slab_clear_kernel(const GulpDesc* __restrict__ desc, size_t n16) {
+    const GulpDesc& d = desc[blockIdx.y];
+    if (!d.pad) return;
+    uint4* scratch = reinterpret_cast<uint4*>(const_cast<uint8_t*>(d.base));
     for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n16; k += (size_t)gridDim.x * 256) scratch[k] = make_uint4(0, 0, 0, 0);
 }
 
 // one wave per packet (any order, duplicates allowed): the validation of snap2_unpack_kernel, rows of npol bytes
-__global__ __launch_bounds__(256) void slab_scatter_kernel(const GulpDesc* __restrict__ desc, SlabArgs a, uint8_t* __restrict__ scratch) {
-    if (!desc->pad) return;
+__global__ __launch_bounds__(256) void slab_scatter_kernel(const GulpDesc* __restrict__ desc, const SlabArgs* __restrict__ args) {
+    const GulpDesc& d = desc[blockIdx.y];
+    if (!d.pad) return;
+    const SlabArgs a = args[blockIdx.y];
+    uint8_t* scratch = const_cast<uint8_t*>(d.base);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int payload_max = (int)a.stride - 32;
     for (int p = blockIdx.x * 4 + wave; p < a.npkt; p += gridDim.x * 4) {

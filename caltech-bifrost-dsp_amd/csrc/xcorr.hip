@@ -85,7 +85,8 @@ struct XgpuContext {
     unsigned long long* stamps = nullptr;   // diagnostic (XENG_DBG_STAMPS=1)
     // packet slabs as gulps (xengXgpuKernelAsyncSlab): per staging area one descriptor per gulp, written on the staging stream
     GulpDesc* gdesc_dev[2] = {nullptr, nullptr};
-    int* slab_bad_dev = nullptr;            // [0]: verify counter (re-armed by the describe kernel), [1]: gulps that took the scratch path
+    SlabArgs* gargs_dev[2] = {nullptr, nullptr};   // ... and what the scatter of a gulp that turns out irregular needs (slab_kernels.h)
+    int* slab_bad_dev = nullptr;            // [1]: gulps that took the scratch path, [2..3]: the 64-bit tally of slab_prepare_kernel
     bool slab_mode = false;                 // the gulps staged since the last flush are slabs (no mixing inside one flush)
     EventTimer timer;
 };
@@ -120,6 +121,8 @@ static int destroy_locked() {
     if (x.out_dev) (void)hipFree(x.out_dev);
     for (int b = 0; b < 2; b++)
         if (x.gdesc_dev[b]) (void)hipFree(x.gdesc_dev[b]);
+    for (int b = 0; b < 2; b++)
+        if (x.gargs_dev[b]) (void)hipFree(x.gargs_dev[b]);
     if (x.slab_bad_dev) (void)hipFree(x.slab_bad_dev);
     x.timer.destroy();
     x = XgpuContext();
@@ -227,6 +230,13 @@ static int flush_locked(void* out, bool dump, void* acc = nullptr, int acc_mode 
                                   (size_t)padk * KT_BYTES, (size_t)x.cfg.nchan * x.nblk64, x.stream));
         stream_tick(STREAM_XGPU);
         nkt += padk;
+    }
+    if (x.slab_mode && !diag_env("XENG_SLAB_SKIP")) {
+        // packet slabs: zero-fill + scatter of the gulps that turned out irregular (slab_kernels.h); for every other gulp the
+        // groups return at once
+        hipLaunchKernelGGL(slab_clear_kernel, dim3(512, x.nfilled), dim3(256), 0, x.stream, x.gdesc_dev[x.cur], x.gulp_bytes / 16);
+        hipLaunchKernelGGL(slab_scatter_kernel, dim3(512, x.nfilled), dim3(256), 0, x.stream, x.gdesc_dev[x.cur], x.gargs_dev[x.cur]);
+        staging_stream_touched();
     }
     XcorrParams p;
     p.stash = x.stash[x.cur]; p.out = (int32_t*)out; p.descs = x.descs_dev;
@@ -560,9 +570,11 @@ static int initialize_locked(int gpu) {
         for (int b = 0; b < 2; b++) {
             XENG_HIP(hipMalloc((void**)&x.gdesc_dev[b], XC_MAX_GULPS * sizeof(GulpDesc)));
             XENG_HIP(hipMemset(x.gdesc_dev[b], 0, XC_MAX_GULPS * sizeof(GulpDesc)));
+            XENG_HIP(hipMalloc((void**)&x.gargs_dev[b], XC_MAX_GULPS * sizeof(SlabArgs)));
+            XENG_HIP(hipMemset(x.gargs_dev[b], 0, XC_MAX_GULPS * sizeof(SlabArgs)));
         }
-        XENG_HIP(hipMalloc((void**)&x.slab_bad_dev, 2 * sizeof(int)));
-        XENG_HIP(hipMemset(x.slab_bad_dev, 0, 2 * sizeof(int)));
+        XENG_HIP(hipMalloc((void**)&x.slab_bad_dev, 4 * sizeof(int)));
+        XENG_HIP(hipMemset(x.slab_bad_dev, 0, 4 * sizeof(int)));
     }
     std::vector<WgDesc> descs = build_wg_descs(x.nblk64);
     x.nwg = (int)descs.size();
@@ -716,10 +728,10 @@ int xengXgpuKernelAsyncSlab(const void* packets_dev, int npkt, size_t pkt_stride
                        pkt_stride % 16 == 0 && ((uintptr_t)packets_dev & 15) == 0 && (uint64_t)a.nblk * pkt_stride * 48 < (1ull << 31);
     uint8_t* scratch = x.stash[x.cur] + (size_t)k * x.gulp_bytes;
     GulpDesc* desc = x.gdesc_dev[x.cur] + k;
-    if (maybe && npkt > 0) hipLaunchKernelGGL(slab_verify_kernel, dim3((npkt + 255) / 256), dim3(256), 0, x.stream, a, x.slab_bad_dev);
-    hipLaunchKernelGGL(slab_describe_kernel, dim3(1), dim3(64), 0, x.stream, a, x.slab_bad_dev, desc, scratch, maybe ? 0 : 1, x.slab_bad_dev + 1);
-    hipLaunchKernelGGL(slab_clear_kernel, dim3(1024), dim3(256), 0, x.stream, desc, (uint4*)scratch, x.gulp_bytes / 16);
-    if (npkt > 0) hipLaunchKernelGGL(slab_scatter_kernel, dim3(std::min(2048, (npkt + 3) / 4)), dim3(256), 0, x.stream, desc, a, scratch);
+    const char* skip = diag_env("XENG_SLAB_SKIP");      // (diagnostic builds, timing only: any value drops the clear / scatter launches, "all" also this one -- descriptors of earlier launches are reused)
+    if (!skip || skip[0] != 'a')
+        hipLaunchKernelGGL(slab_prepare_kernel, dim3(maybe && npkt > 0 ? (npkt + 255) / 256 : 1), dim3(256), 0, x.stream, a, (unsigned long long*)(x.slab_bad_dev + 2), x.slab_bad_dev + 1,
+                           desc, x.gargs_dev[x.cur] + k, scratch, maybe && npkt > 0 ? 0 : 1);
     XENG_HIP(hipGetLastError());
     staging_stream_touched();
     x.gulp_ptr[k] = nullptr;
