@@ -44,6 +44,12 @@ struct BeamContext {
     static constexpr int NMARK = 64;
     hipEvent_t marks[NMARK] = {};
     unsigned long long nmarks = 0;
+    // gulps handed over as packet slabs (xengBeamformRunSlabs; slab.h): descriptors + scatter arguments of the (up to two)
+    // parts, and the scratch gulp that irregular slabs are scattered into -- all used in stream order, so one set
+    SlabSite slab_site;
+    GulpDesc* gdesc = nullptr;
+    SlabArgs* gargs = nullptr;
+    uint8_t* slab_scratch = nullptr;
     EventTimer timer;
 };
 static std::mutex g_bmu;
@@ -70,6 +76,10 @@ static int beam_destroy_locked() {
     for (int k = 0; k < BeamContext::NMARK; k++)
         if (g_b.marks[k]) (void)hipEventDestroy(g_b.marks[k]);
     if (g_b.stamps) (void)hipFree(g_b.stamps);
+    slab_site_destroy(&g_b.slab_site);
+    if (g_b.gdesc) (void)hipFree(g_b.gdesc);
+    if (g_b.gargs) (void)hipFree(g_b.gargs);
+    if (g_b.slab_scratch) (void)hipFree(g_b.slab_scratch);
     g_b.timer.destroy();
     g_b = BeamContext();
     return XENG_STATUS_SUCCESS;
@@ -77,18 +87,19 @@ static int beam_destroy_locked() {
 
 // pow_out != nullptr: integrated-power mode, fused into the int8x3 kernel when that is possible (see the kernel); returns
 // *fused = false when the caller has to run the voltage mode into its scratch and integrate separately
-// in1 / split: the gulp in two parts (samples [split, ntime) at in1; beamform_kernels.h gulp_row); one part: in1 null
+// in1 / split: the gulp in two parts (samples [split, ntime) at in1; beamform_kernels.h GulpAddr); one part: in1 null
+// gd: the parts are described on the device (packet slabs; in / in1 unused), split as above
 static int run_locked(const void* in, float* out, const void* w, long long version, float* pow_out = nullptr, int ntime_sum = 0,
-                      bool* fused = nullptr, bool may_wait = true, const void* in1v = nullptr, int split = 0) {
+                      bool* fused = nullptr, bool may_wait = true, const void* in1v = nullptr, int split = 0, const GulpDesc* gd = nullptr) {
     BeamContext& x = g_b;
     if (fused) *fused = false;
     const uint8_t* in1 = (const uint8_t*)in1v;
-    if (!in1) { in1 = (const uint8_t*)in; split = x.ntime; }
+    if (!in1 && !gd) { in1 = (const uint8_t*)in; split = x.ntime; }
     if (x.use_f32) {
         dim3 grid((x.ntime + BF_NT - 1) / BF_NT, x.nchan, (x.nbeam + 31) / 32);
         int slot = x.timer.begin(x.stream, 0);
-        hipLaunchKernelGGL(beamform_f32_kernel, grid, dim3(256), 0, x.stream, (const uint8_t*)in, (const float*)w, out,
-                           x.ntime, x.nchan, x.ninput, x.nbeam, in1, split);
+        hipLaunchKernelGGL(gd ? beamform_f32_kernel<true> : beamform_f32_kernel<false>, grid, dim3(256), 0, x.stream, (const uint8_t*)in, (const float*)w, out,
+                           x.ntime, x.nchan, x.ninput, x.nbeam, in1, split, gd);
         x.timer.end(x.stream, slot);
     stream_tick(STREAM_BEAM);
         XENG_HIP(hipGetLastError());
@@ -143,13 +154,13 @@ static int run_locked(const void* in, float* out, const void* w, long long versi
             XENG_HIP(hipMemsetAsync(pow_out, 0, (size_t)(x.nbeam / 2) * (x.ntime / ntime_sum) * x.nchan * 4 * sizeof(float), x.stream));
             *fused = true;
         }
-        hipLaunchKernelGGL(beamform_i8x3_kernel, grid, dim3(256), 0, x.stream, (const uint8_t*)in, x.wq, x.wscale, x.wsum, out,
+        hipLaunchKernelGGL(gd ? beamform_i8x3_kernel<true> : beamform_i8x3_kernel<false>, grid, dim3(256), 0, x.stream, (const uint8_t*)in, x.wq, x.wscale, x.wsum, out,
                            x.ntime, x.nchan, x.ninput, x.nbeam, x.nchunk_i8, x.nbtile, x.route, x.out_n, x.out_idx, x.out_R, x.stamps,
-                           fuse ? pow_out : (float*)nullptr, ntime_sum, in1, split);
+                           fuse ? pow_out : (float*)nullptr, ntime_sum, in1, split, gd);
         if (x.need_bf16) {
             dim3 grid3(((x.ntime + BF3_NT - 1) / BF3_NT) * x.nchan * x.nbtile);
-            hipLaunchKernelGGL(beamform_bf16x3_kernel, grid3, dim3(64 * BF3_NW), 0, x.stream, (const uint8_t*)in, x.wprep, out,
-                               x.ntime, x.nchan, x.ninput, x.nbeam, x.nchunk, x.nbtile, x.route, in1, split);
+            hipLaunchKernelGGL(gd ? beamform_bf16x3_kernel<true> : beamform_bf16x3_kernel<false>, grid3, dim3(64 * BF3_NW), 0, x.stream, (const uint8_t*)in, x.wprep, out,
+                               x.ntime, x.nchan, x.ninput, x.nbeam, x.nchunk, x.nbtile, x.route, in1, split, gd);
         }
         x.timer.end(x.stream, slot);
     stream_tick(STREAM_BEAM);
@@ -166,8 +177,8 @@ static int run_locked(const void* in, float* out, const void* w, long long versi
     }
     dim3 grid(((x.ntime + BF3_NT - 1) / BF3_NT) * x.nchan * x.nbtile);
     int slot = x.timer.begin(x.stream, 0);
-    hipLaunchKernelGGL(beamform_bf16x3_kernel, grid, dim3(64 * BF3_NW), 0, x.stream, (const uint8_t*)in, x.wprep, out,
-                       x.ntime, x.nchan, x.ninput, x.nbeam, x.nchunk, x.nbtile, (const int*)nullptr, in1, split);
+    hipLaunchKernelGGL(gd ? beamform_bf16x3_kernel<true> : beamform_bf16x3_kernel<false>, grid, dim3(64 * BF3_NW), 0, x.stream, (const uint8_t*)in, x.wprep, out,
+                       x.ntime, x.nchan, x.ninput, x.nbeam, x.nchunk, x.nbtile, (const int*)nullptr, in1, split, gd);
     x.timer.end(x.stream, slot);
     stream_tick(STREAM_BEAM);
     XENG_HIP(hipGetLastError());
@@ -281,6 +292,64 @@ int xengBeamformRunParts(const void* in0_dev, int ntime0, const void* in1_dev, v
 
 int xengBeamformTryRunParts(const void* in0_dev, int ntime0, const void* in1_dev, void* out_dev, const void* weights_dev, long long weights_version) {
     return run_versioned(in0_dev, out_dev, weights_dev, weights_version, false, in1_dev, ntime0);
+}
+
+// The gulp as the slabs of F-engine packets it arrived in (slab.h): one slab (packets1 null, ntime0 = ntime) or two consecutive
+// ones (samples [0, ntime0) and [ntime0, ntime): two capture gulps per beamformer gulp, lwa352-pipeline.py:172,279-282).  Each is
+// verified on the beam stream; a regular slab is read where it lies, anything else is scattered into the context's scratch gulp
+// first (the rules of xengSnap2UnpackAsync: missing samples read as zero, foreign and out-of-window packets dropped).
+int xengBeamformRunSlabs(const void* packets0_dev, int npkt0, int ntime0, const void* packets1_dev, int npkt1, size_t pkt_stride, uint64_t seq0,
+                         int chan0_pipeline, void* out_dev, const void* weights_dev, long long weights_version) {
+    std::lock_guard<std::mutex> lk(g_bmu);
+    BeamContext& x = g_b;
+    if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "Beamform: not initialized (call xengBeamformInitialize)");
+    if (!packets0_dev || !out_dev || !weights_dev || npkt0 < 0 || npkt1 < 0 || pkt_stride < 32 || pkt_stride > 0x7FFFFFFFu)
+        XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Beamform: bad slab (npkt %d / %d, stride %zu)", npkt0, npkt1, pkt_stride);
+    if (((uintptr_t)weights_dev & 15) || ((uintptr_t)out_dev & 15)) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Beamform: weights/out must be 16-byte aligned");
+    if (!packets1_dev) ntime0 = x.ntime;
+    // (parts on 16-sample boundaries: a wave's 16 rows of one load never straddle two descriptors; and whole 16-byte pieces)
+    if (ntime0 <= 0 || ntime0 > x.ntime || (packets1_dev && (ntime0 == x.ntime || ntime0 % 16)) || x.ninput % 16)
+        XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Beamform: slab parts of %d + %d samples (inputs %d): parts must be multiples of 16 samples, inputs of 16",
+                  ntime0, x.ntime - ntime0, x.ninput);
+    XENG_HIP(hipSetDevice(x.gpu));
+    const size_t row = (size_t)x.nchan * x.ninput;
+    if (!x.gdesc) {
+        if (int rc = slab_site_create(&x.slab_site)) return rc;
+        XENG_HIP(hipMalloc((void**)&x.gdesc, 2 * sizeof(GulpDesc)));
+        XENG_HIP(hipMemset(x.gdesc, 0, 2 * sizeof(GulpDesc)));
+        XENG_HIP(hipMalloc((void**)&x.gargs, 2 * sizeof(SlabArgs)));
+        XENG_HIP(hipMemset(x.gargs, 0, 2 * sizeof(SlabArgs)));
+        XENG_HIP(hipMalloc((void**)&x.slab_scratch, (size_t)x.ntime * row));
+    }
+    const int nparts = packets1_dev ? 2 : 1;
+    for (int k = 0; k < nparts; k++) {
+        SlabArgs a;
+        a.pkts = (const uint8_t*)(k ? packets1_dev : packets0_dev); a.npkt = k ? npkt1 : npkt0; a.stride = (uint32_t)pkt_stride;
+        a.seq0 = seq0 + (k ? (uint64_t)ntime0 : 0); a.ntime = k ? x.ntime - ntime0 : ntime0; a.chan0 = chan0_pipeline; a.nchan = x.nchan;
+        a.ninput = x.ninput; a.nblk = x.ninput / 64;
+        const bool maybe = slab_maybe_regular(a, 1);          // (the kernels form 64-bit row addresses)
+        if (int rc = slab_prepare_enqueue(x.stream, x.slab_site, a, maybe, x.gdesc + k, x.gargs + k, x.slab_scratch + (k ? (size_t)ntime0 * row : 0))) return rc;
+    }
+    if (int rc = slab_fallback_enqueue(x.stream, x.gdesc, x.gargs, nparts)) return rc;
+    stream_tick(STREAM_BEAM);
+    if (x.ntime_blocks == 0) return run_locked(nullptr, (float*)out_dev, weights_dev, weights_version, nullptr, 0, nullptr, true, nullptr, ntime0, x.gdesc);
+    bool fused = false;
+    int rc = run_locked(nullptr, x.scratch, weights_dev, weights_version, (float*)out_dev, x.ntime / x.ntime_blocks, &fused, true, nullptr, ntime0, x.gdesc);
+    if (rc || fused) return rc;
+    return integrate_locked(x.scratch, out_dev, x.ntime / x.ntime_blocks, 0, x.nbeam / 2);
+}
+
+// beamformer gulp parts handed over as slabs that took the scratch path since the last call; waits for the beam stream
+int xengBeamformGetSlabFallbacks(int* nfallback) {
+    std::lock_guard<std::mutex> lk(g_bmu);
+    BeamContext& x = g_b;
+    if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "Beamform: not initialized");
+    if (!nfallback) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "GetSlabFallbacks: null pointer");
+    *nfallback = 0;
+    if (!x.slab_site.tally) return XENG_STATUS_SUCCESS;
+    XENG_HIP(hipSetDevice(x.gpu));
+    stream_tick(STREAM_BEAM);
+    return slab_site_read_fallbacks(x.stream, x.slab_site, nfallback);
 }
 
 static int run_versioned(const void* in_dev, void* out_dev, const void* weights_dev, long long weights_version, bool may_wait,

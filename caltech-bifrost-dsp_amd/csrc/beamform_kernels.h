@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "slab.h"
+
 namespace xeng {
 
 typedef float v16f __attribute__((ext_vector_type(16)));
@@ -30,14 +32,48 @@ constexpr int BF_NT = 128;                // samples per work-group
 // A gulp in up to two parts (round 4): samples [0, split) start at `in`, samples [split, ntime) at `in1` -- two consecutive spans
 // of the input ring taken as one 960-sample gulp without a gathered copy (the reference reads GPU_NGULP = 2 capture gulps per
 // beamformer gulp, lwa352-pipeline.py:172,279-282; bifrost's one circular buffer gives that for free).  One part: split = ntime.
-__device__ __forceinline__ const uint8_t* gulp_row(const uint8_t* in, const uint8_t* in1, int split, int t, size_t row_stride) {
-    return t < split ? in + (size_t)t * row_stride : in1 + (size_t)(t - split) * row_stride;
+//
+// DESC instantiations (round 4, xengBeamformRunSlabs): each part is described in DEVICE memory by a GulpDesc (slab.h) -- a slab
+// of F-engine packets read where it lies, or the scratch copy that an irregular slab was scattered into.  Then the strides
+// are per part: sample, channel and 64-input block steps come from the descriptor (scalar loads), and a row of inputs is no
+// longer contiguous: input i sits (i >> 6) * b_stride + (i & 63) bytes into its row (16-byte pieces never straddle a block).
+// The default instantiations compile to the code they were before.
+template <bool DESC>
+struct GulpAddr {
+    const uint8_t* p[2];
+    uint32_t ts[2], cs[2], bs[2];
+    int split;
+    __device__ __forceinline__ GulpAddr(const uint8_t* in, const uint8_t* in1, int split_, const GulpDesc* __restrict__ gd, int nchan, int ninput) {
+        split = split_;
+        if (DESC) {
+#pragma unroll
+            for (int k = 0; k < 2; k++) { p[k] = gd[k].base; ts[k] = gd[k].t_stride; cs[k] = gd[k].c_stride; bs[k] = gd[k].b_stride; }
+        } else {
+            p[0] = in; p[1] = in1;
+            ts[0] = ts[1] = (uint32_t)nchan * (uint32_t)ninput; cs[0] = cs[1] = (uint32_t)ninput; bs[0] = bs[1] = 64;
+        }
+    }
+    // first byte of the inputs of (sample t, channel c); *bstride: the step between that row's 64-input blocks
+    __device__ __forceinline__ const uint8_t* row(int t, int c, uint32_t* bstride) const {
+        const bool second = t >= split;
+        const uint8_t* base = second ? p[1] : p[0];
+        const uint32_t tstr = DESC ? (second ? ts[1] : ts[0]) : ts[0], cstr = DESC ? (second ? cs[1] : cs[0]) : cs[0];
+        *bstride = DESC ? (second ? bs[1] : bs[0]) : 64u;
+        return base + (size_t)(second ? t - split : t) * tstr + (size_t)c * cstr;
+    }
+};
+template <bool DESC>
+__device__ __forceinline__ size_t gulp_col(int i, uint32_t bstride) {
+    return DESC ? (size_t)(i >> 6) * bstride + (size_t)(i & 63) : (size_t)i;
 }
 
+template <bool DESC = false>
 __global__ __launch_bounds__(256) void beamform_f32_kernel(const uint8_t* __restrict__ in,
                                                            const float* __restrict__ w,
                                                            float* __restrict__ out, int ntime, int nchan,
-                                                           int ninput, int nbeam, const uint8_t* __restrict__ in1, int split) {
+                                                           int ninput, int nbeam, const uint8_t* __restrict__ in1, int split,
+                                                           const GulpDesc* __restrict__ gd) {
+    const GulpAddr<DESC> ga(in, in1, split, gd, nchan, ninput);
     __shared__ __attribute__((aligned(16))) uint8_t lds[32 * BF_WS + BF_NT * BF_XS];
     uint8_t* ldsW = lds;
     uint8_t* ldsX = lds + 32 * BF_WS;
@@ -73,7 +109,9 @@ __global__ __launch_bounds__(256) void beamform_f32_kernel(const uint8_t* __rest
             const int t = t0 + row, i = k0 + col * 16;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (t < ntime && i < ninput) {
-                const uint8_t* src = gulp_row(in, in1, split, t, (size_t)nchan * ninput) + (size_t)c * ninput + i;
+                uint32_t bstr;
+                const uint8_t* src = ga.row(t, c, &bstr);
+                src += gulp_col<DESC>(i, bstr);
                 if (i + 16 <= ninput) v = *reinterpret_cast<const uint4*>(src);
                 else {
                     uint32_t tmp[4] = {0, 0, 0, 0};
@@ -218,11 +256,13 @@ __device__ __forceinline__ v8bf as_v8bf(uint32_t a, uint32_t b, uint32_t c, uint
 // bound by how well the staging latency hides, not by MFMA throughput.  So the LDS-DMA runs two chunks
 // ahead on a ring of three 16 KiB stages (counted vmcnt, one barrier per chunk), and three work-groups per
 // CU (48 KiB each) interleave on every SIMD.
+template <bool DESC = false>
 __global__ __launch_bounds__(64 * BF3_NW, BF3_NW == 8 ? 2 : 3) void beamform_bf16x3_kernel(const uint8_t* __restrict__ in,
                                                                  const uint8_t* __restrict__ wp,
                                                                  float* __restrict__ out, int ntime, int nchan,
                                                                  int ninput, int nbeam, int nchunk, int nbtile,
-                                                                 const int* __restrict__ route, const uint8_t* __restrict__ in1, int split) {
+                                                                 const int* __restrict__ route, const uint8_t* __restrict__ in1, int split,
+                                                                 const GulpDesc* __restrict__ gd) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[BF3_RING * BF3_STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -236,14 +276,15 @@ __global__ __launch_bounds__(64 * BF3_NW, BF3_NW == 8 ? 2 : 3) void beamform_bf1
     if (route && !route[c * nbtile + bt]) return;      // this (channel, beam tile) runs on the int8x3 kernel
     const int h = lane >> 5, j = lane & 31;
     const uint8_t* wsrc = wp + (((size_t)c * nbtile + bt) * nchunk) * BF3_WCHUNK + lane * 16;
-    const size_t row_stride = (size_t)nchan * ninput;
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
     // X piece `wave` of a chunk = samples 32*wave .. +31, 32 B each; this lane: row 32*wave + lane/2, 16-byte half
     // (lane&1) ^ ((row>>3)&1): the swizzle (applied on the source side, the LDS side of the DMA is lane-linear)
     // makes the 8-byte fragment reads below bank-conflict-free.  Rows past ntime: any valid row (never stored).
     int xt = t0 + wave * 32 + (lane >> 1);
     if (xt >= ntime) xt = ntime - 1;
-    const uint8_t* xsrc = gulp_row(in, in1, split, xt, row_stride) + (size_t)c * ninput;
+    const GulpAddr<DESC> ga(in, in1, split, gd, nchan, ninput);
+    uint32_t xbstr;
+    const uint8_t* xsrc = ga.row(xt, c, &xbstr);
     const int xhalf = ((lane & 1) ^ ((lane >> 4) & 1)) * 16;
     // every stage costs exactly BF3_WSLOTS + 1 pieces per wave on the vmcnt counter (chunks past the end re-read
     // the last one; weight slots past the 12th piece re-copy an earlier piece onto itself)
@@ -257,7 +298,7 @@ __global__ __launch_bounds__(64 * BF3_NW, BF3_NW == 8 ? 2 : 3) void beamform_bf1
         }
         int i = cs * BF3_KC + xhalf;
         if (i + 16 > ninput) i = 0;                    // columns past the end meet zero weights
-        lds_dma16(xsrc + i, l + BF3_WCHUNK + wave * 1024);
+        lds_dma16(xsrc + gulp_col<DESC>(i, xbstr), l + BF3_WCHUNK + wave * 1024);
     };
     v16f acc_r = (v16f)(0.f), acc_i = (v16f)(0.f);
     issue(0, 0);
@@ -575,6 +616,7 @@ __global__ __launch_bounds__(256) void beam_weights_prep_i8_kernel(const float* 
     }
 }
 
+template <bool DESC = false>
 __global__ __launch_bounds__(256, 3) void beamform_i8x3_kernel(const uint8_t* __restrict__ in,
                                                                const uint8_t* __restrict__ wq,
                                                                const float* __restrict__ scale, const int* __restrict__ wsum,
@@ -584,7 +626,8 @@ __global__ __launch_bounds__(256, 3) void beamform_i8x3_kernel(const uint8_t* __
                                                                const int* __restrict__ out_idx, const float2* __restrict__ out_R,
                                                                unsigned long long* __restrict__ stamps,
                                                                float* __restrict__ pow_out, int ntime_sum,
-                                                               const uint8_t* __restrict__ in1, int split) {
+                                                               const uint8_t* __restrict__ in1, int split,
+                                                               const GulpDesc* __restrict__ gd) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[BI_RING * BI_STAGE];
     const unsigned long long r0 = stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;   // diagnostic (XENG_BEAM_STAMPS=1)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -598,17 +641,18 @@ __global__ __launch_bounds__(256, 3) void beamform_i8x3_kernel(const uint8_t* __
     const int n_outl = out_n[c * nbtile + bt];         // behind the first DMA; outlier inputs of this tile (epilogue)
     const int h = lane >> 5, j = lane & 31;
     const uint8_t* wsrc = wq + (((size_t)c * nbtile + bt) * nchunk) * BI_WCHUNK + lane * 16;
-    const size_t row_stride = (size_t)nchan * ninput;
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
     // X pieces 2*wave, 2*wave+1 of a chunk = samples 32*wave .. +31, 64 B each (16 rows per 1 KiB piece); lane: row
     // lane/4 of the piece, 16-byte position lane&3 holding source piece (lane&3) ^ ((row>>2)&1): the swizzle (on the
     // source side; the LDS side of the DMA is lane-linear) makes the 16-byte operand reads conflict-free at 64-byte pitch
+    const GulpAddr<DESC> ga(in, in1, split, gd, nchan, ninput);
     const uint8_t* xsrc[BI_XSLOTS];
+    uint32_t xbstr[BI_XSLOTS];
 #pragma unroll
     for (int n = 0; n < BI_XSLOTS; n++) {
         int xt = t0 + wave * 32 + n * 16 + (lane >> 2);
         if (xt >= ntime) xt = ntime - 1;
-        xsrc[n] = gulp_row(in, in1, split, xt, row_stride) + (size_t)c * ninput;
+        xsrc[n] = ga.row(xt, c, &xbstr[n]);
     }
     const int xpiece = ((lane & 3) ^ ((lane >> 4) & 1)) * 16;
     // every stage costs exactly BI_WSLOTS + BI_XSLOTS pieces per wave on the vmcnt counter (chunks past the end
@@ -625,7 +669,7 @@ __global__ __launch_bounds__(256, 3) void beamform_i8x3_kernel(const uint8_t* __
         for (int n = 0; n < BI_XSLOTS; n++) {
             int i = cs * BI_KC + xpiece;
             if (i + 16 > ninput) i = 0;                // columns past the end meet zero digits
-            lds_dma16(xsrc[n] + i, l + BI_WCHUNK + (wave * BI_XSLOTS + n) * 1024);
+            lds_dma16(xsrc[n] + gulp_col<DESC>(i, xbstr[n]), l + BI_WCHUNK + (wave * BI_XSLOTS + n) * 1024);
         }
     };
 #pragma unroll
@@ -697,10 +741,11 @@ __global__ __launch_bounds__(256, 3) void beamform_i8x3_kernel(const uint8_t* __
     }
     if (n_outl > 0) {
         // the tile's outlier weights (zero digits above) times the voltages, in fp32
-        const uint8_t* xcol = gulp_row(in, in1, split, t < ntime ? t : ntime - 1, row_stride) + (size_t)c * ninput;
+        uint32_t cbstr;
+        const uint8_t* xcol = ga.row(t < ntime ? t : ntime - 1, c, &cbstr);
         const int tile = c * nbtile + bt;
         for (int k = 0; k < n_outl; k++) {
-            const int xb = xcol[out_idx[(size_t)tile * BI_TILE_OUT + k]];
+            const int xb = xcol[gulp_col<DESC>(out_idx[(size_t)tile * BI_TILE_OUT + k], cbstr)];
             const float xr = (float)(int)__builtin_amdgcn_sbfe(xb, 4, 4), xi = (float)(int)__builtin_amdgcn_sbfe(xb, 0, 4);
             const float2* Rk = out_R + ((size_t)tile * BI_TILE_OUT + k) * 32;
 #pragma unroll

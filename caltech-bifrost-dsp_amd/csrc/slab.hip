@@ -1,31 +1,11 @@
-// Packet slabs as gulps (round 4): the helper kernels behind xengXgpuKernelAsyncSlab.
-//
-// The F-engines send, per time sample, one packet per group of 64 inputs: 32-byte big-endian header `>QLHHHHLLL` (seq, sync_time,
-// npol, npol_tot, nchan, nchan_tot, chan_block_id, chan0, pol0) + payload u8[nchan][npol] (test_transmitters/test_tx_vectors.py:
-// 38-48,103-108; test_tx_mt.c:39-49).  A receiver that stores them in arrival order produces, when nothing is lost or
-// reordered, a REGULAR slab: packet (t, b) at index t * nblk + b.  Such a slab already is the gulp, in another order of the same
-// bytes: sample t, channel c, input block b at  slab + 32 + (t * nblk + b) * stride + c * 64  -- and the contraction kernel can
-// read it there (GulpDesc, xcorr_kernels.h) instead of reading a copy that a scatter pass made.  These kernels decide that on
-// the device, without a host round trip:
-//   slab_prepare_kernel   one thread per packet: is packet p the packet (p / nblk, p % nblk) of this gulp?  The last group to
-//                         finish writes the gulp's descriptor -- the slab itself, or (any packet out of place, lost, foreign,
-//                         duplicated) the scratch gulp below
-//   slab_clear_kernel, slab_scatter_kernel   once per integration, for the gulps whose descriptor says "scratch": zero-fill +
-//                         scatter with the validation rules of snap2_unpack_kernel (ingest.hip); otherwise they return at once
-#pragma once
-#include <stdint.h>
+// Packet slabs as gulps: the device passes (slab.h) shared by the X-engine (xcorr.hip) and the beamformer (beamform.hip).
+#include "slab.h"
 
-#include "xcorr_kernels.h"
+#include <algorithm>
+
+#include "xeng_common.h"
 
 namespace xeng {
-
-struct SlabArgs {
-    const uint8_t* pkts;
-    int npkt;
-    uint32_t stride;
-    unsigned long long seq0;
-    int ntime, chan0, nchan, ninput, nblk;
-};
 
 __device__ __forceinline__ uint32_t slab_be32(const uint8_t* p) {
     return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
@@ -83,9 +63,10 @@ __global__ __launch_bounds__(256) void slab_prepare_kernel(SlabArgs a, unsigned 
 
 // Once per integration, behind the prepare kernels of its gulps (grid.y = gulp): zero-fill and scatter of the gulps whose
 // descriptor says "scratch"; the groups of every other gulp return at once.
-__global__ __launch_bounds__(256) void slab_clear_kernel(const GulpDesc* __restrict__ desc, size_t n16) {
+__global__ __launch_bounds__(256) void slab_clear_kernel(const GulpDesc* __restrict__ desc, const SlabArgs* __restrict__ args) {
     const GulpDesc& d = desc[blockIdx.y];
     if (!d.pad) return;
+    const size_t n16 = (size_t)args[blockIdx.y].ntime * args[blockIdx.y].nchan * args[blockIdx.y].ninput / 16;     // (scratch gulps are whole 16-byte pieces: checked on the host)
     uint4* scratch = reinterpret_cast<uint4*>(const_cast<uint8_t*>(d.base));
     for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n16; k += (size_t)gridDim.x * 256) scratch[k] = make_uint4(0, 0, 0, 0);
 }
@@ -115,6 +96,48 @@ __global__ __launch_bounds__(256) void slab_scatter_kernel(const GulpDesc* __res
             for (int i = lane; i < n; i += 64) dst[(size_t)(i / h.npol) * a.ninput + (i % h.npol)] = src[i];
         }
     }
+}
+
+
+int slab_site_create(SlabSite* s) {
+    void* p = nullptr;
+    XENG_HIP(hipMalloc(&p, 16));
+    XENG_HIP(hipMemset(p, 0, 16));
+    s->tally = (unsigned long long*)p;
+    s->fallbacks = (int*)p + 2;
+    return XENG_STATUS_SUCCESS;
+}
+
+void slab_site_destroy(SlabSite* s) {
+    if (s->tally) (void)hipFree(s->tally);
+    *s = SlabSite();
+}
+
+bool slab_maybe_regular(const SlabArgs& a, int rows) {
+    return a.ninput > 0 && a.ninput % 64 == 0 && a.npkt > 0 && a.npkt == a.ntime * a.nblk && a.stride >= 32 + (size_t)a.nchan * 64 &&
+           a.stride % 16 == 0 && ((uintptr_t)a.pkts & 15) == 0 && (uint64_t)a.nblk * a.stride * rows < (1ull << 31);
+}
+
+int slab_prepare_enqueue(hipStream_t stream, const SlabSite& site, const SlabArgs& a, bool maybe, GulpDesc* desc, SlabArgs* args_out, uint8_t* scratch) {
+    hipLaunchKernelGGL(slab_prepare_kernel, dim3(maybe ? (a.npkt + 255) / 256 : 1), dim3(256), 0, stream, a, site.tally, site.fallbacks, desc, args_out,
+                       scratch, maybe ? 0 : 1);
+    XENG_HIP(hipGetLastError());
+    return XENG_STATUS_SUCCESS;
+}
+
+int slab_fallback_enqueue(hipStream_t stream, const GulpDesc* descs, const SlabArgs* args, int ngulp) {
+    // (both return at once for every gulp whose descriptor does not say "scratch": small grids, grid-stride loops)
+    hipLaunchKernelGGL(slab_clear_kernel, dim3(512, ngulp), dim3(256), 0, stream, descs, args);
+    hipLaunchKernelGGL(slab_scatter_kernel, dim3(512, ngulp), dim3(256), 0, stream, descs, args);
+    XENG_HIP(hipGetLastError());
+    return XENG_STATUS_SUCCESS;
+}
+
+int slab_site_read_fallbacks(hipStream_t stream, const SlabSite& site, int* n) {
+    XENG_HIP(hipMemcpyAsync(n, site.fallbacks, sizeof(int), hipMemcpyDeviceToHost, stream));
+    XENG_HIP(hipMemsetAsync(site.fallbacks, 0, sizeof(int), stream));
+    XENG_HIP(hipStreamSynchronize(stream));
+    return XENG_STATUS_SUCCESS;
 }
 
 }  // namespace xeng

@@ -9,7 +9,7 @@
 #include <vector>
 
 #include "xcorr_kernels.h"
-#include "slab_kernels.h"
+#include "slab.h"
 #include "xeng_common.h"
 
 namespace xeng {
@@ -85,8 +85,8 @@ struct XgpuContext {
     unsigned long long* stamps = nullptr;   // diagnostic (XENG_DBG_STAMPS=1)
     // packet slabs as gulps (xengXgpuKernelAsyncSlab): per staging area one descriptor per gulp, written on the staging stream
     GulpDesc* gdesc_dev[2] = {nullptr, nullptr};
-    SlabArgs* gargs_dev[2] = {nullptr, nullptr};   // ... and what the scatter of a gulp that turns out irregular needs (slab_kernels.h)
-    int* slab_bad_dev = nullptr;            // [1]: gulps that took the scratch path, [2..3]: the 64-bit tally of slab_prepare_kernel
+    SlabArgs* gargs_dev[2] = {nullptr, nullptr};   // ... and what the scatter of a gulp that turns out irregular needs (slab.h)
+    SlabSite slab_site;                     // the verify pass's tally + the count of gulps that took the scratch path (slab.h)
     bool slab_mode = false;                 // the gulps staged since the last flush are slabs (no mixing inside one flush)
     EventTimer timer;
 };
@@ -123,7 +123,7 @@ static int destroy_locked() {
         if (x.gdesc_dev[b]) (void)hipFree(x.gdesc_dev[b]);
     for (int b = 0; b < 2; b++)
         if (x.gargs_dev[b]) (void)hipFree(x.gargs_dev[b]);
-    if (x.slab_bad_dev) (void)hipFree(x.slab_bad_dev);
+    slab_site_destroy(&x.slab_site);
     x.timer.destroy();
     x = XgpuContext();
     g_epoch++;
@@ -232,10 +232,9 @@ static int flush_locked(void* out, bool dump, void* acc = nullptr, int acc_mode 
         nkt += padk;
     }
     if (x.slab_mode && !diag_env("XENG_SLAB_SKIP")) {
-        // packet slabs: zero-fill + scatter of the gulps that turned out irregular (slab_kernels.h); for every other gulp the
+        // packet slabs: zero-fill + scatter of the gulps that turned out irregular (slab.h); for every other gulp the
         // groups return at once
-        hipLaunchKernelGGL(slab_clear_kernel, dim3(512, x.nfilled), dim3(256), 0, x.stream, x.gdesc_dev[x.cur], x.gulp_bytes / 16);
-        hipLaunchKernelGGL(slab_scatter_kernel, dim3(512, x.nfilled), dim3(256), 0, x.stream, x.gdesc_dev[x.cur], x.gargs_dev[x.cur]);
+        if (int rcs = slab_fallback_enqueue(x.stream, x.gdesc_dev[x.cur], x.gargs_dev[x.cur], x.nfilled)) return rcs;
         staging_stream_touched();
     }
     XcorrParams p;
@@ -573,8 +572,7 @@ static int initialize_locked(int gpu) {
             XENG_HIP(hipMalloc((void**)&x.gargs_dev[b], XC_MAX_GULPS * sizeof(SlabArgs)));
             XENG_HIP(hipMemset(x.gargs_dev[b], 0, XC_MAX_GULPS * sizeof(SlabArgs)));
         }
-        XENG_HIP(hipMalloc((void**)&x.slab_bad_dev, 4 * sizeof(int)));
-        XENG_HIP(hipMemset(x.slab_bad_dev, 0, 4 * sizeof(int)));
+        if (int rcs = slab_site_create(&x.slab_site)) return rcs;
     }
     std::vector<WgDesc> descs = build_wg_descs(x.nblk64);
     x.nwg = (int)descs.size();
@@ -695,7 +693,7 @@ int xengXgpuTryKernelAsyncAcc(const void* in_dev, void* out_dev, int doDump, voi
 
 int xengXgpuWaitLaunchSlot(void) { return wait_for_event_slot(true); }
 
-// A gulp handed over as the slab of packets it arrived in (slab_kernels.h): verified on the device; read in place by the
+// A gulp handed over as the slab of packets it arrived in (slab.h): verified on the device; read in place by the
 // contraction when it is regular, scattered into the library's staging area (and read from there) when it is not.
 int xengXgpuKernelAsyncSlab(const void* packets_dev, int npkt, size_t pkt_stride, uint64_t seq0, int chan0_pipeline, void* out_dev,
                             int doDump, void* acc_dev, int acc_mode) {
@@ -722,16 +720,11 @@ int xengXgpuKernelAsyncSlab(const void* packets_dev, int npkt, size_t pkt_stride
     SlabArgs a;
     a.pkts = (const uint8_t*)packets_dev; a.npkt = npkt; a.stride = (uint32_t)pkt_stride; a.seq0 = seq0;
     a.ntime = x.cfg.ntime_gulp; a.chan0 = chan0_pipeline; a.nchan = x.cfg.nchan; a.ninput = x.ninput; a.nblk = x.ninput / 64;
-    // regular at all?  whole 64-input blocks, one packet per (sample, block), payload rows of 64 bytes, 16-byte pieces, and the
-    // kernel's 32-bit per-lane offsets must hold 48 rows
-    const bool maybe = x.ninput % 64 == 0 && npkt == x.cfg.ntime_gulp * a.nblk && pkt_stride >= 32 + (size_t)x.cfg.nchan * 64 &&
-                       pkt_stride % 16 == 0 && ((uintptr_t)packets_dev & 15) == 0 && (uint64_t)a.nblk * pkt_stride * 48 < (1ull << 31);
+    const bool maybe = slab_maybe_regular(a, 48);       // (the kernel's 32-bit per-lane offsets hold 48 sample rows)
     uint8_t* scratch = x.stash[x.cur] + (size_t)k * x.gulp_bytes;
-    GulpDesc* desc = x.gdesc_dev[x.cur] + k;
     const char* skip = diag_env("XENG_SLAB_SKIP");      // (diagnostic builds, timing only: any value drops the clear / scatter launches, "all" also this one -- descriptors of earlier launches are reused)
     if (!skip || skip[0] != 'a')
-        hipLaunchKernelGGL(slab_prepare_kernel, dim3(maybe && npkt > 0 ? (npkt + 255) / 256 : 1), dim3(256), 0, x.stream, a, (unsigned long long*)(x.slab_bad_dev + 2), x.slab_bad_dev + 1,
-                           desc, x.gargs_dev[x.cur] + k, scratch, maybe && npkt > 0 ? 0 : 1);
+        if (int rcs = slab_prepare_enqueue(x.stream, x.slab_site, a, maybe, x.gdesc_dev[x.cur] + k, x.gargs_dev[x.cur] + k, scratch)) return rcs;
     XENG_HIP(hipGetLastError());
     staging_stream_touched();
     x.gulp_ptr[k] = nullptr;
@@ -749,12 +742,10 @@ int xengXgpuGetSlabFallbacks(int* nfallback) {
     if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized");
     if (!nfallback) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "GetSlabFallbacks: null pointer");
     *nfallback = 0;
-    if (!x.slab_bad_dev) return XENG_STATUS_SUCCESS;
+    if (!x.slab_site.tally) return XENG_STATUS_SUCCESS;
     XENG_HIP(hipSetDevice(x.gpu));
-    XENG_HIP(hipMemcpyAsync(nfallback, x.slab_bad_dev + 1, sizeof(int), hipMemcpyDeviceToHost, x.stream));
-    XENG_HIP(hipMemsetAsync(x.slab_bad_dev + 1, 0, sizeof(int), x.stream));
     stream_tick(STREAM_XGPU);
-    XENG_HIP(hipStreamSynchronize(x.stream));
+    if (int rcs = slab_site_read_fallbacks(x.stream, x.slab_site, nfallback)) return rcs;
     return XENG_STATUS_SUCCESS;
 }
 

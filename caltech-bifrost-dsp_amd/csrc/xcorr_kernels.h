@@ -35,6 +35,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
+#include "slab.h"
 
 #include "xcorr_tiling.h"
 
@@ -202,20 +203,9 @@ struct XcorrParams {
     int acc2_mode;
     // DESC instantiation (round 4): the gulps of this launch are described in DEVICE memory, one GulpDesc each, written on the
     // staging stream before the launch -- a gulp may then be a slab of F-engine packets read where it lies (xengXgpuKernelAsyncSlab)
-    const struct GulpDesc* gdesc;
+    const GulpDesc* gdesc;
 };
 
-// Where the bytes of one gulp lie: sample t, channel c, 64-input block b, byte j of the block at
-//   base + t * t_stride + c * c_stride + b * b_stride + j.
-// A time-major gulp u8[t][c][input]: (nchan * ninput, ninput, 64).  A regular slab of SNAP2 packets -- packet (t, b) at index
-// t * nblocks + b, 32-byte header + payload [nchan][64 inputs] (test_tx_vectors.py:38-48,103-108) --: base = slab + 32,
-// (nblocks * pkt_stride, 64, pkt_stride): the contraction reads the packets where they lie, no scatter pass.
-struct GulpDesc {
-    const uint8_t* base;
-    uint32_t t_stride, c_stride, b_stride, pad;
-    uint64_t pad2;
-};
-static_assert(sizeof(GulpDesc) == 32, "GulpDesc is read as eight aligned dwords");
 
 struct Frags {   // the 8 unpacked int8 operand fragments of one 64x64 wave tile and one K-tile
     v4i ar[2], ai[2], br[2], bi[2];

@@ -333,6 +333,16 @@ int xengBeamformTryRunVersioned(const void *in_dev, void *out_dev, const void *w
  * waits (see xengBeamformTryRunVersioned). */
 int xengBeamformRunParts(const void *in0_dev, int ntime0, const void *in1_dev, void *out_dev, const void *weights_dev, long long weights_version);
 int xengBeamformTryRunParts(const void *in0_dev, int ntime0, const void *in1_dev, void *out_dev, const void *weights_dev, long long weights_version);
+/* The gulp as the SLABS OF PACKETS it arrived in (round 4; cf. xengXgpuKernelAsyncSlab, layout: "Ingest" below): one slab
+ * (packets1_dev NULL) or two consecutive ones -- samples [0, ntime0) from seq0 on, samples [ntime0, ntime) from seq0 + ntime0 on;
+ * ntime0 a multiple of 16, inputs a multiple of 16.  Each slab is verified on the beam stream; a regular one is read by the
+ * beamformer kernels where it lies, any other is scattered into the context's scratch gulp first (xengSnap2Unpack's rules), so
+ * the beams are those of unpack + Run either way -- bit for bit, the same kernels do the arithmetic.  RunVersioned semantics
+ * otherwise; the slabs must stay valid and unchanged until the call's kernels have completed (xengBeamformMark).
+ * xengBeamformGetSlabFallbacks: parts that took the scatter since it was last called (waits for the beam stream). */
+int xengBeamformRunSlabs(const void *packets0_dev, int npkt0, int ntime0, const void *packets1_dev, int npkt1, size_t pkt_stride,
+                         uint64_t seq0, int chan0_pipeline, void *out_dev, const void *weights_dev, long long weights_version);
+int xengBeamformGetSlabFallbacks(int *nfallback);
 
 /* beamform_sum_beams_block.py:243-246.  in_dev cf32[nchan][nbeam][ntime];
  * out_dev f32[nbeam/2][ntime/ntime_sum][nchan][4] = [XX, YY, Re XY*, Im XY*]. */

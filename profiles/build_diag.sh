@@ -6,7 +6,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 B=${TMPDIR:-/tmp}/diagbuild
 mkdir -p $B $R/profiles/_ab
 cd $R/caltech-bifrost-dsp_amd/csrc
-for f in xeng_util xcorr corracc beamform ingest ring xeng_bfarray; do
+for f in xeng_util xcorr corracc beamform ingest slab ring xeng_bfarray; do
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -DXENG_DIAGNOSTICS -c $f.hip -o $B/$f.o &
 done
 wait

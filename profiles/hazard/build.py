@@ -90,7 +90,7 @@ def main():
     m = re.search(r"s_andn2_b64 exec, exec, s\[14:15\]\n\ts_cbranch_execnz (\.LBB\d+_\d+)\n", text)
     assert m, "loop exit of the failing kernel not found"
     label = m.group(1)
-    objs = [os.path.join(CSRC, o) for o in ("xeng_util.o", "xcorr.o", "corracc.o", "ingest.o", "ring.o", "xeng_bfarray.o")]
+    objs = [os.path.join(CSRC, o) for o in ("xeng_util.o", "xcorr.o", "corracc.o", "ingest.o", "slab.o", "ring.o", "xeng_bfarray.o")]
     want = sys.argv[1:] or list(VARIANTS)
     for name in want:
         why, edits = VARIANTS[name]

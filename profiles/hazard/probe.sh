@@ -8,5 +8,5 @@ O=$R/profiles/hazard/build
 mkdir -p $O
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -I$C -c $R/profiles/hazard/diag_probe.hip -o $O/diag_probe.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $O/libxeng_probe.so $C/xeng_util.o $C/xcorr.o $C/corracc.o $C/beamform.o \
-    $C/ingest.o $C/ring.o $C/xeng_bfarray.o $O/diag_probe.o
+    $C/ingest.o $C/slab.o $C/ring.o $C/xeng_bfarray.o $O/diag_probe.o
 XENG_LIB=$O/libxeng_probe.so python3 $R/profiles/hazard/probe.py "$@"

@@ -181,3 +181,133 @@ def test_streaming_slabs_with_alternating_outputs(gpu):
             d.free()
     for o in outs:
         o.free()
+
+
+# ---- the beamformer on packet slabs (xengBeamformRunSlabs) ----
+
+def _beam_init(ffi, mode, ninput, nchan, ntime, nbeam, ntime_blocks=0):
+    import os
+    old = os.environ.get("XENG_BEAM")
+    if mode:
+        os.environ["XENG_BEAM"] = mode
+    try:
+        ffi.call("xengBeamformInitialize", 0, ninput, nchan, ntime, nbeam, ntime_blocks)
+    finally:
+        if mode:
+            os.environ.pop("XENG_BEAM")
+            if old is not None:
+                os.environ["XENG_BEAM"] = old
+
+
+def _beam_weights(rng, nchan, nbeam, ninput):
+    w = (rng.uniform(-17, 17, (nchan, nbeam, ninput)) + 1j * rng.uniform(-17, 17, (nchan, nbeam, ninput))).astype(np.complex64)
+    w[:, :, 3] *= 4096.0                                                       # an outlier input on every row
+    w[0] *= np.exp(rng.uniform(-12, 12, (nbeam, ninput))).astype(np.float32)    # channel 0: routed to the bf16x3 kernel
+    return w
+
+
+@pytest.mark.parametrize("mode", ["", "bf16x3", "f32"])
+@pytest.mark.parametrize("nstand,nchan,ntime,nbeam,ntime0", [(352, 96, 960, 32, 480), (96, 8, 256, 32, 64), (64, 5, 192, 6, 0)])
+def test_beamformer_reads_regular_slabs_in_place(gpu, mode, nstand, nchan, ntime, nbeam, ntime0):
+    """one or two regular slabs as a beamformer gulp: no part takes the scatter, and the beams are BIT-IDENTICAL to
+    xengBeamformRun on the unpacked gulp (the same kernels do the arithmetic; only the addresses differ) -- on all three
+    kernel routes, with outlier inputs and routed tiles in play"""
+    ffi = gpu.ffi
+    ninput = nstand * 2
+    rng = np.random.default_rng(nstand + ntime0)
+    vin = gpu.synth_voltages(ntime, nchan, nstand, "full", seed=ntime + nchan)
+    w = _beam_weights(rng, nchan, nbeam, ninput)
+    _beam_init(ffi, mode, ninput, nchan, ntime, nbeam)
+    mk = lambda lo, hi: _slab(orc.snap2_packets(vin[lo:hi], seq0=SEQ0 + lo, sync_time=1, nchan_blocks=1, nstand_per_pkt=32, chan0_pipeline=CHAN0))
+    parts = [mk(0, ntime0), mk(ntime0, ntime)] if ntime0 else [mk(0, ntime)]
+    stride = parts[0][1]
+    bufs = [ffi.DeviceBuffer(raw.size).upload(raw) for raw, _ in parts]
+    dfull = ffi.DeviceBuffer(vin.size).upload(vin.reshape(-1))
+    dw = ffi.DeviceBuffer(w.nbytes).upload(w)
+    o1, o2 = ffi.DeviceBuffer(nchan * nbeam * ntime * 8), ffi.DeviceBuffer(nchan * nbeam * ntime * 8)
+    ffi.call("xengMemset", o2.ptr, 0x5A, o2.nbytes)
+    ffi.call("xengBeamformRunVersioned", dfull.ptr, o1.ptr, dw.ptr, 1)
+    if ntime0:
+        ffi.call("xengBeamformRunSlabs", bufs[0].ptr, parts[0][0].size // stride, ntime0, bufs[1].ptr, parts[1][0].size // stride, stride, SEQ0, CHAN0,
+                 o2.ptr, dw.ptr, 1)
+    else:
+        ffi.call("xengBeamformRunSlabs", bufs[0].ptr, parts[0][0].size // stride, ntime, None, 0, stride, SEQ0, CHAN0, o2.ptr, dw.ptr, 1)
+    ffi.call("xengBeamformSync")
+    nfb = ctypes.c_int(-1)
+    ffi.call("xengBeamformGetSlabFallbacks", ctypes.byref(nfb))
+    assert nfb.value == 0
+    assert np.array_equal(o1.download(np.uint32), o2.download(np.uint32))
+    ffi.call("xengBeamformDestroy")
+    for d in bufs + [dfull, dw, o1, o2]:
+        d.free()
+
+
+@pytest.mark.parametrize("mode", ["", "f32"])
+def test_beamformer_irregular_slabs_give_the_unpacked_result(gpu, mode):
+    """a regular first part and a second part with lost, reordered and foreign packets; then both parts irregular: the beams
+    equal xengBeamformRun on what snap2_unpack makes of the packets (missing samples zero), bit for bit"""
+    ffi = gpu.ffi
+    nstand, nchan, ntime, nbeam, ntime0 = 96, 8, 256, 32, 128
+    ninput = nstand * 2
+    rng = np.random.default_rng(77)
+    vin = gpu.synth_voltages(ntime, nchan, nstand, "full", seed=5)
+    w = _beam_weights(rng, nchan, nbeam, ninput)
+    _beam_init(ffi, mode, ninput, nchan, ntime, nbeam)
+    mk = lambda lo, hi: orc.snap2_packets(vin[lo:hi], seq0=SEQ0 + lo, sync_time=1, nchan_blocks=1, nstand_per_pkt=32, chan0_pipeline=CHAN0)
+    p0, p1 = mk(0, ntime0), mk(ntime0, ntime)
+    bad1 = [p1[i] for i in rng.permutation(len(p1))]
+    bad1 = bad1[:50] + bad1[53:]                                                   # three lost
+    bad1[7] = orc.snap2_packets(vin[:1], seq0=SEQ0 + 5000, sync_time=1, nchan_blocks=1, nstand_per_pkt=32, chan0_pipeline=CHAN0)[0]   # outside the window
+    bad1 += [bad1[0]] * 3                                                          # (same count again: duplicates)
+    bad0 = list(p0)
+    bad0[11] = bad0[12]
+    dw = ffi.DeviceBuffer(w.nbytes).upload(w)
+    o1, o2 = ffi.DeviceBuffer(nchan * nbeam * ntime * 8), ffi.DeviceBuffer(nchan * nbeam * ntime * 8)
+    for first, second, nexp in ((p0, bad1, 1), (bad0, bad1, 2), (p0, p1, 0)):       # (the last: the scratch gulp of earlier calls is not read)
+        g0, _, _ = orc.snap2_unpack(first, SEQ0, ntime0, CHAN0, nchan, ninput)
+        g1, _, _ = orc.snap2_unpack(second, SEQ0 + ntime0, ntime - ntime0, CHAN0, nchan, ninput)
+        unpacked = np.concatenate([g0, g1])
+        dfull = ffi.DeviceBuffer(unpacked.size).upload(unpacked.reshape(-1))
+        (r0, stride), (r1, _) = _slab(first), _slab(second)
+        d0, d1 = ffi.DeviceBuffer(r0.size).upload(r0), ffi.DeviceBuffer(r1.size).upload(r1)
+        ffi.call("xengBeamformRunVersioned", dfull.ptr, o1.ptr, dw.ptr, 1)
+        ffi.call("xengBeamformRunSlabs", d0.ptr, r0.size // stride, ntime0, d1.ptr, r1.size // stride, stride, SEQ0, CHAN0, o2.ptr, dw.ptr, 1)
+        ffi.call("xengBeamformSync")
+        nfb = ctypes.c_int(-1)
+        ffi.call("xengBeamformGetSlabFallbacks", ctypes.byref(nfb))
+        assert nfb.value == nexp
+        assert np.array_equal(o1.download(np.uint32), o2.download(np.uint32)), nexp
+        for d in (dfull, d0, d1):
+            d.free()
+    with pytest.raises(ffi.XengError):       # parts must sit on 16-sample boundaries
+        ffi.call("xengBeamformRunSlabs", o1.ptr, 10, 100, o1.ptr, 10, 6176, SEQ0, CHAN0, o2.ptr, dw.ptr, 1)
+    ffi.call("xengBeamformDestroy")
+    for d in (dw, o1, o2):
+        d.free()
+
+
+def test_beamformer_slabs_in_the_integrated_power_mode(gpu):
+    """ntime_blocks > 0 (power sums formed in the kernel's epilogue): slabs give the same words as the unpacked gulp"""
+    ffi = gpu.ffi
+    nstand, nchan, ntime, nbeam, ntime0, nblocks = 96, 8, 256, 32, 128, 8
+    ninput = nstand * 2
+    rng = np.random.default_rng(3)
+    vin = gpu.synth_voltages(ntime, nchan, nstand, "full", seed=9)
+    w = (rng.uniform(-17, 17, (nchan, nbeam, ninput)) + 1j * rng.uniform(-17, 17, (nchan, nbeam, ninput))).astype(np.complex64)
+    _beam_init(ffi, "", ninput, nchan, ntime, nbeam, nblocks)
+    mk = lambda lo, hi: _slab(orc.snap2_packets(vin[lo:hi], seq0=SEQ0 + lo, sync_time=1, nchan_blocks=1, nstand_per_pkt=32, chan0_pipeline=CHAN0))
+    (r0, stride), (r1, _) = mk(0, ntime0), mk(ntime0, ntime)
+    d0, d1 = ffi.DeviceBuffer(r0.size).upload(r0), ffi.DeviceBuffer(r1.size).upload(r1)
+    dfull = ffi.DeviceBuffer(vin.size).upload(vin.reshape(-1))
+    dw = ffi.DeviceBuffer(w.nbytes).upload(w)
+    nout = (nbeam // 2) * nblocks * nchan * 4 * 4
+    o1, o2 = ffi.DeviceBuffer(nout), ffi.DeviceBuffer(nout)
+    for _ in range(2):        # (the second pass: the routing answer is known, the fused epilogue forms the sums)
+        ffi.call("xengBeamformRunVersioned", dfull.ptr, o1.ptr, dw.ptr, 1)
+        ffi.call("xengBeamformRunSlabs", d0.ptr, r0.size // stride, ntime0, d1.ptr, r1.size // stride, stride, SEQ0, CHAN0, o2.ptr, dw.ptr, 1)
+        ffi.call("xengBeamformSync")
+        a, b = o1.download(np.float32), o2.download(np.float32)
+        assert np.allclose(a, b, rtol=1e-6, atol=0) and np.abs(a).max() > 0      # (sums added atomically across work-groups: order may differ in the last bit)
+    ffi.call("xengBeamformDestroy")
+    for d in (d0, d1, dfull, dw, o1, o2):
+        d.free()
