@@ -702,9 +702,14 @@ def main():
         # packets -> visibilities, device resident (BASELINE: "throughput on synthetic F-engine packets"): every gulp of
         # every integration is first scattered out of its packet slab (enqueue-only, on the X-engine's staging stream),
         # then registered with the X-engine; same streaming pattern as the timed region
-        slabs = [dslab] + [ffi.DeviceBuffer(slab.nbytes) for _ in range(2 * gulps_per_step - 1)]
-        for k in range(1, len(slabs)):
-            ffi.call("xengMemcpy", slabs[k].ptr, dslab.ptr, slab.nbytes)
+        # (slab k carries the sequence numbers of gulp k: 480 k .. 480 k + 479)
+        slabs = [dslab]
+        hdr_seq = slab[:, :8].copy()
+        for k in range(1, 2 * gulps_per_step):
+            for t in range(NTIME_GULP):
+                slab[t * npb:(t + 1) * npb, :8] = np.frombuffer(struct.pack(">Q", k * NTIME_GULP + t), dtype=np.uint8)
+            slabs.append(ffi.DeviceBuffer(slab.nbytes).upload(slab))
+        slab[:, :8] = hdr_seq
         # the same packets as a receiver that chooses where each packet lands can place them: payloads on 128-byte lines
         # (49 lines per packet; the header in the last 32 bytes of the line before)
         stride_a, lead_a = 49 * 128, 96
@@ -726,10 +731,10 @@ def main():
                     if direct == 2:
                         ffi.check("slab", L.xengXgpuKernelAsyncSlab(slabs_a[slot].ptr + lead_a, npk, stride_a, 0, 0, outs[it & 1].ptr, int(g == gulps_per_step - 1), None, 0))
                     elif direct:    # the slab IS the gulp: verified on the device, read in place by the contraction (no scatter pass)
-                        ffi.check("slab", L.xengXgpuKernelAsyncSlab(slabs[slot].ptr, npk, stride, 0, 0, outs[it & 1].ptr, int(g == gulps_per_step - 1), None, 0))
+                        ffi.check("slab", L.xengXgpuKernelAsyncSlab(slabs[slot].ptr, npk, stride, slot * NTIME_GULP, 0, outs[it & 1].ptr, int(g == gulps_per_step - 1), None, 0))
                     else:
                         dst = ring.ptr + slot * gulp_bytes
-                        ffi.check("unpack", L.xengSnap2UnpackAsync(slabs[slot].ptr, npk, stride, dst, 0, NTIME_GULP, 0, NCHAN, NINPUT, 1))
+                        ffi.check("unpack", L.xengSnap2UnpackAsync(slabs[slot].ptr, npk, stride, dst, slot * NTIME_GULP, NTIME_GULP, 0, NCHAN, NINPUT, 1))
                         ffi.check(kern, L.xengXgpuKernelAsync(dst, outs[it & 1].ptr, int(g == gulps_per_step - 1)))
                     kk += 1
                 ffi.call("xengXgpuSyncLag", 1)
@@ -762,13 +767,14 @@ def main():
         # (same slabs both ways: the two paths must agree word for word)
         for g in range(gulps_per_step):
             dst = ring.ptr + g * gulp_bytes
-            ffi.check("unpack", L.xengSnap2UnpackAsync(slabs[(4 * gulps_per_step + g) % (2 * gulps_per_step)].ptr, npk, stride, dst, 0, NTIME_GULP, 0, NCHAN, NINPUT, 1))
+            slot = (4 * gulps_per_step + g) % (2 * gulps_per_step)
+            ffi.check("unpack", L.xengSnap2UnpackAsync(slabs[slot].ptr, npk, stride, dst, slot * NTIME_GULP, NTIME_GULP, 0, NCHAN, NINPUT, 1))
             ffi.check(kern, L.xengXgpuKernelAsync(dst, outs[0].ptr, int(g == gulps_per_step - 1)))
         ffi.call("xengXgpuSync")
         want_vis = outs[0].download(np.int32)
         ingest["packets_to_visibilities"]["equals_scatter_path"] = bool(np.array_equal(slab_vis, want_vis))
         ingest["packets_to_visibilities_payloads_on_cache_lines"]["equals_scatter_path"] = bool(np.array_equal(slab_a_vis, want_vis))
-        for b in slabs + slabs_a:
+        for b in slabs_a:
             b.free()
         dgulp.free()
     # outside the timed region: BASELINE config 4 -- Beamform (32 beams, 96 chan, 960 samples, fp32 weights)
@@ -886,6 +892,61 @@ def main():
                 "ms_per_integration": round(elf2 / nfull * 1e3, 4),
                 "note": "the same with the CorrAcc add done in the contraction's epilogue (xengXgpuKernelAsyncAcc, two alternating "
                         "accumulators): one pass over the 191 MB accumulator per dump instead of a 574 MB map kernel"}
+        # ... and fed from PACKETS (north star: "throughput on synthetic F-engine packets"): the ten device-resident packet slabs of
+        # the ingest leg above instead of replay gulps.  Both consumers read the slabs where they lie (xengXgpuKernelAsyncSlab,
+        # xengBeamformRunSlabs: two slabs = one 960-sample beam gulp); the comparison leg scatters every slab into the replay
+        # ring first (xengSnap2UnpackAsync) and runs the plain calls on the copies.
+        if not args.sync_per_call:
+            sfn, ufn, bsl = L.xengXgpuKernelAsyncSlab, L.xengSnap2UnpackAsync, L.xengBeamformRunSlabs
+            nslab = 2 * gulps_per_step
+
+            def full_step_packets(n, first, in_place):
+                o = outs3[n % 3]
+                for g in range(gulps_per_step):
+                    slot = gi[0] % nslab
+                    if in_place:
+                        ffi.check("slab", sfn(slabs[slot].ptr, npk, stride, slot * NTIME_GULP, 0, o.ptr, int(g == gulps_per_step - 1), acc_pair[n & 1].ptr, 1 if first else 2))
+                    else:
+                        dst = ring.ptr + slot * gulp_bytes
+                        ffi.check("unpack", ufn(slabs[slot].ptr, npk, stride, dst, slot * NTIME_GULP, NTIME_GULP, 0, NCHAN, NINPUT, 1))
+                        ffi.check("kernel", afn(dst, o.ptr, int(g == gulps_per_step - 1), acc_pair[n & 1].ptr, 1 if first else 2))
+                    gi[0] += 1
+                for _ in range(2 + (n & 1)):
+                    k0 = (2 * bi[0]) % nslab
+                    if in_place:
+                        ffi.check("run", bsl(slabs[k0].ptr, npk, NTIME_GULP, slabs[k0 + 1].ptr, npk, stride, k0 * NTIME_GULP, 0, dbeam.ptr, dw.ptr, 1))
+                    else:       # (the copies of slabs k0, k0 + 1 lie side by side in the replay ring: scattered by this or an earlier integration)
+                        ffi.check("run", L.xengBeamformRunVersioned(ring.ptr + k0 * gulp_bytes, dbeam.ptr, dw.ptr, 1))
+                    ffi.check("int", L.xengBeamformIntegrate(dbeam.ptr, dpow.ptr, NS))
+                    bi[0] += 1
+                ffi.call("xengXgpuSyncLag", 1)
+            pk = {}
+            snap = {}
+            for in_place in (False, True):
+                gi[0] = bi[0] = 0
+                for n in range(6):
+                    full_step_packets(n, n < 2, in_place)
+                ffi.call("xengDeviceSynchronize")
+                tf = time.perf_counter()
+                for n in range(6, 6 + nfull):
+                    full_step_packets(n, False, in_place)
+                ffi.call("xengDeviceSynchronize")
+                elp = time.perf_counter() - tf
+                pk["in_place" if in_place else "through_scatter"] = {
+                    "ingest_gbps": round(8 * NINPUT * units_per_step_c * nfull / elp / 1e9, 1), "ms_per_integration": round(elp / nfull * 1e3, 4)}
+                snap[in_place] = (outs3[(6 + nfull - 1) % 3].download(np.int32), dbeam.download(np.uint32), dpow.download(np.uint32))
+            nfx, nfb = ctypes.c_int(-1), ctypes.c_int(-1)
+            ffi.call("xengXgpuGetSlabFallbacks", ctypes.byref(nfx))
+            ffi.call("xengBeamformGetSlabFallbacks", ctypes.byref(nfb))
+            pk["slabs_scattered_after_all"] = {"corr": int(nfx.value), "beamform": int(nfb.value)}
+            pk["in_place_equals_through_scatter"] = {"visibilities": bool(np.array_equal(snap[0][0], snap[1][0])), "beams": bool(np.array_equal(snap[0][1], snap[1][1])),
+                                                     "power_sums": bool(np.array_equal(snap[0][2], snap[1][2]))}
+            pk["note"] = ("config 5 with fused CorrAcc, fed from ten device-resident slabs of 5280 SNAP2 packets each: per integration 5 slabs "
+                          "to the correlator and 2.5 slab pairs to the beamformer; in_place = both read the packets where they lie")
+            beam["full_xengine_concurrent"]["from_packet_slabs"] = pk
+            del snap
+        for b in slabs:
+            b.free()
         # the same concurrent pattern once more on KNOWN inputs (three integrations of ring gulps 0..4, beams of gulps 0+1),
         # kept for the oracle to check in the cpu_baseline leg: one dumped span, the CorrAcc sum (= 3 x that span) and one
         # beam gulp with its power sums

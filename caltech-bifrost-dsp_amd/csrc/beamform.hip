@@ -44,12 +44,14 @@ struct BeamContext {
     static constexpr int NMARK = 64;
     hipEvent_t marks[NMARK] = {};
     unsigned long long nmarks = 0;
-    // gulps handed over as packet slabs (xengBeamformRunSlabs; slab.h): descriptors + scatter arguments of the (up to two)
-    // parts, and the scratch gulp that irregular slabs are scattered into -- all used in stream order, so one set
+    // gulps handed over as packet slabs (xengBeamformRunSlabs; slab.h): descriptors + the scratch gulp that an irregular slab is
+    // scattered into -- written and read in stream order on the beam stream, so one set.  ONE helper launch per call: measured
+    // (profiles/r04/slab_paths.txt) four short launches in front of a 35 us kernel pair cost 18 us, the same passes on a
+    // stream of their own with an event each way 9-12 us, one launch 5 us.
     SlabSite slab_site;
-    GulpDesc* gdesc = nullptr;
+    GulpDesc* gdesc = nullptr;          // [part]
     SlabArgs* gargs = nullptr;
-    uint8_t* slab_scratch = nullptr;
+    uint8_t* slab_scratch = nullptr;    // [ntime][nchan][ninput]
     EventTimer timer;
 };
 static std::mutex g_bmu;
@@ -296,7 +298,7 @@ int xengBeamformTryRunParts(const void* in0_dev, int ntime0, const void* in1_dev
 
 // The gulp as the slabs of F-engine packets it arrived in (slab.h): one slab (packets1 null, ntime0 = ntime) or two consecutive
 // ones (samples [0, ntime0) and [ntime0, ntime): two capture gulps per beamformer gulp, lwa352-pipeline.py:172,279-282).  Each is
-// verified on the beam stream; a regular slab is read where it lies, anything else is scattered into the context's scratch gulp
+// verified on the beam stream (one launch); a regular slab is read where it lies, anything else is scattered into the context's scratch gulp
 // first (the rules of xengSnap2UnpackAsync: missing samples read as zero, foreign and out-of-window packets dropped).
 int xengBeamformRunSlabs(const void* packets0_dev, int npkt0, int ntime0, const void* packets1_dev, int npkt1, size_t pkt_stride, uint64_t seq0,
                          int chan0_pipeline, void* out_dev, const void* weights_dev, long long weights_version) {
@@ -322,15 +324,16 @@ int xengBeamformRunSlabs(const void* packets0_dev, int npkt0, int ntime0, const 
         XENG_HIP(hipMalloc((void**)&x.slab_scratch, (size_t)x.ntime * row));
     }
     const int nparts = packets1_dev ? 2 : 1;
+    SlabArgs a[2];
+    bool maybe[2] = {false, false};
+    uint8_t* scratch[2] = {x.slab_scratch, x.slab_scratch + (size_t)ntime0 * row};
     for (int k = 0; k < nparts; k++) {
-        SlabArgs a;
-        a.pkts = (const uint8_t*)(k ? packets1_dev : packets0_dev); a.npkt = k ? npkt1 : npkt0; a.stride = (uint32_t)pkt_stride;
-        a.seq0 = seq0 + (k ? (uint64_t)ntime0 : 0); a.ntime = k ? x.ntime - ntime0 : ntime0; a.chan0 = chan0_pipeline; a.nchan = x.nchan;
-        a.ninput = x.ninput; a.nblk = x.ninput / 64;
-        const bool maybe = slab_maybe_regular(a, 1);          // (the kernels form 64-bit row addresses)
-        if (int rc = slab_prepare_enqueue(x.stream, x.slab_site, a, maybe, x.gdesc + k, x.gargs + k, x.slab_scratch + (k ? (size_t)ntime0 * row : 0))) return rc;
+        a[k].pkts = (const uint8_t*)(k ? packets1_dev : packets0_dev); a[k].npkt = k ? npkt1 : npkt0; a[k].stride = (uint32_t)pkt_stride;
+        a[k].seq0 = seq0 + (k ? (uint64_t)ntime0 : 0); a[k].ntime = k ? x.ntime - ntime0 : ntime0; a[k].chan0 = chan0_pipeline; a[k].nchan = x.nchan;
+        a[k].ninput = x.ninput; a[k].nblk = x.ninput / 64;
+        maybe[k] = slab_maybe_regular(a[k], 1);          // (the kernels form 64-bit row addresses)
     }
-    if (int rc = slab_fallback_enqueue(x.stream, x.gdesc, x.gargs, nparts)) return rc;
+    if (int rc = slab_prepare_enqueue(x.stream, x.slab_site, a, maybe, nparts, x.gdesc, x.gargs, scratch, true)) return rc;
     stream_tick(STREAM_BEAM);
     if (x.ntime_blocks == 0) return run_locked(nullptr, (float*)out_dev, weights_dev, weights_version, nullptr, 0, nullptr, true, nullptr, ntime0, x.gdesc);
     bool fused = false;

@@ -270,7 +270,10 @@ __global__ __launch_bounds__(64 * BF3_NW, BF3_NW == 8 ? 2 : 3) void beamform_bf1
     // so the work-groups of a channel read its split weights through one L2 (speed only).
     const int nttile = (ntime + BF3_NT - 1) / BF3_NT, per_c = nbtile * nttile;
     int c, rem;
-    if ((nchan & 7) == 0) { const int b = blockIdx.x, slot = b >> 3; c = (b & 7) + 8 * (slot / per_c); rem = slot % per_c; }
+    if (DESC && (nchan & 15) == 0) {      // packet slabs: channels 2k, 2k+1 share every cache line of a packet -- both on one XCD, back to back
+        const int b = blockIdx.x, slot = b >> 3, q = slot / per_c;
+        c = 16 * (q >> 1) + 2 * (b & 7) + (q & 1); rem = slot % per_c;
+    } else if ((nchan & 7) == 0) { const int b = blockIdx.x, slot = b >> 3; c = (b & 7) + 8 * (slot / per_c); rem = slot % per_c; }
     else { c = blockIdx.x / per_c; rem = blockIdx.x % per_c; }
     const int bt = rem / nttile, t0 = (rem % nttile) * BF3_NT;
     if (route && !route[c * nbtile + bt]) return;      // this (channel, beam tile) runs on the int8x3 kernel
@@ -634,7 +637,10 @@ __global__ __launch_bounds__(256, 3) void beamform_i8x3_kernel(const uint8_t* __
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nttile = (ntime + BI_NT - 1) / BI_NT, per_c = nbtile * nttile;
     int c, rem;
-    if ((nchan & 7) == 0) { const int b = blockIdx.x, slot = b >> 3; c = (b & 7) + 8 * (slot / per_c); rem = slot % per_c; }
+    if (DESC && (nchan & 15) == 0) {      // packet slabs: channels 2k, 2k+1 share every cache line of a packet -- both on one XCD, back to back
+        const int b = blockIdx.x, slot = b >> 3, q = slot / per_c;
+        c = 16 * (q >> 1) + 2 * (b & 7) + (q & 1); rem = slot % per_c;
+    } else if ((nchan & 7) == 0) { const int b = blockIdx.x, slot = b >> 3; c = (b & 7) + 8 * (slot / per_c); rem = slot % per_c; }
     else { c = blockIdx.x / per_c; rem = blockIdx.x % per_c; }
     const int bt = rem / nttile, t0 = (rem % nttile) * BI_NT;
     const int routed = route[c * nbtile + bt];         // this (channel, beam tile) runs on the bf16x3 kernel: checked below,

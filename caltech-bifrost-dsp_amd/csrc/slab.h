@@ -41,7 +41,7 @@ struct SlabArgs {
 
 // One consumer's device-side state (slab.hip): every consumer verifies on its own stream, with its own tally.
 struct SlabSite {
-    unsigned long long* tally = nullptr;     // the 64-bit word of slab_prepare_kernel
+    unsigned long long* tally = nullptr;     // the 64-bit words of slab_prepare_kernel (one per gulp of a launch)
     int* fallbacks = nullptr;                // gulps that took the scratch path since they were last read
 };
 int slab_site_create(SlabSite* s);
@@ -49,8 +49,11 @@ void slab_site_destroy(SlabSite* s);
 // could this slab be regular at all?  (whole 64-input blocks, one packet per (sample, block), payload rows of 64 bytes, 16-byte
 // pieces, and 32-bit per-lane offsets that hold `rows` sample rows)
 bool slab_maybe_regular(const SlabArgs& a, int rows);
-// enqueue on `stream`: verify the slab and write *desc (the slab itself, or `scratch`) and *args_out
-int slab_prepare_enqueue(hipStream_t stream, const SlabSite& site, const SlabArgs& a, bool maybe, GulpDesc* desc, SlabArgs* args_out, uint8_t* scratch);
+// enqueue on `stream`, ONE launch: verify ngulp (1 or 2) slabs and write descs[k] (the slab itself, or scratch[k]) and args_out[k].
+// inline_fallback: an irregular gulp is also zero-filled and scattered by this launch (one work-group: slow, rare); otherwise
+// slab_fallback_enqueue has to follow
+int slab_prepare_enqueue(hipStream_t stream, const SlabSite& site, const SlabArgs* a, const bool* maybe, int ngulp, GulpDesc* descs, SlabArgs* args_out,
+                         uint8_t* const* scratch, bool inline_fallback);
 // enqueue on `stream`, behind the prepare passes of these gulps: zero-fill + scatter of those whose descriptor says "scratch"
 int slab_fallback_enqueue(hipStream_t stream, const GulpDesc* descs, const SlabArgs* args, int ngulp);
 // gulps that took the scratch path since the last call (waits for the stream)

@@ -21,65 +21,18 @@ __device__ __forceinline__ SlabHeader slab_header(const uint8_t* h, int chan0_pi
     return r;
 }
 
-// verify + describe in one launch.  Every wave checks its 64 packets and adds ONE word to the tally: (packets out of place) << 32
-// | 1.  The wave that reads back "all other waves have added theirs" has, in the same word, the gulp's total: it writes the
-// descriptor and re-arms the tally.  One returning atomic per wave carries both the count and the ticket, so nothing has to be
-// ordered and the kernel needs NO fence: an agent-scope fence on this part is an L2 write-back + invalidate on every XCD, and
-// beside a running contraction (which lives on L2 hits of the gulps) that cost 7 % of the streaming rate (measured:
-// profiles/r04/slab_paths.txt).  No LDS either.
-// tally: the 64-bit word; fallbacks: gulps that took the scratch path (read by xengXgpuGetSlabFallbacks).
-// force_scratch: the host already knows the slab cannot be regular (packet count, stride, alignment); then one wave, no check.
-__global__ __launch_bounds__(256) void slab_prepare_kernel(SlabArgs a, unsigned long long* __restrict__ tally, int* __restrict__ fallbacks,
-                                                           GulpDesc* __restrict__ desc, SlabArgs* __restrict__ args_out, uint8_t* scratch,
-                                                           int force_scratch) {
-    bool ok = true;
-    if (!force_scratch) {
-        const int p = blockIdx.x * 256 + threadIdx.x;
-        if (p < a.npkt) {
-            const SlabHeader h = slab_header(a.pkts + (size_t)p * a.stride, a.chan0);
-            const int t = p / a.nblk, b = p % a.nblk;
-            ok = h.seq == a.seq0 + (unsigned long long)t && h.pol0 == (long long)b * 64 && h.npol == 64 && h.nchan == a.nchan && h.chan0 == 0;
-        }
-    }
-    const unsigned long long nbad = (unsigned long long)__popcll(__ballot(!ok));
-    if ((threadIdx.x & 63) != 0) return;
-    const unsigned long long nwaves = (unsigned long long)gridDim.x * (blockDim.x >> 6);
-    const unsigned long long before = atomicAdd(tally, (nbad << 32) | 1ull);
-    if ((before & 0xFFFFFFFFull) != nwaves - 1) return;
-    const bool fb = force_scratch || ((before >> 32) + nbad) != 0;
-    GulpDesc d;
-    if (fb) {
-        d.base = scratch; d.t_stride = (uint32_t)a.nchan * (uint32_t)a.ninput; d.c_stride = (uint32_t)a.ninput; d.b_stride = 64;
-        atomicAdd(fallbacks, 1);
-    } else {
-        d.base = a.pkts + 32; d.t_stride = (uint32_t)a.nblk * a.stride; d.c_stride = 64; d.b_stride = a.stride;
-    }
-    d.pad = fb ? 1u : 0u;
-    d.pad2 = 0;
-    *desc = d;
-    *args_out = a;            // (for the scatter at flush time, should this gulp need it)
-    *tally = 0;               // (re-armed for the next gulp: launches on one stream, in order)
+// zero-fill: `nthreads` threads (this one: `tid`) share the 16-byte pieces of the scratch gulp
+__device__ __forceinline__ void slab_clear_part(const SlabArgs& a, uint8_t* scratch, size_t tid, size_t nthreads) {
+    const size_t n16 = (size_t)a.ntime * a.nchan * a.ninput / 16;     // (scratch gulps are whole 16-byte pieces: checked on the host)
+    uint4* dst = reinterpret_cast<uint4*>(scratch);
+    for (size_t k = tid; k < n16; k += nthreads) dst[k] = make_uint4(0, 0, 0, 0);
 }
 
-// Once per integration, behind the prepare kernels of its gulps (grid.y = gulp): zero-fill and scatter of the gulps whose
-// descriptor says "scratch"; the groups of every other gulp return at once.
-__global__ __launch_bounds__(256) void slab_clear_kernel(const GulpDesc* __restrict__ desc, const SlabArgs* __restrict__ args) {
-    const GulpDesc& d = desc[blockIdx.y];
-    if (!d.pad) return;
-    const size_t n16 = (size_t)args[blockIdx.y].ntime * args[blockIdx.y].nchan * args[blockIdx.y].ninput / 16;     // (scratch gulps are whole 16-byte pieces: checked on the host)
-    uint4* scratch = reinterpret_cast<uint4*>(const_cast<uint8_t*>(d.base));
-    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n16; k += (size_t)gridDim.x * 256) scratch[k] = make_uint4(0, 0, 0, 0);
-}
-
-// one wave per packet (any order, duplicates allowed): the validation of snap2_unpack_kernel, rows of npol bytes
-__global__ __launch_bounds__(256) void slab_scatter_kernel(const GulpDesc* __restrict__ desc, const SlabArgs* __restrict__ args) {
-    const GulpDesc& d = desc[blockIdx.y];
-    if (!d.pad) return;
-    const SlabArgs a = args[blockIdx.y];
-    uint8_t* scratch = const_cast<uint8_t*>(d.base);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// scatter: one wave per packet (any order, duplicates allowed), `nwaves` waves (this one: `wave`) share the packets; the
+// validation of snap2_unpack_kernel (ingest.hip), rows of npol bytes
+__device__ __forceinline__ void slab_scatter_part(const SlabArgs& a, uint8_t* scratch, int wave, int nwaves, int lane) {
     const int payload_max = (int)a.stride - 32;
-    for (int p = blockIdx.x * 4 + wave; p < a.npkt; p += gridDim.x * 4) {
+    for (int p = wave; p < a.npkt; p += nwaves) {
         const uint8_t* hp = a.pkts + (size_t)p * a.stride;
         const SlabHeader h = slab_header(hp, a.chan0);
         const bool ok = h.seq >= a.seq0 && h.seq - a.seq0 < (unsigned long long)a.ntime && h.npol > 0 && h.nchan > 0 && h.chan0 >= 0 &&
@@ -98,13 +51,97 @@ __global__ __launch_bounds__(256) void slab_scatter_kernel(const GulpDesc* __res
     }
 }
 
+// verify + describe in one launch.  Every wave checks its 64 packets and adds ONE word to the tally: (packets out of place) << 32
+// | 1.  The wave that reads back "all other waves have added theirs" has, in the same word, the gulp's total: it writes the
+// descriptor and re-arms the tally.  One returning atomic per wave carries both the count and the ticket, so nothing has to be
+// ordered and the kernel needs NO fence: an agent-scope fence on this part is an L2 write-back + invalidate on every XCD, and
+// beside a running contraction (which lives on L2 hits of the gulps) that cost 7 % of the streaming rate (measured:
+// profiles/r04/slab_paths.txt).  No LDS either.
+// One launch serves up to two gulps (grid.y; the beamformer's two parts): gulp k has its own tally word, descriptor, scratch.
+// fallbacks: gulps that took the scratch path (read by xeng*GetSlabFallbacks).
+// force[k]: the host already knows the slab cannot be regular (packet count, stride, alignment); then one work-group, no check.
+struct SlabJob {
+    SlabArgs a[2];
+    uint8_t* scratch[2];
+    int force[2];
+};
+// INLINE (the beamformer's calls: one launch per call on the stream of its kernels, nothing else): a gulp that turns out
+// irregular is zero-filled and scattered HERE, by the one work-group whose wave took the last ticket -- 1024 threads instead of
+// a grid, a few hundred microseconds for a 32 MB gulp, on the rare path; the regular case costs one short launch and no
+// launch that only finds out that it has nothing to do.  Otherwise (the X-engine: per integration, off its critical path)
+// slab_clear_kernel + slab_scatter_kernel follow.
+template <bool INLINE>
+__global__ __launch_bounds__(INLINE ? 1024 : 256) void slab_prepare_kernel(SlabJob job, unsigned long long* __restrict__ tallies, int* __restrict__ fallbacks,
+                                                                          GulpDesc* __restrict__ descs, SlabArgs* __restrict__ args_out) {
+    __shared__ int s_fallback_here;                         // (INLINE only; 4 bytes of LDS fit beside any resident kernel)
+    const int k = blockIdx.y;
+    const SlabArgs& a = job.a[k];
+    const int force_scratch = job.force[k];
+    const unsigned int nblocks = force_scratch ? 1u : (unsigned int)((a.npkt + (int)blockDim.x - 1) / (int)blockDim.x);
+    if (blockIdx.x >= nblocks) return;                      // (the grid is sized for the larger gulp; whole work-groups leave)
+    if (INLINE) {
+        if (threadIdx.x == 0) s_fallback_here = 0;
+        __syncthreads();
+    }
+    bool ok = true;
+    if (!force_scratch) {
+        const int p = blockIdx.x * blockDim.x + threadIdx.x;
+        if (p < a.npkt) {
+            const SlabHeader h = slab_header(a.pkts + (size_t)p * a.stride, a.chan0);
+            const int t = p / a.nblk, b = p % a.nblk;
+            ok = h.seq == a.seq0 + (unsigned long long)t && h.pol0 == (long long)b * 64 && h.npol == 64 && h.nchan == a.nchan && h.chan0 == 0;
+        }
+    }
+    const unsigned long long nbad = (unsigned long long)__popcll(__ballot(!ok));
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned long long nwaves = (unsigned long long)nblocks * (blockDim.x >> 6);
+        const unsigned long long before = atomicAdd(&tallies[k], (nbad << 32) | 1ull);
+        if ((before & 0xFFFFFFFFull) == nwaves - 1) {
+            const bool fb = force_scratch || ((before >> 32) + nbad) != 0;
+            GulpDesc d;
+            if (fb) {
+                d.base = job.scratch[k]; d.t_stride = (uint32_t)a.nchan * (uint32_t)a.ninput; d.c_stride = (uint32_t)a.ninput; d.b_stride = 64;
+                atomicAdd(fallbacks, 1);
+            } else {
+                d.base = a.pkts + 32; d.t_stride = (uint32_t)a.nblk * a.stride; d.c_stride = 64; d.b_stride = a.stride;
+            }
+            d.pad = fb ? 1u : 0u;
+            d.pad2 = 0;
+            descs[k] = d;
+            args_out[k] = a;          // (for the scatter kernels, should this gulp need them)
+            tallies[k] = 0;           // (re-armed for the next gulp: launches on one stream, in order)
+            if (INLINE && fb) s_fallback_here = 1;
+        }
+    }
+    if (!INLINE) return;
+    __syncthreads();
+    if (!s_fallback_here) return;
+    slab_clear_part(a, job.scratch[k], threadIdx.x, blockDim.x);
+    __syncthreads();                  // (the zero-fill of this work-group is ordered before its scatter)
+    slab_scatter_part(a, job.scratch[k], threadIdx.x >> 6, blockDim.x >> 6, threadIdx.x & 63);
+}
+
+// Once per integration, behind the prepare kernels of its gulps (grid.y = gulp): zero-fill and scatter of the gulps whose
+// descriptor says "scratch"; the groups of every other gulp return at once.
+__global__ __launch_bounds__(256) void slab_clear_kernel(const GulpDesc* __restrict__ desc, const SlabArgs* __restrict__ args) {
+    const GulpDesc& d = desc[blockIdx.y];
+    if (!d.pad) return;
+    slab_clear_part(args[blockIdx.y], const_cast<uint8_t*>(d.base), (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
+}
+
+__global__ __launch_bounds__(256) void slab_scatter_kernel(const GulpDesc* __restrict__ desc, const SlabArgs* __restrict__ args) {
+    const GulpDesc& d = desc[blockIdx.y];
+    if (!d.pad) return;
+    const SlabArgs a = args[blockIdx.y];
+    slab_scatter_part(a, const_cast<uint8_t*>(d.base), blockIdx.x * 4 + (threadIdx.x >> 6), gridDim.x * 4, threadIdx.x & 63);
+}
 
 int slab_site_create(SlabSite* s) {
     void* p = nullptr;
-    XENG_HIP(hipMalloc(&p, 16));
-    XENG_HIP(hipMemset(p, 0, 16));
-    s->tally = (unsigned long long*)p;
-    s->fallbacks = (int*)p + 2;
+    XENG_HIP(hipMalloc(&p, 32));
+    XENG_HIP(hipMemset(p, 0, 32));
+    s->tally = (unsigned long long*)p;       // two words: one per gulp of a launch
+    s->fallbacks = (int*)p + 4;
     return XENG_STATUS_SUCCESS;
 }
 
@@ -118,9 +155,18 @@ bool slab_maybe_regular(const SlabArgs& a, int rows) {
            a.stride % 16 == 0 && ((uintptr_t)a.pkts & 15) == 0 && (uint64_t)a.nblk * a.stride * rows < (1ull << 31);
 }
 
-int slab_prepare_enqueue(hipStream_t stream, const SlabSite& site, const SlabArgs& a, bool maybe, GulpDesc* desc, SlabArgs* args_out, uint8_t* scratch) {
-    hipLaunchKernelGGL(slab_prepare_kernel, dim3(maybe ? (a.npkt + 255) / 256 : 1), dim3(256), 0, stream, a, site.tally, site.fallbacks, desc, args_out,
-                       scratch, maybe ? 0 : 1);
+int slab_prepare_enqueue(hipStream_t stream, const SlabSite& site, const SlabArgs* a, const bool* maybe, int ngulp, GulpDesc* descs, SlabArgs* args_out,
+                         uint8_t* const* scratch, bool inline_fallback) {
+    SlabJob job;
+    const int bs = inline_fallback ? 1024 : 256;
+    unsigned int nblocks = 1;
+    for (int k = 0; k < 2; k++) {
+        const int kk = k < ngulp ? k : 0;
+        job.a[k] = a[kk]; job.scratch[k] = scratch[kk]; job.force[k] = maybe[kk] ? 0 : 1;
+        if (maybe[kk]) nblocks = std::max(nblocks, (unsigned int)((a[kk].npkt + bs - 1) / bs));
+    }
+    hipLaunchKernelGGL(inline_fallback ? slab_prepare_kernel<true> : slab_prepare_kernel<false>, dim3(nblocks, ngulp), dim3(bs), 0, stream, job, site.tally,
+                       site.fallbacks, descs, args_out);
     XENG_HIP(hipGetLastError());
     return XENG_STATUS_SUCCESS;
 }

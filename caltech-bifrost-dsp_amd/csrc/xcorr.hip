@@ -724,7 +724,7 @@ int xengXgpuKernelAsyncSlab(const void* packets_dev, int npkt, size_t pkt_stride
     uint8_t* scratch = x.stash[x.cur] + (size_t)k * x.gulp_bytes;
     const char* skip = diag_env("XENG_SLAB_SKIP");      // (diagnostic builds, timing only: any value drops the clear / scatter launches, "all" also this one -- descriptors of earlier launches are reused)
     if (!skip || skip[0] != 'a')
-        if (int rcs = slab_prepare_enqueue(x.stream, x.slab_site, a, maybe, x.gdesc_dev[x.cur] + k, x.gargs_dev[x.cur] + k, scratch)) return rcs;
+        if (int rcs = slab_prepare_enqueue(x.stream, x.slab_site, &a, &maybe, 1, x.gdesc_dev[x.cur] + k, x.gargs_dev[x.cur] + k, &scratch, false)) return rcs;
     XENG_HIP(hipGetLastError());
     staging_stream_touched();
     x.gulp_ptr[k] = nullptr;

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Diagnostic (round 4): the beamformer pair (Beamform 960 samples + power sums, config 4 shape) on plain gulps, on packed packet
+slabs (stride 6176) and on slabs whose payloads start on 128-byte lines (stride 6272), alone on the GPU.
+usage: slab_beam_probe.py [rounds] [gulps per round]"""
+import os
+import struct
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import caltech_bifrost_dsp_amd  # noqa: E402,F401
+from caltech_bifrost_dsp_amd import ffi  # noqa: E402
+
+NSTAND, NCHAN, NT, NB, NS = 352, 96, 480, 32, 24
+NINPUT = NSTAND * 2
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+ngulp = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+ffi.call("xengSetDevice", 0)
+ffi.call("xengBeamformInitialize", 0, NINPUT, NCHAN, 2 * NT, NB, 0)
+L = ffi.lib()
+npb = NSTAND // 32
+stride = 32 + NCHAN * 64
+npk = NT * npb
+rs = np.random.RandomState(5)
+STRIDE_A, LEAD_A = 49 * 128, 96
+slabs, slabs_a = [], []
+for k in range(10):
+    slab = np.zeros((npk, stride), dtype=np.uint8)
+    i = 0
+    for t in range(NT):
+        for pb in range(npb):
+            slab[i, :32] = np.frombuffer(struct.pack(">QLHHHHLLL", k * NT + t, 0, 64, NINPUT, NCHAN, NCHAN, 0, 0, pb * 64), dtype=np.uint8)
+            i += 1
+    slab[:, 32:] = rs.randint(0, 256, size=(npk, stride - 32), dtype=np.uint8)
+    slabs.append(ffi.DeviceBuffer(slab.nbytes).upload(slab))
+    a = np.zeros(LEAD_A + npk * STRIDE_A, dtype=np.uint8)
+    a[LEAD_A:].reshape(npk, STRIDE_A)[:, :stride] = slab
+    slabs_a.append(ffi.DeviceBuffer(a.nbytes).upload(a))
+gulp = NT * NCHAN * NINPUT
+ring = ffi.DeviceBuffer(10 * gulp)
+for k in range(10):
+    ffi.check("u", L.xengSnap2UnpackAsync(slabs[k].ptr, npk, stride, ring.ptr + k * gulp, k * NT, NT, 0, NCHAN, NINPUT, 1))
+ffi.call("xengXgpuSync") if False else ffi.call("xengDeviceSynchronize")
+w = (rs.uniform(-17, 17, (NCHAN, NB, NINPUT)) + 1j * rs.uniform(-17, 17, (NCHAN, NB, NINPUT))).astype(np.complex64)
+dw = ffi.DeviceBuffer(w.nbytes).upload(w)
+dbeam = ffi.DeviceBuffer(NCHAN * NB * 2 * NT * 8)
+dpow = ffi.DeviceBuffer((NB // 2) * (2 * NT // NS) * NCHAN * 16)
+
+
+def run(mode, n):
+    for it in range(n + 20):
+        if it == 20:
+            ffi.call("xengBeamformSync")
+            t0 = time.perf_counter()
+        k0 = (2 * it) % 10
+        if mode == "plain":
+            ffi.check("r", L.xengBeamformRunVersioned(ring.ptr + k0 * gulp, dbeam.ptr, dw.ptr, 1))
+        elif mode == "packed":
+            ffi.check("r", L.xengBeamformRunSlabs(slabs[k0].ptr, npk, NT, slabs[k0 + 1].ptr, npk, stride, k0 * NT, 0, dbeam.ptr, dw.ptr, 1))
+        else:
+            ffi.check("r", L.xengBeamformRunSlabs(slabs_a[k0].ptr + LEAD_A, npk, NT, slabs_a[k0 + 1].ptr + LEAD_A, npk, STRIDE_A, k0 * NT, 0, dbeam.ptr, dw.ptr, 1))
+        ffi.check("i", L.xengBeamformIntegrate(dbeam.ptr, dpow.ptr, NS))
+    ffi.call("xengBeamformSync")
+    return (time.perf_counter() - t0) / n * 1e6
+
+
+res = {}
+for r in range(rounds):
+    for mode in ("plain", "packed", "aligned"):
+        res.setdefault(mode, []).append(run(mode, ngulp))
+for mode, v in res.items():
+    v = sorted(v)
+    print("%-8s median %.1f us per 960-sample gulp (Run + Integrate), min %.1f max %.1f" % (mode, v[len(v) // 2], v[0], v[-1]))
+import ctypes
+nfb = ctypes.c_int()
+ffi.call("xengBeamformGetSlabFallbacks", ctypes.byref(nfb))
+print("parts scattered after all:", nfb.value)
