@@ -43,6 +43,7 @@ struct SlabArgs {
 struct SlabSite {
     unsigned long long* tally = nullptr;     // the 64-bit words of slab_prepare_kernel (one per gulp of a launch)
     int* fallbacks = nullptr;                // gulps that took the scratch path since they were last read
+    int* fallbacks_host = nullptr;           // ... and ever, in pinned host memory: read by the host without a wait (a hint: is the link losing packets?)
 };
 int slab_site_create(SlabSite* s);
 void slab_site_destroy(SlabSite* s);

@@ -65,14 +65,16 @@ struct SlabJob {
     uint8_t* scratch[2];
     int force[2];
 };
-// INLINE (the beamformer's calls: one launch per call on the stream of its kernels, nothing else): a gulp that turns out
-// irregular is zero-filled and scattered HERE, by the one work-group whose wave took the last ticket -- 1024 threads instead of
-// a grid, a few hundred microseconds for a 32 MB gulp, on the rare path; the regular case costs one short launch and no
-// launch that only finds out that it has nothing to do.  Otherwise (the X-engine: per integration, off its critical path)
-// slab_clear_kernel + slab_scatter_kernel follow.
+// INLINE (the beamformer's calls while the link is clean: one launch per call on the stream of its kernels, nothing else): a
+// gulp that turns out irregular is zero-filled and scattered HERE, by the one work-group whose wave took the last ticket --
+// 1024 threads instead of a grid, 0.9 ms for a 32 MB gulp; the regular case costs one short launch and no launch that only
+// finds out that it has nothing to do.  Every such gulp also bumps a counter in pinned host memory; the host, seeing it move,
+// switches its next calls to the other form.  Otherwise (the X-engine: per integration, off its critical path; the beamformer
+// after a recent loss) slab_clear_kernel + slab_scatter_kernel follow.
 template <bool INLINE>
 __global__ __launch_bounds__(INLINE ? 1024 : 256) void slab_prepare_kernel(SlabJob job, unsigned long long* __restrict__ tallies, int* __restrict__ fallbacks,
-                                                                          GulpDesc* __restrict__ descs, SlabArgs* __restrict__ args_out) {
+                                                                          int* __restrict__ fallbacks_host, GulpDesc* __restrict__ descs,
+                                                                          SlabArgs* __restrict__ args_out) {
     __shared__ int s_fallback_here;                         // (INLINE only; 4 bytes of LDS fit beside any resident kernel)
     const int k = blockIdx.y;
     const SlabArgs& a = job.a[k];
@@ -102,6 +104,8 @@ __global__ __launch_bounds__(INLINE ? 1024 : 256) void slab_prepare_kernel(SlabJ
             if (fb) {
                 d.base = job.scratch[k]; d.t_stride = (uint32_t)a.nchan * (uint32_t)a.ninput; d.c_stride = (uint32_t)a.ninput; d.b_stride = 64;
                 atomicAdd(fallbacks, 1);
+                // (the host's hint that the link is losing packets: pinned memory, read there without a wait)
+                __hip_atomic_fetch_add(fallbacks_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             } else {
                 d.base = a.pkts + 32; d.t_stride = (uint32_t)a.nblk * a.stride; d.c_stride = 64; d.b_stride = a.stride;
             }
@@ -142,11 +146,14 @@ int slab_site_create(SlabSite* s) {
     XENG_HIP(hipMemset(p, 0, 32));
     s->tally = (unsigned long long*)p;       // two words: one per gulp of a launch
     s->fallbacks = (int*)p + 4;
+    XENG_HIP(hipHostMalloc((void**)&s->fallbacks_host, sizeof(int)));
+    *s->fallbacks_host = 0;
     return XENG_STATUS_SUCCESS;
 }
 
 void slab_site_destroy(SlabSite* s) {
     if (s->tally) (void)hipFree(s->tally);
+    if (s->fallbacks_host) (void)hipHostFree(s->fallbacks_host);
     *s = SlabSite();
 }
 
@@ -166,7 +173,7 @@ int slab_prepare_enqueue(hipStream_t stream, const SlabSite& site, const SlabArg
         if (maybe[kk]) nblocks = std::max(nblocks, (unsigned int)((a[kk].npkt + bs - 1) / bs));
     }
     hipLaunchKernelGGL(inline_fallback ? slab_prepare_kernel<true> : slab_prepare_kernel<false>, dim3(nblocks, ngulp), dim3(bs), 0, stream, job, site.tally,
-                       site.fallbacks, descs, args_out);
+                       site.fallbacks, site.fallbacks_host, descs, args_out);
     XENG_HIP(hipGetLastError());
     return XENG_STATUS_SUCCESS;
 }

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic (round 4): the beamformer pair (Beamform 960 samples + power sums, config 4 shape) on plain gulps, on packed packet
-slabs (stride 6176) and on slabs whose payloads start on 128-byte lines (stride 6272), alone on the GPU.
+slabs (stride 6176), on slabs whose payloads start on 128-byte lines (stride 6272) and on slabs with two packets out of order (the
+slow path: both parts scattered by one work-group each), alone on the GPU.
 usage: slab_beam_probe.py [rounds] [gulps per round]"""
 import os
 import struct
@@ -26,7 +27,7 @@ stride = 32 + NCHAN * 64
 npk = NT * npb
 rs = np.random.RandomState(5)
 STRIDE_A, LEAD_A = 49 * 128, 96
-slabs, slabs_a = [], []
+slabs, slabs_a, slabs_irr = [], [], []
 for k in range(10):
     slab = np.zeros((npk, stride), dtype=np.uint8)
     i = 0
@@ -36,6 +37,9 @@ for k in range(10):
             i += 1
     slab[:, 32:] = rs.randint(0, 256, size=(npk, stride - 32), dtype=np.uint8)
     slabs.append(ffi.DeviceBuffer(slab.nbytes).upload(slab))
+    swapped = slab.copy()
+    swapped[[0, 1]] = swapped[[1, 0]]                      # two packets out of order: the gulp takes the scatter
+    slabs_irr.append(ffi.DeviceBuffer(slab.nbytes).upload(swapped))
     a = np.zeros(LEAD_A + npk * STRIDE_A, dtype=np.uint8)
     a[LEAD_A:].reshape(npk, STRIDE_A)[:, :stride] = slab
     slabs_a.append(ffi.DeviceBuffer(a.nbytes).upload(a))
@@ -58,6 +62,8 @@ def run(mode, n):
         k0 = (2 * it) % 10
         if mode == "plain":
             ffi.check("r", L.xengBeamformRunVersioned(ring.ptr + k0 * gulp, dbeam.ptr, dw.ptr, 1))
+        elif mode == "irregular":
+            ffi.check("r", L.xengBeamformRunSlabs(slabs_irr[k0].ptr, npk, NT, slabs_irr[k0 + 1].ptr, npk, stride, k0 * NT, 0, dbeam.ptr, dw.ptr, 1))
         elif mode == "packed":
             ffi.check("r", L.xengBeamformRunSlabs(slabs[k0].ptr, npk, NT, slabs[k0 + 1].ptr, npk, stride, k0 * NT, 0, dbeam.ptr, dw.ptr, 1))
         else:
@@ -69,11 +75,11 @@ def run(mode, n):
 
 res = {}
 for r in range(rounds):
-    for mode in ("plain", "packed", "aligned"):
-        res.setdefault(mode, []).append(run(mode, ngulp))
+    for mode in ("plain", "packed", "aligned", "irregular"):
+        res.setdefault(mode, []).append(run(mode, ngulp if mode != "irregular" else max(10, ngulp // 10)))
 for mode, v in res.items():
     v = sorted(v)
-    print("%-8s median %.1f us per 960-sample gulp (Run + Integrate), min %.1f max %.1f" % (mode, v[len(v) // 2], v[0], v[-1]))
+    print("%-9s median %.1f us per 960-sample gulp (Run + Integrate), min %.1f max %.1f" % (mode, v[len(v) // 2], v[0], v[-1]))
 import ctypes
 nfb = ctypes.c_int()
 ffi.call("xengBeamformGetSlabFallbacks", ctypes.byref(nfb))

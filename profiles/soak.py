@@ -7,7 +7,8 @@ dump / beam gulp / power block / sub-selection / payload set / unpacked gulp mus
 alone on an idle GPU.  Results are added word-wise as int32 bit patterns (xengMapAddI32: wrap-around arithmetic, so floats
 are summed as their bit patterns too) and the sum is compared with N x the stand-alone pattern modulo 2^32.  Exercised
 together: contraction streams (lag-1 streaming, the dumps of phase 1 also feed two alternating long accumulators), beam stream (weight re-split every third round, Run + Integrate, then the
-fused integrated-power mode), map stream, consumer stream (SubSelect, Packetize), staging stream (SNAP2 unpack).
+fused integrated-power mode), map stream, consumer stream (SubSelect, Packetize), staging stream (SNAP2 unpack); phase 3: both
+consumers fed from packet slabs read in place (and, now and then, through the scatter of an irregular slab).
 
 This is what found the wrong power sums of round 2: a kernel that is right alone on the GPU and in every
 parity test can still be wrong beside the contraction.
@@ -200,6 +201,67 @@ def soak(N=1500, packets=None, log=print):
     p1, p2 = ref_pow.view(np.float32).reshape(-1, 4), ref_pow2.view(np.float32).reshape(-1, 4)
     scale = np.sqrt(p1[:, 0] * p1[:, 1])[:, None] + 1e-30
     log("  fused vs composed power sums: max |diff| / sqrt(XX YY) = %.2e" % float(np.max(np.abs(p2 - p1) / scale)))
+    # ---- phase 3 (round 4): the same five gulps handed over as PACKET SLABS, read in place by both consumers beside each
+    # other; every other round one of the correlator's slabs, every third round the beamformer's second slab comes with its
+    # packets in a shuffled order (the scatter path) -- the results must still be the stand-alone ones
+    if can_fuse:
+        import struct
+        ffi.call("xengXgpuSync")
+        ffi.call("xengBeamformInitialize", 0, NINPUT, NCHAN, NT_B, NB, 0)
+        nblk, stride = NINPUT // 64, 32 + NCHAN * 64
+        npk = NTIME_GULP * nblk
+        seq_base = 10 ** 12 + 5
+        slabs, slabs_shuffled = [], []
+        for g in range(G):
+            gulp = ring.download(np.uint8, count=gulp_bytes, offset=g * gulp_bytes)
+            pay = gulp.reshape(NTIME_GULP, NCHAN, nblk, 64).transpose(0, 2, 1, 3).reshape(npk, NCHAN * 64)
+            slab = np.zeros((npk, stride), dtype=np.uint8)
+            slab[:, 32:] = pay
+            k = 0
+            for t in range(NTIME_GULP):
+                for b in range(nblk):
+                    slab[k, :32] = np.frombuffer(struct.pack(">QLHHHHLLL", seq_base + g * NTIME_GULP + t, 3, 64, NINPUT, NCHAN, NCHAN, 0, 0, b * 64), dtype=np.uint8)
+                    k += 1
+            slabs.append(ffi.DeviceBuffer(slab.nbytes).upload(slab))
+            slabs_shuffled.append(ffi.DeviceBuffer(slab.nbytes).upload(slab[rng.permutation(npk)]))
+        for a in (acc_vis, acc_beam, acc_pow, acc_fused[0], acc_fused[1]):
+            ffi.call("xengMemset", a.ptr, 0, a.nbytes)
+        N3 = max(6, N // 2)
+        t0 = time.perf_counter()
+        for n in range(N3):
+            ffi.call("xengMapSync")
+            for g in range(G):
+                src = slabs_shuffled[g] if (n & 1) and g == n % G else slabs[g]
+                ffi.check("slab", L.xengXgpuKernelAsyncSlab(src.ptr, npk, stride, seq_base + g * NTIME_GULP, 0, outs[n % 3].ptr, int(g == G - 1),
+                                                            acc_fused[n & 1].ptr, 1 if n < 2 else 2))
+            second = slabs_shuffled[1] if n % 3 == 2 else slabs[1]
+            ffi.check("run", L.xengBeamformRunSlabs(slabs[0].ptr, npk, NTIME_GULP, second.ptr, npk, stride, seq_base, 0, dbeam[n & 1].ptr, dw.ptr, 1 + n // 3))
+            ffi.check("int", L.xengBeamformIntegrate(dbeam[n & 1].ptr, dpow[n & 1].ptr, NS))
+            ffi.call("xengXgpuSyncLag", 1)
+            if n >= 1:
+                ffi.check("map", L.xengMapAddI32(acc_vis.ptr, outs[(n - 1) % 3].ptr, 2 * matlen))
+            ffi.call("xengBeamformSync")
+            ffi.check("map", L.xengMapAddI32(acc_beam.ptr, dbeam[n & 1].ptr, nbeam_words))
+            ffi.check("map", L.xengMapAddI32(acc_pow.ptr, dpow[n & 1].ptr, npow_words))
+        ffi.call("xengXgpuSync")
+        ffi.call("xengMapSync")
+        ffi.check("map", L.xengMapAddI32(acc_vis.ptr, outs[(N3 - 1) % 3].ptr, 2 * matlen))
+        ffi.check("map", L.xengMapAddI32(acc_fused[0].ptr, acc_fused[1].ptr, 2 * matlen))
+        ffi.call("xengMapSync")
+        el = time.perf_counter() - t0
+        log("phase 3: %d concurrent rounds on packet slabs in %.2f s (%.3f ms each)" % (N3, el, el / N3 * 1e3))
+        report("visibility dumps from slabs", acc_vis, ref_vis, N3)
+        report("long accumulation from slabs", acc_fused[0], ref_vis, N3)
+        report("voltage beams from slabs", acc_beam, ref_beam, N3)
+        report("power sums from slabs", acc_pow, ref_pow, N3)
+        nfx, nfb = ctypes.c_int(-1), ctypes.c_int(-1)
+        ffi.call("xengXgpuGetSlabFallbacks", ctypes.byref(nfx))
+        ffi.call("xengBeamformGetSlabFallbacks", ctypes.byref(nfb))
+        want = (N3 // 2, N3 // 3)
+        log("  slabs that took the scatter: correlator %d (expected %d), beamformer %d (expected %d)" % (nfx.value, want[0], nfb.value, want[1]))
+        results.append(("slab scatter counts", N3, int(nfx.value != want[0]) + int(nfb.value != want[1])))
+        for b in slabs + slabs_shuffled:
+            b.free()
     ffi.call("xengBeamformDestroy")
     ffi.call("xengXgpuDestroy")
     return results
