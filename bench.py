@@ -118,9 +118,9 @@ def corr_block_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=100):
     r0.resize(gulp_bytes, total_span=2 * gulps_per_step * gulp_bytes)
     blk = Corr(logging.getLogger("bench-corr"), r0, r1, ntime_gulp=NTIME_GULP, nchan=NCHAN, npol=NPOL, nstand=NSTAND,
                acc_len=ACC_LEN, autostartat=0, gpu=gpu)
-    spans = [XArray(shape=(gulp_bytes,), dtype=np.uint8, space="cuda", _ptr=ring.ptr + g * gulp_bytes, _base=ring) for g in range(ring_gulps)]
     hdr = {'nchan': NCHAN, 'chan0': 0, 'bw_hz': NCHAN * 23925.78125, 'fs_hz': 196000000, 'sfreq': 0.0, 'nstand': NSTAND, 'npol': NPOL,
            'seq0': 0, 'sync_time': 0, 'pipeline_id': 0, 'system_nchan': 32 * NCHAN}
+    spans = [XArray(shape=(gulp_bytes,), dtype=np.uint8, space="cuda", _ptr=ring.ptr + g * gulp_bytes, _base=ring) for g in range(ring_gulps)]
     stamps = []
 
     def source():
@@ -155,12 +155,16 @@ def corr_block_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=100):
                     "`throughput` stat of its last integration (corr_block.py:453 formula)"}
 
 
-def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=400, long_len=50):
+def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=400, long_len=50, from_slabs=False):
     """BASELINE config 5 through the BLOCKS on one GPU: Corr -> CorrAcc and Beamform -> BeamformSumBeams as four Python
     threads on in-repo rings (gpu-input read in place by Corr and Beamform), fed by a zero-copy replay source.  CorrAcc's
     long accumulation (`long_len` dumps) is done by the dumps' own epilogue (fused mode, blocks/corr_acc_block.py).  The warm-up
     covers the start of the pipeline: the first long integrations allocate the 383 MB pinned-host spans of the slow ring
-    (hipHostMalloc: ~0.1 s each, device-wide synchronisations), which the ring then recycles."""
+    (hipHostMalloc: ~0.1 s each, device-wide synchronisations), which the ring then recycles.
+    from_slabs: the input ring holds PACKET SLABS (5280 SNAP2 packets per 480-sample gulp, header layout 'snap2_slab') as a
+    receiver -- or Snap2Ingest(unpack=False) -- leaves them; Corr and Beamform hand them to the library's slab calls, which
+    read them in place.  Every gulp of the leg is its own slab (sequence numbers advance): (nwarm + nint) x 5 x 32.6 MB on
+    the device."""
     import json as _json
     import logging
     import threading
@@ -169,6 +173,23 @@ def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=4
     from caltech_bifrost_dsp_amd.ring import Ring
     gulps_per_step = ACC_LEN // NTIME_GULP
     nbeam, ns = 32, 24
+    if from_slabs:
+        import struct
+        nblk, stride = NINPUT // 64, 32 + NCHAN * 64
+        npk = NTIME_GULP * nblk
+        slab = np.zeros((npk, stride), dtype=np.uint8)
+        for t in range(NTIME_GULP):
+            for b in range(nblk):
+                slab[t * nblk + b, 8:32] = np.frombuffer(struct.pack(">LHHHHLLL", 0, 64, NINPUT, NCHAN, NCHAN, 0, 0, b * 64), dtype=np.uint8)
+        slab[:, 32:] = np.random.RandomState(5).randint(0, 256, size=(npk, stride - 32), dtype=np.uint8)
+        nslabs = (nwarm + nint) * gulps_per_step
+        slab_pool = ffi.DeviceBuffer(nslabs * slab.nbytes)
+        tcol = np.repeat(np.arange(NTIME_GULP, dtype=np.uint64), nblk)
+        for k in range(nslabs):
+            slab[:, :8] = (tcol + np.uint64(k * NTIME_GULP)).astype(">u8").view(np.uint8).reshape(npk, 8)
+            slab_pool.upload(slab, offset=k * slab.nbytes)
+        spans = [XArray(shape=(slab.nbytes,), dtype=np.uint8, space="cuda", _ptr=slab_pool.ptr + k * slab.nbytes, _base=slab_pool) for k in range(nslabs)]
+        gulp_bytes, ring_gulps = slab.nbytes, nslabs
     r_in = Ring("gpu-input", space="cuda")
     r_vis, r_slow = Ring("corr-output", space="cuda"), Ring("corr-slow-output", space="cuda_host")
     r_bf, r_pow = Ring("bf-output", space="cuda"), Ring("bf-pow-output", space="cuda_host")
@@ -186,9 +207,12 @@ def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=4
     sb = BeamformSumBeams(log, r_bf, r_pow, nchan=NCHAN, ntime_gulp=nt_b, ntime_sum=ns, gpu=gpu)
     rng = np.random.default_rng(7)
     bf.gains_cpu[...] = (rng.uniform(-17, 17, bf.gains_cpu.shape) + 1j * rng.uniform(-17, 17, bf.gains_cpu.shape)).astype(np.complex64)
-    spans = [XArray(shape=(gulp_bytes,), dtype=np.uint8, space="cuda", _ptr=ring.ptr + g * gulp_bytes, _base=ring) for g in range(ring_gulps)]
     hdr = {'nchan': NCHAN, 'chan0': 0, 'bw_hz': NCHAN * 23925.78125, 'fs_hz': 196000000, 'sfreq': 0.0, 'nstand': NSTAND, 'npol': NPOL,
            'seq0': 0, 'sync_time': 0, 'pipeline_id': 0, 'system_nchan': 32 * NCHAN}
+    if from_slabs:
+        hdr.update({'layout': 'snap2_slab', 'slab_ntime': NTIME_GULP, 'npkt_per_gulp': npk, 'pkt_stride': stride})
+    else:
+        spans = [XArray(shape=(gulp_bytes,), dtype=np.uint8, space="cuda", _ptr=ring.ptr + g * gulp_bytes, _base=ring) for g in range(ring_gulps)]
     stamps, nslow = [], [0]
 
     def source():
@@ -227,6 +251,19 @@ def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=4
     n = len(stamps)
     ok = n > nwarm + 1
     el = (stamps[-1] - stamps[nwarm]) if ok else 0.0
+    if from_slabs:
+        import ctypes as _ct
+        nfx, nfb = _ct.c_int(-1), _ct.c_int(-1)
+        ffi.call("xengXgpuGetSlabFallbacks", _ct.byref(nfx))
+        ffi.call("xengBeamformGetSlabFallbacks", _ct.byref(nfb))
+        del spans
+        slab_pool.free()
+        return {"value": round(8 * NINPUT * ACC_LEN * NCHAN * (n - 1 - nwarm) / el / 1e9, 1) if ok else 0.0, "unit": "Gb/s",
+                "ms_per_integration": round(el / max(n - 1 - nwarm, 1) * 1e3, 4) if ok else None, "integrations": n,
+                "slabs_scattered_after_all": {"corr": int(nfx.value), "beamform": int(nfb.value)},
+                "corracc_fused_into_dumps": bool(cacc.stats.get('fused')) and cacc.fused_dumps == n,
+                "note": "config5_blocks with an input ring of packet slabs (%d slabs of 5280 SNAP2 packets, %.1f GB on the device; every gulp "
+                        "its own slab): the blocks hand the slabs to xengXgpuKernelAsyncSlab / xengBeamformRunSlabs, which read them in place" % (nslabs, nslabs * slab.nbytes / 1e9)}
     return {"value": round(8 * NINPUT * ACC_LEN * NCHAN * (n - 1 - nwarm) / el / 1e9, 1) if ok else 0.0, "unit": "Gb/s",
             "ms_per_integration": round(el / max(n - 1 - nwarm, 1) * 1e3, 4) if ok else None, "integrations": n,
             "long_integrations_published": nslow[0], "corracc_fused_into_dumps": bool(cacc.stats.get('fused')) and cacc.fused_dumps == n,
@@ -370,6 +407,12 @@ def config5_workload(args, ffi, dist, rank, world, gpu, ring, gulp_bytes, pin, i
         "rank_placement": {"numa_node": pin["numa_node"], "ncpus": len(pin["cpus"]), "source": pin["source"]},
         "device": info,
     }
+
+
+def _leg(name):
+    """XENG_BENCH_TRACE=1: names each leg on stderr as it starts (a fault under a profiler then says where it was)"""
+    if os.environ.get("XENG_BENCH_TRACE"):
+        print("[bench] %s" % name, file=sys.stderr, flush=True)
 
 
 def main():
@@ -561,6 +604,7 @@ def main():
     ffi.call("xengDeviceSynchronize")
     el = time.perf_counter() - t0
     ffi.call("xengXgpuGetTimes", tm, cn)
+    _leg('one-launch-at-a-time')
     # outside the timed region: the same kernels launched one integration at a time (no overlap between
     # launches), to document the stand-alone duration of each kernel next to the streaming one
     iso_tm = (ctypes.c_double * 2)()
@@ -575,6 +619,7 @@ def main():
             ffi.call("xengXgpuSync")
         ffi.call("xengXgpuGetTimes", iso_tm, iso_cn)
     ffi.call("xengXgpuSetProfiling", 0)
+    _leg('sustained')
     # outside the timed region: the same streaming pattern SUSTAINED -- 10 000 integrations (> 2 s) in windows of 1000, on the
     # replay ring of the timed region and on one of 40 gulps (1.3 GB: past the 256 MB Infinity Cache, so every gulp comes
     # from HBM whatever the last-level cache holds)
@@ -614,6 +659,7 @@ def main():
         sustained["note"] = ("outside the driver's timed region: the timed pattern (enqueue integration n, wait for dump n-%d) held for %d "
                              "integrations; per-1000-integration windows; the second run reads a 1.3 GB ring, larger than the "
                              "256 MB Infinity Cache" % (args.lag, args.sustained))
+    _leg('pcie')
     # outside the timed region: PCIe-inclusive regime (SURVEY 8d "two reporting regimes", ii): gulps start in
     # pinned host memory, are copied H2D (xengMemcpy, the Copy block's copy_array) and then correlated
     verify = None
@@ -637,6 +683,7 @@ def main():
                 "h2d_GBs": round(gulp_bytes * gulps_per_step * nint / el2 / 1e9, 1),
                 "note": "pinned host -> H2D -> X-engine, %d integrations; link-bound (PCIe Gen5 x16)" % nint}
         hostbuf.free()
+    _leg('packetize')
     # outside the timed region: the slow-visibility output step (SURVEY 8f rows 2+4): device reorder of one
     # integration into per-baseline packet payloads (CorrOutputFull), HBM-bound
     pktz = None
@@ -665,6 +712,7 @@ def main():
                         "synchronous call (includes launch + stream sync)" % nbl}
         for b in (dbl, dcj, dpay):
             b.free()
+    _leg('ingest')
     # outside the timed region: the ingest step: one config-2 gulp worth of SNAP2 packets
     # (5280 packets of 32 + 6144 bytes, device-resident) scattered into the gulp layout
     ingest = None
@@ -740,12 +788,14 @@ def main():
                 ffi.call("xengXgpuSyncLag", 1)
             ffi.call("xengXgpuSync")
             return time.perf_counter() - t1, nrep
+        _leg('packets via scatter')
         el4, nrep = packets_leg(False)
         ingest["packets_to_visibilities_scatter"] = {
             "value": round(8 * NINPUT * units_per_step_c * nrep / el4 / 1e9, 1), "unit": "Gb/s",
             "ms_per_step": round(el4 / nrep * 1e3, 4),
             "note": "device-resident packet slabs (5280 packets per gulp) -> xengSnap2UnpackAsync -> xengXgpuKernelAsync, "
                     "%d integrations (the path of rounds 2-3)" % nrep}
+        _leg('packets in place, aligned')
         el4, nrep = packets_leg(2)
         nfb = ctypes.c_int(-1)
         ffi.call("xengXgpuGetSlabFallbacks", ctypes.byref(nfb))
@@ -755,6 +805,7 @@ def main():
             "ms_per_step": round(el4 / nrep * 1e3, 4), "gulps_scattered_after_all": int(nfb.value), "packet_stride": stride_a,
             "note": "as packets_to_visibilities with every packet placed so that its payload starts on a 128-byte line (stride 6272, "
                     "the slab handed over at +96): in the packed slab half of the 64-byte rows straddle a 64-byte boundary"}
+        _leg('packets in place, packed')
         el4, nrep = packets_leg(1)
         nfb = ctypes.c_int(-1)
         ffi.call("xengXgpuGetSlabFallbacks", ctypes.byref(nfb))
@@ -777,6 +828,7 @@ def main():
         for b in slabs_a:
             b.free()
         dgulp.free()
+    _leg('beamform')
     # outside the timed region: BASELINE config 4 -- Beamform (32 beams, 96 chan, 960 samples, fp32 weights)
     # + BeamformSumBeams (16 dual-pol power beams, ntime_sum 24) on the same GPU
     beam = None
@@ -828,6 +880,7 @@ def main():
                               "note": "int8 MFMA ops issued = 3 x 8 x nbeam x ninput per (sample, chan) (three base-255 "
                                       "digits per fp32 weight); algorithmic fp32 flops are 1/3 of that (algorithmic_tflops, "
                                       "against the 157 TFLOP/s fp32 MFMA peak the survey names)"})}
+        _leg('config 5')
         # ---- BASELINE config 5 (one GPU's share): Corr + CorrAcc + Beamform + SumBeams concurrently, each on
         # its own HIP stream, all fed from the same device-resident gulps
         ffi.call("xengXgpuSync")
@@ -892,6 +945,7 @@ def main():
                 "ms_per_integration": round(elf2 / nfull * 1e3, 4),
                 "note": "the same with the CorrAcc add done in the contraction's epilogue (xengXgpuKernelAsyncAcc, two alternating "
                         "accumulators): one pass over the 191 MB accumulator per dump instead of a 574 MB map kernel"}
+        _leg('config 5 from packets')
         # ... and fed from PACKETS (north star: "throughput on synthetic F-engine packets"): the ten device-resident packet slabs of
         # the ingest leg above instead of replay gulps.  Both consumers read the slabs where they lie (xengXgpuKernelAsyncSlab,
         # xengBeamformRunSlabs: two slabs = one 960-sample beam gulp); the comparison leg scatters every slab into the replay
@@ -1103,6 +1157,7 @@ def main():
             "note": "same kernel, one integration at a time (outside the timed region): in the timed streaming "
                     "region consecutive launches overlap (the next one takes over CUs as work-groups of the "
                     "previous one run out of items), which lengthens each launch but shortens the step"}
+    _leg('sync per call')
     # outside the timed region: the reference's own call semantics (corr_block.py:445: synchronous bfXgpuKernel per gulp:
     # the input may be recycled on return, the dump is complete on return) -- what an unmodified Corr on a circular
     # bifrost ring would see
@@ -1121,12 +1176,15 @@ def main():
                                 "ms_per_step": round(el5 / nrep * 1e3, 4),
                                 "note": "the drop-in synchronous call per gulp (raw device copy of every non-dump gulp + wait; the "
                                         "dump gulp is read in place and the call returns when the visibilities are complete), %d integrations" % nrep}
+    _leg('blocks')
     # outside the timed region: the Corr BLOCK itself (blocks/corr_block.py: ring protocol, header handling, state machine,
     # one Python thread) on in-repo device rings at config-2 size, fed by a zero-copy replay source: the rate a pipeline
     # user of the block sees, next to the C-ABI rate above
     if rank == 0 and world == 1 and args.beamform and not args.sync_per_call and not args.sync_per_integration:
         res["corr_block"] = corr_block_leg(ffi, ring, gulp_bytes, args.ring_gulps, gpu)
         res["config5_blocks"] = config5_blocks_leg(ffi, ring, gulp_bytes, args.ring_gulps, gpu)
+        res["config5_blocks"]["from_packet_slabs"] = config5_blocks_leg(ffi, ring, gulp_bytes, args.ring_gulps, gpu, nint=120, nwarm=60, long_len=30, from_slabs=True)
+    _leg('one call per integration')
     # outside the timed region: SURVEY 8d's other device-resident case, one 2400-sample call per integration
     # (xGPU's NTIME = acc_len; needs its own context, so it runs last)
     if args.beamform and rank == 0 and world == 1 and args.ring_gulps >= 2 * gulps_per_step:

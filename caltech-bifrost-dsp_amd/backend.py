@@ -87,6 +87,13 @@ class HipBackend:
         `acc` -- CorrAcc's "a = b" / "a += b" (corr_acc_block.py:304-306) done by the contraction's epilogue."""
         return self._x.xgpu_kernel_async_acc(_dev(in_arr), _dev(out_arr), int(do_dump), acc.ptr, int(acc_mode))
 
+    def bfXgpuKernelSlab(self, slab, npkt, pkt_stride, seq0, chan0, out_arr, do_dump, acc=None, acc_mode=0):
+        """bfXgpuKernelAsync[Acc] on a gulp handed over as the slab of SNAP2 packets it arrived in (include/xeng.h
+        xengXgpuKernelAsyncSlab): read in place when the slab is complete and in order, scattered on the device otherwise.
+        No reference counterpart: bifrost's capture scatters on the CPU (capture_block.py:221-305)."""
+        return self._x.xgpu_kernel_slab(slab.ptr, int(npkt), int(pkt_stride), int(seq0), int(chan0), _dev(out_arr), int(do_dump),
+                                        acc.ptr if acc is not None else 0, int(acc_mode))
+
     def xgpu_fused_acc_supported(self):
         """True when the live X-engine context runs the default (fused corner turn) contraction kernel, the one whose
         epilogue can feed a long accumulator; other gulp shapes take the two-pass path and CorrAcc keeps its map."""
@@ -174,6 +181,12 @@ class HipBackend:
         hands the reference's 2-gulp read (lwa352-pipeline.py:172,279-282) out contiguously."""
         ntime0 = part0.nbytes // (self._beam_row_bytes or 1)
         return self._x.beam_run_parts(part0.ptr, ntime0, part1.ptr, _dev(out_arr), _dev(weights), int(version))
+
+    def bfBeamformRunSlabs(self, slab0, npkt0, ntime0, slab1, npkt1, pkt_stride, seq0, chan0, out_arr, weights, version=0):
+        """bfBeamformRun on a gulp handed over as one (slab1 None) or two consecutive slabs of SNAP2 packets (include/xeng.h
+        xengBeamformRunSlabs)."""
+        return self._x.beam_run_slabs(slab0.ptr, int(npkt0), int(ntime0), slab1.ptr if slab1 is not None else 0, int(npkt1), int(pkt_stride),
+                                      int(seq0), int(chan0), _dev(out_arr), _dev(weights), int(version))
 
     def bfBeamformIntegrate(self, in_arr, out_arr, ntime_sum):
         # (bfBeamformIntegrate reads only the two data pointers from its structs: the raw entry point, no structs built per gulp)

@@ -174,6 +174,19 @@ class Beamform(Block):
                 # A gulp that lies in two spans of the input ring (ntime_gulp = 2 x the writer's gulp, as the reference runs it:
                 # lwa352-pipeline.py:172,279-282) is taken as two windows and beamformed in ONE launch, without a gathered copy
                 read_parts = getattr(iseq, 'read_parts', None) if hasattr(self._bf, 'bfBeamformRunParts') else None
+                # A sequence of PACKET SLABS (Snap2Ingest(unpack=False), or a receiver that writes into a device ring): a gulp is
+                # one or two slabs of SNAP2 packets, handed to the library as they are (xengBeamformRunSlabs: read in place when
+                # complete and in order, scattered on the device otherwise)
+                slab = ihdr.get('layout') == 'snap2_slab'
+                igulp_size = self.ntime_gulp * self.nchan * self.ninput
+                if slab:
+                    slab_ntime, slab_npkt, slab_stride = ihdr['slab_ntime'], ihdr['npkt_per_gulp'], ihdr['pkt_stride']
+                    if self.ntime_gulp not in (slab_ntime, 2 * slab_ntime) or not hasattr(self._bf, 'bfBeamformRunSlabs'):
+                        raise RuntimeError("BEAMFORM: slabs of %d samples cannot make gulps of %d" % (slab_ntime, self.ntime_gulp))
+                    slab_bytes = slab_npkt * slab_stride
+                    igulp_size = (self.ntime_gulp // slab_ntime) * slab_bytes
+                    for k in ('layout', 'slab_ntime', 'npkt_per_gulp', 'pkt_stride'):
+                        ohdr.pop(k, None)
                 with oring.begin_sequence(time_tag=iseq.time_tag, header=json.dumps(ohdr)) as oseq:
                     for ispan in (read_parts(igulp_size) if read_parts is not None else iseq.read(igulp_size)):
                         self.update_stats({'curr_sample': this_gulp_time})
@@ -211,7 +224,20 @@ class Beamform(Block):
                             # (the reference takes typed views, ispan.data_view('i8') / ospan.data_view(np.float32), :441-444; the
                             # call only needs the spans' addresses, and two fewer objects per gulp is time under the interpreter lock)
                             parts = getattr(ispan, 'parts', None)
-                            if parts is not None and len(parts) == 2:
+                            if slab:
+                                if parts is not None and len(parts) == 2:
+                                    held = parts
+                                    s0, s1 = parts
+                                elif igulp_size == slab_bytes:
+                                    held = s0 = ispan.data
+                                    s1 = None
+                                else:       # two slabs side by side in one span
+                                    held = ispan.data
+                                    s0 = XArray.window(held.ptr, slab_bytes, held.space, held)
+                                    s1 = XArray.window(held.ptr + slab_bytes, slab_bytes, held.space, held)
+                                rv = self._bf.bfBeamformRunSlabs(s0, slab_npkt, slab_ntime, s1, slab_npkt, slab_stride, this_gulp_time, ihdr['chan0'],
+                                                                 ospan.data.as_BFarray(), self.gains_gpu.as_BFarray(), version=self._gains_version)
+                            elif parts is not None and len(parts) == 2:
                                 held = parts
                                 rv = self._bf.bfBeamformRunParts(parts[0], parts[1], ospan.data.as_BFarray(), self.gains_gpu.as_BFarray(),
                                                                  version=self._gains_version)

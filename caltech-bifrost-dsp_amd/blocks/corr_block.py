@@ -186,15 +186,30 @@ class Corr(Block):
                 ohdr.pop('ant_to_input', None)
                 ohdr.pop('input_to_ant', None)
                 self.sequence_proclog.update(ohdr)
-                for ispan in iseq.read(self.igulp_size):
-                    if ispan.size < self.igulp_size:
-                        self.log.info("CORR >>> Ignoring final gulp (expected %d bytes but got %d)" % (self.igulp_size, ispan.size))
+                # A sequence of PACKET SLABS (Snap2Ingest(unpack=False), or a receiver that writes into a device ring): every
+                # gulp is the slab of SNAP2 packets it arrived in, handed to the library as it is -- read in place by the
+                # contraction when it is complete and in order, scattered on the device otherwise (xengXgpuKernelAsyncSlab).
+                # The downstream header describes the visibilities, not the input layout.
+                slab = ihdr.get('layout') == 'snap2_slab'
+                igulp_size = self.igulp_size
+                if slab:
+                    if not in_place or self.test:
+                        raise RuntimeError("CORR: packet-slab input needs the in-place (streaming) mode of the in-repo rings, and no test mode")
+                    if ihdr.get('slab_ntime', self.ntime_gulp) != self.ntime_gulp:
+                        raise RuntimeError("CORR: slabs of %d samples, ntime_gulp %d" % (ihdr['slab_ntime'], self.ntime_gulp))
+                    slab_npkt, slab_stride, slab_chan0 = ihdr['npkt_per_gulp'], ihdr['pkt_stride'], ihdr['chan0']
+                    igulp_size = slab_npkt * slab_stride
+                    for k in ('layout', 'slab_ntime', 'npkt_per_gulp', 'pkt_stride'):
+                        ohdr.pop(k, None)
+                for ispan in iseq.read(igulp_size):
+                    if ispan.size < igulp_size:
+                        self.log.info("CORR >>> Ignoring final gulp (expected %d bytes but got %d)" % (igulp_size, ispan.size))
                         continue
                     if getattr(ispan, 'skipped', 0):
                         # gulps this reader never saw (overwritten before it got to them; whole gulps, ring.py): the sample
                         # count moves on with them, and an integration they belonged to is lost -- realigned like a new
                         # upstream sequence (:360-371)
-                        now += (ispan.skipped // self.igulp_size) * self.ntime_gulp
+                        now += (ispan.skipped // igulp_size) * self.ntime_gulp
                         self.log.warning("CORR >> %d bytes of input were overwritten before they were read" % ispan.skipped)
                         if gate.recover(now):
                             self._abort_integration()
@@ -260,7 +275,10 @@ class Corr(Block):
                         acc = None
                         if now == gate.last and long_acc is not None:
                             acc, acc_mode = long_acc.plan_dump()
-                        if acc is not None:
+                        if slab:
+                            rv = self._bf.bfXgpuKernelSlab(ispan.data, slab_npkt, slab_stride, now, slab_chan0, ospan.data.as_BFarray(),
+                                                           int(now == gate.last), acc, acc_mode if acc is not None else 0)
+                        elif acc is not None:
                             rv = self._bf.bfXgpuKernelAsyncAcc(ispan.data.as_BFarray(), ospan.data.as_BFarray(), 1, acc, acc_mode)
                         else:
                             rv = self._bf.bfXgpuKernelAsync(ispan.data.as_BFarray(), ospan.data.as_BFarray(), int(now == gate.last))

@@ -6,7 +6,8 @@ the CPU and `Copy` moves the assembled gulps across PCIe.  Here the receiver onl
 slabs -- one slab per window of `ntime_gulp` sequence numbers, packets in arrival order, `pkt_stride` bytes
 apart, unused slots left zero -- and this block moves each slab across PCIe as it is and scatters it on the
 device (`xengSnap2Unpack`): the host never touches a payload byte, and the output is the `gpu-input` ring
-the X-engine and beamformer read.  (Sockets / verbs receive are out of scope: the block reads slabs from a
+the X-engine and beamformer read.  With `unpack=False` the slabs are only moved: the output ring holds packet slabs, which
+Corr and Beamform read in place (see __init__).  (Sockets / verbs receive are out of scope: the block reads slabs from a
 ring; tests and the emulator of test_tx_vectors.py fill it.)
 
 Packet format: test_tx_vectors.py:38-48,103-108 / test_tx_mt.c:39-49, header `>QLHHHHLLL`.
@@ -30,7 +31,7 @@ class Snap2Ingest(Block):
     def __init__(self, log, iring, oring, ntime_gulp=480, nchan=96, nstand=352, npol=2,
                  nchan_per_pkt=96, nstand_per_pkt=32, npkt_per_gulp=None,
                  fs_hz=196000000, chan_bw_hz=23925.78125, system_nchan=184 * 16,
-                 guarantee=True, core=-1, gpu=-1, buffer_multiplier=4, backend=None):
+                 guarantee=True, core=-1, gpu=-1, buffer_multiplier=4, backend=None, unpack=True):
         super(Snap2Ingest, self).__init__(log, iring, oring, guarantee, core, etcd_client=None)
         from .block_base import declare_streams
         declare_streams(iring, 'copy', 'xgpu')  # (the scatter runs on the copy stream, or enqueue-only on the X-engine's staging stream)
@@ -47,6 +48,13 @@ class Snap2Ingest(Block):
         self.npkt_per_gulp = npkt_per_gulp if npkt_per_gulp is not None else self.npkt_nominal
         self.igulp_size = self.npkt_per_gulp * self.pkt_stride
         self.ogulp_size = ntime_gulp * nchan * nstand * npol
+        # unpack=False (round 4): the slabs go to the device as they are and STAY slabs -- the output ring holds packet slabs, its
+        # sequence header says so ('layout': 'snap2_slab', 'slab_ntime', 'npkt_per_gulp', 'pkt_stride'), and Corr / Beamform hand
+        # them to the library's slab calls, which read complete, in-order slabs in place and scatter only the others
+        # (xengXgpuKernelAsyncSlab, xengBeamformRunSlabs): no scatter pass and no second copy of the voltages on the device.
+        self.unpack = unpack
+        if not unpack:
+            self.ogulp_size = self.igulp_size
         self.oring.resize(self.ogulp_size, total_span=buffer_multiplier * self.ogulp_size)
         self._slab_dev = None
         self.time_tag = 0
@@ -69,6 +77,8 @@ class Snap2Ingest(Block):
                         'chan0': chan0, 'nchan': self.nchan, 'system_nchan': self.system_nchan, 'fs_hz': self.fs_hz,
                         'sfreq': chan0 * self.chan_bw_hz, 'bw_hz': self.nchan * self.chan_bw_hz, 'nstand': self.nstand,
                         'pipeline_id': self.pipeline_id, 'npol': self.npol, 'complex': True, 'nbit': 4}
+                if not self.unpack:
+                    ohdr.update({'layout': 'snap2_slab', 'slab_ntime': self.ntime_gulp, 'npkt_per_gulp': npkt, 'pkt_stride': stride})
                 prev_time = time.time()
                 placed_tot = dropped_tot = nwin = 0
                 with oring.begin_sequence(time_tag=self.time_tag, header=json.dumps(ohdr), nringlet=iseq.nringlet) as oseq:
@@ -79,6 +89,20 @@ class Snap2Ingest(Block):
                         acquire_time = curr_time - prev_time
                         prev_time = curr_time
                         slab = ispan.data
+                        if not self.unpack:
+                            with oseq.reserve(igulp) as ospan:
+                                curr_time = time.time()
+                                reserve_time = curr_time - prev_time
+                                prev_time = curr_time
+                                copy_array(ospan.data, slab)             # one H2D (or D2D) of the raw packets; nothing else
+                            curr_time = time.time()
+                            process_time = curr_time - prev_time
+                            prev_time = curr_time
+                            nwin += 1
+                            self.perf_proclog.update({'acquire_time': acquire_time, 'reserve_time': reserve_time, 'process_time': process_time,
+                                                      'gbps': 8 * igulp / max(process_time, 1e-9) / 1e9})
+                            self.update_stats({'curr_sample': seq0 + nwin * self.ntime_gulp})
+                            continue
                         if slab.space != self._bf.space_in:          # pinned host slab: one H2D of the raw packets
                             if self._slab_dev is None or self._slab_dev.nbytes != igulp:
                                 self._slab_dev = XArray(shape=[igulp], dtype='u8', space=self._bf.space_in)

@@ -302,8 +302,8 @@ int xengBeamformTryRunParts(const void* in0_dev, int ntime0, const void* in1_dev
 // ones (samples [0, ntime0) and [ntime0, ntime): two capture gulps per beamformer gulp, lwa352-pipeline.py:172,279-282).  Each is
 // verified on the beam stream (one launch); a regular slab is read where it lies, anything else is scattered into the context's scratch gulp
 // first (the rules of xengSnap2UnpackAsync: missing samples read as zero, foreign and out-of-window packets dropped).
-int xengBeamformRunSlabs(const void* packets0_dev, int npkt0, int ntime0, const void* packets1_dev, int npkt1, size_t pkt_stride, uint64_t seq0,
-                         int chan0_pipeline, void* out_dev, const void* weights_dev, long long weights_version) {
+static int run_slabs(const void* packets0_dev, int npkt0, int ntime0, const void* packets1_dev, int npkt1, size_t pkt_stride, uint64_t seq0,
+                     int chan0_pipeline, void* out_dev, const void* weights_dev, long long weights_version, bool may_wait) {
     std::lock_guard<std::mutex> lk(g_bmu);
     BeamContext& x = g_b;
     if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "Beamform: not initialized (call xengBeamformInitialize)");
@@ -346,9 +346,21 @@ int xengBeamformRunSlabs(const void* packets0_dev, int npkt0, int ntime0, const 
     stream_tick(STREAM_BEAM);
     if (x.ntime_blocks == 0) return run_locked(nullptr, (float*)out_dev, weights_dev, weights_version, nullptr, 0, nullptr, true, nullptr, ntime0, x.gdesc);
     bool fused = false;
-    int rc = run_locked(nullptr, x.scratch, weights_dev, weights_version, (float*)out_dev, x.ntime / x.ntime_blocks, &fused, true, nullptr, ntime0, x.gdesc);
+    int rc = run_locked(nullptr, x.scratch, weights_dev, weights_version, (float*)out_dev, x.ntime / x.ntime_blocks, &fused, may_wait, nullptr, ntime0, x.gdesc);
     if (rc || fused) return rc;
     return integrate_locked(x.scratch, out_dev, x.ntime / x.ntime_blocks, 0, x.nbeam / 2);
+}
+
+int xengBeamformRunSlabs(const void* packets0_dev, int npkt0, int ntime0, const void* packets1_dev, int npkt1, size_t pkt_stride, uint64_t seq0,
+                         int chan0_pipeline, void* out_dev, const void* weights_dev, long long weights_version) {
+    return run_slabs(packets0_dev, npkt0, ntime0, packets1_dev, npkt1, pkt_stride, seq0, chan0_pipeline, out_dev, weights_dev, weights_version, true);
+}
+
+// (never waits: see xengBeamformTryRunVersioned.  A WOULD_BLOCK call has enqueued its verify pass; the blocking call that follows
+// enqueues it again -- harmless, same stream, same result)
+int xengBeamformTryRunSlabs(const void* packets0_dev, int npkt0, int ntime0, const void* packets1_dev, int npkt1, size_t pkt_stride, uint64_t seq0,
+                            int chan0_pipeline, void* out_dev, const void* weights_dev, long long weights_version) {
+    return run_slabs(packets0_dev, npkt0, ntime0, packets1_dev, npkt1, pkt_stride, seq0, chan0_pipeline, out_dev, weights_dev, weights_version, false);
 }
 
 // beamformer gulp parts handed over as slabs that took the scratch path since the last call; waits for the beam stream

@@ -206,6 +206,22 @@ PyObject* xgpu_kernel_async_acc(PyObject*, PyObject* args) {
     return PyLong_FromLong(kernel_async(in, out, dump, acc, mode));
 }
 
+// xgpu_kernel_slab(packets, npkt, stride, seq0, chan0, out, dump, acc, mode): a gulp as the slab of packets it arrived in
+PyObject* xgpu_kernel_slab(PyObject*, PyObject* args) {
+    unsigned long long pk, seq0, out, acc;
+    int npkt, chan0, dump, mode;
+    Py_ssize_t stride;
+    if (!PyArg_ParseTuple(args, "KinKiKiKi", &pk, &npkt, &stride, &seq0, &chan0, &out, &dump, &acc, &mode)) return nullptr;
+    for (;;) {
+        int rc = xengXgpuTryKernelAsyncSlab((const void*)(uintptr_t)pk, npkt, (size_t)stride, (uint64_t)seq0, chan0, (void*)(uintptr_t)out, dump, (void*)(uintptr_t)acc, mode);
+        if (rc != XENG_STATUS_WOULD_BLOCK) return PyLong_FromLong(rc);
+        Py_BEGIN_ALLOW_THREADS
+        rc = xengXgpuWaitLaunchSlot();
+        Py_END_ALLOW_THREADS
+        if (rc) return PyLong_FromLong(rc);
+    }
+}
+
 // xgpu_dump_done(lag) -> -status | 0 (not done) | 1 (done)
 PyObject* xgpu_dump_done(PyObject*, PyObject* args) {
     int lag, done = 0;
@@ -237,6 +253,24 @@ PyObject* beam_run_parts(PyObject*, PyObject* args) {
     if (rc == XENG_STATUS_WOULD_BLOCK) {
         Py_BEGIN_ALLOW_THREADS
         rc = xengBeamformRunParts((const void*)(uintptr_t)in0, ntime0, (const void*)(uintptr_t)in1, (void*)(uintptr_t)out, (const void*)(uintptr_t)w, version);
+        Py_END_ALLOW_THREADS
+    }
+    return PyLong_FromLong(rc);
+}
+
+// beam_run_slabs(pk0, npkt0, ntime0, pk1, npkt1, stride, seq0, chan0, out, w, version): a beamformer gulp as one or two packet slabs
+PyObject* beam_run_slabs(PyObject*, PyObject* args) {
+    unsigned long long pk0, pk1, seq0, out, w;
+    int npkt0, ntime0, npkt1, chan0;
+    Py_ssize_t stride;
+    long long version;
+    if (!PyArg_ParseTuple(args, "KiiKinKiKKL", &pk0, &npkt0, &ntime0, &pk1, &npkt1, &stride, &seq0, &chan0, &out, &w, &version)) return nullptr;
+    int rc = xengBeamformTryRunSlabs((const void*)(uintptr_t)pk0, npkt0, ntime0, (const void*)(uintptr_t)pk1, npkt1, (size_t)stride, (uint64_t)seq0, chan0,
+                                     (void*)(uintptr_t)out, (const void*)(uintptr_t)w, version);
+    if (rc == XENG_STATUS_WOULD_BLOCK) {
+        Py_BEGIN_ALLOW_THREADS
+        rc = xengBeamformRunSlabs((const void*)(uintptr_t)pk0, npkt0, ntime0, (const void*)(uintptr_t)pk1, npkt1, (size_t)stride, (uint64_t)seq0, chan0,
+                                  (void*)(uintptr_t)out, (const void*)(uintptr_t)w, version);
         Py_END_ALLOW_THREADS
     }
     return PyLong_FromLong(rc);
@@ -284,9 +318,11 @@ PyMethodDef methods[] = {
     {"ring_acquire_parts", ring_acquire_parts, METH_VARARGS, "(ring_obj, handle, reader, advance, gulp) -> None | (skipped, (ptr, nbytes, SpanRef), ...)"},
     {"xgpu_kernel_async", xgpu_kernel_async, METH_VARARGS, "xengXgpuKernelAsync -> status"},
     {"xgpu_kernel_async_acc", xgpu_kernel_async_acc, METH_VARARGS, "xengXgpuKernelAsyncAcc -> status"},
+    {"xgpu_kernel_slab", xgpu_kernel_slab, METH_VARARGS, "xengXgpuKernelAsyncSlab (a gulp as its packet slab) -> status"},
     {"xgpu_dump_done", xgpu_dump_done, METH_VARARGS, "xengXgpuDumpDone(lag) -> -status | 0 | 1"},
     {"beam_run", beam_run, METH_VARARGS, "xengBeamformRunVersioned -> status"},
     {"beam_run_parts", beam_run_parts, METH_VARARGS, "xengBeamformRunParts (two ring spans as one gulp) -> status"},
+    {"beam_run_slabs", beam_run_slabs, METH_VARARGS, "xengBeamformRunSlabs (a gulp as one or two packet slabs) -> status"},
     {"beam_integrate", beam_integrate, METH_VARARGS, "xengBeamformIntegrate -> status"},
     {"beam_mark", beam_mark, METH_NOARGS, "xengBeamformMark -> ticket | -status"},
     {"beam_ticket_done", beam_ticket_done, METH_VARARGS, "xengBeamformTicketDone -> -status | 0 | 1"},

@@ -695,9 +695,9 @@ int xengXgpuWaitLaunchSlot(void) { return wait_for_event_slot(true); }
 
 // A gulp handed over as the slab of packets it arrived in (slab.h): verified on the device; read in place by the
 // contraction when it is regular, scattered into the library's staging area (and read from there) when it is not.
-int xengXgpuKernelAsyncSlab(const void* packets_dev, int npkt, size_t pkt_stride, uint64_t seq0, int chan0_pipeline, void* out_dev,
-                            int doDump, void* acc_dev, int acc_mode) {
-    int rc0 = wait_for_event_slot();
+static int kernel_slab(const void* packets_dev, int npkt, size_t pkt_stride, uint64_t seq0, int chan0_pipeline, void* out_dev,
+                       int doDump, void* acc_dev, int acc_mode, bool may_block) {
+    int rc0 = wait_for_event_slot(may_block);
     if (rc0) return rc0;
     std::lock_guard<std::mutex> lk(g_mu);
     XgpuContext& x = g_ctx;
@@ -732,6 +732,17 @@ int xengXgpuKernelAsyncSlab(const void* packets_dev, int npkt, size_t pkt_stride
     x.nfilled++;
     if (doDump || x.nfilled == x.cap_gulps) return flush_locked(out_dev, doDump != 0, acc_dev, acc_dev ? acc_mode : 0);
     return XENG_STATUS_SUCCESS;
+}
+
+int xengXgpuKernelAsyncSlab(const void* packets_dev, int npkt, size_t pkt_stride, uint64_t seq0, int chan0_pipeline, void* out_dev,
+                            int doDump, void* acc_dev, int acc_mode) {
+    return kernel_slab(packets_dev, npkt, pkt_stride, seq0, chan0_pipeline, out_dev, doDump, acc_dev, acc_mode, true);
+}
+
+// (never waits: XENG_STATUS_WOULD_BLOCK 256 launches ahead of the GPU -- xengXgpuWaitLaunchSlot, then retry)
+int xengXgpuTryKernelAsyncSlab(const void* packets_dev, int npkt, size_t pkt_stride, uint64_t seq0, int chan0_pipeline, void* out_dev,
+                               int doDump, void* acc_dev, int acc_mode) {
+    return kernel_slab(packets_dev, npkt, pkt_stride, seq0, chan0_pipeline, out_dev, doDump, acc_dev, acc_mode, false);
 }
 
 // gulps handed over as slabs that took the scratch path (lost / reordered / foreign packets) since the last call; waits for the

@@ -68,7 +68,7 @@ SYMBOLS = {
     "xengMemcpyAsync": [_vp, _vp, _sz], "xengMemset": [_vp, _i, _sz], "xengStreamSynchronize": [],
     "xengXgpuConfigure": [_i, _i, _i, _i, _i], "xengXgpuInitialize": [_i], "xengXgpuDestroy": [],
     "xengXgpuKernel": [_vp, _vp, _i], "xengXgpuKernelAsync": [_vp, _vp, _i], "xengXgpuKernelAsyncAcc": [_vp, _vp, _i, _vp, _i], "xengXgpuTryKernelAsyncAcc": [_vp, _vp, _i, _vp, _i], "xengXgpuWaitLaunchSlot": [],
-    "xengXgpuKernelAsyncSlab": [_vp, _i, _sz, ctypes.c_uint64, _i, _vp, _i, _vp, _i], "xengXgpuGetSlabFallbacks": [_pi], "xengXgpuSync": [], "xengXgpuSyncLag": [_i], "xengXgpuDumpDone": [_i, _pi], "xengXgpuReset": [],
+    "xengXgpuKernelAsyncSlab": [_vp, _i, _sz, ctypes.c_uint64, _i, _vp, _i, _vp, _i], "xengXgpuTryKernelAsyncSlab": [_vp, _i, _sz, ctypes.c_uint64, _i, _vp, _i, _vp, _i], "xengXgpuGetSlabFallbacks": [_pi], "xengXgpuSync": [], "xengXgpuSyncLag": [_i], "xengXgpuDumpDone": [_i, _pi], "xengXgpuReset": [],
     "xengXgpuCorrelate": [_vp, _vp, _i], "xengXgpuGetOrder": [_vp, _vp, _vp],
     "xengXgpuSubSelect": [_vp, _vp, _vp, _vp, _i, _i], "xengXgpuReorder": [_vp, _vp, _vp, _vp],
     "xengXgpuGetInfo": [_pi, _pi, _pi, _pi, ctypes.POINTER(ctypes.c_int64), _pi],
@@ -82,7 +82,7 @@ SYMBOLS = {
     "xengBeamformInitialize": [_i, _i, _i, _i, _i, _i], "xengBeamformDestroy": [],
     "xengBeamformRun": [_vp, _vp, _vp], "xengBeamformRunVersioned": [_vp, _vp, _vp, ctypes.c_longlong], "xengBeamformTryRunVersioned": [_vp, _vp, _vp, ctypes.c_longlong],
     "xengBeamformRunParts": [_vp, _i, _vp, _vp, _vp, ctypes.c_longlong], "xengBeamformTryRunParts": [_vp, _i, _vp, _vp, _vp, ctypes.c_longlong],
-    "xengBeamformRunSlabs": [_vp, _i, _i, _vp, _i, _sz, ctypes.c_uint64, _i, _vp, _vp, ctypes.c_longlong], "xengBeamformGetSlabFallbacks": [_pi],
+    "xengBeamformRunSlabs": [_vp, _i, _i, _vp, _i, _sz, ctypes.c_uint64, _i, _vp, _vp, ctypes.c_longlong], "xengBeamformTryRunSlabs": [_vp, _i, _i, _vp, _i, _sz, ctypes.c_uint64, _i, _vp, _vp, ctypes.c_longlong], "xengBeamformGetSlabFallbacks": [_pi],
     "xengBeamformIntegrate": [_vp, _vp, _i],
     "xengBeamformIntegrateSingleBeam": [_vp, _vp, _i, _i], "xengBeamformMark": [ctypes.POINTER(ctypes.c_ulonglong)], "xengBeamformWait": [ctypes.c_ulonglong], "xengBeamformTicketDone": [ctypes.c_ulonglong, _pi], "xengBeamformSync": [],
     "xengBeamformSetProfiling": [_i], "xengBeamformGetTimes": [ctypes.POINTER(ctypes.c_double), _pi],
@@ -124,7 +124,7 @@ def lib():
 # flight and xengBeamformRun* waits once after a weight upload in the integrated-power mode: their Try* forms return
 # XENG_STATUS_WOULD_BLOCK instead, and the caller gives the lock up to wait; xengSnap2UnpackAsync shares a mutex with the
 # synchronous call, which polls: it is made on the releasing handle.)
-ENQUEUE_ONLY = ["xengXgpuTryKernelAsyncAcc", "xengBeamformTryRunVersioned", "xengBeamformTryRunParts",
+ENQUEUE_ONLY = ["xengXgpuTryKernelAsyncAcc", "xengXgpuTryKernelAsyncSlab", "xengBeamformTryRunVersioned", "xengBeamformTryRunParts", "xengBeamformTryRunSlabs",
                 "xengBeamformIntegrate", "xengBeamformIntegrateSingleBeam", "xengBeamformMark", "xengMapAssignI32",
                 "xengMapAddI32", "xengXgpuDumpDone", "xengBeamformTicketDone", "bfBeamformIntegrate", "bfBeamformIntegrateSingleBeam",
                 # the span rings: bookkeeping calls, and the calls that can wait asked with may_block = 0 first

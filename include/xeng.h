@@ -222,6 +222,8 @@ int xengXgpuWaitLaunchSlot(void);
  * scatter since it was last called (waits for the staging stream).  No reference counterpart: bifrost's capture scatters on the CPU. */
 int xengXgpuKernelAsyncSlab(const void *packets_dev, int npkt, size_t pkt_stride, uint64_t seq0, int chan0_pipeline, void *out_dev,
                             int doDump, void *acc_dev, int acc_mode);
+int xengXgpuTryKernelAsyncSlab(const void *packets_dev, int npkt, size_t pkt_stride, uint64_t seq0, int chan0_pipeline, void *out_dev,
+                               int doDump, void *acc_dev, int acc_mode);      /* never waits: see xengXgpuTryKernelAsyncAcc */
 int xengXgpuGetSlabFallbacks(int *nfallback);
 int xengXgpuSync(void);
 /* Wait until all but the last `lag` (0..3) dumps are complete -- lag 1 lets a streaming caller enqueue
@@ -342,6 +344,8 @@ int xengBeamformTryRunParts(const void *in0_dev, int ntime0, const void *in1_dev
  * xengBeamformGetSlabFallbacks: parts that took the scatter since it was last called (waits for the beam stream). */
 int xengBeamformRunSlabs(const void *packets0_dev, int npkt0, int ntime0, const void *packets1_dev, int npkt1, size_t pkt_stride,
                          uint64_t seq0, int chan0_pipeline, void *out_dev, const void *weights_dev, long long weights_version);
+int xengBeamformTryRunSlabs(const void *packets0_dev, int npkt0, int ntime0, const void *packets1_dev, int npkt1, size_t pkt_stride,
+                            uint64_t seq0, int chan0_pipeline, void *out_dev, const void *weights_dev, long long weights_version);   /* never waits: see xengBeamformTryRunVersioned */
 int xengBeamformGetSlabFallbacks(int *nfallback);
 
 /* beamform_sum_beams_block.py:243-246.  in_dev cf32[nchan][nbeam][ntime];

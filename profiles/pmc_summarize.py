@@ -28,7 +28,11 @@ res = {"xcorr_sources_sha256": h.hexdigest(), "xcorr_sources": srcs,
                      "WRITE_SIZE exact for 16-B-per-lane stores; separate --pmc passes (profiles/pmc_run.sh)"}
 for k, d in agg.items():
     if "xcorr_" in k and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
-        name = ("xcorr_fused_kernel_lacc" if "true>" in k else "xcorr_fused_kernel") if "fused_kernel" in k else k.strip()
+        if "fused_kernel<" in k:      # template arguments <ABL, LACC, DESC>: long accumulation in the epilogue; gulps by descriptor (packet slabs)
+            targs = [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")]
+            name = "xcorr_fused_kernel" + ("_lacc" if targs[1] == "true" else "") + ("_slabs" if len(targs) > 2 and targs[2] == "true" else "")
+        else:
+            name = k.strip()
         f, w = d["FETCH_SIZE"][0] / d["FETCH_SIZE"][1], d["WRITE_SIZE"][0] / d["WRITE_SIZE"][1]
         res[name + "_bytes_per_launch"] = int(round((2 * f + w) * 1024))
         res[name] = {"FETCH_SIZE_KB_per_dispatch": round(f, 1), "WRITE_SIZE_KB_per_dispatch": round(w, 1),

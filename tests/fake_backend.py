@@ -85,6 +85,24 @@ class OracleBackend:
             orc.map_i32(acc.numpy().reshape(-1), dumped, add=(acc_mode == 2))
         return rv
 
+    def _unpack_slab(self, slab, npkt, pkt_stride, seq0, ntime, chan0, nchan, ninput):
+        raw = slab.numpy().reshape(-1).view(np.uint8)
+        pkts = [raw[i * pkt_stride:(i + 1) * pkt_stride].tobytes() for i in range(npkt)]
+        gulp, _, _ = orc.snap2_unpack(pkts, seq0, ntime, chan0, nchan, ninput)
+        return gulp
+
+    def bfXgpuKernelSlab(self, slab, npkt, pkt_stride, seq0, chan0, out_arr, do_dump, acc=None, acc_mode=0):
+        """the oracle's unpack, then the plain call on the unpacked gulp"""
+        from caltech_bifrost_dsp_amd.ndarray import XArray
+        c = self.cfg
+        self.slab_calls = getattr(self, "slab_calls", 0) + 1
+        gulp = self._unpack_slab(slab, npkt, pkt_stride, seq0, c["ntime"], chan0, c["nchan"], c["nstand"] * c["npol"])
+        g = XArray(shape=[gulp.size], dtype='u8', space='system')
+        g.numpy().reshape(-1).view(np.uint8)[...] = gulp.ravel()
+        if acc is not None:
+            return self.bfXgpuKernelAsyncAcc(g.as_BFarray(), out_arr, do_dump, acc, acc_mode)
+        return self.bfXgpuKernelAsync(g.as_BFarray(), out_arr, do_dump)
+
     def xgpu_fused_acc_supported(self):
         return True
 
@@ -166,6 +184,20 @@ class OracleBackend:
         self.parts_calls = getattr(self, "parts_calls", 0) + 1
         vin = np.concatenate([part0.numpy().reshape(-1), part1.numpy().reshape(-1)]).view(np.uint8)
         assert vin.size == b["ntime"] * b["nchan"] * b["ninput"]
+        w = _np(weights, np.complex64, b["nchan"] * b["nbeam"] * b["ninput"])
+        out = orc.beamform(vin, w, b["ntime"], b["nchan"], b["ninput"], b["nbeam"])
+        _np(out_arr, np.complex64, out.size)[...] = out.ravel()
+        return 0
+
+    def bfBeamformRunSlabs(self, slab0, npkt0, ntime0, slab1, npkt1, pkt_stride, seq0, chan0, out_arr, weights, version=0):
+        b = self.beam
+        self.beam_slab_calls = getattr(self, "beam_slab_calls", 0) + 1
+        if slab1 is None:
+            ntime0 = b["ntime"]
+        parts = [self._unpack_slab(slab0, npkt0, pkt_stride, seq0, ntime0, chan0, b["nchan"], b["ninput"])]
+        if slab1 is not None:
+            parts.append(self._unpack_slab(slab1, npkt1, pkt_stride, seq0 + ntime0, b["ntime"] - ntime0, chan0, b["nchan"], b["ninput"]))
+        vin = np.concatenate([p.reshape(-1) for p in parts])
         w = _np(weights, np.complex64, b["nchan"] * b["nbeam"] * b["ninput"])
         out = orc.beamform(vin, w, b["ntime"], b["nchan"], b["ninput"], b["nbeam"])
         _np(out_arr, np.complex64, out.size)[...] = out.ravel()

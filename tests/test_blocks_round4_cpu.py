@@ -201,3 +201,51 @@ def test_fused_corracc_publishes_without_stopping():
     assert len(spans) == nlong
     for k, sp in enumerate(spans):
         assert np.array_equal(sp.view(np.int32), orc.xgpu_correlate(vin[lacc * k:lacc * (k + 1)], S, C)), k
+
+
+def test_packet_slabs_stay_slabs_from_ingest_to_corr_and_beamform():
+    """Snap2Ingest(unpack=False) -> a ring of PACKET SLABS -> Corr and Beamform (two slabs per beamformer gulp): the blocks hand
+    every slab to the library's slab calls (here: the oracle's unpack + the plain call) with the right sequence number and
+    channel offset, the downstream headers describe the products (no layout keys), and the results are those of the unpacked
+    pipeline -- also for a window whose packets arrived in another order and one that lost a packet."""
+    from caltech_bifrost_dsp_amd.blocks import Beamform, Snap2Ingest
+    C, S, P, g, nbeam = 4, 16, 2, 8, 4
+    T = 4 * g
+    ninput = S * P
+    rng = np.random.default_rng(12)
+    vin = rng.integers(0, 256, (T, C, S, P), dtype=np.uint8)
+    seq0, chan0 = 6000, 192
+    pk = orc.snap2_packets(vin, seq0=seq0, sync_time=77, nchan_blocks=1, nstand_per_pkt=8, chan0_pipeline=chan0)
+    per_win = len(pk) // (T // g)
+    wins = [list(pk[w * per_win:(w + 1) * per_win]) for w in range(T // g)]
+    wins[1] = [wins[1][i] for i in rng.permutation(per_win)]                  # arrival order is arbitrary
+    lost = wins[2][5]
+    wins[2][5] = wins[2][6]                                                     # one packet lost, its slot holds a duplicate
+    received = vin.copy().reshape(T, C, ninput)
+    import struct
+    lseq, _, lnpol, _, lnchan, _, _, lc0, lp0 = struct.unpack(orc.SNAP2_HDR, lost[:32])
+    received[lseq - seq0, lc0 - chan0:lc0 - chan0 + lnchan, lp0:lp0 + lnpol] = 0
+    be = OracleBackend()
+    r_pk, r_slab, r_vis, r_beam = Ring("packets"), Ring("gpu-input-slabs"), Ring("corr-output"), Ring("bf-output")
+    ing = Snap2Ingest(LOG, r_pk, r_slab, ntime_gulp=g, nchan=C, nstand=S, npol=P, nchan_per_pkt=C, nstand_per_pkt=8, backend=be, unpack=False)
+    assert ing.ogulp_size == ing.igulp_size == per_win * len(pk[0])
+    hdr_src = source_header(C, S, P, seq0=seq0, chan0=chan0)
+    cblk = Corr(LOG, r_slab, r_vis, ntime_gulp=g, nchan=C, npol=P, nstand=S, acc_len=2 * g, autostartat=seq0,
+                ant_to_input=hdr_src['ant_to_input'], backend=be)
+    bf = Beamform(LOG, r_slab, r_beam, nchan=C, nbeam=nbeam, ninput=ninput, ntime_gulp=2 * g, backend=be)
+    w = (rng.uniform(-1, 1, (C, nbeam, ninput)) + 1j * rng.uniform(-1, 1, (C, nbeam, ninput))).astype(np.complex64)
+    bf.gains_cpu[...] = w
+    vis_sink, beam_sink = Sink(r_vis, cblk.ogulp_size), Sink(r_beam, 2 * g * C * nbeam * 8)
+    slabs = b"".join(b"".join(wn) for wn in wins)
+    run_blocks([ing, cblk, bf], Source(r_pk, [({'seq0': seq0, 'chan0': chan0, 'sync_time': 77}, slabs, ing.igulp_size)]), [vis_sink, beam_sink])
+    assert be.slab_calls == T // g and be.beam_slab_calls == T // (2 * g)
+    (vh, _, vspans), = vis_sink.sequences
+    (bh, _, bspans), = beam_sink.sequences
+    for h in (vh, bh):
+        assert not any(k in h for k in ('layout', 'slab_ntime', 'npkt_per_gulp', 'pkt_stride')) and h['chan0'] == chan0
+    assert len(vspans) == 2 and len(bspans) == 2
+    for k in range(2):
+        exp = orc.xgpu_correlate(received[2 * k * g:(2 * k + 2) * g].reshape(2 * g, C, S, P), S, C)
+        assert np.array_equal(vspans[k].view(np.int32), exp.ravel()), k
+        expb = orc.beamform(received[2 * k * g:(2 * k + 2) * g], w, 2 * g, C, ninput, nbeam)
+        assert np.array_equal(bspans[k].view(np.complex64).reshape(expb.shape), expb), k

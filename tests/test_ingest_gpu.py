@@ -184,6 +184,65 @@ def test_ingest_corr_on_device_rings():
     assert ing.stats['packets_placed'] == len(pk) and ing.stats['missing_frac'] == 0.0
 
 
+def test_ingest_leaves_slabs_and_corr_and_beamform_read_them_in_place():
+    """pinned packet slabs -> Snap2Ingest(unpack=False): one H2D per slab, nothing else -> a device ring of SLABS -> Corr
+    (xengXgpuKernelAsyncSlab, with a CorrAcc fed from its dumps) and Beamform (xengBeamformRunSlabs, two slabs per gulp) ->
+    BeamformSumBeams.  Regular windows are read where they lie; one window arrives in another order and one has lost a packet
+    (scattered on the device).  Every product equals the oracle on what was received."""
+    import ctypes
+    import struct
+    from caltech_bifrost_dsp_amd.blocks import Beamform, BeamformSumBeams, CorrAcc
+    T, C, S, g, acc, nbeam, ntime_sum = 768, 8, 64, 96, 192, 32, 16           # (gulps of 96 samples: the fused contraction kernel)
+    ninput = S * 2
+    rng = np.random.default_rng(14)
+    vin = rng.integers(0, 256, (T, C, S, 2), dtype=np.uint8)
+    seq0, chan0 = 9600, 192                                   # (a start time on a gulp boundary)
+    pk = orc.snap2_packets(vin, seq0=seq0, sync_time=5, nchan_blocks=1, nstand_per_pkt=32, chan0_pipeline=chan0)
+    per_win = len(pk) // (T // g)
+    wins = [list(pk[w * per_win:(w + 1) * per_win]) for w in range(T // g)]
+    wins[2] = [wins[2][i] for i in rng.permutation(per_win)]
+    lost = wins[5][9]
+    wins[5][9] = wins[5][10]
+    received = vin.copy().reshape(T, C, ninput)
+    lseq, _, lnpol, _, lnchan, _, _, lc0, lp0 = struct.unpack(orc.SNAP2_HDR, lost[:32])
+    received[lseq - seq0, lc0 - chan0:lc0 - chan0 + lnchan, lp0:lp0 + lnpol] = 0
+    slabs = b"".join(b"".join(wn) for wn in wins)
+    r_pk, r_slab = Ring("packets", space="cuda_host"), Ring("gpu-input-slabs", space="cuda")
+    r_vis, r_slow, r_beam, r_pow = Ring("corr-output", space="cuda"), Ring("corr-slow", space="cuda_host"), Ring("bf-output", space="cuda"), Ring("bf-pow", space="cuda_host")
+    ing = Snap2Ingest(LOG, r_pk, r_slab, ntime_gulp=g, nchan=C, nstand=S, npol=2, nchan_per_pkt=C, nstand_per_pkt=32, gpu=0, unpack=False,
+                      buffer_multiplier=8)
+    hdr = source_header(C, S, 2)
+    corr = Corr(LOG, r_slab, r_vis, ntime_gulp=g, nchan=C, npol=2, nstand=S, acc_len=acc, autostartat=seq0, gpu=0, ant_to_input=hdr['ant_to_input'])
+    cacc = CorrAcc(LOG, r_vis, r_slow, nchan=C, npol=2, nstand=S, acc_len=2 * acc, autostartat=seq0, gpu=0)
+    bf = Beamform(LOG, r_slab, r_beam, nchan=C, nbeam=nbeam, ninput=ninput, ntime_gulp=2 * g, gpu=0)
+    w = (rng.uniform(-1, 1, (C, nbeam, ninput)) + 1j * rng.uniform(-1, 1, (C, nbeam, ninput))).astype(np.complex64)
+    bf.gains_cpu[...] = w
+    sb = BeamformSumBeams(LOG, r_beam, r_pow, nchan=C, ntime_gulp=2 * g, ntime_sum=ntime_sum, gpu=0)
+    vis_sink, slow_sink, pow_sink = Sink(r_vis, corr.ogulp_size), Sink(r_slow, corr.ogulp_size), Sink(r_pow, (nbeam // 2) * (2 * g // ntime_sum) * C * 16)
+    run_blocks([ing, corr, cacc, bf, sb], Source(r_pk, [({'seq0': seq0, 'chan0': chan0, 'sync_time': 5}, slabs, ing.igulp_size)]),
+               [vis_sink, slow_sink, pow_sink])
+    (h, _, spans), = vis_sink.sequences
+    assert h['seq0'] == seq0 and h['chan0'] == chan0 and 'layout' not in h and len(spans) == T // acc
+    exp_vis = [orc.xgpu_correlate(received[k * acc:(k + 1) * acc].reshape(acc, C, S, 2), S, C) for k in range(T // acc)]
+    for k, sp in enumerate(spans):
+        assert np.array_equal(sp.view(np.int32), exp_vis[k].ravel()), k
+    (_, _, slow), = slow_sink.sequences
+    assert len(slow) == T // (2 * acc)
+    for k, sp in enumerate(slow):
+        assert np.array_equal(sp.view(np.int32), (exp_vis[2 * k] + exp_vis[2 * k + 1]).ravel()), k
+    (_, _, pows), = pow_sink.sequences
+    assert len(pows) == T // (2 * g)
+    for k, sp in enumerate(pows):
+        beams = orc.beamform(received[2 * k * g:(2 * k + 2) * g], w, 2 * g, C, ninput, nbeam)
+        exp = orc.beamform_integrate(beams, ntime_sum)
+        got = sp.view(np.float32).reshape(exp.shape)
+        assert np.max(np.abs(got - exp)) <= 2e-5 * np.sqrt(np.mean(exp[..., :2] ** 2)), k
+    nfx, nfb = ctypes.c_int(-1), ctypes.c_int(-1)
+    ffi.call("xengXgpuGetSlabFallbacks", ctypes.byref(nfx))
+    ffi.call("xengBeamformGetSlabFallbacks", ctypes.byref(nfb))
+    assert nfx.value == 2 and nfb.value == 2          # windows 2 and 5, once per consumer; the other six were read in place
+
+
 def test_unpack_async_is_ordered_before_the_contraction():
     """xengSnap2UnpackAsync + xengXgpuKernelAsync: the scatter runs on the X-engine's staging stream, so the dump's
     contraction reads complete gulps; visibilities equal the oracle on the original voltages."""
