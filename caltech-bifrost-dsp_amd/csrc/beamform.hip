@@ -227,7 +227,7 @@ int xengBeamformInitialize(int gpu, int ninput, int nchan, int ntime, int nbeam,
     x.nbtile = (nbeam + 31) / 32;
     x.wprep_bytes = (size_t)nchan * x.nbtile * x.nchunk * BF3_WCHUNK;
     XENG_HIP(hipMalloc((void**)&x.wprep, x.wprep_bytes));
-    XENG_HIP(hipMemset(x.wprep, 0, x.wprep_bytes));
+    XENG_HIP(hip_memset_now(x.wprep, 0, x.wprep_bytes));
     // the bf16x3 kernel moves the packed voltages by 16-byte LDS-DMA columns: inputs must be a multiple of 16
     const char* mode = getenv("XENG_BEAM");
     x.use_f32 = getenv("XENG_BEAM_F32") != nullptr || (mode && !strcmp(mode, "f32")) || (ninput % 16) != 0;
@@ -236,7 +236,7 @@ int xengBeamformInitialize(int gpu, int ninput, int nchan, int ntime, int nbeam,
         x.nchunk_i8 = (ninput + BI_KC - 1) / BI_KC;
         const size_t qb = (size_t)nchan * x.nbtile * x.nchunk_i8 * BI_WCHUNK;
         XENG_HIP(hipMalloc((void**)&x.wq, qb));
-        XENG_HIP(hipMemset(x.wq, 0, qb));
+        XENG_HIP(hip_memset_now(x.wq, 0, qb));
         XENG_HIP(hipMalloc((void**)&x.wscale, (size_t)nchan * x.nbtile * 32 * sizeof(float)));
         XENG_HIP(hipMalloc((void**)&x.wmax, (size_t)nchan * x.nbtile * 32 * sizeof(float)));
         XENG_HIP(hipMalloc((void**)&x.wsum, (size_t)nchan * x.nbtile * 3 * 32 * sizeof(int)));
@@ -251,7 +251,7 @@ int xengBeamformInitialize(int gpu, int ninput, int nchan, int ntime, int nbeam,
         if (diag_env("XENG_BEAM_STAMPS")) {
             const size_t nw = (size_t)((ntime + BI_NT - 1) / BI_NT) * nchan * x.nbtile * 4 * 4;
             XENG_HIP(hipMalloc((void**)&x.stamps, nw * sizeof(unsigned long long)));
-            XENG_HIP(hipMemset(x.stamps, 0, nw * sizeof(unsigned long long)));
+            XENG_HIP(hip_memset_now(x.stamps, 0, nw * sizeof(unsigned long long)));
         }
     }
     int rc = get_stream(STREAM_BEAM, &x.stream);
@@ -320,9 +320,9 @@ static int run_slabs(const void* packets0_dev, int npkt0, int ntime0, const void
     if (!x.gdesc) {
         if (int rc = slab_site_create(&x.slab_site)) return rc;
         XENG_HIP(hipMalloc((void**)&x.gdesc, 2 * sizeof(GulpDesc)));
-        XENG_HIP(hipMemset(x.gdesc, 0, 2 * sizeof(GulpDesc)));
+        XENG_HIP(hip_memset_now(x.gdesc, 0, 2 * sizeof(GulpDesc)));
         XENG_HIP(hipMalloc((void**)&x.gargs, 2 * sizeof(SlabArgs)));
-        XENG_HIP(hipMemset(x.gargs, 0, 2 * sizeof(SlabArgs)));
+        XENG_HIP(hip_memset_now(x.gargs, 0, 2 * sizeof(SlabArgs)));
         XENG_HIP(hipMalloc((void**)&x.slab_scratch, (size_t)x.ntime * row));
     }
     const int nparts = packets1_dev ? 2 : 1;

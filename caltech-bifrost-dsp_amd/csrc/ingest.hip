@@ -245,7 +245,7 @@ static int snap2_check(const void* packets_dev, int npkt, size_t pkt_stride, voi
         const size_t nb = 8 + SNAP2_MAX_ROWS * (sizeof(unsigned long long) + sizeof(unsigned int)) + 8 + 16 + 128;
         uint8_t* base = nullptr;
         XENG_HIP(hipMalloc((void**)&base, nb));
-        XENG_HIP(hipMemset(base, 0, nb));
+        XENG_HIP(hip_memset_now(base, 0, nb));
         XENG_HIP(hipHostMalloc(&st.host, nb + 8, hipHostMallocDefault));     // (coherent pinned memory: the kernel writes it)
         memset(st.host, 0, nb + 8);
         st.async_drops = (int*)(base + nb - 128 - 16);

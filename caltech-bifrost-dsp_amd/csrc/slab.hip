@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void slab_scatter_kernel(const GulpDesc* __res
 int slab_site_create(SlabSite* s) {
     void* p = nullptr;
     XENG_HIP(hipMalloc(&p, 32));
-    XENG_HIP(hipMemset(p, 0, 32));
+    XENG_HIP(hip_memset_now(p, 0, 32));
     s->tally = (unsigned long long*)p;       // two words: one per gulp of a launch
     s->fallbacks = (int*)p + 4;
     XENG_HIP(hipHostMalloc((void**)&s->fallbacks_host, sizeof(int)));

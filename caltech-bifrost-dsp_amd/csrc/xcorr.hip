@@ -562,15 +562,15 @@ static int initialize_locked(int gpu) {
 
     for (int b = 0; b < 2; b++) {
         XENG_HIP(hipMalloc((void**)&x.stash[b], x.stash_bytes));
-        XENG_HIP(hipMemset(x.stash[b], 0, x.stash_bytes));
+        XENG_HIP(hip_memset_now(x.stash[b], 0, x.stash_bytes));
     }
     XENG_HIP(hipEventCreateWithFlags(&x.ev_ct, hipEventDisableTiming));
     if (x.raw) {
         for (int b = 0; b < 2; b++) {
             XENG_HIP(hipMalloc((void**)&x.gdesc_dev[b], XC_MAX_GULPS * sizeof(GulpDesc)));
-            XENG_HIP(hipMemset(x.gdesc_dev[b], 0, XC_MAX_GULPS * sizeof(GulpDesc)));
+            XENG_HIP(hip_memset_now(x.gdesc_dev[b], 0, XC_MAX_GULPS * sizeof(GulpDesc)));
             XENG_HIP(hipMalloc((void**)&x.gargs_dev[b], XC_MAX_GULPS * sizeof(SlabArgs)));
-            XENG_HIP(hipMemset(x.gargs_dev[b], 0, XC_MAX_GULPS * sizeof(SlabArgs)));
+            XENG_HIP(hip_memset_now(x.gargs_dev[b], 0, XC_MAX_GULPS * sizeof(SlabArgs)));
         }
         if (int rcs = slab_site_create(&x.slab_site)) return rcs;
     }
@@ -615,7 +615,7 @@ static int initialize_locked(int gpu) {
     if (diag_env("XENG_DBG_STAMPS")) {
         const int ng = std::max(x.nwg, x.nfg);
         XENG_HIP(hipMalloc((void**)&x.stamps, (size_t)x.cfg.nchan * ng * 4 * 8 * sizeof(unsigned long long)));
-        XENG_HIP(hipMemset(x.stamps, 0, (size_t)x.cfg.nchan * ng * 4 * 8 * sizeof(unsigned long long)));
+        XENG_HIP(hip_memset_now(x.stamps, 0, (size_t)x.cfg.nchan * ng * 4 * 8 * sizeof(unsigned long long)));
     }
     x.live = true;
     return XENG_STATUS_SUCCESS;

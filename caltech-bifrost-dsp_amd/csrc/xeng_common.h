@@ -81,6 +81,17 @@ unsigned long long xgpu_last_writer(const void* buf);               // number of
 
 // Experiment / diagnostic switches (grid sizes, map variants, clock stamps, item order ...) exist only in
 // -DXENG_DIAGNOSTICS builds (profiles/); the shipped library reads XENG_RAW, XENG_BEAM[_F32] and XENG_TILING only.
+// hipMemset on the null stream, COMPLETE on return.  hipMemset itself may return before the fill has run (it is a kernel on the
+// null stream, which the library's non-blocking streams do not wait for): a kernel enqueued right afterwards on one of those
+// streams can then write the buffer first and have its words zeroed under it.  Seen once the fill was delayed: under
+// `rocprofv3 --pmc`, which runs one kernel at a time in submission order, the first xengBeamformRunSlabs call beside a
+// running contraction lost its descriptors to the late fill and the beamformer kernel read a null base.
+inline hipError_t hip_memset_now(void* p, int value, size_t n) {
+    hipError_t e = hipMemset(p, value, n);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(nullptr);
+}
+
 inline const char* diag_env(const char* name) {
 #ifdef XENG_DIAGNOSTICS
     return getenv(name);
