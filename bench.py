@@ -438,6 +438,7 @@ def main():
                     help="integrations of the untimed `sustained` leg (two runs of this many; 0 = skip)")
     ap.add_argument("--no-h2d", dest="h2d", action="store_false", help="skip the PCIe-inclusive measurement")
     ap.add_argument("--no-beamform", dest="beamform", action="store_false", help="skip the config-4 beamformer leg")
+    ap.add_argument("--no-blocks", dest="blocks", action="store_false", help="skip the legs that run the Python blocks (profiler passes: thousands of launches per leg)")
     ap.add_argument("--data", default="random", choices=["random", "zeros", "0x88", "gaussian"],
                     help="diagnostic only: constant inputs show the DVFS give-back (the reported value uses random)")
     ap.add_argument("--sync-per-call", action="store_true",
@@ -1180,7 +1181,7 @@ def main():
     # outside the timed region: the Corr BLOCK itself (blocks/corr_block.py: ring protocol, header handling, state machine,
     # one Python thread) on in-repo device rings at config-2 size, fed by a zero-copy replay source: the rate a pipeline
     # user of the block sees, next to the C-ABI rate above
-    if rank == 0 and world == 1 and args.beamform and not args.sync_per_call and not args.sync_per_integration:
+    if rank == 0 and world == 1 and args.beamform and args.blocks and not args.sync_per_call and not args.sync_per_integration:
         res["corr_block"] = corr_block_leg(ffi, ring, gulp_bytes, args.ring_gulps, gpu)
         res["config5_blocks"] = config5_blocks_leg(ffi, ring, gulp_bytes, args.ring_gulps, gpu)
         res["config5_blocks"]["from_packet_slabs"] = config5_blocks_leg(ffi, ring, gulp_bytes, args.ring_gulps, gpu, nint=120, nwarm=60, long_len=30, from_slabs=True)

@@ -256,6 +256,7 @@ int xengBeamformInitialize(int gpu, int ninput, int nchan, int ntime, int nbeam,
     }
     int rc = get_stream(STREAM_BEAM, &x.stream);
     if (rc) return rc;
+    XENG_HIP(hipStreamSynchronize(nullptr));       // (null-stream fills above: complete before the beam stream's first kernel; hip_memset_now)
     x.live = true;
     return XENG_STATUS_SUCCESS;
 }

@@ -617,6 +617,9 @@ static int initialize_locked(int gpu) {
         XENG_HIP(hipMalloc((void**)&x.stamps, (size_t)x.cfg.nchan * ng * 4 * 8 * sizeof(unsigned long long)));
         XENG_HIP(hip_memset_now(x.stamps, 0, (size_t)x.cfg.nchan * ng * 4 * 8 * sizeof(unsigned long long)));
     }
+    // (the uploads above went through the null stream; the context's streams do not wait for it: everything is in place
+    // before the first launch can be enqueued -- see hip_memset_now, xeng_common.h)
+    XENG_HIP(hipStreamSynchronize(nullptr));
     x.live = true;
     return XENG_STATUS_SUCCESS;
 }

@@ -14,7 +14,7 @@ for set in \
   "FETCH_SIZE" \
   "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  timeout -k 10 240 rocprofv3 --pmc $set --output-format csv -d $OUT/pass$i -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --sustained 0 "$@" > $OUT/pass$i.log 2>&1 || echo "pass $i failed" >> $OUT/fail.log
+  timeout -k 10 240 rocprofv3 --pmc $set --output-format csv -d $OUT/pass$i -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --sustained 0 --no-blocks --no-h2d "$@" > $OUT/pass$i.log 2>&1 || echo "pass $i failed" >> $OUT/fail.log
 done
 python3 $R/profiles/pmc_summarize.py "$OUT"
 rm -rf $OUT/pass1 $OUT/pass2 $OUT/pass3 $OUT/pass4     # (the raw per-dispatch CSVs are tens of MB: the summary and pmc_traffic.json stay)
