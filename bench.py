@@ -264,8 +264,13 @@ def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=4
                 "corracc_fused_into_dumps": bool(cacc.stats.get('fused')) and cacc.fused_dumps == n,
                 "note": "config5_blocks with an input ring of packet slabs (%d slabs of 5280 SNAP2 packets, %.1f GB on the device; every gulp "
                         "its own slab): the blocks hand the slabs to xengXgpuKernelAsyncSlab / xengBeamformRunSlabs, which read them in place" % (nslabs, nslabs * slab.nbytes / 1e9)}
+    # (the leg in four windows: the Python threads settle into an interleaving, and not always into the same one)
+    wins = []
+    if ok:
+        q = (n - 1 - nwarm) // 4
+        wins = [round((stamps[nwarm + (k + 1) * q] - stamps[nwarm + k * q]) / q * 1e3, 4) for k in range(4)] if q > 0 else []
     return {"value": round(8 * NINPUT * ACC_LEN * NCHAN * (n - 1 - nwarm) / el / 1e9, 1) if ok else 0.0, "unit": "Gb/s",
-            "ms_per_integration": round(el / max(n - 1 - nwarm, 1) * 1e3, 4) if ok else None, "integrations": n,
+            "ms_per_integration": round(el / max(n - 1 - nwarm, 1) * 1e3, 4) if ok else None, "integrations": n, "window_ms": wins,
             "long_integrations_published": nslow[0], "corracc_fused_into_dumps": bool(cacc.stats.get('fused')) and cacc.fused_dumps == n,
             # span allocations per ring over the whole leg: made, really freed, reissued from the free list, waits for a stamp at reissue
             "ring_allocations": {r.name: {k: int(v) for k, v in dict(r.counters).items() if k in ("alloc", "free", "reuse", "stamp_wait")}
@@ -1184,7 +1189,7 @@ def main():
     if rank == 0 and world == 1 and args.beamform and args.blocks and not args.sync_per_call and not args.sync_per_integration:
         res["corr_block"] = corr_block_leg(ffi, ring, gulp_bytes, args.ring_gulps, gpu)
         res["config5_blocks"] = config5_blocks_leg(ffi, ring, gulp_bytes, args.ring_gulps, gpu)
-        res["config5_blocks"]["from_packet_slabs"] = config5_blocks_leg(ffi, ring, gulp_bytes, args.ring_gulps, gpu, nint=120, nwarm=60, long_len=30, from_slabs=True)
+        res["config5_blocks"]["from_packet_slabs"] = config5_blocks_leg(ffi, ring, gulp_bytes, args.ring_gulps, gpu, nint=100, nwarm=100, long_len=40, from_slabs=True)
     _leg('one call per integration')
     # outside the timed region: SURVEY 8d's other device-resident case, one 2400-sample call per integration
     # (xGPU's NTIME = acc_len; needs its own context, so it runs last)

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Diagnostic (round 4): bench.py's config5_blocks leg repeated in one process -- how far do the runs differ on one box?
+usage: config5_blocks_repeat.py [runs] [nint] [nwarm] [gc: default|freeze|off]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import caltech_bifrost_dsp_amd  # noqa: E402,F401
+from caltech_bifrost_dsp_amd import ffi  # noqa: E402
+
+runs = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+nint = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+nwarm = int(sys.argv[3]) if len(sys.argv) > 3 else 400
+import gc
+gcmode = sys.argv[4] if len(sys.argv) > 4 else "default"
+ffi.call("xengSetDevice", 0)
+ffi.call("xengXgpuConfigure", bench.NSTAND, bench.NPOL, bench.NCHAN, bench.NTIME_GULP, bench.ACC_LEN // bench.NTIME_GULP)
+ffi.call("xengXgpuInitialize", 0)
+gulp_bytes = bench.NTIME_GULP * bench.NCHAN * bench.NINPUT
+ring = ffi.DeviceBuffer(10 * gulp_bytes)
+ring.upload(np.random.RandomState(1).randint(0, 256, size=10 * gulp_bytes, dtype=np.uint8))
+for r in range(runs):
+    gc.collect()
+    if gcmode == "freeze":
+        gc.freeze()
+    elif gcmode == "off":
+        gc.disable()
+    n0 = [g["collections"] for g in gc.get_stats()]
+    res = bench.config5_blocks_leg(ffi, ring, gulp_bytes, 10, 0, nint=nint, nwarm=nwarm)
+    print("run %d: %.4f ms per integration, windows %s, fused %s" % (r, res["ms_per_integration"], res["window_ms"], res["corracc_fused_into_dumps"]),
+          "gc collections per generation during the run:", [g["collections"] - a for g, a in zip(gc.get_stats(), n0)], flush=True)
