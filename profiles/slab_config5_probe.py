@@ -89,7 +89,10 @@ def run(corr, beam, n):
 
 
 res = {}
+COMBOS = os.environ.get("PROBE_COMBOS")
 combos = [("plain", "plain"), ("slab", "plain"), ("plain", "slab"), ("slab", "slab"), ("plain", "none"), ("slab", "none"), ("none", "plain"), ("none", "slab")]
+if COMBOS:
+    combos = [tuple(c.split("/")) for c in COMBOS.split(",")]
 for r in range(rounds):
     for c in combos:
         res.setdefault(c, []).append(run(c[0], c[1], nint))
