@@ -155,7 +155,7 @@ def corr_block_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=100):
                     "`throughput` stat of its last integration (corr_block.py:453 formula)"}
 
 
-def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=400, long_len=50, from_slabs=False):
+def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=400, long_len=50, from_slabs=False, in_ring_integrations=4):
     """BASELINE config 5 through the BLOCKS on one GPU: Corr -> CorrAcc and Beamform -> BeamformSumBeams as four Python
     threads on in-repo rings (gpu-input read in place by Corr and Beamform), fed by a zero-copy replay source.  CorrAcc's
     long accumulation (`long_len` dumps) is done by the dumps' own epilogue (fused mode, blocks/corr_acc_block.py).  The warm-up
@@ -196,7 +196,7 @@ def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=4
     # (input ring of four integrations: Beamform alone keeps up to five 960-sample gulps = ten input spans referenced while their
     # kernels are in flight, which was the whole of round 3's two-integration ring -- Corr then waited for gulps, not for the GPU;
     # the spans are windows on the replay buffer, the depth costs no memory)
-    r_in.resize(gulp_bytes, total_span=4 * gulps_per_step * gulp_bytes)
+    r_in.resize(gulp_bytes, total_span=in_ring_integrations * gulps_per_step * gulp_bytes)
     log = logging.getLogger("bench-config5")
     corr = Corr(log, r_in, r_vis, ntime_gulp=NTIME_GULP, nchan=NCHAN, npol=NPOL, nstand=NSTAND, acc_len=ACC_LEN, autostartat=0, gpu=gpu)
     cacc = CorrAcc(log, r_vis, r_slow, nchan=NCHAN, npol=NPOL, nstand=NSTAND, acc_len=long_len * ACC_LEN, autostartat=0, gpu=gpu)

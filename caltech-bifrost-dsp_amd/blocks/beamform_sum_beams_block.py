@@ -43,28 +43,50 @@ class BeamformSumBeams(Block):
             self._bf.set_device(self.gpu)
         self.bind_proclog.update({'ncore': 1, 'core0': cpu_affinity.get_core(), 'ngpu': 1,
                                   'gpu0': self._bf.get_device()})
-        # Streaming (in-repo rings): up to STREAM_DEPTH gulps in flight; the kernel writes the power sums straight into the
-        # output span (pinned host memory in the pipeline, lwa352-pipeline.py:155 -- device-visible), and the span is committed
-        # when that kernel has completed.  On a bifrost ring: the reference's Integrate -> wait -> copy (:243-250).
+        # Streaming (in-repo rings): up to STREAM_DEPTH gulps in flight; a span is committed when its own kernel (and copy) has
+        # completed.  On a bifrost ring: the reference's Integrate -> wait -> copy (:243-250).
+        # Where the sums go: the pipeline's output ring is pinned host memory (lwa352-pipeline.py:155).  Round 3 let the kernel
+        # write the span itself; that saves a copy but makes the kernel wait for 1 MB of PCIe stores -- 31 us instead of 12, on
+        # the stream the beamformer kernels queue on, 2.5 times per integration (profiles/r04/blocks_kernel_time.txt).  So
+        # (round 4) the kernel writes a device buffer, and once ITS ticket is done the buffer goes to the pinned span on the
+        # copy stream; the span is committed when that copy has completed.  A device output ring still takes the sums directly.
         streaming = (getattr(self.iring, 'span_memory_outlives_release', False) and getattr(self.oring, 'span_memory_outlives_release', False)
                      and hasattr(self._bf, 'beam_mark') and self.oring.space in ('cuda', 'cuda_host'))
-        pending = collections.deque()
+        staged = streaming and self.oring.space == 'cuda_host' and hasattr(self._bf, 'copy_async')
+        pending = collections.deque()           # (ticket, output span, input kept alive, device buffer or None)
+        copying = collections.deque()           # (stamp of the copy, output span, device buffer)
+        self._stages_free = []
+
+        def finish_copies(keep):
+            while copying and (len(copying) > keep or self._bf.copy_done(copying[0][0])):
+                stamp, osp, stage = copying.popleft()
+                self._bf.copy_wait(stamp)       # (returns at once when it is done)
+                osp.close()
+                self._stages_free.append(stage)
 
         def retire(keep):
             while len(pending) > keep:
-                ticket, osp, _ = pending.popleft()
+                ticket, osp, _, stage = pending.popleft()
                 self._bf.beam_wait(ticket)
-                osp.close()
+                if stage is None:
+                    osp.close()
+                else:
+                    copying.append((self._bf.copy_async(osp.data, stage), osp, stage))
+            finish_copies(2 if keep else 0)
+        self._staged = staged
         try:
             self._main_loop(streaming, pending, retire)
         finally:
             # (as in Beamform: spans of kernels in flight are not released by an exception before the stream is idle)
-            if pending:
+            if pending or copying:
                 try:
                     self._bf.beam_sync()
+                    for stamp, _, _ in copying:
+                        self._bf.copy_wait(stamp)
                 except Exception:
                     pass
                 pending.clear()
+                copying.clear()
 
     def _main_loop(self, streaming, pending, retire):
         with self.oring.begin_writing() as oring:
@@ -99,12 +121,17 @@ class BeamformSumBeams(Block):
                             reserve_time = curr_time - prev_time
                             prev_time = curr_time
                             # (streaming: the kernel writes into the span itself; the call only needs addresses, so no typed views)
-                            target = ospan.data if streaming else self.bf_output
+                            stage = None
+                            if self._staged:
+                                stage = self._stages_free.pop() if self._stages_free else None
+                                if stage is None or stage.nbytes != ogulp_size:
+                                    stage = XArray(shape=(ogulp_size,), dtype=np.uint8, space=self._bf.space_in)
+                            target = stage if stage is not None else (ospan.data if streaming else self.bf_output)
                             rv = self._bf.bfBeamformIntegrate(ispan.data.as_BFarray(), target.as_BFarray(), self.ntime_sum)
                             if rv != self._bf.BF_STATUS_SUCCESS:
                                 raise RuntimeError("bfBeamformIntegrate returned %d: %s" % (rv, self._bf.last_error()))
                             if streaming:
-                                pending.append((self._bf.beam_mark(), ospan, ispan.data))
+                                pending.append((self._bf.beam_mark(), ospan, ispan.data, stage))
                                 ospan = None
                                 retire(self.STREAM_DEPTH)
                             else:

@@ -53,6 +53,8 @@ class _Decision:
 
 
 class CorrAcc(Block):
+    PUBLISH_PIECE_BYTES = 8 << 20        # a long integration goes to the pinned output span in pieces of this size (see main)
+
     def __init__(self, log, iring, oring,
                  guarantee=True, core=-1, nchan=192, npol=2, nstand=352, acc_len=24000, gpu=-1, etcd_client=None,
                  autostartat=0, backend=None):
@@ -246,12 +248,20 @@ class CorrAcc(Block):
         self._publishing = None                   # (helper thread, copy stamp, [exception])
         async_publish = hasattr(self._bf, 'copy_async')
 
-        def start_publish(osp, acc_set, stamp):
+        def start_publish(osp, acc_set, dst, src):
             err = []
 
             def complete():
                 try:
-                    self._bf.copy_wait(stamp)
+                    # In pieces, each waited for before the next is enqueued: one 191 MB copy keeps the copy stream and the
+                    # PCIe link to itself for 3.2 ms, and BeamformSumBeams' power sums (1 MB per gulp, same stream, same link)
+                    # queue up behind it -- its thread stops, bf-output fills, Beamform stops, the input ring fills, Corr
+                    # starves: the GPU sat idle for ~3 ms at every long integration (profiles/r04/blocks_gpu_idle.txt).
+                    # Between two pieces the other copies get their turn.
+                    nbytes, piece = src.nbytes, self.PUBLISH_PIECE_BYTES
+                    for off in range(0, nbytes, piece):
+                        m = min(piece, nbytes - off)
+                        self._bf.copy_wait(self._bf.copy_async(XArray.window(dst.ptr + off, m, dst.space, dst), XArray.window(src.ptr + off, m, src.space, src)))
                     osp.close()
                 except Exception as e:            # (re-raised by the block's thread at the next join)
                     err.append(e)
@@ -260,7 +270,7 @@ class CorrAcc(Block):
                         self._set_busy[acc_set] = False
                         self._plan_cv.notify_all()
             th = threading.Thread(target=complete, name="corracc-publish", daemon=True)
-            self._publishing = (th, stamp, err)
+            self._publishing = (th, None, err)
             th.start()
 
         def finish_publish():
@@ -350,7 +360,7 @@ class CorrAcc(Block):
                             ospan = WriteSpan(oseq.ring, self.ogulp_size, nonblocking=False)
                             odata = ospan.data_view('i32').reshape(result.shape)
                             if fused and async_publish:
-                                start_publish(ospan, d.acc_set, self._bf.copy_async(odata, result))
+                                start_publish(ospan, d.acc_set, odata, result)
                                 ospan = None
                             else:
                                 copy_array(odata, result)     # (synchronous: complete before the span is committed)

@@ -59,7 +59,12 @@ struct StreamClock {
     std::atomic<unsigned long long> enq{0};     // enqueues so far (ticked after each)
     std::mutex mu;
     unsigned long long done = 0;                // everything up to this tick is known to have completed
-    static constexpr int NMARK = 8;
+    // marks: events recorded on this stream with the tick they cover.  Sixty-four: two blocks that keep eight gulps in flight
+    // each on the beam stream have sixteen of their own Mark events pending at any time; with eight slots the older half was
+    // forgotten, a released span's stamp was then only covered by one of the NEWEST marks -- complete a whole queue (1 ms)
+    // later -- and Beamform's reserve waited for span memory 157 times per 2000 gulps while the beam queue ran dry
+    // (profiles/r04/blocks_gpu_idle.txt).
+    static constexpr int NMARK = 64;
     struct Mark { unsigned long long upto = 0; hipEvent_t ev = nullptr; bool pending = false; hipEvent_t own = nullptr; } marks[NMARK];   // own: the slot's own event (ev may be a borrowed one)
 };
 static StreamClock g_clock[MAXDEV][STREAM_COUNT];
@@ -128,21 +133,25 @@ static int clock_poll(int dev, StreamId which, unsigned long long t, bool* done,
     StreamClock::Mark* cover = nullptr;
     StreamClock::Mark* free_slot = nullptr;
     StreamClock::Mark* oldest = nullptr;
+    // events of one stream complete in the order of their records: ask the oldest pending mark, go on while the answer is yes
+    for (;;) {
+        oldest = nullptr;
+        for (auto& m : c.marks)
+            if (m.pending && (!oldest || m.upto < oldest->upto)) oldest = &m;
+        if (!oldest) break;
+        const hipError_t e = hipEventQuery(oldest->ev);
+        if (e == hipSuccess) {
+            oldest->pending = false;
+            if (oldest->upto > c.done) c.done = oldest->upto;
+            continue;
+        }
+        if (e != hipErrorNotReady) XENG_HIP(e);
+        (void)hipGetLastError();
+        break;
+    }
     for (auto& m : c.marks) {
         if (m.pending) {
-            const hipError_t e = hipEventQuery(m.ev);
-            if (e == hipSuccess) {
-                m.pending = false;
-                if (m.upto > c.done) c.done = m.upto;
-            } else if (e == hipErrorNotReady) {
-                (void)hipGetLastError();
-            } else {
-                XENG_HIP(e);
-            }
-        }
-        if (m.pending) {
             if (m.upto >= t && (!cover || m.upto < cover->upto)) cover = &m;
-            if (!oldest || m.upto < oldest->upto) oldest = &m;
         } else if (!free_slot) {
             free_slot = &m;
         }

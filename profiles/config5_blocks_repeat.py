@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic (round 4): bench.py's config5_blocks leg repeated in one process -- how far do the runs differ on one box?
-usage: config5_blocks_repeat.py [runs] [nint] [nwarm] [gc: default|freeze|off]"""
+usage: config5_blocks_repeat.py [runs] [nint] [nwarm] [gc: default|freeze|off] [input ring in integrations, e.g. 4,8,16: one run each per round]"""
 import os
 import sys
 
@@ -23,13 +23,15 @@ ffi.call("xengXgpuInitialize", 0)
 gulp_bytes = bench.NTIME_GULP * bench.NCHAN * bench.NINPUT
 ring = ffi.DeviceBuffer(10 * gulp_bytes)
 ring.upload(np.random.RandomState(1).randint(0, 256, size=10 * gulp_bytes, dtype=np.uint8))
-for r in range(runs):
+depths = [int(v) for v in sys.argv[5].split(",")] if len(sys.argv) > 5 else [4]
+for r in range(runs * len(depths)):
     gc.collect()
     if gcmode == "freeze":
         gc.freeze()
     elif gcmode == "off":
         gc.disable()
     n0 = [g["collections"] for g in gc.get_stats()]
-    res = bench.config5_blocks_leg(ffi, ring, gulp_bytes, 10, 0, nint=nint, nwarm=nwarm)
-    print("run %d: %.4f ms per integration, windows %s, fused %s" % (r, res["ms_per_integration"], res["window_ms"], res["corracc_fused_into_dumps"]),
-          "gc collections per generation during the run:", [g["collections"] - a for g, a in zip(gc.get_stats(), n0)], flush=True)
+    res = bench.config5_blocks_leg(ffi, ring, gulp_bytes, 10, 0, nint=nint, nwarm=nwarm, in_ring_integrations=depths[r % len(depths)])
+    print("input ring %2d integrations, run %d: %.4f ms per integration, windows %s, fused %s" % (depths[r % len(depths)], r, res["ms_per_integration"], res["window_ms"], res["corracc_fused_into_dumps"]),
+          "gc collections per generation during the run:", [g["collections"] - a for g, a in zip(gc.get_stats(), n0)],
+          "ring allocations:", {k: (v["alloc"], v["stamp_wait"]) for k, v in res["ring_allocations"].items()}, flush=True)
