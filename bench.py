@@ -260,6 +260,8 @@ def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=4
         slab_pool.free()
         return {"value": round(8 * NINPUT * ACC_LEN * NCHAN * (n - 1 - nwarm) / el / 1e9, 1) if ok else 0.0, "unit": "Gb/s",
                 "ms_per_integration": round(el / max(n - 1 - nwarm, 1) * 1e3, 4) if ok else None, "integrations": n,
+                "window_ms": [round((stamps[nwarm + (k + 1) * ((n - 1 - nwarm) // 4)] - stamps[nwarm + k * ((n - 1 - nwarm) // 4)]) / ((n - 1 - nwarm) // 4) * 1e3, 4)
+                              for k in range(4)] if ok and (n - 1 - nwarm) >= 4 else [],
                 "slabs_scattered_after_all": {"corr": int(nfx.value), "beamform": int(nfb.value)},
                 "corracc_fused_into_dumps": bool(cacc.stats.get('fused')) and cacc.fused_dumps == n,
                 "note": "config5_blocks with an input ring of packet slabs (%d slabs of 5280 SNAP2 packets, %.1f GB on the device; every gulp "

@@ -67,12 +67,12 @@ struct SlabJob {
 };
 // INLINE (the beamformer's calls while the link is clean: one launch per call on the stream of its kernels, nothing else): a
 // gulp that turns out irregular is zero-filled and scattered HERE, by the one work-group whose wave took the last ticket --
-// 1024 threads instead of a grid, 0.9 ms for a 32 MB gulp; the regular case costs one short launch and no launch that only
+// 256 threads instead of a grid, a few milliseconds for a 32 MB gulp; the regular case costs one short launch and no launch that only
 // finds out that it has nothing to do.  Every such gulp also bumps a counter in pinned host memory; the host, seeing it move,
 // switches its next calls to the other form.  Otherwise (the X-engine: per integration, off its critical path; the beamformer
 // after a recent loss) slab_clear_kernel + slab_scatter_kernel follow.
 template <bool INLINE>
-__global__ __launch_bounds__(INLINE ? 1024 : 256) void slab_prepare_kernel(SlabJob job, unsigned long long* __restrict__ tallies, int* __restrict__ fallbacks,
+__global__ __launch_bounds__(256) void slab_prepare_kernel(SlabJob job, unsigned long long* __restrict__ tallies, int* __restrict__ fallbacks,
                                                                           int* __restrict__ fallbacks_host, GulpDesc* __restrict__ descs,
                                                                           SlabArgs* __restrict__ args_out) {
     __shared__ int s_fallback_here;                         // (INLINE only; 4 bytes of LDS fit beside any resident kernel)
@@ -165,7 +165,10 @@ bool slab_maybe_regular(const SlabArgs& a, int rows) {
 int slab_prepare_enqueue(hipStream_t stream, const SlabSite& site, const SlabArgs* a, const bool* maybe, int ngulp, GulpDesc* descs, SlabArgs* args_out,
                          uint8_t* const* scratch, bool inline_fallback) {
     SlabJob job;
-    const int bs = inline_fallback ? 1024 : 256;
+    // (256 threads either way: four waves of <= 40 registers fit on a CU beside a contraction work-group -- 444 of 512 registers per
+    // lane taken --; with 1024-thread groups the verify pass of the beamformer waited for a whole CU, i.e. for the running
+    // contraction to end: 63 us on average instead of 8, profiles/r04/slab_paths.txt)
+    const int bs = 256;
     unsigned int nblocks = 1;
     for (int k = 0; k < 2; k++) {
         const int kk = k < ngulp ? k : 0;

@@ -52,7 +52,10 @@ gulp_bytes = bench.NTIME_GULP * bench.NCHAN * bench.NINPUT
 ring = ffi.DeviceBuffer(10 * gulp_bytes)
 ring.upload(np.random.RandomState(1).randint(0, 256, size=10 * gulp_bytes, dtype=np.uint8))
 t_begin = pc()
-res = bench.config5_blocks_leg(ffi, ring, gulp_bytes, 10, 0, nint=nint, nwarm=nwarm)
+SLABS = bool(os.environ.get("REPEAT_SLABS"))          # the leg on a ring of packet slabs
+for n in ("xgpu_kernel_slab", "beam_run_slabs"):
+    timed(_xfast, n, n)
+res = bench.config5_blocks_leg(ffi, ring, gulp_bytes, 10, 0, nint=nint, nwarm=nwarm, **(dict(long_len=40, from_slabs=True) if SLABS else {}))
 print("%.4f ms per integration, windows %s" % (res["ms_per_integration"], res["window_ms"]))
 t_warm = t_begin + 0.0
 log.sort()

@@ -31,7 +31,9 @@ npk = NT * npb
 rs = np.random.RandomState(5)
 stride, lead = (49 * 128, 96) if ALIGNED else (pstride, 0)
 slabs = []
-for k in range(10):
+POOL, pool = bool(os.environ.get("PROBE_POOL")), None      # all slabs in ONE allocation (as bench.py's blocks-from-slabs leg holds them)
+NSL = int(os.environ.get("PROBE_NSLABS", "10"))      # distinct slabs (and plain gulps) in the replay: 10 = 326 MB, more than fits in the caches beyond ~8
+for k in range(NSL):
     slab = np.zeros((npk, pstride), dtype=np.uint8)
     i = 0
     for t in range(NT):
@@ -41,10 +43,21 @@ for k in range(10):
     slab[:, 32:] = rs.randint(0, 256, size=(npk, pstride - 32), dtype=np.uint8)
     a = np.zeros(lead + npk * stride, dtype=np.uint8)
     a[lead:].reshape(npk, stride)[:, :pstride] = slab
-    slabs.append(ffi.DeviceBuffer(a.nbytes).upload(a))
+    if POOL:
+        if pool is None:
+            pool = ffi.DeviceBuffer(NSL * a.nbytes)
+
+        class _W:                                  # (a window on the pool with the attributes the loop uses)
+            pass
+        w_ = _W()
+        w_.ptr = pool.ptr + k * a.nbytes
+        pool.upload(a, offset=k * a.nbytes)
+        slabs.append(w_)
+    else:
+        slabs.append(ffi.DeviceBuffer(a.nbytes).upload(a))
 gulp = NT * NCHAN * NINPUT
-ring = ffi.DeviceBuffer(10 * gulp)
-for k in range(10):
+ring = ffi.DeviceBuffer(NSL * gulp)
+for k in range(NSL):
     ffi.check("u", L.xengSnap2UnpackAsync(slabs[k].ptr + lead, npk, stride, ring.ptr + k * gulp, k * NT, NT, 0, NCHAN, NINPUT, 1))
 ffi.call("xengDeviceSynchronize")
 w = (rs.uniform(-17, 17, (NCHAN, NB, NINPUT)) + 1j * rs.uniform(-17, 17, (NCHAN, NB, NINPUT))).astype(np.complex64)
@@ -65,7 +78,7 @@ def run(corr, beam, n):
         o = outs3[it % 3]
         if corr != "none":
             for g in range(G):
-                s = gi % 10
+                s = gi % NSL
                 if corr == "slab":
                     ffi.check("s", L.xengXgpuKernelAsyncSlab(slabs[s].ptr + lead, npk, stride, s * NT, 0, o.ptr, int(g == G - 1), acc_pair[it & 1].ptr, 1 if it < 2 else 2))
                 else:
@@ -73,7 +86,7 @@ def run(corr, beam, n):
                 gi += 1
         if beam != "none":
             for _ in range(2 + (it & 1)):
-                k0 = (2 * bi) % 10
+                k0 = (2 * bi) % NSL
                 if beam == "slab":
                     ffi.check("r", L.xengBeamformRunSlabs(slabs[k0].ptr + lead, npk, NT, slabs[k0 + 1].ptr + lead, npk, stride, k0 * NT, 0, dbeam.ptr, dw.ptr, 1))
                 else:
@@ -96,7 +109,7 @@ if COMBOS:
 for r in range(rounds):
     for c in combos:
         res.setdefault(c, []).append(run(c[0], c[1], nint))
-print("packet stride %d%s" % (stride, " (payloads on 128-byte lines)" if ALIGNED else " (packed)"))
+print("%d distinct slabs / gulps in the replay;" % NSL, "packet stride %d%s" % (stride, " (payloads on 128-byte lines)" if ALIGNED else " (packed)"))
 for c, v in res.items():
     v = sorted(v)
     print("corr %-5s beam %-5s  median %.4f ms per integration (min %.4f max %.4f)" % (c[0], c[1], v[len(v) // 2], v[0], v[-1]))
