@@ -147,19 +147,13 @@ class HipBackend:
         """Enqueue dst <- src on the library's copy stream; returns the stamp that completes when the copy has (copy_done /
         copy_wait).  The caller keeps both arrays alive and unchanged until then."""
         assert dst.nbytes == src.nbytes
-        ffi.call("xengMemcpyAsync", dst.ptr, src.ptr, dst.nbytes)
-        s = ffi.XengStamp()
-        ffi.check("xengStampNow", self._enq.xengStampNow(ctypes.byref(s)))
-        s.w[0] = (s.w[0] & 0xFFFFFFFF) | (ffi.STREAMS["copy"] << 32)          # (this stamp waits for the copy stream only)
-        return s
+        return self._x.copy_async(dst.ptr, src.ptr, dst.nbytes)
 
     def copy_done(self, stamp):
-        d = ctypes.c_int()
-        ffi.check("xengStampDone", self._enq.xengStampDone(ctypes.byref(stamp), ctypes.byref(d), None))
-        return bool(d.value)
+        return self._x.stamp_done(stamp)
 
     def copy_wait(self, stamp):
-        ffi.call("xengStampWait", ctypes.byref(stamp))
+        self._x.stamp_wait(stamp)
 
     # ---- beamformer (beamform_block.py:251,449; beamform_sum_beams_block.py:245)
     _beam_row_bytes = 0

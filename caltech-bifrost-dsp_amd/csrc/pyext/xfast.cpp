@@ -300,6 +300,53 @@ PyObject* beam_ticket_done(PyObject*, PyObject* args) {
     return PyLong_FromLong(rc ? -rc : (done ? 1 : 0));
 }
 
+// copy_async(dst, src, nbytes) -> stamp (bytes): dst <- src on the copy stream, only enqueued; the stamp completes when the copy has
+PyObject* copy_async(PyObject*, PyObject* args) {
+    unsigned long long dst, src;
+    Py_ssize_t n;
+    if (!PyArg_ParseTuple(args, "KKn", &dst, &src, &n)) return nullptr;
+    int rc = xengMemcpyAsync((void*)(uintptr_t)dst, (const void*)(uintptr_t)src, (size_t)n);
+    if (rc) return raise_xeng("xengMemcpyAsync", rc);
+    xengStamp st;
+    rc = xengStampNowFor(&st, nullptr, XENG_STREAMS_COPY);
+    if (rc) return raise_xeng("xengStampNowFor", rc);
+    return PyBytes_FromStringAndSize((const char*)&st, sizeof(st));
+}
+
+static bool stamp_arg(PyObject* args, xengStamp* st) {
+    const char* p;
+    Py_ssize_t n;
+    if (!PyArg_ParseTuple(args, "y#", &p, &n)) return false;
+    if (n != (Py_ssize_t)sizeof(xengStamp)) { PyErr_SetString(PyExc_ValueError, "not a stamp"); return false; }
+    memcpy(st, p, sizeof(*st));
+    return true;
+}
+
+// stamp_done(stamp) -> bool, never waits
+PyObject* stamp_done(PyObject*, PyObject* args) {
+    xengStamp st;
+    if (!stamp_arg(args, &st)) return nullptr;
+    int done = 0;
+    const int rc = xengStampDone(&st, &done, nullptr);
+    if (rc) return raise_xeng("xengStampDone", rc);
+    return PyBool_FromLong(done);
+}
+
+// stamp_wait(stamp): asks first; gives the interpreter lock up only to wait
+PyObject* stamp_wait(PyObject*, PyObject* args) {
+    xengStamp st;
+    if (!stamp_arg(args, &st)) return nullptr;
+    int done = 0;
+    int rc = xengStampDone(&st, &done, nullptr);
+    if (!rc && !done) {
+        Py_BEGIN_ALLOW_THREADS
+        rc = xengStampWait(&st);
+        Py_END_ALLOW_THREADS
+    }
+    if (rc) return raise_xeng("xengStampWait", rc);
+    Py_RETURN_NONE;
+}
+
 PyObject* map_i32(PyObject*, PyObject* args) {
     unsigned long long a, b;
     Py_ssize_t n;
@@ -327,6 +374,9 @@ PyMethodDef methods[] = {
     {"beam_mark", beam_mark, METH_NOARGS, "xengBeamformMark -> ticket | -status"},
     {"beam_ticket_done", beam_ticket_done, METH_VARARGS, "xengBeamformTicketDone -> -status | 0 | 1"},
     {"map_i32", map_i32, METH_VARARGS, "(a, b, nwords, add) -> status"},
+    {"copy_async", copy_async, METH_VARARGS, "(dst, src, nbytes) -> stamp of the enqueued copy (bytes)"},
+    {"stamp_done", stamp_done, METH_VARARGS, "(stamp) -> bool"},
+    {"stamp_wait", stamp_wait, METH_VARARGS, "(stamp): waits (interpreter lock released) unless it is done"},
     {nullptr, nullptr, 0, nullptr}};
 
 PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_xfast", "direct binding of libxeng's per-gulp calls (include/xeng.h)", -1, methods};

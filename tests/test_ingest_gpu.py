@@ -190,8 +190,11 @@ def test_ingest_leaves_slabs_and_corr_and_beamform_read_them_in_place():
     BeamformSumBeams.  Regular windows are read where they lie; one window arrives in another order and one has lost a packet
     (scattered on the device).  Every product equals the oracle on what was received."""
     import ctypes
+    import os
     import struct
     from caltech_bifrost_dsp_amd.blocks import Beamform, BeamformSumBeams, CorrAcc
+    if os.environ.get("XENG_RAW") == "0":
+        pytest.skip("packet slabs need the fused contraction kernel (the two-pass X-engine refuses them)")
     T, C, S, g, acc, nbeam, ntime_sum = 768, 8, 64, 96, 192, 32, 16           # (gulps of 96 samples: the fused contraction kernel)
     ninput = S * 2
     rng = np.random.default_rng(14)
