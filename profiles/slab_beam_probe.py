@@ -47,7 +47,7 @@ gulp = NT * NCHAN * NINPUT
 ring = ffi.DeviceBuffer(10 * gulp)
 for k in range(10):
     ffi.check("u", L.xengSnap2UnpackAsync(slabs[k].ptr, npk, stride, ring.ptr + k * gulp, k * NT, NT, 0, NCHAN, NINPUT, 1))
-ffi.call("xengXgpuSync") if False else ffi.call("xengDeviceSynchronize")
+ffi.call("xengDeviceSynchronize")
 w = (rs.uniform(-17, 17, (NCHAN, NB, NINPUT)) + 1j * rs.uniform(-17, 17, (NCHAN, NB, NINPUT))).astype(np.complex64)
 dw = ffi.DeviceBuffer(w.nbytes).upload(w)
 dbeam = ffi.DeviceBuffer(NCHAN * NB * 2 * NT * 8)

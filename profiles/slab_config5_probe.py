@@ -2,7 +2,6 @@
 """Diagnostic (round 4): config 5 (Corr with fused CorrAcc + Beamform + power sums, concurrent) with each consumer fed either
 from plain gulps or from packet slabs read in place -- which of the two pays what when both run together.
 usage: slab_config5_probe.py [rounds] [integrations] [aligned]"""
-import ctypes
 import os
 import struct
 import sys
