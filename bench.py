@@ -215,6 +215,11 @@ def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=4
         spans = [XArray(shape=(gulp_bytes,), dtype=np.uint8, space="cuda", _ptr=ring.ptr + g * gulp_bytes, _base=ring) for g in range(ring_gulps)]
     stamps, nslow = [], [0]
 
+    # The source and the three sinks are the harness, not the product: on the native ring they run as loops inside the
+    # extension with the interpreter lock released (`_xfast.ring_feed_external` / `ring_drain`), so that the lock is shared by
+    # the four block threads (+ CorrAcc's publish helper) only, as in a pipeline whose neighbours are not Python loops.
+    native_harness = hasattr(r_in, "_h") and hasattr(getattr(r_in, "_x", None), "ring_drain")
+
     def source():
         import time as _t
         t0 = _t.time()
@@ -222,25 +227,45 @@ def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=4
             _t.sleep(0.002)
         with r_in.begin_writing() as w:
             with w.begin_sequence(time_tag=0, header=_json.dumps(hdr), nringlet=1) as oseq:
-                for k in range((nwarm + nint) * gulps_per_step):
-                    oseq.commit_external(spans[k % ring_gulps])
+                total = (nwarm + nint) * gulps_per_step
+                if native_harness:
+                    ptrs = np.array([sp.ptr for sp in spans], dtype=np.uint64).tobytes()
+                    r_in._x.ring_feed_external(r_in._h, oseq._seq_id, ptrs, gulp_bytes, total)
+                else:
+                    for k in range(total):
+                        oseq.commit_external(spans[k % ring_gulps])
 
-    def drain(rg, gulp, on_span=None):
+    def drain(rg, gulp, on_span=None, times=None):
+        if native_harness:
+            import ctypes as _ct
+            rid = _ct.c_int()
+            ffi.check("xengRingOpenReader", rg._enq.xengRingOpenReader(rg._h, 1, _ct.byref(rid)))       # (registered now, before any thread starts)
+
+            def run_native():
+                nsp, tt = rg._x.ring_drain(rg._h, rid.value, gulp, times is not None)
+                if times is not None:
+                    times.extend(tt)
+                if on_span:
+                    for _ in range(nsp):
+                        on_span()
+            return threading.Thread(target=run_native, daemon=True)
         gen = rg.read(guarantee=True)
 
         def run():
             for iseq in gen:
                 for ispan in iseq.read(gulp):
+                    if times is not None:
+                        times.append(time.perf_counter())
                     if on_span:
                         on_span()
         return threading.Thread(target=run, daemon=True)
 
     def slow_span():
         nslow[0] += 1
-    ths = [drain(r_vis, corr.ogulp_size, lambda: stamps.append(time.perf_counter())), drain(r_slow, cacc.ogulp_size, slow_span),
+    ths = [drain(r_vis, corr.ogulp_size, times=stamps), drain(r_slow, cacc.ogulp_size, slow_span),
            drain(r_pow, (nbeam // 2) * (nt_b // ns) * NCHAN * 16)]
     ths += [threading.Thread(target=f, daemon=True) for f in (corr.main, cacc.main, bf.main, sb.main, source)]
-    # Eight Python threads under one interpreter lock.  The blocks keep the lock across their enqueue-only library calls and ask
+    # Four block threads (+ the harness threads on the Python ring) under one interpreter lock.  The blocks keep the lock across their enqueue-only library calls and ask
     # before they wait (ffi.enqueue_lib, backend.beam_wait / xgpu_sync_lag), so a thread gives the lock up only when it really
     # has to sleep; the interpreter's switch interval stays at its default (a short one, 5e-5 s, measured 0.51-1.25 ms per
     # integration over six runs against 0.51-0.62 for the default: profiles/r03/blocks_lock_handoff.txt).
@@ -1089,7 +1114,7 @@ def main():
     kname = "xcorr_fused_kernel" if fused.value else ("xcorr_fp6_kernel" if fp6.value else "xcorr_mfma_kernel")
     # (PMC counters cannot be collected inside this run; the committed figure counts only while the X-engine sources it was
     # taken from are the ones this library was built from, else traffic is null)
-    traffic = None
+    traffic = traffic_slabs = None
     import hashlib
     for rnd in ("r04", "r03"):                     # (the latest PMC pass whose X-engine sources are the ones this library was built from)
         try:
@@ -1101,6 +1126,7 @@ def main():
                     hh.update(fh.read())
             if hh.hexdigest() == pmc.get("xcorr_sources_sha256"):
                 traffic = pmc.get(kname + "_bytes_per_launch")
+                traffic_slabs = pmc.get(kname + "_slabs_bytes_per_launch")
                 break
         except (OSError, ValueError):
             pass
@@ -1154,6 +1180,17 @@ def main():
     if pktz is not None:
         res["corr_output_packetize"] = pktz
     if ingest is not None:
+        # the contraction of the packet legs against the same roofline as the headline (one launch per integration; the scatter /
+        # verify passes run beside it).  traffic: PMC, the descriptor instantiation on packed slabs (stride 6176), else null
+        for key, tr, alg in (("packets_to_visibilities", traffic_slabs, units_per_step_c * NINPUT + 2 * matlen * 4 + gulps_per_step * NTIME_GULP * (NINPUT // 64) * 32),
+                             ("packets_to_visibilities_payloads_on_cache_lines", None, units_per_step_c * NINPUT + 2 * matlen * 4 + gulps_per_step * NTIME_GULP * (NINPUT // 64) * 32),
+                             ("packets_to_visibilities_scatter", None, None)):
+            leg = ingest.get(key)
+            if isinstance(leg, dict) and leg.get("ms_per_step"):
+                ach = OPS_PER_UNIT * units_per_step_c / (leg["ms_per_step"] * 1e-3)
+                leg["roofline"] = {"kernel": "xcorr_fused_kernel" + ("" if key.endswith("scatter") else " (gulps by descriptor)"), "bound": "mfma",
+                                   "achieved": round(ach / 1e12, 1), "peak": round(PEAK_INT8_OPS / 1e12, 1), "unit": "TFLOP/s",
+                                   "frac": round(ach / PEAK_INT8_OPS, 4), "traffic": tr, "algorithmic_bytes_per_launch": alg}
         res["ingest_unpack"] = ingest
     if iso_cn[1] > 0:
         iso_mm = iso_tm[1] / iso_cn[1]

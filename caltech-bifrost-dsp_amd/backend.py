@@ -182,6 +182,16 @@ class HipBackend:
         return self._x.beam_run_slabs(slab0.ptr, int(npkt0), int(ntime0), slab1.ptr if slab1 is not None else 0, int(npkt1), int(pkt_stride),
                                       int(seq0), int(chan0), _dev(out_arr), _dev(weights), int(version))
 
+    def beam_pump(self, iring, reader, oring, oseq_id, igulp, ogulp, mode, row_bytes=0, ntime_sum=0, depth=8, staged=False):
+        """The steady-state per-gulp loop of Beamform (mode 0) / BeamformSumBeams (mode 1) between two NATIVE rings as an object
+        whose run() works without the interpreter lock (csrc/pyext/xfast.cpp BeamPump); None when the rings are not native
+        or XENG_PUMP=0."""
+        import os
+        if os.environ.get("XENG_PUMP") == "0" or not (hasattr(iring, "_h") and hasattr(oring, "_h")):
+            return None
+        return self._x.beam_pump(iring, iring._h, int(reader), oring, oring._h, int(oseq_id), int(igulp), int(ogulp), int(mode), int(row_bytes),
+                                 int(ntime_sum), int(depth), int(bool(staged)))
+
     def bfBeamformIntegrate(self, in_arr, out_arr, ntime_sum):
         # (bfBeamformIntegrate reads only the two data pointers from its structs: the raw entry point, no structs built per gulp)
         return self._x.beam_integrate(_dev(in_arr), _dev(out_arr), int(ntime_sum))

@@ -50,6 +50,8 @@ class Beamform(Block):
         self.gains_gpu = XArray(shape=(nchan, nbeam, ninput), dtype=np.complex64, space=self._bf.space_in)
         self.gains_load_sample = np.zeros(nbeam)
         self._gains_version = 0       # bumped whenever gains_gpu is rewritten
+        import ctypes
+        self._pump_stop = ctypes.c_int(0)
         self.define_command_key('coeffs', type=dict, initial_val={})
         for b in range(self.nbeam):
             self.update_stats({'cal_gains%d' % b: [False, ] * ninput})
@@ -60,6 +62,19 @@ class Beamform(Block):
             rv = self._bf.bfBeamformInitialize(self.gpu, self.ninput, self.nchan, self.ntime_gulp, self.nbeam, 0)
         if rv != self._bf.BF_STATUS_SUCCESS:
             raise RuntimeError("bfBeamformInitialize returned %d: %s" % (rv, self._bf.last_error()))
+
+    # `update_pending` is set by the command thread; the native per-gulp loop (backend.beam_pump) watches the word behind
+    # `_pump_stop` and hands control back to this block's Python as soon as a gulp arrives with it up
+    @property
+    def update_pending(self):
+        return self.__dict__.get('_update_pending', False)
+
+    @update_pending.setter
+    def update_pending(self, value):
+        self.__dict__['_update_pending'] = value
+        stop = self.__dict__.get('_pump_stop')
+        if stop is not None and value:
+            stop.value = 1
 
     def _etcd_callback(self, watchresponse):
         """Every command is enacted immediately (all coefficient commands share one key, so a later
@@ -150,6 +165,51 @@ class Beamform(Block):
                     pass
                 pending.clear()
 
+    PUMP_GULPS = 8          # gulps per call of the native loop while no command is pending
+
+    def _pump_sequence(self, pump, this_gulp_time, igulp_size, copy_pending):
+        """One input sequence through the native per-gulp loop (native rings, in-place gulps): this method keeps what is not
+        steady state -- coefficient loads at their load times (one gulp per call while any is pending, as the per-gulp loop
+        checks before every gulp), the upload of new weights (everything in flight retired first), statistics."""
+        import ctypes
+        stop_addr = ctypes.addressof(self._pump_stop)
+        prev_time = time.time()
+        try:
+            while True:
+                self._pump_stop.value = 0       # (lowered BEFORE the flag is read: a command that comes in from here on raises it again)
+                if self.update_pending:
+                    self.acquire_control_lock()
+                    for b in range(self.nbeam):
+                        if self.gains_load_sample[b] == 0:      # 0 = nothing pending for this beam
+                            continue
+                        if this_gulp_time >= self.gains_load_sample[b]:
+                            self.gains_cpu[:, b, :] = self.gains_cpu_new[:, b, :]
+                            self.gains_load_sample[b] = 0
+                            copy_pending = True
+                    if self.gains_load_sample.sum() == 0:
+                        self.update_pending = False
+                    self.stats['update_pending'] = self.update_pending
+                    self.stats['last_cmd_proc_time'] = time.time()
+                    self.release_control_lock()
+                if copy_pending:
+                    pump.drain()                # (kernels in flight may still read the device copy of the weights)
+                    self.gains_gpu[...] = self.gains_cpu
+                    self._gains_version += 1
+                    copy_pending = False
+                n, skipped, status = pump.run(self.gains_gpu.ptr, self._gains_version, 1 if self.update_pending else self.PUMP_GULPS, stop_addr)
+                this_gulp_time += ((skipped // igulp_size) + n) * self.ntime_gulp
+                curr_time = time.time()
+                if n:
+                    self.update_stats({'curr_sample': this_gulp_time - self.ntime_gulp})
+                    self.perf_proclog.update({'acquire_time': 0.0, 'reserve_time': 0.0, 'process_time': (curr_time - prev_time) / n,
+                                              'gbps': 8 * igulp_size * n / max(curr_time - prev_time, 1e-9) / 1e9})
+                prev_time = curr_time
+                if status == 1:
+                    return this_gulp_time
+        except BaseException:
+            pump.abort()
+            raise
+
     def _main_loop(self, igulp_size, ogulp_size, streaming, pending, retire):
         with self.oring.begin_writing() as oring:
             for iseq in self.iring.read(guarantee=self.guarantee):
@@ -188,6 +248,13 @@ class Beamform(Block):
                     for k in ('layout', 'slab_ntime', 'npkt_per_gulp', 'pkt_stride'):
                         ohdr.pop(k, None)
                 with oring.begin_sequence(time_tag=iseq.time_tag, header=json.dumps(ohdr)) as oseq:
+                    pump = None
+                    if streaming and not slab and read_parts is not None and hasattr(self._bf, 'beam_pump') and hasattr(iseq, '_rid') and hasattr(oseq, '_seq_id'):
+                        pump = self._bf.beam_pump(self.iring, iseq._rid, self.oring, oseq._seq_id, igulp_size, ogulp_size, 0,
+                                                  row_bytes=self.nchan * self.ninput, depth=self.STREAM_DEPTH)
+                    if pump is not None:
+                        this_gulp_time = self._pump_sequence(pump, this_gulp_time, igulp_size, copy_pending)
+                        continue
                     for ispan in (read_parts(igulp_size) if read_parts is not None else iseq.read(igulp_size)):
                         self.update_stats({'curr_sample': this_gulp_time})
                         if ispan.size < igulp_size:

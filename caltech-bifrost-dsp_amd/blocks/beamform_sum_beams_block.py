@@ -109,6 +109,27 @@ class BeamformSumBeams(Block):
                 self.oring.resize(ogulp_size * self.ntime_sum * 4)
                 prev_time = time.time()
                 with oring.begin_sequence(time_tag=iseq.time_tag, header=json.dumps(ohdr)) as oseq:
+                    pump = None
+                    if streaming and hasattr(self._bf, 'beam_pump') and hasattr(iseq, '_rid') and hasattr(oseq, '_seq_id'):
+                        pump = self._bf.beam_pump(self.iring, iseq._rid, self.oring, oseq._seq_id, igulp_size, ogulp_size, 1,
+                                                  ntime_sum=self.ntime_sum, depth=self.STREAM_DEPTH, staged=self._staged)
+                    if pump is not None:
+                        # the native per-gulp loop (csrc/pyext/xfast.cpp BeamPump): this block has no commands; back here every few
+                        # gulps for the statistics
+                        try:
+                            while True:
+                                n, _, status = pump.run(0, 0, 8, 0)
+                                curr_time = time.time()
+                                if n:
+                                    self.perf_proclog.update({'acquire_time': 0.0, 'reserve_time': 0.0, 'process_time': (curr_time - prev_time) / n,
+                                                              'gbps': 8 * igulp_size * n / max(curr_time - prev_time, 1e-9) / 1e9})
+                                prev_time = curr_time
+                                if status == 1:
+                                    break
+                        except BaseException:
+                            pump.abort()
+                            raise
+                        continue
                     for ispan in iseq.read(igulp_size):
                         if ispan.size < igulp_size:
                             continue

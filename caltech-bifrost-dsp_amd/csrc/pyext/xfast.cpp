@@ -13,6 +13,11 @@
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 
+#include <time.h>
+
+#include <deque>
+#include <vector>
+
 #include "../../../include/xeng.h"
 
 namespace {
@@ -347,6 +352,318 @@ PyObject* stamp_wait(PyObject*, PyObject* args) {
     Py_RETURN_NONE;
 }
 
+// ---------------------------------------------------------------- harness helpers (bench.py, probes): a data source and sinks that are not Python threads
+// ring_feed_external(h, seq, ptrs (bytes: uint64 each), nbytes, count): commits ptrs[k % n] as external spans, `count` times, waiting for
+// room like any writer; the interpreter lock is released for the whole loop
+PyObject* ring_feed_external(PyObject*, PyObject* args) {
+    unsigned long long h;
+    long long seq;
+    const char* pp;
+    Py_ssize_t plen, nbytes, count;
+    if (!PyArg_ParseTuple(args, "KLy#nn", &h, &seq, &pp, &plen, &nbytes, &count)) return nullptr;
+    const Py_ssize_t nptr = plen / 8;
+    if (nptr <= 0) { PyErr_SetString(PyExc_ValueError, "no span addresses"); return nullptr; }
+    std::vector<unsigned long long> ptrs((size_t)nptr);
+    memcpy(ptrs.data(), pp, (size_t)nptr * 8);
+    int rc = 0;
+    Py_BEGIN_ALLOW_THREADS
+    for (Py_ssize_t k = 0; k < count && !rc; k++)
+        rc = xengRingCommitExternal((xengRing*)h, seq, (void*)(uintptr_t)ptrs[(size_t)(k % nptr)], (size_t)nbytes, 1);
+    Py_END_ALLOW_THREADS
+    if (rc) return raise_xeng("xengRingCommitExternal", rc);
+    Py_RETURN_NONE;
+}
+
+// ring_drain(h, reader, gulp, want_times) -> (spans seen, [time.perf_counter() of each span] or []): reads every sequence to its end,
+// releasing each span at once; the interpreter lock is released for the whole loop
+PyObject* ring_drain(PyObject*, PyObject* args) {
+    unsigned long long h;
+    int reader, want_times;
+    Py_ssize_t gulp;
+    if (!PyArg_ParseTuple(args, "Kinp", &h, &reader, &gulp, &want_times)) return nullptr;
+    std::vector<double> times;
+    long long nspans = 0;
+    int rc = 0;
+    Py_BEGIN_ALLOW_THREADS
+    for (;;) {
+        long long seq = 0, tag = 0;
+        int nringlet = 1;
+        const void* hdr = nullptr;
+        size_t hlen = 0;
+        rc = xengRingNextSequence((xengRing*)h, reader, 1, &seq, &tag, &nringlet, &hdr, &hlen);
+        if (rc) break;
+        size_t advance = 0;
+        for (;;) {
+            void* data = nullptr;
+            size_t n = 0, skipped = 0;
+            long long span = 0;
+            rc = xengRingAcquire((xengRing*)h, reader, advance, (size_t)gulp, 1, &data, &n, &span, &skipped);
+            if (rc) break;
+            if (want_times) {
+                struct timespec ts;
+                clock_gettime(CLOCK_MONOTONIC, &ts);          // (the clock of time.perf_counter())
+                times.push_back((double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec);
+            }
+            nspans++;
+            (void)xengRingSpanRelease(span);
+            advance = n;
+            if (n < (size_t)gulp) { rc = XENG_STATUS_END_OF_DATA; break; }
+        }
+        if (rc != XENG_STATUS_END_OF_DATA) break;
+    }
+    Py_END_ALLOW_THREADS
+    if (rc != XENG_STATUS_END_OF_DATA) return raise_xeng("ring_drain", rc);
+    PyObject* lst = PyList_New((Py_ssize_t)times.size());
+    if (!lst) return nullptr;
+    for (size_t k = 0; k < times.size(); k++) PyList_SET_ITEM(lst, (Py_ssize_t)k, PyFloat_FromDouble(times[k]));
+    return Py_BuildValue("(LN)", nspans, lst);
+}
+
+
+// ---------------------------------------------------------------- BeamPump: the per-gulp loop of Beamform / BeamformSumBeams
+// What the two blocks do per gulp in steady state -- take the next input gulp, reserve an output span, enqueue the kernel, mark
+// it, and retire the oldest gulp in flight (wait for its ticket, commit its span, give its input back) -- as one loop inside the
+// extension with the interpreter lock released.  Everything that is not steady state stays in the block's Python: sequences
+// and headers, commands and coefficient uploads (the block passes the address of a flag; the pump looks at it after every
+// gulp it has taken and returns with that gulp still in hand), statistics.  Two block threads then touch the interpreter
+// lock once per `max_gulps` gulps instead of ~15 times per gulp: the lock belongs to Corr and CorrAcc, and a block thread
+// that the OS takes off its core no longer holds everybody else up (profiles/r04/blocks_gpu_idle.txt).
+struct PumpItem {
+    unsigned long long ticket = 0;
+    long long out_span = 0;
+    void* out_ptr = nullptr;
+    long long in_span[2] = {0, 0};
+    int nin = 0;
+    void* stage = nullptr;
+    xengStamp copy_stamp;
+};
+
+struct BeamPump {
+    PyObject_HEAD
+    PyObject* rin_obj;
+    PyObject* rout_obj;
+    xengRing* rin;
+    xengRing* rout;
+    int reader, mode, ntime_sum, depth, staged, row_bytes;
+    long long oseq;
+    size_t igulp, ogulp, advance;
+    std::deque<PumpItem>* pending;
+    std::deque<PumpItem>* copying;
+    std::vector<void*>* stages_free;
+    // a gulp taken from the input ring but not yet processed (the stop flag was up when it arrived)
+    int have_carry;
+    void* carry_data[2];
+    size_t carry_n[2];
+    long long carry_span[2];
+    int carry_nparts;
+};
+
+static void pump_release_item(PumpItem& it, bool commit, BeamPump* p) {
+    if (it.out_span) {
+        if (commit) (void)xengRingCommit(p->rout, p->oseq, it.out_span, p->ogulp);
+        (void)xengRingSpanRelease(it.out_span);
+        it.out_span = 0;
+    }
+    for (int k = 0; k < it.nin; k++)
+        if (it.in_span[k]) { (void)xengRingSpanRelease(it.in_span[k]); it.in_span[k] = 0; }
+    if (it.stage) { p->stages_free->push_back(it.stage); it.stage = nullptr; }
+}
+
+// (no interpreter lock held) commits whose copy has completed; keep > 0: leave that many in flight unless they are done anyway
+static int pump_finish_copies(BeamPump* p, size_t keep) {
+    while (!p->copying->empty()) {
+        PumpItem& it = p->copying->front();
+        int done = 0;
+        int rc = xengStampDone(&it.copy_stamp, &done, nullptr);
+        if (rc) return rc;
+        if (!done) {
+            if (p->copying->size() <= keep) break;
+            rc = xengStampWait(&it.copy_stamp);
+            if (rc) return rc;
+        }
+        pump_release_item(it, true, p);
+        p->copying->pop_front();
+    }
+    return XENG_STATUS_SUCCESS;
+}
+
+static int pump_retire(BeamPump* p, size_t keep) {
+    while (p->pending->size() > keep) {
+        PumpItem it = p->pending->front();
+        int rc = xengBeamformWait(it.ticket);
+        if (rc) return rc;
+        p->pending->pop_front();
+        if (it.stage) {
+            // the kernel's sums are in the device buffer: on to the pinned span on the copy stream; committed when that is done
+            rc = xengMemcpyAsync(it.out_ptr, it.stage, p->ogulp);
+            if (!rc) rc = xengStampNowFor(&it.copy_stamp, nullptr, XENG_STREAMS_COPY);
+            if (rc) { pump_release_item(it, false, p); return rc; }
+            for (int k = 0; k < it.nin; k++)
+                if (it.in_span[k]) { (void)xengRingSpanRelease(it.in_span[k]); it.in_span[k] = 0; }
+            it.nin = 0;
+            p->copying->push_back(it);
+        } else {
+            pump_release_item(it, true, p);
+        }
+    }
+    return pump_finish_copies(p, keep ? 2 : 0);
+}
+
+// after an error: nothing in flight may still touch a span when it goes back to its ring
+static void pump_abort(BeamPump* p) {
+    (void)xengBeamformSync();
+    for (auto& it : *p->copying) (void)xengStampWait(&it.copy_stamp);
+    for (auto& it : *p->pending) pump_release_item(it, false, p);
+    for (auto& it : *p->copying) pump_release_item(it, false, p);
+    p->pending->clear();
+    p->copying->clear();
+    if (p->have_carry) {
+        for (int k = 0; k < p->carry_nparts; k++) (void)xengRingSpanRelease(p->carry_span[k]);
+        p->have_carry = 0;
+    }
+}
+
+void BeamPump_dealloc(BeamPump* self) {
+    if (self->pending) {
+        Py_BEGIN_ALLOW_THREADS
+        pump_abort(self);
+        Py_END_ALLOW_THREADS
+        for (void* st : *self->stages_free) (void)xengFree(st, XENG_SPACE_CUDA);
+        delete self->pending;
+        delete self->copying;
+        delete self->stages_free;
+    }
+    Py_CLEAR(self->rin_obj);
+    Py_CLEAR(self->rout_obj);
+    Py_TYPE(self)->tp_free((PyObject*)self);
+}
+
+PyTypeObject BeamPumpType = {PyVarObject_HEAD_INIT(nullptr, 0)};
+
+// beam_pump(in_ring_obj, in_handle, reader, out_ring_obj, out_handle, out_seq, igulp, ogulp, mode (0 Beamform | 1 SumBeams), row_bytes,
+//           ntime_sum, depth, staged) -> BeamPump
+PyObject* beam_pump_new(PyObject*, PyObject* args) {
+    PyObject *rin_obj, *rout_obj;
+    unsigned long long hin, hout;
+    int reader, mode, row_bytes, ntime_sum, depth, staged;
+    long long oseq;
+    Py_ssize_t igulp, ogulp;
+    if (!PyArg_ParseTuple(args, "OKiOKLnniiiii", &rin_obj, &hin, &reader, &rout_obj, &hout, &oseq, &igulp, &ogulp, &mode, &row_bytes, &ntime_sum, &depth, &staged))
+        return nullptr;
+    BeamPump* p = PyObject_New(BeamPump, &BeamPumpType);
+    if (!p) return nullptr;
+    Py_INCREF(rin_obj); Py_INCREF(rout_obj);
+    p->rin_obj = rin_obj; p->rout_obj = rout_obj;
+    p->rin = (xengRing*)hin; p->rout = (xengRing*)hout;
+    p->reader = reader; p->mode = mode; p->ntime_sum = ntime_sum; p->depth = depth > 0 ? depth : 1; p->staged = staged; p->row_bytes = row_bytes > 0 ? row_bytes : 1;
+    p->oseq = oseq; p->igulp = (size_t)igulp; p->ogulp = (size_t)ogulp; p->advance = 0;
+    p->pending = new std::deque<PumpItem>(); p->copying = new std::deque<PumpItem>(); p->stages_free = new std::vector<void*>();
+    p->have_carry = 0; p->carry_nparts = 0;
+    return (PyObject*)p;
+}
+
+// run(weights, version, max_gulps, stop_flag_address) -> (gulps enqueued, bytes skipped, status)
+//   status 0: max_gulps done;  1: the input sequence is over (everything in flight has been committed);
+//          2: the stop flag was up when a gulp arrived -- that gulp is kept and is the first of the next run()
+PyObject* BeamPump_run(BeamPump* p, PyObject* args) {
+    unsigned long long weights, stop_addr;
+    long long version;
+    int max_gulps;
+    if (!PyArg_ParseTuple(args, "KLiK", &weights, &version, &max_gulps, &stop_addr)) return nullptr;
+    volatile int* stop = (volatile int*)(uintptr_t)stop_addr;
+    long long ngulps = 0;
+    size_t skipped_total = 0;
+    int status = 0, rc = 0;
+    const char* where = "";
+    Py_BEGIN_ALLOW_THREADS
+    while (ngulps < max_gulps) {
+        void* data[2] = {nullptr, nullptr};
+        size_t n[2] = {0, 0}, skipped = 0;
+        long long span[2] = {0, 0};
+        int nparts = 1;
+        if (p->have_carry) {
+            for (int k = 0; k < 2; k++) { data[k] = p->carry_data[k]; n[k] = p->carry_n[k]; span[k] = p->carry_span[k]; }
+            nparts = p->carry_nparts;
+            p->have_carry = 0;
+        } else {
+            if (p->mode == 0) rc = xengRingAcquireParts(p->rin, p->reader, p->advance, p->igulp, 1, data, n, span, &nparts, &skipped);
+            else rc = xengRingAcquire(p->rin, p->reader, p->advance, p->igulp, 1, &data[0], &n[0], &span[0], &skipped);
+            if (rc == XENG_STATUS_END_OF_DATA) { rc = 0; status = 1; break; }
+            if (rc) { where = "xengRingAcquire"; break; }
+            skipped_total += skipped;
+            size_t got = 0;
+            for (int k = 0; k < nparts; k++) got += n[k];
+            p->advance = got;
+            if (got < p->igulp) {             // the short tail of an ended sequence: not a gulp (the blocks skip it)
+                for (int k = 0; k < nparts; k++) (void)xengRingSpanRelease(span[k]);
+                status = 1;
+                break;
+            }
+            if (stop && *stop) {              // a command came in while this thread waited for the gulp: the block looks first
+                for (int k = 0; k < 2; k++) { p->carry_data[k] = data[k]; p->carry_n[k] = n[k]; p->carry_span[k] = span[k]; }
+                p->carry_nparts = nparts;
+                p->have_carry = 1;
+                status = 2;
+                break;
+            }
+        }
+        PumpItem it;
+        it.nin = nparts;
+        for (int k = 0; k < nparts; k++) it.in_span[k] = span[k];
+        rc = xengRingReserve(p->rout, p->oseq, p->ogulp, 0, 1, &it.out_ptr, &it.out_span);
+        if (rc) { where = "xengRingReserve"; pump_release_item(it, false, p); break; }
+        if (p->mode == 0) {
+            if (nparts == 2) rc = xengBeamformRunParts(data[0], (int)(n[0] / (size_t)p->row_bytes), data[1], it.out_ptr, (const void*)(uintptr_t)weights, version);
+            else rc = xengBeamformRunVersioned(data[0], it.out_ptr, (const void*)(uintptr_t)weights, version);
+            where = "xengBeamformRun";
+        } else {
+            void* target = it.out_ptr;
+            if (p->staged) {
+                if (!p->stages_free->empty()) { it.stage = p->stages_free->back(); p->stages_free->pop_back(); }
+                else rc = xengMalloc(&it.stage, p->ogulp, XENG_SPACE_CUDA);
+                target = it.stage;
+            }
+            if (!rc) rc = xengBeamformIntegrate(data[0], target, p->ntime_sum);
+            where = "xengBeamformIntegrate";
+        }
+        if (!rc) { rc = xengBeamformMark(&it.ticket); if (rc) where = "xengBeamformMark"; }
+        if (rc) { (void)xengBeamformSync(); pump_release_item(it, false, p); break; }
+        p->pending->push_back(it);
+        ngulps++;
+        rc = pump_retire(p, (size_t)p->depth);
+        if (rc) { where = "retire"; break; }
+    }
+    if (!rc && status == 1) { rc = pump_retire(p, 0); if (rc) where = "retire"; }
+    if (rc) pump_abort(p);
+    Py_END_ALLOW_THREADS
+    if (rc) return raise_xeng(where, rc);
+    return Py_BuildValue("(Lni)", ngulps, (Py_ssize_t)skipped_total, status);
+}
+
+// drain(): everything in flight is waited for and committed (before the weights on the device are rewritten; at the end)
+PyObject* BeamPump_drain(BeamPump* p, PyObject*) {
+    int rc;
+    Py_BEGIN_ALLOW_THREADS
+    rc = pump_retire(p, 0);
+    if (rc) pump_abort(p);
+    Py_END_ALLOW_THREADS
+    if (rc) return raise_xeng("BeamPump.drain", rc);
+    Py_RETURN_NONE;
+}
+
+PyObject* BeamPump_abort(BeamPump* p, PyObject*) {
+    Py_BEGIN_ALLOW_THREADS
+    pump_abort(p);
+    Py_END_ALLOW_THREADS
+    Py_RETURN_NONE;
+}
+
+PyMethodDef BeamPump_methods[] = {
+    {"run", (PyCFunction)BeamPump_run, METH_VARARGS, "(weights, version, max_gulps, stop_flag_address) -> (gulps, skipped bytes, status)"},
+    {"drain", (PyCFunction)BeamPump_drain, METH_NOARGS, "wait for and commit everything in flight"},
+    {"abort", (PyCFunction)BeamPump_abort, METH_NOARGS, "after an error elsewhere: wait for the stream, give every span back uncommitted"},
+    {nullptr, nullptr, 0, nullptr}};
+
 PyObject* map_i32(PyObject*, PyObject* args) {
     unsigned long long a, b;
     Py_ssize_t n;
@@ -374,6 +691,9 @@ PyMethodDef methods[] = {
     {"beam_mark", beam_mark, METH_NOARGS, "xengBeamformMark -> ticket | -status"},
     {"beam_ticket_done", beam_ticket_done, METH_VARARGS, "xengBeamformTicketDone -> -status | 0 | 1"},
     {"map_i32", map_i32, METH_VARARGS, "(a, b, nwords, add) -> status"},
+    {"ring_feed_external", ring_feed_external, METH_VARARGS, "harness: (handle, seq, addresses, nbytes, count) -- a source that is not a Python thread"},
+    {"ring_drain", ring_drain, METH_VARARGS, "harness: (handle, reader, gulp, want_times) -> (spans, times) -- a sink that is not a Python thread"},
+    {"beam_pump", beam_pump_new, METH_VARARGS, "(in_ring, in_handle, reader, out_ring, out_handle, out_seq, igulp, ogulp, mode, row_bytes, ntime_sum, depth, staged) -> BeamPump"},
     {"copy_async", copy_async, METH_VARARGS, "(dst, src, nbytes) -> stamp of the enqueued copy (bytes)"},
     {"stamp_done", stamp_done, METH_VARARGS, "(stamp) -> bool"},
     {"stamp_wait", stamp_wait, METH_VARARGS, "(stamp): waits (interpreter lock released) unless it is done"},
@@ -390,6 +710,13 @@ PyMODINIT_FUNC PyInit__xfast(void) {
     SpanRefType.tp_dealloc = (destructor)SpanRef_dealloc;
     SpanRefType.tp_doc = "a reference on a ring span's memory, given back when this object dies";
     if (PyType_Ready(&SpanRefType) < 0) return nullptr;
+    BeamPumpType.tp_name = "_xfast.BeamPump";
+    BeamPumpType.tp_basicsize = sizeof(BeamPump);
+    BeamPumpType.tp_flags = Py_TPFLAGS_DEFAULT;
+    BeamPumpType.tp_dealloc = (destructor)BeamPump_dealloc;
+    BeamPumpType.tp_methods = BeamPump_methods;
+    BeamPumpType.tp_doc = "the steady-state per-gulp loop of Beamform / BeamformSumBeams, run without the interpreter lock";
+    if (PyType_Ready(&BeamPumpType) < 0) return nullptr;
     PyObject* m = PyModule_Create(&moddef);
     if (!m) return nullptr;
     Py_INCREF(&SpanRefType);

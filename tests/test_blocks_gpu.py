@@ -119,6 +119,59 @@ def test_beamform_sumbeams_on_device_rings():
         assert np.all(np.isclose(pgot, pexp, rtol=1e-5, atol=1e-5 * np.abs(pexp).max()))
 
 
+@pytest.mark.parametrize("pump", ["1", "0"])
+def test_beamform_timed_coefficient_load_on_device_rings(pump, monkeypatch):
+    """Thirty gulps through Beamform -> BeamformSumBeams with coefficients that load at gulp 11 (beamform_block.py:416-429), on
+    the native per-gulp loop (csrc/pyext/xfast.cpp BeamPump, which hands control back to the block when a load is pending) and
+    on the Python loop (XENG_PUMP=0): zero beams before the load sample, the commanded ones from it on, every gulp against the
+    oracle, power sums included; a command that arrives WHILE the pipeline runs takes effect at its load sample too."""
+    import threading
+    import time
+    monkeypatch.setenv("XENG_PUMP", pump)
+    nchan, nstand, nbeam, g, ns, ngulp = 4, 32, 8, 96, 24, 30
+    ninput = nstand * 2
+    rng = np.random.default_rng(0xbeef)
+    vin = rng.integers(0, 256, (ngulp * g, nchan, ninput), dtype=np.uint8)
+    r0, r1, r2 = Ring("gpu-input", space="cuda"), Ring("bf-output", space="cuda"), Ring("bf-pow-output", space="cuda_host")
+    bf = Beamform(LOG, r0, r1, nchan=nchan, nbeam=nbeam, ninput=ninput, ntime_gulp=g, gpu=0)
+    sb = BeamformSumBeams(LOG, r1, r2, nchan=nchan, ntime_gulp=g, ntime_sum=ns, gpu=0)
+    sfreq, bw = 40e6, 23925.78125
+    bf.freqs = sfreq + bw * np.arange(nchan)
+    cmds, cal, delays, amps = _beam_cmds(nchan, nbeam, ninput, rng, load_sample=11 * g)
+    bf.process_command_strings(cmds)
+    first = bf.gains_cpu_new.copy()
+    # a second set of coefficients, commanded from another thread once the pipeline is running, to load at gulp 23
+    cmds2, _, _, _ = _beam_cmds(nchan, nbeam, ninput, np.random.default_rng(99), load_sample=23 * g)
+    second = {}
+
+    def late_command():
+        t0 = time.time()
+        while bf.stats.get('curr_sample', -1) < 12 * g and time.time() - t0 < 20:
+            time.sleep(0.0005)
+        bf.process_command_strings(cmds2)
+        second['gains'] = bf.gains_cpu_new.copy()
+        second['at'] = bf.stats.get('curr_sample', -1)
+    s1, s2 = Sink(r1, g * nchan * nbeam * 8), Sink(r2, (nbeam // 2) * (g // ns) * nchan * 16)
+    th = threading.Thread(target=late_command, daemon=True)
+    th.start()
+    # (the source paces itself so that the late command finds the pipeline between gulps 12 and 23)
+    run_blocks([bf, sb], Source(r0, [(source_header(nchan, nstand, 2, sfreq=sfreq, chan_bw=bw), vin, g * nchan * ninput)], gap=0.01), [s1, s2])
+    th.join(20)
+    (h1, _, sp1), = s1.sequences
+    (h2, _, sp2), = s2.sequences
+    assert len(sp1) == ngulp and len(sp2) == ngulp
+    assert 'gains' in second and 12 * g <= second['at'] < 23 * g, second.get('at')
+    zero = np.zeros_like(first)
+    for k in range(ngulp):
+        w = zero if k < 11 else first if k < 23 else second['gains']
+        exp = orc.beamform(vin[k * g:(k + 1) * g], w, g, nchan, ninput, nbeam)
+        got = sp1[k].view(np.complex64).reshape(exp.shape)
+        assert np.max(np.abs(got - exp)) <= 1e-5 * max(np.sqrt(np.mean(np.abs(exp) ** 2)), 1e-30), k
+        pexp = orc.beamform_integrate(got, ns)
+        pgot = sp2[k].view(np.float32).reshape(pexp.shape)
+        assert np.all(np.isclose(pgot, pexp, rtol=1e-5, atol=1e-5 * max(np.abs(pexp).max(), 1e-30))), k
+
+
 def test_ingest_copy_corr_subsel_chain():
     """The ingest side and the fast-visibility side of Corr: pinned host ring
     -> Copy (H2D) -> gpu-input (cuda) -> Corr -> corr-output (cuda) -> CorrSubsel -> cuda_host ring."""
