@@ -167,7 +167,7 @@ class Beamform(Block):
 
     PUMP_GULPS = 8          # gulps per call of the native loop while no command is pending
 
-    def _pump_sequence(self, pump, this_gulp_time, igulp_size, copy_pending):
+    def _pump_sequence(self, pump, this_gulp_time, igulp_size, copy_pending, slab=False):
         """One input sequence through the native per-gulp loop (native rings, in-place gulps): this method keeps what is not
         steady state -- coefficient loads at their load times (one gulp per call while any is pending, as the per-gulp loop
         checks before every gulp), the upload of new weights (everything in flight retired first), statistics."""
@@ -196,7 +196,8 @@ class Beamform(Block):
                     self.gains_gpu[...] = self.gains_cpu
                     self._gains_version += 1
                     copy_pending = False
-                n, skipped, status = pump.run(self.gains_gpu.ptr, self._gains_version, 1 if self.update_pending else self.PUMP_GULPS, stop_addr)
+                n, skipped, status = pump.run(self.gains_gpu.ptr, self._gains_version, 1 if self.update_pending else self.PUMP_GULPS, stop_addr,
+                                              int(this_gulp_time) if slab else 0)
                 this_gulp_time += ((skipped // igulp_size) + n) * self.ntime_gulp
                 curr_time = time.time()
                 if n:
@@ -249,11 +250,13 @@ class Beamform(Block):
                         ohdr.pop(k, None)
                 with oring.begin_sequence(time_tag=iseq.time_tag, header=json.dumps(ohdr)) as oseq:
                     pump = None
-                    if streaming and not slab and read_parts is not None and hasattr(self._bf, 'beam_pump') and hasattr(iseq, '_rid') and hasattr(oseq, '_seq_id'):
+                    if streaming and read_parts is not None and hasattr(self._bf, 'beam_pump') and hasattr(iseq, '_rid') and hasattr(oseq, '_seq_id'):
                         pump = self._bf.beam_pump(self.iring, iseq._rid, self.oring, oseq._seq_id, igulp_size, ogulp_size, 0,
                                                   row_bytes=self.nchan * self.ninput, depth=self.STREAM_DEPTH)
                     if pump is not None:
-                        this_gulp_time = self._pump_sequence(pump, this_gulp_time, igulp_size, copy_pending)
+                        if slab:
+                            pump.set_slabs(slab_npkt, slab_stride, slab_ntime, ihdr['chan0'], self.ntime_gulp)
+                        this_gulp_time = self._pump_sequence(pump, this_gulp_time, igulp_size, copy_pending, slab)
                         continue
                     for ispan in (read_parts(igulp_size) if read_parts is not None else iseq.read(igulp_size)):
                         self.update_stats({'curr_sample': this_gulp_time})

@@ -445,6 +445,9 @@ struct BeamPump {
     xengRing* rin;
     xengRing* rout;
     int reader, mode, ntime_sum, depth, staged, row_bytes;
+    // mode 0 on a sequence of packet slabs (slab_npkt > 0): a gulp is one or two slabs, handed to xengBeamformRunSlabs
+    int slab_npkt, slab_ntime, slab_chan0, ntime_gulp;
+    size_t slab_stride;
     long long oseq;
     size_t igulp, ogulp, advance;
     std::deque<PumpItem>* pending;
@@ -559,6 +562,7 @@ PyObject* beam_pump_new(PyObject*, PyObject* args) {
     p->oseq = oseq; p->igulp = (size_t)igulp; p->ogulp = (size_t)ogulp; p->advance = 0;
     p->pending = new std::deque<PumpItem>(); p->copying = new std::deque<PumpItem>(); p->stages_free = new std::vector<void*>();
     p->have_carry = 0; p->carry_nparts = 0;
+    p->slab_npkt = 0; p->slab_ntime = 0; p->slab_chan0 = 0; p->ntime_gulp = 0; p->slab_stride = 0;
     return (PyObject*)p;
 }
 
@@ -566,10 +570,10 @@ PyObject* beam_pump_new(PyObject*, PyObject* args) {
 //   status 0: max_gulps done;  1: the input sequence is over (everything in flight has been committed);
 //          2: the stop flag was up when a gulp arrived -- that gulp is kept and is the first of the next run()
 PyObject* BeamPump_run(BeamPump* p, PyObject* args) {
-    unsigned long long weights, stop_addr;
+    unsigned long long weights, stop_addr, seq0 = 0;
     long long version;
     int max_gulps;
-    if (!PyArg_ParseTuple(args, "KLiK", &weights, &version, &max_gulps, &stop_addr)) return nullptr;
+    if (!PyArg_ParseTuple(args, "KLiK|K", &weights, &version, &max_gulps, &stop_addr, &seq0)) return nullptr;
     volatile int* stop = (volatile int*)(uintptr_t)stop_addr;
     long long ngulps = 0;
     size_t skipped_total = 0;
@@ -591,6 +595,7 @@ PyObject* BeamPump_run(BeamPump* p, PyObject* args) {
             if (rc == XENG_STATUS_END_OF_DATA) { rc = 0; status = 1; break; }
             if (rc) { where = "xengRingAcquire"; break; }
             skipped_total += skipped;
+            if (p->slab_npkt > 0 && p->igulp) seq0 += (unsigned long long)(skipped / p->igulp) * (unsigned long long)p->ntime_gulp;
             size_t got = 0;
             for (int k = 0; k < nparts; k++) got += n[k];
             p->advance = got;
@@ -612,7 +617,15 @@ PyObject* BeamPump_run(BeamPump* p, PyObject* args) {
         for (int k = 0; k < nparts; k++) it.in_span[k] = span[k];
         rc = xengRingReserve(p->rout, p->oseq, p->ogulp, 0, 1, &it.out_ptr, &it.out_span);
         if (rc) { where = "xengRingReserve"; pump_release_item(it, false, p); break; }
-        if (p->mode == 0) {
+        if (p->mode == 0 && p->slab_npkt > 0) {
+            const size_t slab_bytes = (size_t)p->slab_npkt * p->slab_stride;
+            const void* s0 = data[0];
+            const void* s1 = nparts == 2 ? data[1] : (n[0] >= 2 * slab_bytes ? (const void*)((const char*)data[0] + slab_bytes) : nullptr);
+            rc = xengBeamformRunSlabs(s0, p->slab_npkt, p->slab_ntime, s1, p->slab_npkt, p->slab_stride, (uint64_t)seq0, p->slab_chan0, it.out_ptr,
+                                      (const void*)(uintptr_t)weights, version);
+            seq0 += (unsigned long long)p->ntime_gulp;
+            where = "xengBeamformRunSlabs";
+        } else if (p->mode == 0) {
             if (nparts == 2) rc = xengBeamformRunParts(data[0], (int)(n[0] / (size_t)p->row_bytes), data[1], it.out_ptr, (const void*)(uintptr_t)weights, version);
             else rc = xengBeamformRunVersioned(data[0], it.out_ptr, (const void*)(uintptr_t)weights, version);
             where = "xengBeamformRun";
@@ -658,8 +671,18 @@ PyObject* BeamPump_abort(BeamPump* p, PyObject*) {
     Py_RETURN_NONE;
 }
 
+// set_slabs(npkt, stride, slab_ntime, chan0, ntime_gulp): the input sequence holds packet slabs (Beamform only)
+PyObject* BeamPump_set_slabs(BeamPump* p, PyObject* args) {
+    int npkt, slab_ntime, chan0, ntime_gulp;
+    Py_ssize_t stride;
+    if (!PyArg_ParseTuple(args, "iniii", &npkt, &stride, &slab_ntime, &chan0, &ntime_gulp)) return nullptr;
+    p->slab_npkt = npkt; p->slab_stride = (size_t)stride; p->slab_ntime = slab_ntime; p->slab_chan0 = chan0; p->ntime_gulp = ntime_gulp;
+    Py_RETURN_NONE;
+}
+
 PyMethodDef BeamPump_methods[] = {
-    {"run", (PyCFunction)BeamPump_run, METH_VARARGS, "(weights, version, max_gulps, stop_flag_address) -> (gulps, skipped bytes, status)"},
+    {"set_slabs", (PyCFunction)BeamPump_set_slabs, METH_VARARGS, "(npkt, stride, slab_ntime, chan0, ntime_gulp): gulps are packet slabs"},
+    {"run", (PyCFunction)BeamPump_run, METH_VARARGS, "(weights, version, max_gulps, stop_flag_address[, seq0 of the next gulp: slab sequences]) -> (gulps, skipped bytes, status)"},
     {"drain", (PyCFunction)BeamPump_drain, METH_NOARGS, "wait for and commit everything in flight"},
     {"abort", (PyCFunction)BeamPump_abort, METH_NOARGS, "after an error elsewhere: wait for the stream, give every span back uncommitted"},
     {nullptr, nullptr, 0, nullptr}};
