@@ -17,6 +17,18 @@ nint = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 nwarm = int(sys.argv[3]) if len(sys.argv) > 3 else 400
 import gc
 gcmode = sys.argv[4] if len(sys.argv) > 4 else "default"
+PIN = os.environ.get("REPEAT_PIN", "none")      # none | node (the GPU's NUMA node, as bench.py pins) | N (the first N CPUs of that node)
+if PIN != "none":
+    from caltech_bifrost_dsp_amd import sharding
+    import ctypes as _ct
+    bus = _ct.create_string_buffer(64)
+    ffi.call("xengSetDevice", 0)
+    ffi.call("xengGetDevicePciBusId", 0, bus, 64)
+    info = sharding.pin_rank(0, 1, bus.value.decode())
+    if PIN != "node":
+        cpus = sorted(os.sched_getaffinity(0))[:int(PIN)]
+        os.sched_setaffinity(0, cpus)
+    print("pinned (%s): %d CPUs, %s" % (PIN, len(os.sched_getaffinity(0)), sorted(os.sched_getaffinity(0))[:4]), flush=True)
 ffi.call("xengSetDevice", 0)
 ffi.call("xengXgpuConfigure", bench.NSTAND, bench.NPOL, bench.NCHAN, bench.NTIME_GULP, bench.ACC_LEN // bench.NTIME_GULP)
 ffi.call("xengXgpuInitialize", 0)
@@ -32,8 +44,8 @@ for r in range(runs * len(depths)):
         gc.disable()
     n0 = [g["collections"] for g in gc.get_stats()]
     if os.environ.get("REPEAT_SLABS"):
-        res = bench.config5_blocks_leg(ffi, ring, gulp_bytes, 10, 0, nint=nint, nwarm=nwarm, long_len=40, from_slabs=True)
-        print("from slabs, run %d: %.4f ms per integration, windows %s, scattered %s" % (r, res["ms_per_integration"], res["window_ms"], res["slabs_scattered_after_all"]), flush=True)
+        res = bench.config5_blocks_leg(ffi, ring, gulp_bytes, 10, 0, nint=nint, nwarm=nwarm, long_len=40, from_slabs=True, in_ring_integrations=depths[r % len(depths)])
+        print("from slabs, input ring %2d integrations, run %d: %.4f ms per integration, windows %s, scattered %s" % (depths[r % len(depths)], r, res["ms_per_integration"], res["window_ms"], res["slabs_scattered_after_all"]), flush=True)
         continue
     res = bench.config5_blocks_leg(ffi, ring, gulp_bytes, 10, 0, nint=nint, nwarm=nwarm, in_ring_integrations=depths[r % len(depths)])
     print("input ring %2d integrations, run %d: %.4f ms per integration, windows %s, fused %s" % (depths[r % len(depths)], r, res["ms_per_integration"], res["window_ms"], res["corracc_fused_into_dumps"]),
