@@ -218,7 +218,7 @@ def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=4
     # The source and the three sinks are the harness, not the product: on the native ring they run as loops inside the
     # extension with the interpreter lock released (`_xfast.ring_feed_external` / `ring_drain`), so that the lock is shared by
     # the four block threads (+ CorrAcc's publish helper) only, as in a pipeline whose neighbours are not Python loops.
-    native_harness = hasattr(r_in, "_h") and hasattr(getattr(r_in, "_x", None), "ring_drain")
+    native_harness = hasattr(r_in, "_h") and hasattr(getattr(r_in, "_x", None), "ring_drain") and not os.environ.get("XENG_BENCH_PY_HARNESS")
 
     def source():
         import time as _t

@@ -55,7 +55,8 @@ t_begin = pc()
 SLABS = bool(os.environ.get("REPEAT_SLABS"))          # the leg on a ring of packet slabs
 for n in ("xgpu_kernel_slab", "beam_run_slabs"):
     timed(_xfast, n, n)
-res = bench.config5_blocks_leg(ffi, ring, gulp_bytes, 10, 0, nint=nint, nwarm=nwarm, **(dict(long_len=40, from_slabs=True) if SLABS else {}))
+res = bench.config5_blocks_leg(ffi, ring, gulp_bytes, 10, 0, nint=nint, nwarm=nwarm, in_ring_integrations=int(os.environ.get("IN_RING", "4")),
+                               **(dict(long_len=40, from_slabs=True) if SLABS else {}))
 print("%.4f ms per integration, windows %s" % (res["ms_per_integration"], res["window_ms"]))
 t_warm = t_begin + 0.0
 log.sort()
