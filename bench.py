@@ -289,6 +289,8 @@ def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=4
                               for k in range(4)] if ok and (n - 1 - nwarm) >= 4 else [],
                 "slabs_scattered_after_all": {"corr": int(nfx.value), "beamform": int(nfb.value)},
                 "corracc_fused_into_dumps": bool(cacc.stats.get('fused')) and cacc.fused_dumps == n,
+                "ring_allocations": {r.name: {k: int(v) for k, v in dict(r.counters).items() if k in ("alloc", "free", "reuse", "stamp_wait")}
+                                     for r in (r_vis, r_slow, r_bf, r_pow)},
                 "note": "config5_blocks with an input ring of packet slabs (%d slabs of 5280 SNAP2 packets, %.1f GB on the device; every gulp "
                         "its own slab): the blocks hand the slabs to xengXgpuKernelAsyncSlab / xengBeamformRunSlabs, which read them in place" % (nslabs, nslabs * slab.nbytes / 1e9)}
     # (the leg in four windows: the Python threads settle into an interleaving, and not always into the same one)
