@@ -205,6 +205,8 @@ def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=4
     nt_b = 2 * NTIME_GULP
     bf = Beamform(log, r_in, r_bf, nchan=NCHAN, nbeam=nbeam, ninput=NINPUT, ntime_gulp=nt_b, gpu=gpu)
     sb = BeamformSumBeams(log, r_bf, r_pow, nchan=NCHAN, ntime_gulp=nt_b, ntime_sum=ns, gpu=gpu)
+    if os.environ.get("XENG_BENCH_VIS_SPANS"):       # (diagnosis: a deeper corr-output ring)
+        r_vis.resize(corr.ogulp_size, total_span=int(os.environ["XENG_BENCH_VIS_SPANS"]) * corr.ogulp_size)
     rng = np.random.default_rng(7)
     bf.gains_cpu[...] = (rng.uniform(-17, 17, bf.gains_cpu.shape) + 1j * rng.uniform(-17, 17, bf.gains_cpu.shape)).astype(np.complex64)
     hdr = {'nchan': NCHAN, 'chan0': 0, 'bw_hz': NCHAN * 23925.78125, 'fs_hz': 196000000, 'sfreq': 0.0, 'nstand': NSTAND, 'npol': NPOL,
