@@ -163,8 +163,8 @@ def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=4
     (hipHostMalloc: ~0.1 s each, device-wide synchronisations), which the ring then recycles.
     from_slabs: the input ring holds PACKET SLABS (5280 SNAP2 packets per 480-sample gulp, header layout 'snap2_slab') as a
     receiver -- or Snap2Ingest(unpack=False) -- leaves them; Corr and Beamform hand them to the library's slab calls, which
-    read them in place.  Every gulp of the leg is its own slab (sequence numbers advance): (nwarm + nint) x 5 x 32.6 MB on
-    the device."""
+    read them in place.  The source is a receiver's set of 64 slab buffers reused round robin, each re-stamped with its window's
+    sequence numbers before it goes out."""
     import json as _json
     import logging
     import threading
@@ -182,11 +182,12 @@ def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=4
             for b in range(nblk):
                 slab[t * nblk + b, 8:32] = np.frombuffer(struct.pack(">LHHHHLLL", 0, 64, NINPUT, NCHAN, NCHAN, 0, 0, b * 64), dtype=np.uint8)
         slab[:, 32:] = np.random.RandomState(5).randint(0, 256, size=(npk, stride - 32), dtype=np.uint8)
-        nslabs = (nwarm + nint) * gulps_per_step
+        # a receiver's set of slab buffers, reused round robin: window k lands in buffer k mod nslabs, its headers stamped with the
+        # window's sequence numbers just before it is handed on (xengSnap2StampSeq).  nslabs = the input ring (20 slabs) + what Corr
+        # (10) and Beamform (18) keep in flight + 16: nobody still reads a buffer when its turn comes again.
+        nslabs = in_ring_integrations * gulps_per_step + 44
         slab_pool = ffi.DeviceBuffer(nslabs * slab.nbytes)
-        tcol = np.repeat(np.arange(NTIME_GULP, dtype=np.uint64), nblk)
         for k in range(nslabs):
-            slab[:, :8] = (tcol + np.uint64(k * NTIME_GULP)).astype(">u8").view(np.uint8).reshape(npk, 8)
             slab_pool.upload(slab, offset=k * slab.nbytes)
         spans = [XArray(shape=(slab.nbytes,), dtype=np.uint8, space="cuda", _ptr=slab_pool.ptr + k * slab.nbytes, _base=slab_pool) for k in range(nslabs)]
         gulp_bytes, ring_gulps = slab.nbytes, nslabs
@@ -232,9 +233,14 @@ def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=4
                 total = (nwarm + nint) * gulps_per_step
                 if native_harness:
                     ptrs = np.array([sp.ptr for sp in spans], dtype=np.uint64).tobytes()
-                    r_in._x.ring_feed_external(r_in._h, oseq._seq_id, ptrs, gulp_bytes, total)
+                    if from_slabs:
+                        r_in._x.ring_feed_slabs(r_in._h, oseq._seq_id, ptrs, gulp_bytes, total, npk, stride, nblk, NTIME_GULP)
+                    else:
+                        r_in._x.ring_feed_external(r_in._h, oseq._seq_id, ptrs, gulp_bytes, total)
                 else:
                     for k in range(total):
+                        if from_slabs:
+                            ffi.call("xengSnap2StampSeq", spans[k % ring_gulps].ptr, npk, stride, k * NTIME_GULP, nblk)
                         oseq.commit_external(spans[k % ring_gulps])
 
     def drain(rg, gulp, on_span=None, times=None):
@@ -293,8 +299,8 @@ def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=4
                 "corracc_fused_into_dumps": bool(cacc.stats.get('fused')) and cacc.fused_dumps == n,
                 "ring_allocations": {r.name: {k: int(v) for k, v in dict(r.counters).items() if k in ("alloc", "free", "reuse", "stamp_wait")}
                                      for r in (r_vis, r_slow, r_bf, r_pow)},
-                "note": "config5_blocks with an input ring of packet slabs (%d slabs of 5280 SNAP2 packets, %.1f GB on the device; every gulp "
-                        "its own slab): the blocks hand the slabs to xengXgpuKernelAsyncSlab / xengBeamformRunSlabs, which read them in place" % (nslabs, nslabs * slab.nbytes / 1e9)}
+                "note": "config5_blocks with an input ring of packet slabs (a set of %d slab buffers of 5280 SNAP2 packets, %.1f GB, reused round robin and "
+                        "re-stamped per window): the blocks hand the slabs to xengXgpuKernelAsyncSlab / xengBeamformRunSlabs, which read them in place" % (nslabs, nslabs * slab.nbytes / 1e9)}
     # (the leg in four windows: the Python threads settle into an interleaving, and not always into the same one)
     wins = []
     if ok:
@@ -1232,7 +1238,7 @@ def main():
     if rank == 0 and world == 1 and args.beamform and args.blocks and not args.sync_per_call and not args.sync_per_integration:
         res["corr_block"] = corr_block_leg(ffi, ring, gulp_bytes, args.ring_gulps, gpu)
         res["config5_blocks"] = config5_blocks_leg(ffi, ring, gulp_bytes, args.ring_gulps, gpu)
-        res["config5_blocks"]["from_packet_slabs"] = config5_blocks_leg(ffi, ring, gulp_bytes, args.ring_gulps, gpu, nint=100, nwarm=100, long_len=40, from_slabs=True)
+        res["config5_blocks"]["from_packet_slabs"] = config5_blocks_leg(ffi, ring, gulp_bytes, args.ring_gulps, gpu, nint=300, nwarm=300, long_len=50, from_slabs=True)
     _leg('one call per integration')
     # outside the timed region: SURVEY 8d's other device-resident case, one 2400-sample call per integration
     # (xGPU's NTIME = acc_len; needs its own context, so it runs last)

@@ -356,3 +356,36 @@ extern "C" int xengSnap2GetAsyncDrops(int* ndropped) {
     *ndropped = *g_ingest[dev].host_async;
     return XENG_STATUS_SUCCESS;
 }
+
+// ---------------------------------------------------------------- emulator side (tests, bench): re-stamp a slab's sequence numbers
+// A receiver reuses its slab buffers: the same memory holds the packets of window k, then of window k + N.  The benchmark's
+// replay source does the same with a fixed set of slabs and needs their headers to say the new window: packet p of the slab
+// gets sequence number seq0 + p / pkts_per_seq (big-endian, first 8 bytes of the header: test_tx_vectors.py:38-48), nothing
+// else is touched.  On the copy stream, complete on return.
+namespace xeng {
+__global__ void snap2_stamp_seq_kernel(uint8_t* pkts, int npkt, size_t stride, unsigned long long seq0, int pkts_per_seq) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npkt) return;
+    const unsigned long long seq = seq0 + (unsigned long long)(p / pkts_per_seq);
+    uint8_t* h = pkts + (size_t)p * stride;
+    uint32_t hi = (uint32_t)(seq >> 32), lo = (uint32_t)seq;
+    *reinterpret_cast<uint32_t*>(h) = __builtin_bswap32(hi);
+    *reinterpret_cast<uint32_t*>(h + 4) = __builtin_bswap32(lo);
+}
+}  // namespace xeng
+
+extern "C" int xengSnap2StampSeq(void* packets_dev, int npkt, size_t pkt_stride, uint64_t seq0, int pkts_per_seq) {
+    if (!packets_dev || npkt < 0 || pkt_stride < 32 || (pkt_stride & 3) || ((uintptr_t)packets_dev & 3) || pkts_per_seq <= 0)
+        XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "Snap2StampSeq: bad arguments (npkt %d, stride %zu, packets per sequence number %d)", npkt, pkt_stride, pkts_per_seq);
+    if (npkt == 0) return XENG_STATUS_SUCCESS;
+    hipStream_t s;
+    int rc = get_stream(STREAM_COPY, &s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(xeng::snap2_stamp_seq_kernel, dim3((npkt + 255) / 256), dim3(256), 0, s, (uint8_t*)packets_dev, npkt, pkt_stride,
+                       (unsigned long long)seq0, pkts_per_seq);
+    XENG_HIP(hipGetLastError());
+    stream_tick(STREAM_COPY);
+    XENG_HIP(hipStreamSynchronize(s));
+    return XENG_STATUS_SUCCESS;
+}
+

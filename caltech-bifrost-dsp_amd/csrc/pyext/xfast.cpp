@@ -374,6 +374,35 @@ PyObject* ring_feed_external(PyObject*, PyObject* args) {
     Py_RETURN_NONE;
 }
 
+// ring_feed_slabs(h, seq, ptrs, nbytes, count, npkt, stride, pkts_per_seq, ntime): as ring_feed_external for a set of slab buffers that
+// is reused like a receiver's: before slab k goes out its headers are stamped with the sequence numbers of window k
+// (xengSnap2StampSeq), and it is not reused before `nptr` more windows have gone out -- the caller sizes the set so that nobody
+// still holds it then (ring capacity + what the readers keep in flight)
+PyObject* ring_feed_slabs(PyObject*, PyObject* args) {
+    unsigned long long h;
+    long long seq;
+    const char* pp;
+    Py_ssize_t plen, nbytes, count, stride;
+    int npkt, pkts_per_seq, ntime;
+    if (!PyArg_ParseTuple(args, "KLy#nninii", &h, &seq, &pp, &plen, &nbytes, &count, &npkt, &stride, &pkts_per_seq, &ntime)) return nullptr;
+    const Py_ssize_t nptr = plen / 8;
+    if (nptr <= 0) { PyErr_SetString(PyExc_ValueError, "no slab addresses"); return nullptr; }
+    std::vector<unsigned long long> ptrs((size_t)nptr);
+    memcpy(ptrs.data(), pp, (size_t)nptr * 8);
+    int rc = 0;
+    const char* where = "xengRingCommitExternal";
+    Py_BEGIN_ALLOW_THREADS
+    for (Py_ssize_t k = 0; k < count && !rc; k++) {
+        void* slab = (void*)(uintptr_t)ptrs[(size_t)(k % nptr)];
+        rc = xengSnap2StampSeq(slab, npkt, (size_t)stride, (uint64_t)k * (uint64_t)ntime, pkts_per_seq);
+        if (rc) { where = "xengSnap2StampSeq"; break; }
+        rc = xengRingCommitExternal((xengRing*)h, seq, slab, (size_t)nbytes, 1);
+    }
+    Py_END_ALLOW_THREADS
+    if (rc) return raise_xeng(where, rc);
+    Py_RETURN_NONE;
+}
+
 // ring_drain(h, reader, gulp, want_times) -> (spans seen, [time.perf_counter() of each span] or []): reads every sequence to its end,
 // releasing each span at once; the interpreter lock is released for the whole loop
 PyObject* ring_drain(PyObject*, PyObject* args) {
@@ -715,6 +744,7 @@ PyMethodDef methods[] = {
     {"beam_ticket_done", beam_ticket_done, METH_VARARGS, "xengBeamformTicketDone -> -status | 0 | 1"},
     {"map_i32", map_i32, METH_VARARGS, "(a, b, nwords, add) -> status"},
     {"ring_feed_external", ring_feed_external, METH_VARARGS, "harness: (handle, seq, addresses, nbytes, count) -- a source that is not a Python thread"},
+    {"ring_feed_slabs", ring_feed_slabs, METH_VARARGS, "harness: (handle, seq, addresses, nbytes, count, npkt, stride, pkts_per_seq, ntime) -- a receiver that reuses its slab buffers"},
     {"ring_drain", ring_drain, METH_VARARGS, "harness: (handle, reader, gulp, want_times) -> (spans, times) -- a sink that is not a Python thread"},
     {"beam_pump", beam_pump_new, METH_VARARGS, "(in_ring, in_handle, reader, out_ring, out_handle, out_seq, igulp, ogulp, mode, row_bytes, ntime_sum, depth, staged) -> BeamPump"},
     {"copy_async", copy_async, METH_VARARGS, "(dst, src, nbytes) -> stamp of the enqueued copy (bytes)"},

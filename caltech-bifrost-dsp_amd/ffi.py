@@ -76,7 +76,7 @@ SYMBOLS = {
     "xengXgpuPacketize": [_vp, _vp, _vp, _vp, _i],
     "xengSnap2Unpack": [_vp, _i, ctypes.c_size_t, _vp, ctypes.c_uint64, _i, _i, _i, _i, _i, _pi, _pi],
     "xengSnap2UnpackAsync": [_vp, _i, ctypes.c_size_t, _vp, ctypes.c_uint64, _i, _i, _i, _i, _i],
-    "xengSnap2GetAsyncDrops": [_pi],
+    "xengSnap2GetAsyncDrops": [_pi], "xengSnap2StampSeq": [_vp, _i, _sz, ctypes.c_uint64, _i],
     "xengXgpuSetProfiling": [_i], "xengXgpuGetTimes": [ctypes.POINTER(ctypes.c_double), _pi],
     "xengMapAssignI32": [_vp, _vp, _sz], "xengMapAddI32": [_vp, _vp, _sz], "xengMapSync": [],
     "xengBeamformInitialize": [_i, _i, _i, _i, _i, _i], "xengBeamformDestroy": [],

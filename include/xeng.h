@@ -299,6 +299,10 @@ int xengSnap2UnpackAsync(const void *packets_dev, int npkt, size_t pkt_stride, v
 /* Packets the enqueue-only calls have dropped (out of window / foreign / malformed) since this was last called; waits for
  * the staging stream and clears the count.  The synchronous call reports its own drops in *ndropped. */
 int xengSnap2GetAsyncDrops(int *ndropped);
+/* Emulator side (tests, bench): a receiver reuses its slab buffers; this re-stamps the sequence numbers of a device-resident slab
+ * for its next window -- packet p gets seq0 + p / pkts_per_seq (big-endian, header bytes 0..7), nothing else changes.  Complete
+ * on return. */
+int xengSnap2StampSeq(void *packets_dev, int npkt, size_t pkt_stride, uint64_t seq0, int pkts_per_seq);
 
 /* ---------------------------------------------------------------- CorrAcc
  * replaces bifrost.map "a = b" / "a += b" on int32 (corr_acc_block.py:304,306).  Device pointers;

@@ -44,7 +44,7 @@ for r in range(runs * len(depths)):
         gc.disable()
     n0 = [g["collections"] for g in gc.get_stats()]
     if os.environ.get("REPEAT_SLABS"):
-        res = bench.config5_blocks_leg(ffi, ring, gulp_bytes, 10, 0, nint=nint, nwarm=nwarm, long_len=40, from_slabs=True, in_ring_integrations=depths[r % len(depths)])
+        res = bench.config5_blocks_leg(ffi, ring, gulp_bytes, 10, 0, nint=nint, nwarm=nwarm, long_len=50, from_slabs=True, in_ring_integrations=depths[r % len(depths)])
         print("from slabs, input ring %2d integrations, run %d: %.4f ms per integration, windows %s, scattered %s" % (depths[r % len(depths)], r, res["ms_per_integration"], res["window_ms"], res["slabs_scattered_after_all"]),
               {k: (v["alloc"], v["stamp_wait"]) for k, v in res["ring_allocations"].items()}, flush=True)
         continue
