@@ -246,6 +246,37 @@ def test_ingest_leaves_slabs_and_corr_and_beamform_read_them_in_place():
     assert nfx.value == 2 and nfb.value == 2          # windows 2 and 5, once per consumer; the other six were read in place
 
 
+def test_stamp_seq_rewrites_the_sequence_numbers_only():
+    """xengSnap2StampSeq (the emulator's side of a receiver that reuses its slab buffers): packet p gets seq0 + p / pkts_per_seq in
+    its first eight header bytes, big-endian; every other byte of the slab is what it was; the stamped slab unpacks as the window
+    that starts at seq0."""
+    import struct
+    T, C, S = 96, 8, 64
+    rng = np.random.default_rng(4)
+    vin = rng.integers(0, 256, (T, C, S, 2), dtype=np.uint8)
+    pk = orc.snap2_packets(vin, seq0=5, sync_time=9, nchan_blocks=1, nstand_per_pkt=32, chan0_pipeline=0)
+    stride, nblk = len(pk[0]) + 32, S // 32              # (a stride with slack between the packets: the slack stays untouched too)
+    raw = np.full((len(pk), stride), 0xA5, dtype=np.uint8)
+    for i, p in enumerate(pk):
+        raw[i, :len(p)] = np.frombuffer(p, dtype=np.uint8)
+    d = ffi.DeviceBuffer(raw.nbytes).upload(raw)
+    seq0 = 10 ** 13 + 77
+    ffi.call("xengSnap2StampSeq", d.ptr, len(pk), stride, seq0, nblk)
+    got = d.download(np.uint8).reshape(len(pk), stride)
+    want = raw.copy()
+    for i in range(len(pk)):
+        want[i, :8] = np.frombuffer(struct.pack(">Q", seq0 + i // nblk), dtype=np.uint8)
+    assert np.array_equal(got, want)
+    out = ffi.DeviceBuffer(vin.size)
+    placed = ctypes.c_int()
+    ffi.call("xengSnap2Unpack", d.ptr, len(pk), stride, out.ptr, seq0, T, 0, C, S * 2, 1, ctypes.byref(placed), None)
+    assert placed.value == len(pk) and np.array_equal(out.download(np.uint8), vin.reshape(-1))
+    with pytest.raises(ffi.XengError):
+        ffi.call("xengSnap2StampSeq", d.ptr, len(pk), stride, seq0, 0)
+    d.free()
+    out.free()
+
+
 def test_unpack_async_is_ordered_before_the_contraction():
     """xengSnap2UnpackAsync + xengXgpuKernelAsync: the scatter runs on the X-engine's staging stream, so the dump's
     contraction reads complete gulps; visibilities equal the oracle on the original voltages."""
