@@ -121,14 +121,14 @@ def test_beamform_sumbeams_on_device_rings():
 
 @pytest.mark.parametrize("pump", ["1", "0"])
 def test_beamform_timed_coefficient_load_on_device_rings(pump, monkeypatch):
-    """Thirty gulps through Beamform -> BeamformSumBeams with coefficients that load at gulp 11 (beamform_block.py:416-429), on
+    """Forty gulps through Beamform -> BeamformSumBeams with coefficients that load at gulp 11 (beamform_block.py:416-429), on
     the native per-gulp loop (csrc/pyext/xfast.cpp BeamPump, which hands control back to the block when a load is pending) and
     on the Python loop (XENG_PUMP=0): zero beams before the load sample, the commanded ones from it on, every gulp against the
     oracle, power sums included; a command that arrives WHILE the pipeline runs takes effect at its load sample too."""
     import threading
     import time
     monkeypatch.setenv("XENG_PUMP", pump)
-    nchan, nstand, nbeam, g, ns, ngulp = 4, 32, 8, 96, 24, 30
+    nchan, nstand, nbeam, g, ns, ngulp = 4, 32, 8, 96, 24, 40
     ninput = nstand * 2
     rng = np.random.default_rng(0xbeef)
     vin = rng.integers(0, 256, (ngulp * g, nchan, ninput), dtype=np.uint8)
@@ -140,8 +140,8 @@ def test_beamform_timed_coefficient_load_on_device_rings(pump, monkeypatch):
     cmds, cal, delays, amps = _beam_cmds(nchan, nbeam, ninput, rng, load_sample=11 * g)
     bf.process_command_strings(cmds)
     first = bf.gains_cpu_new.copy()
-    # a second set of coefficients, commanded from another thread once the pipeline is running, to load at gulp 23
-    cmds2, _, _, _ = _beam_cmds(nchan, nbeam, ninput, np.random.default_rng(99), load_sample=23 * g)
+    # a second set of coefficients, commanded from another thread once the pipeline is running, to load at gulp 33 (far enough ahead for 500 command strings to be parsed on a busy host)
+    cmds2, _, _, _ = _beam_cmds(nchan, nbeam, ninput, np.random.default_rng(99), load_sample=33 * g)
     second = {}
 
     def late_command():
@@ -154,16 +154,16 @@ def test_beamform_timed_coefficient_load_on_device_rings(pump, monkeypatch):
     s1, s2 = Sink(r1, g * nchan * nbeam * 8), Sink(r2, (nbeam // 2) * (g // ns) * nchan * 16)
     th = threading.Thread(target=late_command, daemon=True)
     th.start()
-    # (the source paces itself so that the late command finds the pipeline between gulps 12 and 23)
-    run_blocks([bf, sb], Source(r0, [(source_header(nchan, nstand, 2, sfreq=sfreq, chan_bw=bw), vin, g * nchan * ninput)], gap=0.01), [s1, s2])
+    # (the source paces itself so that the late command finds the pipeline between gulps 12 and 33)
+    run_blocks([bf, sb], Source(r0, [(source_header(nchan, nstand, 2, sfreq=sfreq, chan_bw=bw), vin, g * nchan * ninput)], gap=0.015), [s1, s2])
     th.join(20)
     (h1, _, sp1), = s1.sequences
     (h2, _, sp2), = s2.sequences
     assert len(sp1) == ngulp and len(sp2) == ngulp
-    assert 'gains' in second and 12 * g <= second['at'] < 23 * g, second.get('at')
+    assert 'gains' in second and 12 * g <= second['at'] < 33 * g, second.get('at')
     zero = np.zeros_like(first)
     for k in range(ngulp):
-        w = zero if k < 11 else first if k < 23 else second['gains']
+        w = zero if k < 11 else first if k < 33 else second['gains']
         exp = orc.beamform(vin[k * g:(k + 1) * g], w, g, nchan, ninput, nbeam)
         got = sp1[k].view(np.complex64).reshape(exp.shape)
         assert np.max(np.abs(got - exp)) <= 1e-5 * max(np.sqrt(np.mean(np.abs(exp) ** 2)), 1e-30), k
