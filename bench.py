@@ -277,10 +277,21 @@ def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=4
     # before they wait (ffi.enqueue_lib, backend.beam_wait / xgpu_sync_lag), so a thread gives the lock up only when it really
     # has to sleep; the interpreter's switch interval stays at its default (a short one, 5e-5 s, measured 0.51-1.25 ms per
     # integration over six runs against 0.51-0.62 for the default: profiles/r03/blocks_lock_handoff.txt).
+    import gc
+    gc_mode = os.environ.get("XENG_BENCH_GC", "")           # (diagnosis: "freeze" / "off" for the duration of the leg)
+    if gc_mode == "freeze":
+        gc.collect()
+        gc.freeze()
+    elif gc_mode == "off":
+        gc.disable()
     for t in ths:
         t.start()
     for t in ths:
         t.join(300)
+    if gc_mode == "freeze":
+        gc.unfreeze()
+    elif gc_mode == "off":
+        gc.enable()
     n = len(stamps)
     ok = n > nwarm + 1
     el = (stamps[-1] - stamps[nwarm]) if ok else 0.0
