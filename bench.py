@@ -116,6 +116,10 @@ def corr_block_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=100):
     gulps_per_step = ACC_LEN // NTIME_GULP
     r0, r1 = Ring("gpu-input", space="cuda"), Ring("corr-output", space="cuda")
     r0.resize(gulp_bytes, total_span=2 * gulps_per_step * gulp_bytes)
+    # (every user of a ring declares the library streams it puts work on -- the harness's source and sink enqueue nothing -- or
+    # the ring's stamps wait for all streams: include/xeng.h xengRingDeclareStreams)
+    r0.declare_streams()
+    r1.declare_streams()
     blk = Corr(logging.getLogger("bench-corr"), r0, r1, ntime_gulp=NTIME_GULP, nchan=NCHAN, npol=NPOL, nstand=NSTAND,
                acc_len=ACC_LEN, autostartat=0, gpu=gpu)
     hdr = {'nchan': NCHAN, 'chan0': 0, 'bw_hz': NCHAN * 23925.78125, 'fs_hz': 196000000, 'sfreq': 0.0, 'nstand': NSTAND, 'npol': NPOL,
@@ -198,6 +202,7 @@ def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=4
     # kernels are in flight, which was the whole of round 3's two-integration ring -- Corr then waited for gulps, not for the GPU;
     # the spans are windows on the replay buffer, the depth costs no memory)
     r_in.resize(gulp_bytes, total_span=in_ring_integrations * gulps_per_step * gulp_bytes)
+    r_in.declare_streams()          # (the harness's source: commits windows on the replay buffer, enqueues nothing; the sinks declare in drain())
     log = logging.getLogger("bench-config5")
     corr = Corr(log, r_in, r_vis, ntime_gulp=NTIME_GULP, nchan=NCHAN, npol=NPOL, nstand=NSTAND, acc_len=ACC_LEN, autostartat=0, gpu=gpu)
     cacc = CorrAcc(log, r_vis, r_slow, nchan=NCHAN, npol=NPOL, nstand=NSTAND, acc_len=long_len * ACC_LEN, autostartat=0, gpu=gpu)
@@ -244,6 +249,7 @@ def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=4
                         oseq.commit_external(spans[k % ring_gulps])
 
     def drain(rg, gulp, on_span=None, times=None):
+        rg.declare_streams()        # (a sink that only counts spans)
         if native_harness:
             import ctypes as _ct
             rid = _ct.c_int()

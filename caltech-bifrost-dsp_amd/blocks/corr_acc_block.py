@@ -100,6 +100,31 @@ class CorrAcc(Block):
             iring.long_accumulator = self
             self._iseqs = iring.read(guarantee=True)
 
+    def shutdown(self):
+        """Give back the reader registered at construction when main() never ran (or raised before its first iteration): an
+        unstarted generator's `finally` never runs, the reader would stay open and the upstream Corr would wait for room on a
+        full ring for ever.  Idempotent; main() consumes the same generator, whose own `finally` closes the reader normally."""
+        gen, self._iseqs = self._iseqs, None
+        if gen is not None:
+            if getattr(self.iring, 'long_accumulator', None) is self:
+                self.iring.long_accumulator = None
+            close = getattr(gen, 'close', None)     # (ring.py _SequenceReader: closes the registration even if never iterated)
+            if close is not None:
+                try:
+                    close()
+                except Exception:
+                    pass
+        with self._plan_cv:
+            self._stopping = True
+            self._plan_cv.notify_all()
+
+    def __del__(self):
+        try:
+            if getattr(self, '_iseqs', None) is not None and not getattr(self, '_main_entered', False):
+                self.shutdown()
+        except Exception:
+            pass
+
     # ------------------------------------------------------------------ the gate, one step per upstream sequence / span
     def _check_compat(self, gate, upstream_acc_len, upstream_start_time):
         if upstream_acc_len and gate.acc_len % upstream_acc_len != 0:
@@ -229,6 +254,7 @@ class CorrAcc(Block):
 
     # ------------------------------------------------------------------ this block's thread
     def main(self):
+        self._main_entered = True
         cpu_affinity.set_core(self.core)
         if self.gpu != -1:
             self._bf.set_device(self.gpu)
@@ -253,6 +279,10 @@ class CorrAcc(Block):
 
             def complete():
                 try:
+                    # (the library takes the device from the calling thread: without this the copies of a pipeline on GPU 1 would
+                    # go onto GPU 0's copy stream and clock, and create a context on another pipeline's GPU)
+                    if self.gpu != -1:
+                        self._bf.set_device(self.gpu)
                     # In pieces, each waited for before the next is enqueued: one 191 MB copy keeps the copy stream and the
                     # PCIe link to itself for 3.2 ms, and BeamformSumBeams' power sums (1 MB per gulp, same stream, same link)
                     # queue up behind it -- its thread stops, bf-output fills, Beamform stops, the input ring fills, Corr

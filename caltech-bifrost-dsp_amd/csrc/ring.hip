@@ -37,6 +37,8 @@ struct Buf {
     void* ptr = nullptr;
     size_t nbytes = 0;
     int space = XENG_SPACE_SYSTEM;
+    int dev = -1;                    // device the allocation belongs to (device / pinned spaces): its stamps are taken and polled THERE,
+                                     // whatever device is current on the thread that happens to drop the last reference
     bool owned = true;               // false: the caller's memory (xengRingCommitExternal), never freed or pooled here
     RingCore* ring = nullptr;        // (holds a reference on the ring)
     Stamp stamp;                     // library clocks at the moment the last user let go
@@ -89,7 +91,12 @@ struct RingCore {
     xengRingStampWaitFn hook_wait = nullptr;
     void* hook_user = nullptr;
     bool recycle_system = false;     // system space: recycle span memory like the device spaces do (default: fresh zeroed memory per span)
-    unsigned stream_mask = 0;        // stream classes the ring's blocks have declared (0: none declared -> a stamp waits for all)
+    unsigned stream_mask = 0;        // union of the stream classes the ring's users have declared (xengRingDeclareStreams)
+    // A stamp is narrowed to stream_mask only while EVERY user of the ring has declared: `declared` counts declarations, `users`
+    // counts the readers ever opened plus the writer (its first sequence).  One user that never declared -- a duck-typed block, a
+    // test reader with kernels of its own -- and every stamp of the ring waits for all streams again.
+    std::atomic<unsigned> declared{0}, users{0};
+    bool writer_seen = false;        // (under mu)
     std::atomic<size_t> owned_bytes{0};      // span allocations the ring owns, in the free list or out
     // statistics
     std::atomic<unsigned long long> n_alloc{0}, n_free{0}, n_reuse{0}, n_stamp_wait{0}, n_skipped{0};
@@ -128,11 +135,18 @@ static void raw_free(int space, void* p) {
     else (void)xengFree(p, space);
 }
 
+// the classes a stamp of this ring waits for: the declared union while every user has declared, else everything
+static unsigned effective_mask(const RingCore* r) {
+    const unsigned m = r->stream_mask;
+    if (!m || r->declared.load() < r->users.load()) return (unsigned)STAMP_ALL;
+    return m;
+}
+
 static void buf_stamp(Buf* b) {
     RingCore* r = b->ring;
     if (r->hook_now) r->hook_now(r->hook_user, b->hook_stamp);
     else if (b->space != XENG_SPACE_SYSTEM) {
-        (void)stamp_now(&b->stamp, b->ptr, r->stream_mask ? r->stream_mask : (unsigned)STAMP_ALL);
+        (void)stamp_now(&b->stamp, b->ptr, effective_mask(r), b->dev);
     }
 }
 
@@ -253,6 +267,7 @@ static int buf_obtain(RingCore* r, size_t nbytes, int may_block, Buf** out) {
     if (rc) return rc;
     Buf* b = new Buf();
     b->ptr = p; b->nbytes = nbytes; b->space = r->space; b->ring = r;
+    if (r->space != XENG_SPACE_SYSTEM && hipGetDevice(&b->dev) != hipSuccess) { (void)hipGetLastError(); b->dev = -1; }
     r->refs.fetch_add(1);
     r->n_alloc++;
     r->owned_bytes += nbytes;
@@ -403,6 +418,15 @@ int xengRingDeclareStreams(xengRing* ring, unsigned classes) {
     RING_ARG(ring);
     std::lock_guard<std::mutex> lk(r->pool_mu);
     r->stream_mask |= classes & (STAMP_ALL | STAMP_XGPU_OUT);
+    r->declared.fetch_add(1);          // one declaration per user (classes may be 0: a user that enqueues nothing on the spans)
+    return XENG_STATUS_SUCCESS;
+}
+
+int xengRingGetStampClasses(xengRing* ring, unsigned* classes, unsigned* declared, unsigned* users) {
+    RING_ARG(ring);
+    if (classes) *classes = effective_mask(r);
+    if (declared) *declared = r->declared.load();
+    if (users) *users = r->users.load();
     return XENG_STATUS_SUCCESS;
 }
 
@@ -452,6 +476,7 @@ int xengRingBeginSequence(xengRing* ring, long long time_tag, const void* header
     std::lock_guard<std::mutex> lk(r->mu);
     if (r->destroyed) XENG_FAIL(XENG_STATUS_INVALID_STATE, "ring '%s' was destroyed", r->name.c_str());
     if (r->open_seq) r->open_seq->ended = true;
+    if (!r->writer_seen) { r->writer_seen = true; r->users.fetch_add(1); }
     std::unique_ptr<Seq> s(new Seq());
     s->index = r->nseq++;
     s->time_tag = time_tag;
@@ -552,6 +577,7 @@ int xengRingOpenReader(xengRing* ring, int guarantee, int* reader) {
     Reader& rd = r->readers[k];
     rd = Reader();
     rd.open = true;
+    r->users.fetch_add(1);
     rd.guarantee = guarantee != 0;
     // A reader that registers late starts at the oldest sequence that still holds data (or is still being written), as
     // a bifrost reader opens the earliest sequence in the ring -- never at data that is gone.
@@ -677,6 +703,12 @@ static int acquire_common(xengRing* ring, int reader, size_t advance, size_t gul
         }
         if (nparts) *nparts = (int)pieces.size();
         return XENG_STATUS_SUCCESS;
+    }
+    if (!may_block) {
+        // the gathered copy may wait for span memory and copies synchronously: not with the caller's interpreter lock held.  The
+        // cursor has moved on already; the caller asks again with advance = 0 and may_block = 1 (xfast.cpp: ask first, then wait).
+        for (Chunk& c : pieces) buf_release(c.buf);
+        return XENG_STATUS_WOULD_BLOCK;
     }
     *nbytes = n;
     if (nparts) *nparts = 1;

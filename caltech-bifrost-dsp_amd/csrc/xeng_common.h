@@ -65,7 +65,7 @@ struct Stamp {
     unsigned long long xgpu_launch = 0, xgpu_ctx = 0;               // contractions enqueued so far (each owns a completion event: none is recorded for a stamp)
     bool xgpu_exact = false;                                        // xgpu_launch is the one launch that writes the buffer (STAMP_XGPU_OUT)
 };
-int stamp_now(Stamp* s, const void* buf = nullptr, unsigned mask = STAMP_ALL);
+int stamp_now(Stamp* s, const void* buf = nullptr, unsigned mask = STAMP_ALL, int of_dev = -1);    // of_dev < 0: the calling thread's current device
 // *done: every clock has passed; *waitable false: it waits for a launch nobody has enqueued yet (only its enqueuer can end that wait)
 int stamp_poll(const Stamp& s, bool* done, bool* waitable);
 int stamp_wait(const Stamp& s);                                     // blocks (event waits happen outside every library lock)

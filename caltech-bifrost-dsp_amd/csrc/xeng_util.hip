@@ -199,14 +199,17 @@ static unsigned class_of(int stream) {
     }
 }
 
-int stamp_now(Stamp* s, const void* buf, unsigned mask) {
+int stamp_now(Stamp* s, const void* buf, unsigned mask, int of_dev) {
     *s = Stamp();
     s->mask = mask;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) {
+    // of_dev: the device whose clocks are read (a ring buffer's own device: the thread that drops the last reference -- a helper
+    // thread, a finaliser, teardown -- may have another device current, and that device's clocks say nothing about this memory)
+    int dev = of_dev;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) {
         (void)hipGetLastError();
         return XENG_STATUS_SUCCESS;                // no device: nothing can be in flight
     }
+    if (dev < 0 || dev >= MAXDEV) return XENG_STATUS_SUCCESS;
     s->dev = dev;
     for (int k = 0; k < STREAM_COUNT; k++) s->clk[k] = g_clock[dev][k].enq.load(std::memory_order_acquire);
     xgpu_pending_launch(&s->xgpu_seq, &s->xgpu_epoch, &s->xgpu_launch, &s->xgpu_ctx);

@@ -52,7 +52,7 @@ _ll, _pll, _psz, _pvp = ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong), ct
 _pst = ctypes.POINTER(XengStamp)
 SYMBOLS = {
     "xengStampNow": [_pst], "xengStampNowFor": [_pst, _vp, ctypes.c_uint], "xengStampDone": [_pst, _pi, _pi], "xengStampWait": [_pst],
-    "xengRingCreate": [_pvp, ctypes.c_char_p, _i], "xengRingDestroy": [_vp], "xengRingResize": [_vp, _sz, _sz], "xengRingSetRecycle": [_vp, _i], "xengRingDeclareStreams": [_vp, ctypes.c_uint],
+    "xengRingCreate": [_pvp, ctypes.c_char_p, _i], "xengRingDestroy": [_vp], "xengRingResize": [_vp, _sz, _sz], "xengRingSetRecycle": [_vp, _i], "xengRingDeclareStreams": [_vp, ctypes.c_uint], "xengRingGetStampClasses": [_vp, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint)],
     "xengRingGetInfo": [_vp, _psz, _psz, _psz, _pi, _pll, ctypes.POINTER(ctypes.c_ulonglong)],
     "xengRingBeginSequence": [_vp, _ll, ctypes.c_char_p, _sz, _i, _pll], "xengRingEndSequence": [_vp, _ll], "xengRingEndWriting": [_vp],
     "xengRingReserve": [_vp, _ll, _sz, _i, _i, _pvp, _pll], "xengRingCommit": [_vp, _ll, _ll, _sz],
@@ -131,7 +131,7 @@ ENQUEUE_ONLY = ["xengXgpuTryKernelAsyncAcc", "xengXgpuTryKernelAsyncSlab", "xeng
                 "xengRingBeginSequence", "xengRingEndSequence", "xengRingEndWriting", "xengRingReserve", "xengRingCommit",
                 "xengRingCommitExternal", "xengRingNextSequence", "xengRingAcquire", "xengRingAcquireParts", "xengRingSpanRelease", "xengRingGetInfo",
                 "xengRingOpenReader", "xengRingCloseReader", "xengRingResize",
-                "xengStampNow", "xengStampNowFor", "xengStampDone"]
+                "xengStampNow", "xengStampNowFor", "xengStampDone", "xengGetDevice", "xengSetDevice"]
 _enq = None
 
 

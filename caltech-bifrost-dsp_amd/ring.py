@@ -53,12 +53,30 @@ def _stream_mask(classes):
 
 class LibraryStamps:
     """Stamps from libxeng's stream clocks (xengStampNow / Done / Wait): the source every device / pinned ring uses.
-    `mask`: the stream classes the ring's blocks have declared (0: none yet -> wait for all)."""
+    `mask`: the union of the stream classes the ring's users have declared; it narrows a stamp only while EVERY user has
+    declared (`declared` >= `users`: readers ever opened + the writer) -- one user that never did, and a stamp waits for all
+    streams again (include/xeng.h xengRingDeclareStreams)."""
     mask = 0
+    declared = 0
+    users = 0
 
-    def now(self, ptr=None):
+    def effective_mask(self):
+        return self.mask if (self.mask and self.declared >= self.users) else 0
+
+    def now(self, ptr=None, dev=None):
+        """`dev`: the device the memory belongs to -- its clocks are the ones that count, whatever device is current on the thread
+        that happens to drop the last reference (a helper thread, a finaliser)."""
         s = ffi.XengStamp()
-        ffi.check("xengStampNowFor", ffi.enqueue_lib().xengStampNowFor(ctypes.byref(s), ptr, self.mask))
+        L = ffi.enqueue_lib()
+        cur = ctypes.c_int(-1)
+        switch = dev is not None and dev >= 0 and L.xengGetDevice(ctypes.byref(cur)) == 0 and cur.value != dev
+        if switch:
+            L.xengSetDevice(dev)
+        try:
+            ffi.check("xengStampNowFor", L.xengStampNowFor(ctypes.byref(s), ptr, self.effective_mask()))
+        finally:
+            if switch:
+                L.xengSetDevice(cur.value)
         return s
 
     def done(self, s):
@@ -74,10 +92,11 @@ class LibraryStamps:
 class _Allocation:
     """One span allocation of a PyRing in a device / pinned space: raw address + size, no finaliser of its own (the ring's
     free list holds these; only `_SpanOwner.__del__` and the ring's teardown ever free one, both behind the stamp)."""
-    __slots__ = ("ptr", "nbytes", "space", "stamp", "keep")
+    __slots__ = ("ptr", "nbytes", "space", "stamp", "keep", "dev")
 
-    def __init__(self, ptr, nbytes, space, keep=None):
+    def __init__(self, ptr, nbytes, space, keep=None, dev=None):
         self.ptr, self.nbytes, self.space, self.stamp, self.keep = ptr, nbytes, space, None, keep      # keep: numpy memory behind a system-space allocation
+        self.dev = dev             # device the allocation was made on (device / pinned spaces)
 
 
 def _free_allocation(a, stamps):
@@ -118,6 +137,43 @@ class _SpanOwner:
         try:
             self.ring._pool_put(a)
         except Exception:          # interpreter shutdown: the process is going away with its allocations
+            pass
+
+
+class _SequenceReader:
+    """What `ring.read()` returns: the iterator over sequences plus the reader registration it stands for.  The registration is
+    given back when the iteration ends, on close(), or when the object dies -- also when it was NEVER started (a generator that
+    never ran has no `finally` to run: a block that registers its reader at construction and is torn down before main() would
+    leave a guaranteed reader behind that blocks the ring's writer for ever)."""
+
+    def __init__(self, gen, close_reader):
+        self._gen, self._close_reader = gen, close_reader
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        try:
+            return next(self._gen)
+        except BaseException:
+            self.close()
+            raise
+
+    def close(self):
+        gen, self._gen = self._gen, None
+        cr, self._close_reader = self._close_reader, None
+        if gen is not None:
+            try:
+                gen.close()
+            except Exception:
+                pass
+        if cr is not None:
+            cr()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
             pass
 
 
@@ -353,6 +409,18 @@ class PyRing:
         calls accumulate): a released span then waits for those only (include/xeng.h xengRingDeclareStreams)."""
         if isinstance(self._stamps, LibraryStamps):
             self._stamps.mask |= _stream_mask(classes)
+            self._stamps.declared += 1
+
+    def _count_user(self):
+        if isinstance(self._stamps, LibraryStamps):
+            self._stamps.users += 1
+
+    def stamp_classes(self):
+        """(classes a span released now would wait for -- 31 = all --, declarations made, users seen)"""
+        st = self._stamps
+        if not isinstance(st, LibraryStamps):
+            return 31, 0, 0
+        return (st.effective_mask() or 31), st.declared, st.users
 
     def __del__(self):
         try:
@@ -411,7 +479,8 @@ class PyRing:
             else:
                 buf = ffi.DeviceBuffer(max(nbytes, 1), _SPACE_ID[self.space])
                 ffi.call("xengMemset", buf.ptr, 0, max(nbytes, 1))
-                a = _Allocation(buf.ptr, nbytes, self.space)
+                cur = ctypes.c_int(-1)
+                a = _Allocation(buf.ptr, nbytes, self.space, dev=cur.value if ffi.enqueue_lib().xengGetDevice(ctypes.byref(cur)) == 0 else None)
                 buf.ptr = None                    # (the allocation is the ring's now: DeviceBuffer.__del__ must never free it)
         return XArray(shape=(nbytes,), dtype=np.uint8, space=self.space, _ptr=a.ptr, _base=_SpanOwner(self, a))
 
@@ -419,7 +488,7 @@ class PyRing:
         """The last user of a span allocation has let go: stamp it and keep it for reuse (up to the ring's capacity in bytes;
         beyond that it is really freed, behind its stamp)."""
         if self._stamps is not None:
-            a.stamp = self._stamps.now(a.ptr) if isinstance(self._stamps, LibraryStamps) else self._stamps.now()
+            a.stamp = self._stamps.now(a.ptr, a.dev) if isinstance(self._stamps, LibraryStamps) else self._stamps.now()
         with self._pool_lock:
             # (one bound for what the ring may own: really freed only past it -- steady state neither allocates nor frees)
             if not self._dead and (self._owned_bytes <= 8 * max(self._capacity, 2 * a.nbytes) or self._stamps is None or not isinstance(self._stamps, LibraryStamps)):
@@ -443,6 +512,8 @@ class PyRing:
         with self._cond:
             if self._open_seq is not None and not self._open_seq.ended:
                 self._open_seq.ended = True
+            if not self._seqs:
+                self._count_user()          # (the writer)
             seq = _Sequence(self, len(self._seqs), time_tag, header, nringlet)
             self._seqs.append(seq)
             self._open_seq = seq
@@ -560,6 +631,7 @@ class PyRing:
         next()), so data written between the call and the first iteration is kept for it.  A reader that registers late
         starts at the oldest sequence that still holds data or is still being written -- never at data that is gone."""
         rd = _Reader(guarantee)
+        self._count_user()
         with self._cond:
             rd.seq_index = len(self._seqs)
             for seq in self._seqs[self._gc_seq:]:
@@ -567,28 +639,29 @@ class PyRing:
                     rd.seq_index = seq.index
                     break
             self._readers.append(rd)
-        return self._read_sequences(rd)
+        return _SequenceReader(self._read_sequences(rd), lambda: self._close_reader(rd))
+
+    def _close_reader(self, rd):
+        with self._cond:
+            if rd in self._readers:
+                self._readers.remove(rd)
+                self._gc()
+            self._cond.notify_all()
 
     def _read_sequences(self, rd):
-        try:
-            while True:
-                with self._cond:
-                    while len(self._seqs) <= rd.seq_index and not self._writing_ended:
-                        self._cond.wait(0.5)
-                    if len(self._seqs) <= rd.seq_index:
-                        return
-                    seq = self._seqs[rd.seq_index]
-                    rd.offset = 0
-                yield ReadSequence(seq, rd)
-                with self._cond:
-                    rd.seq_index += 1
-                    rd.offset = 0
-                    self._gc()
-                    self._cond.notify_all()
-        finally:
+        while True:
             with self._cond:
-                if rd in self._readers:
-                    self._readers.remove(rd)
+                while len(self._seqs) <= rd.seq_index and not self._writing_ended:
+                    self._cond.wait(0.5)
+                if len(self._seqs) <= rd.seq_index:
+                    return
+                seq = self._seqs[rd.seq_index]
+                rd.offset = 0
+            yield ReadSequence(seq, rd)
+            with self._cond:
+                rd.seq_index += 1
+                rd.offset = 0
+                self._gc()
                 self._cond.notify_all()
 
 
@@ -791,6 +864,12 @@ class NativeRing:
         calls accumulate): a released span then waits for those only (include/xeng.h xengRingDeclareStreams)."""
         ffi.call("xengRingDeclareStreams", self._h, _stream_mask(classes))
 
+    def stamp_classes(self):
+        """(classes a span released now would wait for -- 31 = all --, declarations made, users seen)"""
+        c, d, u = ctypes.c_uint(), ctypes.c_uint(), ctypes.c_uint()
+        ffi.call("xengRingGetStampClasses", self._h, ctypes.byref(c), ctypes.byref(d), ctypes.byref(u))
+        return c.value, d.value, u.value
+
     def set_recycle(self, on=True):
         """System-space ring: recycle released span memory (no zero fill per span), as the device / pinned rings always do."""
         ffi.call("xengRingSetRecycle", self._h, int(bool(on)))
@@ -811,19 +890,20 @@ class NativeRing:
         # (registered without giving up the interpreter lock: a reader thread that has just been started is registered before
         # the thread that started it runs on, as with the Python ring)
         ffi.check("xengRingOpenReader", self._enq.xengRingOpenReader(self._h, int(bool(guarantee)), ctypes.byref(rid)))
-        return self._read_sequences(rid.value)
+        rid = rid.value
+        return _SequenceReader(self._read_sequences(rid), lambda: self._close_reader(rid))
+
+    def _close_reader(self, rid):
+        if self._h:
+            self._enq.xengRingCloseReader(self._h, rid)
 
     def _read_sequences(self, rid):
         nxt = self._x.ring_next_sequence
-        try:
-            while True:
-                got = nxt(self._h, rid)
-                if got is None:
-                    return
-                yield _NReadSequence(self, rid, _Header(got[0]), got[1], got[2])
-        finally:
-            if self._h:
-                self._enq.xengRingCloseReader(self._h, rid)
+        while True:
+            got = nxt(self._h, rid)
+            if got is None:
+                return
+            yield _NReadSequence(self, rid, _Header(got[0]), got[1], got[2])
 
 
 def Ring(name="", space="system", core=None):

@@ -123,11 +123,16 @@ typedef struct xengRing_ xengRing;
 int xengRingCreate(xengRing **ring, const char *name, int space);
 int xengRingDestroy(xengRing *ring);     /* wakes every waiter; spans still referenced stay valid until released */
 int xengRingResize(xengRing *ring, size_t contig_bytes, size_t total_span);        /* ring.resize(): capacity in bytes (0: 4 x contig) */
-/* Which of the library's streams touch this ring's spans (XENG_STREAMS_*; calls accumulate).  Until somebody declares, a
- * released span waits for everything the library had enqueued; the blocks declare what they use -- the beamformer's rings
- * XENG_STREAMS_BEAM, Corr's XENG_STREAMS_XGPU ... -- so that a beam span is not held back by the 200 us contraction that
- * happened to be enqueued before its release. */
+/* Which of the library's streams touch this ring's spans (XENG_STREAMS_*; calls accumulate).  Every USER of a ring -- its
+ * writer and each of its readers -- calls this exactly once (classes may be 0: a user that enqueues nothing on the spans, e.g.
+ * a host reader whose copies are complete when it lets go).  A released span waits for the declared union -- the beamformer's
+ * rings XENG_STREAMS_BEAM, Corr's XENG_STREAMS_XGPU ... -- so that a beam span is not held back by the 200 us contraction that
+ * happened to be enqueued before its release; but ONLY while every user has declared: the ring counts the readers it has ever
+ * opened plus its writer, and as long as there are more of those than declarations (a block that does not know the call, a
+ * test reader with kernels of its own) every stamp waits for everything the library had enqueued, as on an undeclared ring. */
 int xengRingDeclareStreams(xengRing *ring, unsigned classes);
+/* the classes a span released now would wait for (XENG_STREAMS_* union, or all of them), declarations made, users seen */
+int xengRingGetStampClasses(xengRing *ring, unsigned *classes, unsigned *declared, unsigned *users);
 /* system-space rings hand out fresh zero-filled memory per span by default; on != 0 recycles released spans as the device /
  * pinned rings always do (contents: whatever the last user left, as in a circular bifrost ring) */
 int xengRingSetRecycle(xengRing *ring, int on);

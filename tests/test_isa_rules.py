@@ -95,3 +95,46 @@ def test_rule_matches_the_failing_instruction():
                "v_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7] op_sel:[0,0,1]",
                "v_pk_add_f32 v[10:11], v[10:11], v[28:29]"):
         assert not BAD_PK.search(ok), ok
+
+
+# ---- Rule 2 (round 5; DESIGN.md 4.7, profiles/r04/pmc_fault_diagnosis.txt): no bare hipMemset / hipMemsetD* in the library's
+# sources.  hipMemset returns before its fill has run, and the library's streams are non-blocking (they do not wait for the null
+# stream): a kernel enqueued right after such a call can write the buffer first and lose its words to the late fill -- the GPU
+# fault of round 4 (null descriptor base under rocprofv3 --pmc).  Initialisation-time fills go through hip_memset_now
+# (xeng_common.h: fill + wait); fills on a library stream use hipMemsetAsync on THAT stream.  A source rule, because a twelfth
+# bare call compiles and passes every test.
+CSRC = os.path.join(ROOT, "caltech-bifrost-dsp_amd", "csrc")
+BARE_MEMSET = re.compile(r"\bhipMemset(?:D8|D16|D32|2D|3D)?\s*\(")
+
+
+def _strip_comments(text):
+    text = re.sub(r"/\*.*?\*/", lambda m: "\n" * m.group(0).count("\n"), text, flags=re.S)
+    return re.sub(r"//[^\n]*", "", text)
+
+
+def test_no_bare_hipmemset_in_library_sources():
+    bad, seen_helper = [], False
+    for dirpath, _, files in os.walk(CSRC):
+        for f in files:
+            if not f.endswith((".hip", ".h", ".cpp", ".hpp")):
+                continue
+            path = os.path.join(dirpath, f)
+            lines = _strip_comments(open(path).read()).split("\n")
+            inside_helper = False
+            for no, line in enumerate(lines, 1):
+                if "hip_memset_now(void*" in line.replace(" *", "*"):
+                    inside_helper, seen_helper = True, True
+                if BARE_MEMSET.search(line) and not inside_helper:
+                    bad.append("%s:%d: %s" % (os.path.relpath(path, ROOT), no, line.strip()))
+                if inside_helper and line.startswith("}"):
+                    inside_helper = False
+    assert seen_helper, "hip_memset_now (xeng_common.h) not found: the rule has lost its anchor"
+    assert not bad, "bare hipMemset outside hip_memset_now (returns before the fill has run; see DESIGN.md 4.7):\n" + "\n".join(bad)
+
+
+def test_memset_rule_matches():
+    assert BARE_MEMSET.search("    XENG_HIP(hipMemset(p, 0, n));")
+    assert BARE_MEMSET.search("hipMemsetD32 (p, 0, n)")
+    assert not BARE_MEMSET.search("XENG_HIP(hipMemsetAsync(dst, value, nbytes, s));")
+    assert not BARE_MEMSET.search("XENG_HIP(hip_memset_now(p, 0, n));")
+    assert not BARE_MEMSET.search(_strip_comments("// hipMemset(p, 0, n) returns early\nint x; /* hipMemset( */"))

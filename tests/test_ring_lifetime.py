@@ -266,3 +266,108 @@ def test_library_stamps_without_a_device():
     s = src.now()
     assert src.done(s) == (True, True)
     src.wait(s)
+
+
+# ---------------------------------------------------------------- round 5 (review W2/W3)
+def test_a_reader_that_was_registered_but_never_iterated_is_given_back(ring_impl):
+    """`ring.read()` registers the reader at the call.  A block that registers at construction (CorrAcc) and is torn down before
+    main() ever runs must not leave a guaranteed reader behind: the writer would wait for room for ever."""
+    r = Ring(name="never-started", space="system")
+    r.resize(8, 16)                          # room for two spans
+    gen = r.read(guarantee=True)
+    assert len(r._readers) == 1
+    del gen                                  # never iterated: no generator `finally` runs -- the registration object closes the reader
+    gc.collect()
+    assert len(r._readers) == 0
+    gen2 = r.read(guarantee=True)
+    gen2.close()                             # ... and so does an explicit close() (CorrAcc.shutdown)
+    assert len(r._readers) == 0
+    done = []
+
+    def writer():
+        with r.begin_writing() as w:
+            with w.begin_sequence(time_tag=0, header="{}") as oseq:
+                for k in range(6):           # three times the ring: would block behind a guaranteed reader that never reads
+                    with oseq.reserve(8) as sp:
+                        sp.data.numpy()[...] = k
+        done.append(True)
+
+    th = threading.Thread(target=writer, daemon=True)
+    th.start()
+    th.join(10)
+    assert done == [True]
+
+
+def test_a_span_released_from_a_foreign_thread_keeps_its_stamp(ring_impl):
+    """The last reference of a span may be dropped by any thread -- a publish helper, the collector, teardown.  The stamp is taken
+    at that moment, by that thread, and the allocation still is not reissued before the stamp completes."""
+    tk = FakeTickets()
+    r = Ring(name="foreign", space="system")
+    r.resize(64, 256)
+    r.set_stamp_source(tk)
+    gen = r.read(guarantee=True)
+    with r.begin_writing() as w:
+        with w.begin_sequence(time_tag=0, header="{}") as oseq:
+            with oseq.reserve(64) as sp:
+                addr = sp.data.ptr
+            del sp
+    held = []
+    for iseq in gen:
+        for ispan in iseq.read(64):
+            held.append(ispan.data)
+        del ispan
+    del iseq, gen
+    t1 = tk.issue()                          # "a kernel that reads the span" is enqueued ...
+
+    def foreign():
+        held.clear()                         # ... and a thread that never touched the ring drops the last reference
+        gc.collect()
+
+    th = threading.Thread(target=foreign)
+    th.start()
+    th.join()
+    got = []
+
+    def writer():
+        with r.begin_writing() as w:
+            with w.begin_sequence(time_tag=1, header="{}") as oseq:
+                sp = oseq.reserve(64)
+                got.append(sp.data.ptr)
+                sp.close()
+
+    th = threading.Thread(target=writer, daemon=True)
+    th.start()
+    time.sleep(0.3)
+    assert not got and tk.waits == [t1]
+    tk.complete(t1)
+    th.join(10)
+    assert got == [addr]
+
+
+def test_declared_streams_narrow_a_stamp_only_while_every_user_has_declared(ring_impl):
+    """xengRingDeclareStreams: one user of the ring that never declared (a duck-typed block, a test reader with kernels of its
+    own) and every stamp waits for all streams again -- a declaration by the others must not uncover its spans."""
+    import pytest
+    from caltech_bifrost_dsp_amd import ffi
+    if ring_impl == "python":
+        n = __import__("ctypes").c_int(-1)
+        if not (ffi.lib().xengGetDeviceCount(__import__("ctypes").byref(n)) == 0 and n.value > 0):
+            pytest.skip("the Python ring keeps library stamps only in the device spaces: needs a GPU")
+    ALL, BEAM = 31, ffi.STREAMS["beam"]
+    r = Ring(name="decl", space="system" if ring_impl == "native" else "cuda")
+    assert r.stamp_classes() == (ALL, 0, 0)
+    r.declare_streams("beam")                # the writer's block
+    w = r.begin_writing()
+    oseq = w.begin_sequence(time_tag=0, header="{}")
+    assert r.stamp_classes() == (BEAM, 1, 1)
+    g1 = r.read(guarantee=True)              # a reader whose block has not declared
+    assert r.stamp_classes() == (ALL, 1, 2)
+    r.declare_streams("beam")                # ... now it has
+    assert r.stamp_classes() == (BEAM, 2, 2)
+    g2 = r.read(guarantee=False)             # a second, undeclared reader (a test sink, a third-party block)
+    assert r.stamp_classes() == (ALL, 2, 3)
+    r.declare_streams()                      # a host-only user declares "no streams"
+    assert r.stamp_classes() == (BEAM, 3, 3)
+    g1.close(); g2.close()
+    oseq.end()
+    w.__exit__(None, None, None)
