@@ -89,7 +89,8 @@ def config5_check(verify, first_int, gulps):
     from oracle import xeng_oracle as orc
     chk = {"visibilities_bit_exact": bool(np.array_equal(verify["vis"], first_int)),
            "corracc_sum_bit_exact": bool(verify.get("corracc") is None or np.array_equal(verify["corracc"], 3 * first_int.astype(np.int64))),
-           "corracc_fused_in_dump_bit_exact": bool(np.array_equal(verify["corracc_fused"], 3 * first_int.astype(np.int64)))}
+           "corracc_fused_in_dump_bit_exact": bool(verify.get("corracc_fused") is None or np.array_equal(verify["corracc_fused"], 3 * first_int.astype(np.int64))),
+           "corracc_grouped_bit_exact": bool(verify.get("corracc_grouped") is None or np.array_equal(verify["corracc_grouped"], 3 * first_int.astype(np.int64)))}
     nt_b, nb = verify["beams"].shape[2], verify["beams"].shape[1]
     v2 = np.concatenate([gulps[0], gulps[1]]).reshape(nt_b, NCHAN, NINPUT)
     exp = orc.beamform(v2, verify["weights"].reshape(NCHAN, nb, NINPUT), nt_b, NCHAN, NINPUT, nb)
@@ -100,7 +101,7 @@ def config5_check(verify, first_int, gulps):
     chk["power_beams_max_err_over_max"] = float(np.max(np.abs(verify["power"] - pexp)) / np.abs(pexp).max())
     chk["power_beams_ok"] = bool(chk["power_beams_max_err_over_max"] <= 1e-5)
     chk["ok"] = bool(chk["visibilities_bit_exact"] and chk["corracc_sum_bit_exact"] and chk["corracc_fused_in_dump_bit_exact"] and
-                     chk["beams_within_1e-5"] and chk["power_beams_ok"])
+                     chk["corracc_grouped_bit_exact"] and chk["beams_within_1e-5"] and chk["power_beams_ok"])
     return chk
 
 
@@ -313,7 +314,7 @@ def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=4
                 "window_ms": [round((stamps[nwarm + (k + 1) * ((n - 1 - nwarm) // 4)] - stamps[nwarm + k * ((n - 1 - nwarm) // 4)]) / ((n - 1 - nwarm) // 4) * 1e3, 4)
                               for k in range(4)] if ok and (n - 1 - nwarm) >= 4 else [],
                 "slabs_scattered_after_all": {"corr": int(nfx.value), "beamform": int(nfb.value)},
-                "corracc_fused_into_dumps": bool(cacc.stats.get('fused')) and cacc.fused_dumps == n,
+                "corracc_mode": "fused" if cacc.stats.get('fused') else ("grouped, %d dumps per pass" % cacc.group_dumps) if cacc.stats.get('grouped') else "map",
                 "ring_allocations": {r.name: {k: int(v) for k, v in dict(r.counters).items() if k in ("alloc", "free", "reuse", "stamp_wait")}
                                      for r in (r_vis, r_slow, r_bf, r_pow)},
                 "note": "config5_blocks with an input ring of packet slabs (a set of %d slab buffers of 5280 SNAP2 packets, %.1f GB, reused round robin and "
@@ -325,12 +326,12 @@ def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=4
         wins = [round((stamps[nwarm + (k + 1) * q] - stamps[nwarm + k * q]) / q * 1e3, 4) for k in range(4)] if q > 0 else []
     return {"value": round(8 * NINPUT * ACC_LEN * NCHAN * (n - 1 - nwarm) / el / 1e9, 1) if ok else 0.0, "unit": "Gb/s",
             "ms_per_integration": round(el / max(n - 1 - nwarm, 1) * 1e3, 4) if ok else None, "integrations": n, "window_ms": wins,
-            "long_integrations_published": nslow[0], "corracc_fused_into_dumps": bool(cacc.stats.get('fused')) and cacc.fused_dumps == n,
+            "long_integrations_published": nslow[0], "corracc_mode": "fused" if cacc.stats.get('fused') else ("grouped, %d dumps per pass" % cacc.group_dumps) if cacc.stats.get('grouped') else "map",
             # span allocations per ring over the whole leg: made, really freed, reissued from the free list, waits for a stamp at reissue
             "ring_allocations": {r.name: {k: int(v) for k, v in dict(r.counters).items() if k in ("alloc", "free", "reuse", "stamp_wait")}
                                  for r in (r_vis, r_slow, r_bf, r_pow)},
-            "note": "config 5 through the blocks on one GPU: Corr -> CorrAcc (%d dumps per long integration, accumulated by the "
-                    "dumps' epilogue; published to a pinned-host ring) and Beamform (960-sample gulps = two input spans per call) -> BeamformSumBeams, four "
+            "note": "config 5 through the blocks on one GPU: Corr -> CorrAcc (%d dumps per long integration, the spans of every ten summed in one "
+                    "pass; published to a pinned-host ring) and Beamform (960-sample gulps = two input spans per call) -> BeamformSumBeams, four "
                     "Python threads on in-repo rings, zero-copy replay source; wall rate between visibility spans at a sink" % long_len}
 
 
@@ -352,9 +353,9 @@ def config5_workload(args, ffi, dist, rank, world, gpu, ring, gulp_bytes, pin, i
     """`--workload config5`: BASELINE config 5 as N ranks run it -- "Full X-engine: corner-turn + Corr + CorrAcc long-accum +
     Beamform concurrent on HIP streams, 704 inputs, 768 chan across 8 GPUs" (lwa352-start-pipeline.sh:1-8: one pipeline
     process per channel block).  Every rank runs, on its own GPU and its own 96 channels (chan0 = 96 * rank, input seed
-    0xdeadbeef + rank): per 2400-sample integration five gulps registered in place + one fused contraction whose epilogue
-    also feeds CorrAcc's long accumulators (X-engine streams), and 2.5 beamformer gulps of 960 samples + their power sums
-    (beam stream).  No collective: the process group carries the barriers and the max over ranks.  One step = one
+    0xdeadbeef + rank): per 2400-sample integration five gulps registered in place + one contraction (X-engine streams), 2.5
+    beamformer gulps of 960 samples + their power sums (beam stream), and CorrAcc's long accumulation as one pass over the
+    spans of every ten dumps (map stream).  No collective: the process group carries the barriers and the max over ranks.  One step = one
     integration of every rank; value = ingest of all ranks / max-over-ranks time.  Outside the timed region every rank
     holds one dumped span, the accumulator sum, one beam gulp and its power sums to the oracle."""
     L = ffi.lib()
@@ -367,9 +368,11 @@ def config5_workload(args, ffi, dist, rank, world, gpu, ring, gulp_bytes, pin, i
     dw = ffi.DeviceBuffer(wts.nbytes).upload(wts)
     dbeam = ffi.DeviceBuffer(NCHAN * NB * NT_B * 8)
     dpow = ffi.DeviceBuffer((NB // 2) * (NT_B // NS) * NCHAN * 16)
-    outs3 = [ffi.DeviceBuffer(2 * matlen * 4) for _ in range(3)]
-    acc_pair = [ffi.DeviceBuffer(2 * matlen * 4) for _ in range(2)]
-    afn = L.xengXgpuKernelAsyncAcc
+    KG = 10                               # dumps per group of CorrAcc's long accumulation (one xengMapSumI32 pass per group)
+    outs_g = [ffi.DeviceBuffer(2 * matlen * 4) for _ in range(KG + 3)]
+    acc_long = ffi.DeviceBuffer(2 * matlen * 4)
+    kfn = L.xengXgpuKernelAsync
+    SrcArr = ctypes.c_void_p * KG
     gi, bi = [0], [0]
 
     def bstep(i):
@@ -378,15 +381,19 @@ def config5_workload(args, ffi, dist, rank, world, gpu, ring, gulp_bytes, pin, i
         ffi.check("int", L.xengBeamformIntegrate(dbeam.ptr, dpow.ptr, NS))
 
     def step(n):
-        o = outs3[n % 3]
+        o = outs_g[n % len(outs_g)]
         for g in range(gulps_per_step):
-            ffi.check("kernel", afn(ring.ptr + (gi[0] % args.ring_gulps) * gulp_bytes, o.ptr, int(g == gulps_per_step - 1),
-                                    acc_pair[n & 1].ptr, 1 if n < 2 else 2))
+            ffi.check("kernel", kfn(ring.ptr + (gi[0] % args.ring_gulps) * gulp_bytes, o.ptr, int(g == gulps_per_step - 1)))
             gi[0] += 1
         for _ in range(2 + (n & 1)):
             bstep(bi[0])
             bi[0] += 1
-        ffi.call("xengXgpuSyncLag", 1)
+        ffi.call("xengXgpuSyncLag", 1)              # dump n-1 is complete
+        if n >= KG and n % KG == 0:                 # ... and with it the group n-K .. n-1: one pass over its spans (map stream)
+            srcs = SrcArr(*[outs_g[(n - KG + j) % len(outs_g)].ptr for j in range(KG)])
+            ffi.check("sum", L.xengMapSumI32(acc_long.ptr, srcs, KG, 2 * matlen, int(n > KG)))
+        elif n % KG == 1:
+            ffi.call("xengMapSync")                 # (read before dump n + 2 writes the first of those spans again)
 
     def barrier():
         ffi.call("xengDeviceSynchronize")
@@ -414,16 +421,20 @@ def config5_workload(args, ffi, dist, rank, world, gpu, ring, gulp_bytes, pin, i
         for g in range(gulps_per_step):
             ring.upload(gulps[g], offset=g * gulp_bytes)
         ffi.call("xengXgpuSync")
+        ffi.call("xengMapSync")
         for k in range(3):
             for g in range(gulps_per_step):
-                ffi.check("kernel", afn(ring.ptr + g * gulp_bytes, outs3[k].ptr, int(g == gulps_per_step - 1), acc_pair[k & 1].ptr, 1 if k < 2 else 2))
+                ffi.check("kernel", kfn(ring.ptr + g * gulp_bytes, outs_g[k].ptr, int(g == gulps_per_step - 1)))
             ffi.check("run", L.xengBeamformRunVersioned(ring.ptr, dbeam.ptr, dw.ptr, 1))
             ffi.check("int", L.xengBeamformIntegrate(dbeam.ptr, dpow.ptr, NS))
             ffi.call("xengXgpuSyncLag", 1)
         ffi.call("xengXgpuSync")
+        g3 = (ctypes.c_void_p * 3)(*[outs_g[k].ptr for k in range(3)])
+        ffi.check("sum", L.xengMapSumI32(acc_long.ptr, g3, 3, 2 * matlen, 0))
+        ffi.call("xengMapSync")
         ffi.call("xengBeamformSync")
-        verify = {"vis": outs3[2].download(np.int32), "corracc": None,
-                  "corracc_fused": acc_pair[0].download(np.int32).astype(np.int64) + acc_pair[1].download(np.int32).astype(np.int64),
+        verify = {"vis": outs_g[2].download(np.int32), "corracc": None, "corracc_fused": None,
+                  "corracc_grouped": acc_long.download(np.int32).astype(np.int64),
                   "beams": dbeam.download(np.complex64).reshape(NCHAN, NB, NT_B), "weights": wts, "ntime_sum": NS,
                   "power": dpow.download(np.float32).reshape(NB // 2, NT_B // NS, NCHAN, 4)}
         g4 = [g.reshape(NTIME_GULP, NCHAN, NSTAND, NPOL) for g in gulps]
@@ -448,7 +459,7 @@ def config5_workload(args, ffi, dist, rank, world, gpu, ring, gulp_bytes, pin, i
         "metric": "xengine_ingest_gbps_704in_96ch", "value": round(gbps, 2), "unit": "Gb/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int8 (4+4-bit samples) -> int32; beams fp32", "data": "synthetic",
-        "config": {"workload": "config 5, full X-engine per GPU: Corr (5 x 480-sample gulps, fused corner turn) + CorrAcc fused into the dumps "
+        "config": {"workload": "config 5, full X-engine per GPU: Corr (5 x 480-sample gulps, fused corner turn) + CorrAcc (groups of 10 dumps summed in one pass) "
                                "+ Beamform (32 beams, 960-sample gulps) + power beams, concurrent on HIP streams; 704 inputs, %d chan/GPU" % NCHAN,
                    "nchan_total": NCHAN * world, "chan0_per_rank": [NCHAN * r for r in range(world)],
                    "sharding": "channels, %d per GPU, no collective" % NCHAN,
@@ -461,7 +472,7 @@ def config5_workload(args, ffi, dist, rank, world, gpu, ring, gulp_bytes, pin, i
                      "achieved": round(OPS_PER_UNIT * ACC_LEN * NCHAN / (el / args.steps) / 1e12, 1), "peak": round(PEAK_INT8_OPS / 1e12, 1),
                      "frac": round(OPS_PER_UNIT * ACC_LEN * NCHAN / (el / args.steps) / PEAK_INT8_OPS, 4), "traffic": None,
                      "note": "the contraction's algorithmic int8 ops per integration / time per integration of the slowest rank, while the "
-                             "beamformer, the power sums and the fused CorrAcc share the GPU (config 5: not the contraction alone)"},
+                             "beamformer, the power sums and CorrAcc's group sums share the GPU (config 5: not the contraction alone)"},
         "verified": {"ok": all(bool(o and o["ok"]) for o in oks) if oks[0] is not None else None, "per_rank": oks},
         "rank_placement": {"numa_node": pin["numa_node"], "ncpus": len(pin["cpus"]), "source": pin["source"]},
         "device": info,
@@ -1005,6 +1016,44 @@ def main():
                 "ms_per_integration": round(elf2 / nfull * 1e3, 4),
                 "note": "the same with the CorrAcc add done in the contraction's epilogue (xengXgpuKernelAsyncAcc, two alternating "
                         "accumulators): one pass over the 191 MB accumulator per dump instead of a 574 MB map kernel"}
+        # ... and with CorrAcc's long accumulation done GROUP by group (round 5, the CorrAcc block's default): the dumps of a group of
+        # K integrations stay in their spans (K + 3 of them: 2.5 GB of 288) and are summed in one pass (xengMapSumI32) -- 191 + 382 / K
+        # MB of traffic per dump instead of 574 (map) or 382 read-modify-written inside the contraction's epilogue (fused)
+        KG = 10
+        outs_g = outs3 + [ffi.DeviceBuffer(2 * matlen * 4) for _ in range(KG + 3 - len(outs3))]
+        SrcArr = ctypes.c_void_p * KG
+
+        def full_step_grouped(n):
+            o = outs_g[n % len(outs_g)]
+            for g in range(gulps_per_step):
+                ffi.check(kern, kfn(ring.ptr + (gi[0] % args.ring_gulps) * gulp_bytes, o.ptr, int(g == gulps_per_step - 1)))
+                gi[0] += 1
+            for _ in range(2 + (n & 1)):
+                bstep(bi[0])
+                bi[0] += 1
+            ffi.call("xengXgpuSyncLag", 1)          # dump n-1 is complete
+            if n >= KG and n % KG == 0:             # ... and with it the whole group n-K .. n-1: one pass over its spans
+                srcs = SrcArr(*[outs_g[(n - KG + j) % len(outs_g)].ptr for j in range(KG)])
+                ffi.check("sum", L.xengMapSumI32(acc_long.ptr, srcs, KG, 2 * matlen, int(n > KG)))
+            elif n % KG == 1:
+                ffi.call("xengMapSync")             # (the sum has read its spans before dump n + 2 writes the first of them again)
+        if not args.sync_per_call:
+            for n in range(KG, KG + 6):
+                full_step_grouped(n)
+            ffi.call("xengDeviceSynchronize")
+            tf = time.perf_counter()
+            for n in range(2 * KG, 2 * KG + nfull):
+                full_step_grouped(n)
+            ffi.call("xengDeviceSynchronize")
+            elf3 = time.perf_counter() - tf
+            fx = beam["full_xengine_concurrent"]
+            fx["map_per_dump"] = {"ingest_gbps": fx["ingest_gbps"], "ms_per_integration": fx["ms_per_integration"], "note": fx["note"]}
+            fx.update({"ingest_gbps": round(8 * NINPUT * units_per_step_c * nfull / elf3 / 1e9, 1), "ms_per_integration": round(elf3 / nfull * 1e3, 4),
+                       "corracc": "grouped: %d dumps per xengMapSumI32 pass" % KG,
+                       "note": "config 5 on one GPU: per 2400-sample integration 5 gulps registered in place + 1 fused-corner-turn MFMA contraction (X-engine "
+                               "streams), 2.5 beamformer gulps + power sums (beam stream), and CorrAcc's long accumulation as one pass over the spans of every "
+                               "%d dumps (map stream: 191 + 382 / %d MB per dump); map_per_dump / fused_corracc: the same with the reference's per-dump "
+                               "map and with the add in the contraction's epilogue" % (KG, KG)})
         _leg('config 5 from packets')
         # ... and fed from PACKETS (north star: "throughput on synthetic F-engine packets"): the ten device-resident packet slabs of
         # the ingest leg above instead of replay gulps.  Both consumers read the slabs where they lie (xengXgpuKernelAsyncSlab,
@@ -1092,8 +1141,13 @@ def main():
                                             acc_pair[n & 1].ptr, 1 if n < 2 else 2))
                 ffi.call("xengXgpuSyncLag", 1)
             ffi.call("xengXgpuSync")
+            # the grouped flavour: the three dumps above, still in their spans, summed in one pass
+            g3 = (ctypes.c_void_p * 3)(*[outs3[n].ptr for n in range(3)])
+            ffi.check("sum", L.xengMapSumI32(acc_long.ptr, g3, 3, 2 * matlen, 0))
+            ffi.call("xengMapSync")
             verify = {"vis": outs3[2].download(np.int32), "corracc": corracc_sum,
                       "corracc_fused": acc_pair[0].download(np.int32).astype(np.int64) + acc_pair[1].download(np.int32).astype(np.int64),
+                      "corracc_grouped": acc_long.download(np.int32).astype(np.int64),
                       "beams": dbeam.download(np.complex64).reshape(NCHAN, NB, NT_B), "weights": wts, "ntime_sum": NS,
                       "power": dpow.download(np.float32).reshape(NB // 2, NT_B // NS, NCHAN, 4)}
         # the reference's "integrated" mode (bfBeamformInitialize ntime_blocks > 0, beamform_block.py:108-110): power sums

@@ -142,6 +142,14 @@ class HipBackend:
     def map_add_i32(self, a, b):
         return self._x.map_i32(a.ptr, b.ptr, a.nbytes // 4, True)
 
+    def map_sum_i32(self, a, srcs, add):
+        """a = (add ? a : 0) + srcs[0] + ... + srcs[-1] in one pass (include/xeng.h xengMapSumI32): the long accumulation of a
+        GROUP of dumps, their spans read once each.  Enqueued on the map stream like the two calls above; the caller may let go of
+        the source spans at once on in-repo rings (released memory is reissued only behind its stamp)."""
+        n = len(srcs)
+        arr = (ctypes.c_void_p * n)(*[x.ptr for x in srcs])
+        return self._enq.xengMapSumI32(a.ptr, arr, n, a.nbytes // 4, int(bool(add)))
+
     # ---- a copy that is only enqueued (CorrAcc's publish of a long integration: 383 MB over PCIe, 7 ms)
     def copy_async(self, dst, src):
         """Enqueue dst <- src on the library's copy stream; returns the stamp that completes when the copy has (copy_done /

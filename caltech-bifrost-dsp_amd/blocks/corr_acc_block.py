@@ -11,7 +11,16 @@ Input header needs `seq0`, `acc_len` (:214-215); output adds `upstream_acc_len` 
 rewrites `acc_len` / `seq0`.  `start_time == -1` starts on the current block (:244-245);
 recovery after a new upstream sequence skips 2 integrations (:227).
 
-Fused mode (round 3; no reference counterpart).  When the input ring is the in-repo one and the upstream `Corr` streams
+Grouped mode (round 5; the default on in-repo rings; no reference counterpart).  The reference adds every dump into the
+accumulator as it arrives -- per dump 191 MB read + 191 MB read-modify-written.  That order saves memory, it is not part of the
+result (int32 addition wraps: any grouping of the sum gives the same words), and an MI355X has 288 GB: this block keeps the
+spans of up to `group_dumps` dumps referenced (the in-repo ring keeps a span's memory alive while it is referenced, and reissues
+it only behind its stamp) and sums them in ONE pass (`xengMapSumI32`): 191 + 382 / K MB per dump instead of 574.  Config 5 through
+the C ABI, one box, interleaved: 0.316 ms per integration grouped (K = 10) against 0.359 with the per-dump map and 0.375 with the
+fused epilogue below (profiles/r05/corracc_modes_k10.txt).  The gate is stepped per span exactly as before; long integrations
+alternate between two accumulators so that one is published (helper thread, 8 MB pieces) while the next accumulates.
+
+Fused mode (round 3, now opt-in: `XENG_CORRACC=fused`; no reference counterpart).  When the input ring is the in-repo one and the upstream `Corr` streams
 (blocks/corr_block.py), the "a = b" / "a += b" of every dump is done by the contraction kernel's own epilogue
 (`xengXgpuKernelAsyncAcc`, csrc/xcorr_kernels.h `LACC`): one pass over the accumulator per dump instead of a 574 MB map
 kernel.  The gate below is the same state machine either way; what changes is WHO steps it and WHEN:
@@ -27,6 +36,7 @@ kernel.  The gate below is the same state machine either way; what changes is WH
 """
 import collections
 import json
+import os
 import threading
 import time
 
@@ -57,7 +67,7 @@ class CorrAcc(Block):
 
     def __init__(self, log, iring, oring,
                  guarantee=True, core=-1, nchan=192, npol=2, nstand=352, acc_len=24000, gpu=-1, etcd_client=None,
-                 autostartat=0, backend=None):
+                 autostartat=0, backend=None, accumulate=None):
         super(CorrAcc, self).__init__(log, iring, oring, guarantee, core, etcd_client=etcd_client)
         self._bf = backend if backend is not None else default_backend()
         self.nchan, self.npol, self.nstand = nchan, npol, nstand
@@ -95,7 +105,16 @@ class CorrAcc(Block):
         # registered here, before anything is written; a second CorrAcc on the same ring, or a reader without the guarantee,
         # keeps the map path.
         self._iseqs = None
-        if (getattr(iring, 'span_memory_outlives_release', False) and hasattr(self._bf, 'bfXgpuKernelAsyncAcc') and guarantee
+        # which way the long accumulation is done (module docstring): 'group' where the ring and the backend allow it, 'fused' only
+        # when asked for, the reference's per-dump map otherwise
+        want = accumulate if accumulate is not None else os.environ.get("XENG_CORRACC", "group")
+        if want not in ("group", "fused", "map"):
+            raise ValueError("CorrAcc: accumulate = %r (group | fused | map)" % (want,))
+        in_repo_ring = getattr(iring, 'span_memory_outlives_release', False)
+        self.group_dumps = max(1, min(16, int(os.environ.get("XENG_CORRACC_GROUP", "10"))))
+        self.acc_mode = 'group' if (want in ('group', 'fused') and in_repo_ring and hasattr(self._bf, 'map_sum_i32')) else 'map'
+        self._accdata2 = None                     # grouped mode: the second accumulator (long integrations alternate)
+        if (want == 'fused' and in_repo_ring and hasattr(self._bf, 'bfXgpuKernelAsyncAcc') and guarantee
                 and getattr(iring, 'long_accumulator', None) is None):
             iring.long_accumulator = self
             self._iseqs = iring.read(guarantee=True)
@@ -274,7 +293,7 @@ class CorrAcc(Block):
         self._publishing = None                   # (helper thread, copy stamp, [exception])
         async_publish = hasattr(self._bf, 'copy_async')
 
-        def start_publish(osp, acc_set, dst, src):
+        def start_publish(osp, acc_set, dst, src, wait_map=False):
             err = []
 
             def complete():
@@ -283,6 +302,8 @@ class CorrAcc(Block):
                     # go onto GPU 0's copy stream and clock, and create a context on another pipeline's GPU)
                     if self.gpu != -1:
                         self._bf.set_device(self.gpu)
+                    if wait_map:                  # grouped mode: the last group's sum, on the map stream, has written `src`
+                        self._bf.map_sync()
                     # In pieces, each waited for before the next is enqueued: one 191 MB copy keeps the copy stream and the
                     # PCIe link to itself for 3.2 ms, and BeamformSumBeams' power sums (1 MB per gulp, same stream, same link)
                     # queue up behind it -- its thread stops, bf-output fills, Beamform stops, the input ring fills, Corr
@@ -296,9 +317,10 @@ class CorrAcc(Block):
                 except Exception as e:            # (re-raised by the block's thread at the next join)
                     err.append(e)
                 finally:
-                    with self._plan_cv:
-                        self._set_busy[acc_set] = False
-                        self._plan_cv.notify_all()
+                    if acc_set is not None:
+                        with self._plan_cv:
+                            self._set_busy[acc_set] = False
+                            self._plan_cv.notify_all()
             th = threading.Thread(target=complete, name="corracc-publish", daemon=True)
             self._publishing = (th, None, err)
             th.start()
@@ -323,7 +345,9 @@ class CorrAcc(Block):
                         self._next_plan(want_seq=True)
                     else:
                         self._begin_upstream_sequence(ihdr)
-                    self.update_stats({'fused': fused})
+                    grouped = not fused and self.acc_mode == 'group'
+                    self.update_stats({'fused': fused, 'grouped': grouped, 'group_dumps': self.group_dumps if grouped else 0})
+                    group, first_sum, acc_cur, nlong = [], True, self.accdata, 0
                     for ispan in iseq.read(self.igulp_size):
                         if ispan.size < self.igulp_size:
                             continue
@@ -360,7 +384,26 @@ class CorrAcc(Block):
                             curr_time = time.time()
                             reserve_time = curr_time - prev_time
                             prev_time = curr_time
-                        if not fused:
+                        if grouped:
+                            if d.first:
+                                # a new long integration: drop what an interrupted one had collected; the other accumulator (the
+                                # previous one may still be on its way to the output ring)
+                                group, first_sum = [], True
+                                nlong += 1
+                                if async_publish:
+                                    if self._accdata2 is None:
+                                        self._accdata2 = XArray(shape=self.accdata.shape, dtype='i32', space=self._bf.space_in)
+                                    acc_cur = self._accdata2 if (nlong & 1) else self.accdata
+                            group.append(ispan.data)          # (the reference keeps the span's memory alive: nothing is copied)
+                            if len(group) >= self.group_dumps or d.last:
+                                rv = self._bf.map_sum_i32(acc_cur, group, add=not first_sum)      # a (+)= b0 + b1 + ... in one pass
+                                if rv != self._bf.BF_STATUS_SUCCESS:
+                                    raise RuntimeError("CorrAcc map returned %d: %s" % (rv, self._bf.last_error()))
+                                first_sum = False
+                                # (the spans go back to the ring here, behind the stamp of the map stream: not reissued before the sum
+                                # has read them -- DESIGN.md 4.8; nothing waits)
+                                group = []
+                        elif not fused:
                             idata = ispan.data_view('i32')
                             if d.first:
                                 rv = self._bf.map_assign_i32(self.accdata, idata)      # "a = b"
@@ -377,7 +420,7 @@ class CorrAcc(Block):
                         process_time += curr_time - prev_time
                         prev_time = curr_time
                         if d.last:
-                            result = self.accdata
+                            result = acc_cur if grouped else self.accdata
                             if fused:
                                 pair = self._fused_accs[d.acc_set]
                                 result = pair[0]
@@ -392,7 +435,12 @@ class CorrAcc(Block):
                             if fused and async_publish:
                                 start_publish(ospan, d.acc_set, odata, result)
                                 ospan = None
+                            elif grouped and async_publish:
+                                start_publish(ospan, None, odata, result, wait_map=True)
+                                ospan = None
                             else:
+                                if grouped:
+                                    self._bf.map_sync()
                                 copy_array(odata, result)     # (synchronous: complete before the span is committed)
                                 ospan.close()
                                 ospan = None

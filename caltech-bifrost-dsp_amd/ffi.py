@@ -79,6 +79,7 @@ SYMBOLS = {
     "xengSnap2GetAsyncDrops": [_pi], "xengSnap2StampSeq": [_vp, _i, _sz, ctypes.c_uint64, _i],
     "xengXgpuSetProfiling": [_i], "xengXgpuGetTimes": [ctypes.POINTER(ctypes.c_double), _pi],
     "xengMapAssignI32": [_vp, _vp, _sz], "xengMapAddI32": [_vp, _vp, _sz], "xengMapSync": [],
+    "xengMapSumI32": [_vp, _pvp, _i, _sz, _i],
     "xengBeamformInitialize": [_i, _i, _i, _i, _i, _i], "xengBeamformDestroy": [],
     "xengBeamformRun": [_vp, _vp, _vp], "xengBeamformRunVersioned": [_vp, _vp, _vp, ctypes.c_longlong], "xengBeamformTryRunVersioned": [_vp, _vp, _vp, ctypes.c_longlong],
     "xengBeamformRunParts": [_vp, _i, _vp, _vp, _vp, ctypes.c_longlong], "xengBeamformTryRunParts": [_vp, _i, _vp, _vp, _vp, ctypes.c_longlong],
@@ -126,7 +127,7 @@ def lib():
 # synchronous call, which polls: it is made on the releasing handle.)
 ENQUEUE_ONLY = ["xengXgpuTryKernelAsyncAcc", "xengXgpuTryKernelAsyncSlab", "xengBeamformTryRunVersioned", "xengBeamformTryRunParts", "xengBeamformTryRunSlabs",
                 "xengBeamformIntegrate", "xengBeamformIntegrateSingleBeam", "xengBeamformMark", "xengMapAssignI32",
-                "xengMapAddI32", "xengXgpuDumpDone", "xengBeamformTicketDone", "bfBeamformIntegrate", "bfBeamformIntegrateSingleBeam",
+                "xengMapAddI32", "xengMapSumI32", "xengXgpuDumpDone", "xengBeamformTicketDone", "bfBeamformIntegrate", "bfBeamformIntegrateSingleBeam",
                 # the span rings: bookkeeping calls, and the calls that can wait asked with may_block = 0 first
                 "xengRingBeginSequence", "xengRingEndSequence", "xengRingEndWriting", "xengRingReserve", "xengRingCommit",
                 "xengRingCommitExternal", "xengRingNextSequence", "xengRingAcquire", "xengRingAcquireParts", "xengRingSpanRelease", "xengRingGetInfo",

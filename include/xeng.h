@@ -314,6 +314,12 @@ int xengSnap2StampSeq(void *packets_dev, int npkt, size_t pkt_stride, uint64_t s
  * enqueued on the library's map stream; xengStreamSynchronize() (corr_acc_block.py:317) completes it. */
 int xengMapAssignI32(void *a_dev, const void *b_dev, size_t nwords);
 int xengMapAddI32(void *a_dev, const void *b_dev, size_t nwords);
+/* a = (add ? a : 0) + srcs[0] + ... + srcs[nsrc - 1] in one pass (srcs: HOST array of nsrc device pointers, 1 <= nsrc <=
+ * XENG_MAP_SUM_MAX).  The reference adds every dump as it arrives (corr_acc_block.py:298-306: 574 MB of traffic per config-2
+ * dump); int32 addition wraps, so any grouping gives the same words, and with 288 GB of HBM CorrAcc keeps the spans of a
+ * group of dumps and sums them together: 191 + 382 / nsrc MB per dump.  Map stream, like the two calls above. */
+#define XENG_MAP_SUM_MAX 16
+int xengMapSumI32(void *a_dev, const void *const *srcs_dev, int nsrc, size_t nwords, int add);
 int xengMapSync(void);   /* wait for the map stream only */
 
 /* ---------------------------------------------------------------- Beamformer

@@ -165,6 +165,13 @@ class OracleBackend:
         orc.map_i32(a.numpy().reshape(-1), b.numpy().reshape(-1), add=True)
         return 0
 
+    def map_sum_i32(self, a, srcs, add):
+        self.sum_calls = getattr(self, "sum_calls", []) + [(len(srcs), bool(add))]
+        acc = a.numpy().reshape(-1)
+        for k, b in enumerate(srcs):
+            orc.map_i32(acc, b.numpy().reshape(-1).view(np.int32), add=(add or k > 0))
+        return 0
+
     # beamformer
     def bfBeamformInitialize(self, gpu, ninput, nchan, ntime, nbeam, ntime_blocks):
         self.beam = dict(ninput=ninput, nchan=nchan, ntime=ntime, nbeam=nbeam, ntime_blocks=ntime_blocks)

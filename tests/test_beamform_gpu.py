@@ -37,6 +37,49 @@ def test_map_assign_and_add(gpu, n):
     assert np.array_equal(da.download(np.int32, n), b)
 
 
+@pytest.mark.parametrize("n,nsrc", [(1, 1), (3, 2), (1000, 5), (4 * 1024 * 1024 + 3, 10), (1 << 20, 16), (47849472, 10)])
+def test_map_sum_of_a_group_of_dumps(gpu, n, nsrc):
+    """xengMapSumI32 (round 5): a = (add ? a : 0) + b_0 + ... + b_{K-1} in one pass == K applications of the reference's
+    'a = b' / 'a += b' (corr_acc_block.py:298-306; int32 wraps, so the grouping does not matter).  Last case: config-2 planes."""
+    import ctypes
+    rng = np.random.default_rng(n + nsrc)
+    a0 = rng.integers(-2**31, 2**31 - 1, n, dtype=np.int64).astype(np.int32)
+    da = gpu.ffi.DeviceBuffer(4 * n + 16).upload(a0)
+    bs, dbs = [], []
+    for j in range(nsrc):
+        b = rng.integers(-2**31, 2**31 - 1, n, dtype=np.int64).astype(np.int32)
+        bs.append(b)
+        dbs.append(gpu.ffi.DeviceBuffer(4 * n + 16).upload(b))
+    srcs = (ctypes.c_void_p * nsrc)(*[d.ptr for d in dbs])
+    exp = a0.copy()
+    for b in bs:
+        exp = orc.map_i32(exp, b, add=True)
+    gpu.ffi.call("xengMapSumI32", da.ptr, srcs, nsrc, n, 1)
+    gpu.ffi.call("xengMapSync")
+    assert np.array_equal(da.download(np.int32, n), exp)
+    exp = bs[0].copy()
+    for b in bs[1:]:
+        exp = orc.map_i32(exp, b, add=True)
+    gpu.ffi.call("xengMapSumI32", da.ptr, srcs, nsrc, n, 0)
+    gpu.ffi.call("xengMapSync")
+    assert np.array_equal(da.download(np.int32, n), exp)
+    for d in dbs + [da]:
+        d.free()
+
+
+def test_map_sum_rejects_bad_arguments(gpu):
+    import ctypes
+    d = gpu.ffi.DeviceBuffer(64)
+    srcs = (ctypes.c_void_p * 17)(*[d.ptr] * 17)
+    L = gpu.ffi.lib()
+    assert L.xengMapSumI32(d.ptr, srcs, 17, 4, 0) != 0          # more than XENG_MAP_SUM_MAX sources
+    assert L.xengMapSumI32(d.ptr, srcs, 0, 4, 0) != 0
+    assert L.xengMapSumI32(None, srcs, 1, 4, 0) != 0
+    bad = (ctypes.c_void_p * 1)(d.ptr + 4)
+    assert L.xengMapSumI32(d.ptr, bad, 1, 4, 0) != 0             # misaligned source
+    d.free()
+
+
 def run_beamform(gpu, vin, w, ntime, nchan, ninput, nbeam):
     gpu.ffi.call("xengBeamformInitialize", 0, ninput, nchan, ntime, nbeam, 0)
     di = gpu.ffi.DeviceBuffer(vin.size).upload(vin)

@@ -555,16 +555,21 @@ def test_corr_subsel_then_output_part_packets(golden_dir):
 
 
 # ---------------------------------------------------------------------------------------------- fused CorrAcc
-def _corr_corracc(seqs, C, S, g, acc, lacc, cacc_start, fused, cacc_cmds=()):
-    """Corr -> CorrAcc on in-repo rings with the oracle backend.  fused: the dumps feed CorrAcc's accumulators themselves
-    (bfXgpuKernelAsyncAcc); classic: CorrAcc maps every span it reads."""
+def _corr_corracc(seqs, C, S, g, acc, lacc, cacc_start, fused, cacc_cmds=(), group_dumps=None):
+    """Corr -> CorrAcc on in-repo rings with the oracle backend.  fused = True: the dumps feed CorrAcc's accumulators themselves
+    (bfXgpuKernelAsyncAcc); False: the reference's map per span (corr_acc_block.py:298-306); 'group' (round 5, the default of
+    the block): the spans of a group of dumps are summed in one pass (map_sum_i32)."""
     r0, r1, r2 = Ring("gpu-input"), Ring("corr-output"), Ring("corr-slow-output")
     be = OracleBackend()
     corr = Corr(LOG, r0, r1, ntime_gulp=g, nchan=C, npol=2, nstand=S, acc_len=acc, autostartat=0, backend=be)
-    cacc = CorrAcc(LOG, r1, r2, nchan=C, npol=2, nstand=S, acc_len=lacc, autostartat=cacc_start, backend=be)
-    assert r1.long_accumulator is cacc
-    if not fused:
-        r1.long_accumulator = None
+    cacc = CorrAcc(LOG, r1, r2, nchan=C, npol=2, nstand=S, acc_len=lacc, autostartat=cacc_start, backend=be,
+                   accumulate='fused' if fused is True else 'map' if fused is False else fused)
+    if group_dumps is not None:
+        cacc.group_dumps = group_dumps
+    if fused is True:
+        assert r1.long_accumulator is cacc
+    else:
+        assert getattr(r1, 'long_accumulator', None) is None
     for c in cacc_cmds:
         cacc.process_command_strings(c)
     fast, slow = Sink(r1, corr.ogulp_size), Sink(r2, cacc.ogulp_size)
@@ -582,16 +587,24 @@ def test_fused_corracc_equals_classic_and_oracle(cacc_start, lacc):
     vin = rng.integers(0, 256, (64, C, S, 2), dtype=np.uint8)
     seqs = [(source_header(C, S, 2), vin, g * C * S * 2)]
     out = {}
-    for fused in (True, False):
-        corr, cacc, be, fast, slow = _corr_corracc(seqs, C, S, g, acc, lacc, cacc_start, fused)
-        assert corr.stats['fused_corracc'] is fused and cacc.stats['fused'] is fused
+    for fused in (True, False, 'group'):
+        corr, cacc, be, fast, slow = _corr_corracc(seqs, C, S, g, acc, lacc, cacc_start, fused, group_dumps=2 if fused == 'group' else None)
+        assert corr.stats['fused_corracc'] is (fused is True) and cacc.stats['fused'] is (fused is True)
+        assert cacc.stats['grouped'] is (fused == 'group')
         (fh, _, fspans), = fast.sequences
         assert len(fspans) == 16                                           # the fast stream is untouched
         for k, sp in enumerate(fspans):
             assert np.array_equal(sp.view(np.int32), orc.xgpu_correlate(vin[acc * k:acc * (k + 1)], S, C))
         out[fused] = [(h, [sp.view(np.int32).copy() for sp in spans]) for h, _, spans in slow.sequences]
         ndumps = getattr(be, "acc_calls", [])
-        if fused:
+        if fused == 'group':
+            # groups of (at most) two dumps, one pass each: the first of a long integration assigns, the others add
+            per = lacc // acc
+            start = 0 if cacc_start == -1 else cacc_start
+            nlong = (64 - start) // lacc
+            one = [(min(2, per - k), k > 0) for k in range(0, per, 2)]
+            assert be.sum_calls[:len(one) * nlong] == one * nlong and ndumps == []
+        elif fused:
             start = 0 if cacc_start == -1 else cacc_start
             nlong = (64 - start) // lacc
             assert len(out[True][0][1]) == nlong
@@ -605,9 +618,10 @@ def test_fused_corracc_equals_classic_and_oracle(cacc_start, lacc):
                 assert np.array_equal(sp, orc.xgpu_correlate(vin[start + lacc * k:start + lacc * (k + 1)], S, C))
         else:
             assert ndumps == []
-    assert len(out[True]) == len(out[False])
-    for (h1, s1), (h2, s2) in zip(out[True], out[False]):
-        assert h1 == h2 and len(s1) == len(s2) and all(np.array_equal(a, b) for a, b in zip(s1, s2))
+    assert len(out[True]) == len(out[False]) == len(out['group'])
+    for other in (False, 'group'):
+        for (h1, s1), (h2, s2) in zip(out[True], out[other]):
+            assert h1 == h2 and len(s1) == len(s2) and all(np.array_equal(a, b) for a, b in zip(s1, s2))
 
 
 def test_fused_corracc_follows_commands_and_new_upstream_sequences():
@@ -620,13 +634,14 @@ def test_fused_corracc_follows_commands_and_new_upstream_sequences():
     d1 = rng.integers(0, 256, (80, C, S, 2), dtype=np.uint8)
     seqs = [(source_header(C, S, 2, seq0=0), d0, g * C * S * 2), (source_header(C, S, 2, seq0=1000), d1, g * C * S * 2)]
     res = {}
-    for fused in (True, False):
+    for fused in (True, False, 'group'):
         corr, cacc, be, fast, slow = _corr_corracc(seqs, C, S, g, acc, lacc, 0, fused, cacc_cmds=[cmd(1, start_time=8)])
         res[fused] = [(h, tag, [sp.view(np.int32).copy() for sp in spans]) for h, tag, spans in slow.sequences]
         assert sum(len(sp) for _, _, sp in res[fused]) >= 2
-    assert len(res[True]) == len(res[False])
-    for (h1, t1, s1), (h2, t2, s2) in zip(res[True], res[False]):
-        assert h1 == h2 and t1 == t2 and len(s1) == len(s2) and all(np.array_equal(a, b) for a, b in zip(s1, s2))
+    assert len(res[True]) == len(res[False]) == len(res['group'])
+    for other in (False, 'group'):
+        for (h1, t1, s1), (h2, t2, s2) in zip(res[True], res[other]):
+            assert h1 == h2 and t1 == t2 and len(s1) == len(s2) and all(np.array_equal(a, b) for a, b in zip(s1, s2))
     (h, _, spans) = res[True][0]
     assert h['seq0'] == 8 and np.array_equal(spans[0], orc.xgpu_correlate(d0[8:16], S, C))
 

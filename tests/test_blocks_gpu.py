@@ -20,18 +20,20 @@ def fused_xengine_expected():
     return os.environ.get("XENG_RAW") != "0"
 
 
+@pytest.mark.parametrize("mode", ["group", "fused", "map"])
 @pytest.mark.parametrize("g", [32, 96])
-def test_corr_corracc_on_device_rings(g):
+def test_corr_corracc_on_device_rings(g, mode):
     """gpu-input (cuda) -> Corr -> corr-output (cuda) -> CorrAcc -> corr-slow-output (cuda_host),
-    the ring spaces of lwa352-pipeline.py:147-155; bit-exact vs the oracle.  Gulps of 96 samples run the default
-    contraction kernel, whose dumps feed CorrAcc's accumulators themselves; gulps of 32 take the two-pass X-engine and
-    CorrAcc's own map."""
+    the ring spaces of lwa352-pipeline.py:147-155; bit-exact vs the oracle, in the three ways CorrAcc can accumulate: the
+    spans of a group of dumps summed in one pass (the default), the add fused into the dumps' epilogue (gulps of 96 samples
+    run the default contraction kernel, which can do that; gulps of 32 take the two-pass X-engine and CorrAcc's own map), and
+    the reference's map per span."""
     C, S, acc, lacc = 8, 48, 2 * g, 4 * g
     rng = np.random.default_rng(5)
     vin = rng.integers(0, 256, (4 * lacc // 2, C, S, 2), dtype=np.uint8)      # 256 samples = 2 long integrations
     r0, r1, r2 = Ring("gpu-input", space="cuda"), Ring("corr-output", space="cuda"), Ring("corr-slow-output", space="cuda_host")
     corr = Corr(LOG, r0, r1, ntime_gulp=g, nchan=C, npol=2, nstand=S, acc_len=acc, autostartat=0, gpu=0, test=True)
-    cacc = CorrAcc(LOG, r1, r2, nchan=C, npol=2, nstand=S, acc_len=lacc, autostartat=0, gpu=0)
+    cacc = CorrAcc(LOG, r1, r2, nchan=C, npol=2, nstand=S, acc_len=lacc, autostartat=0, gpu=0, accumulate=mode)
     fast = Sink(r1, corr.ogulp_size)
     slow = Sink(r2, cacc.ogulp_size)
     run_blocks([corr, cacc], Source(r0, [(source_header(C, S, 2), vin, g * C * S * 2)], wait_readers=1), [fast, slow])
@@ -44,11 +46,12 @@ def test_corr_corracc_on_device_rings(g):
     assert h2['upstream_acc_len'] == acc and h2['acc_len'] == lacc and len(sp2) == 2
     for k, sp in enumerate(sp2):
         assert np.array_equal(sp.view(np.int32), orc.xgpu_correlate(vin[k * lacc:(k + 1) * lacc], S, C))
-    fz = g == 96 and fused_xengine_expected()
+    fz = mode == "fused" and g == 96 and fused_xengine_expected()
     assert cacc.stats['fused'] is fz and cacc.fused_dumps == (4 if fz else 0)   # accumulated by the dumps' own epilogue
+    assert cacc.stats['grouped'] is (mode != "map" and not fz)                   # (a fused CorrAcc whose Corr cannot fuse sums groups)
 
 
-@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("fused", [True, False, "group"])
 def test_corracc_full_size_misaligned_start(fused):
     """BASELINE config 2 size (704 inputs, 96 channels, acc_len 2400 = 5 x 480): CorrAcc starts in the middle of the
     stream (start_time = one upstream integration, not 0) with three dumps per long integration -- two in one partial
@@ -67,9 +70,10 @@ def test_corracc_full_size_misaligned_start(fused):
     r0, r1, r2 = Ring("gpu-input", space="cuda"), Ring("corr-output", space="cuda"), Ring("corr-slow-output", space="cuda_host")
     r0.resize(gulp_bytes, total_span=2 * G * gulp_bytes)
     corr = Corr(LOG, r0, r1, ntime_gulp=g, nchan=C, npol=2, nstand=S, acc_len=acc, autostartat=0, gpu=0)
-    cacc = CorrAcc(LOG, r1, r2, nchan=C, npol=2, nstand=S, acc_len=3 * acc, autostartat=acc, gpu=0)
-    if not fused:
-        r1.long_accumulator = None
+    cacc = CorrAcc(LOG, r1, r2, nchan=C, npol=2, nstand=S, acc_len=3 * acc, autostartat=acc, gpu=0,
+                   accumulate="fused" if fused is True else "map" if fused is False else fused)
+    if fused == "group":
+        cacc.group_dumps = 2              # (three dumps per long integration: one group of two, one of one)
     verdicts, hdrs = [], []
     want = (3 * ref).astype(np.int32).reshape(-1)
 
@@ -89,8 +93,9 @@ def test_corracc_full_size_misaligned_start(fused):
     assert not sink.is_alive()
     assert verdicts == [True, True], verdicts                  # [2400, 9600) and [9600, 16800); the third is cut off
     assert hdrs[0]['seq0'] == acc and hdrs[0]['acc_len'] == 3 * acc and hdrs[0]['upstream_acc_len'] == acc
-    fz = fused and fused_xengine_expected()
+    fz = fused is True and fused_xengine_expected()
     assert cacc.stats['fused'] is fz and (cacc.fused_dumps == 7) is fz
+    assert cacc.stats['grouped'] is (fused == "group" or (fused is True and not fz))
 
 
 def test_beamform_sumbeams_on_device_rings():

@@ -19,11 +19,11 @@ def test_fused_registration_needs_a_guaranteed_first_reader():
     C, S = 2, 8
     be = OracleBackend()
     r1, r2, r3 = Ring("corr-output"), Ring("slow-a"), Ring("slow-b")
-    a = CorrAcc(LOG, r1, r2, nchan=C, npol=2, nstand=S, acc_len=8, backend=be)
-    b = CorrAcc(LOG, r1, r3, nchan=C, npol=2, nstand=S, acc_len=8, backend=be)
+    a = CorrAcc(LOG, r1, r2, nchan=C, npol=2, nstand=S, acc_len=8, backend=be, accumulate='fused')
+    b = CorrAcc(LOG, r1, r3, nchan=C, npol=2, nstand=S, acc_len=8, backend=be, accumulate='fused')
     assert r1.long_accumulator is a and a._iseqs is not None and b._iseqs is None
     r4 = Ring("corr-output-2")
-    c = CorrAcc(LOG, r4, Ring("slow-c"), nchan=C, npol=2, nstand=S, acc_len=8, backend=be, guarantee=False)
+    c = CorrAcc(LOG, r4, Ring("slow-c"), nchan=C, npol=2, nstand=S, acc_len=8, backend=be, guarantee=False, accumulate='fused')
     assert getattr(r4, 'long_accumulator', None) is None and c._iseqs is None
     del a, b, c
 
@@ -34,8 +34,8 @@ def test_two_corraccs_on_one_ring_one_fused_one_classic():
     be = OracleBackend()
     r0, r1, r2, r3 = Ring("gpu-input"), Ring("corr-output"), Ring("slow-a"), Ring("slow-b")
     corr = Corr(LOG, r0, r1, ntime_gulp=g, nchan=C, npol=2, nstand=S, acc_len=acc, autostartat=0, backend=be)
-    a = CorrAcc(LOG, r1, r2, nchan=C, npol=2, nstand=S, acc_len=lacc, autostartat=0, backend=be)
-    b = CorrAcc(LOG, r1, r3, nchan=C, npol=2, nstand=S, acc_len=lacc, autostartat=0, backend=be)
+    a = CorrAcc(LOG, r1, r2, nchan=C, npol=2, nstand=S, acc_len=lacc, autostartat=0, backend=be, accumulate='fused')
+    b = CorrAcc(LOG, r1, r3, nchan=C, npol=2, nstand=S, acc_len=lacc, autostartat=0, backend=be, accumulate='fused')
     sa, sb = Sink(r2, a.ogulp_size), Sink(r3, b.ogulp_size)
     run_blocks([corr, a, b], Source(r0, [(source_header(C, S, 2), vin, g * C * S * 2)]), [sa, sb])
     assert a.stats['fused'] is True and b.stats['fused'] is False         # (the second one maps every span itself)
@@ -99,7 +99,7 @@ def test_fused_plan_waits_for_a_stalled_consumer_instead_of_failing():
     be = OracleBackend()
     r0, r1, r2 = Ring("gpu-input"), Ring("corr-output"), Ring("corr-slow-output")
     corr = Corr(LOG, r0, r1, ntime_gulp=g, nchan=C, npol=2, nstand=S, acc_len=acc, autostartat=0, backend=be)
-    cacc = CorrAcc(LOG, r1, r2, nchan=C, npol=2, nstand=S, acc_len=lacc, autostartat=0, backend=be)
+    cacc = CorrAcc(LOG, r1, r2, nchan=C, npol=2, nstand=S, acc_len=lacc, autostartat=0, backend=be, accumulate="fused")
     r2.resize(cacc.ogulp_size, cacc.ogulp_size)              # room for ONE long integration
     gate = threading.Event()
     got = []
@@ -193,7 +193,7 @@ def test_fused_corracc_publishes_without_stopping():
     be = _AsyncCopyBackend()
     r0, r1, r2 = Ring("gpu-input"), Ring("corr-output"), Ring("corr-slow-output")
     corr = Corr(LOG, r0, r1, ntime_gulp=g, nchan=C, npol=2, nstand=S, acc_len=acc, autostartat=0, backend=be)
-    cacc = CorrAcc(LOG, r1, r2, nchan=C, npol=2, nstand=S, acc_len=lacc, autostartat=0, backend=be)
+    cacc = CorrAcc(LOG, r1, r2, nchan=C, npol=2, nstand=S, acc_len=lacc, autostartat=0, backend=be, accumulate="fused")
     fast, slow = Sink(r1, corr.ogulp_size), Sink(r2, cacc.ogulp_size)
     run_blocks([corr, cacc], Source(r0, [(source_header(C, S, 2), vin, g * C * S * 2)]), [fast, slow])
     assert cacc.stats['fused'] is True and len(be.copies) == nlong and all(c["done"] for c in be.copies)
@@ -201,6 +201,36 @@ def test_fused_corracc_publishes_without_stopping():
     assert len(spans) == nlong
     for k, sp in enumerate(spans):
         assert np.array_equal(sp.view(np.int32), orc.xgpu_correlate(vin[lacc * k:lacc * (k + 1)], S, C)), k
+
+
+def test_grouped_corracc_publishes_without_stopping_and_lets_its_spans_go():
+    """Grouped mode (round 5, the block's default on in-repo rings): the dumps of a group are summed in one pass, long integrations
+    alternate between two accumulators, and the copy of a finished one is only enqueued (a helper waits for it and commits)
+    while the block goes on collecting the next group.  Every long integration arrives complete and in order, equal to N x the
+    oracle's; groups are cut at the long-integration boundary (5 dumps, groups of 2: 2 + 2 + 1); no span stays referenced."""
+    import gc
+    C, S, g, acc, lacc = 2, 8, 2, 2, 10
+    nlong = 5
+    vin = np.random.default_rng(14).integers(0, 256, (nlong * lacc + 2, C, S, 2), dtype=np.uint8)
+    be = _AsyncCopyBackend()
+    r0, r1, r2 = Ring("gpu-input"), Ring("corr-output"), Ring("corr-slow-output")
+    corr = Corr(LOG, r0, r1, ntime_gulp=g, nchan=C, npol=2, nstand=S, acc_len=acc, autostartat=0, backend=be)
+    cacc = CorrAcc(LOG, r1, r2, nchan=C, npol=2, nstand=S, acc_len=lacc, autostartat=0, backend=be)
+    assert cacc.acc_mode == 'group' and getattr(r1, 'long_accumulator', None) is None
+    cacc.group_dumps = 2
+    fast, slow = Sink(r1, corr.ogulp_size), Sink(r2, cacc.ogulp_size)
+    run_blocks([corr, cacc], Source(r0, [(source_header(C, S, 2), vin, g * C * S * 2)]), [fast, slow])
+    assert cacc.stats['grouped'] is True and cacc.stats['fused'] is False and corr.stats['fused_corracc'] is False
+    assert len(be.copies) == nlong and all(c["done"] for c in be.copies)
+    assert be.sum_calls[:3 * nlong] == [(2, False), (2, True), (1, True)] * nlong
+    (_, _, spans), = slow.sequences
+    assert len(spans) == nlong
+    for k, sp in enumerate(spans):
+        assert np.array_equal(sp.view(np.int32), orc.xgpu_correlate(vin[lacc * k:lacc * (k + 1)], S, C)), k
+    del fast, slow, spans
+    gc.collect()
+    if hasattr(r1, "info"):
+        assert r1.info()["live_bytes"] == 0
 
 
 def test_packet_slabs_stay_slabs_from_ingest_to_corr_and_beamform():

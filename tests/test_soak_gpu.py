@@ -121,8 +121,8 @@ def test_full_size_blocks_match_standalone_calls():
         assert not t.is_alive(), "pipeline thread did not finish: %r" % (t,)
     assert fast.verdicts == [True] * nrep, fast.verdicts
     assert slow.verdicts == [True] * (nrep // 2), slow.verdicts
-    # the long accumulation was done by the dumps themselves (fused CorrAcc), not by map kernels
-    assert corr.stats['fused_corracc'] is True and cacc.stats['fused'] is True and cacc.fused_dumps == nrep
+    # the long accumulation was done group by group, each group's spans summed in one pass (the block's default), beside everything else
+    assert corr.stats['fused_corracc'] is False and cacc.stats['grouped'] is True and cacc.fused_dumps == 0
 
     # the beamformer calls alone, same weights, same gulps
     ffi.call("xengBeamformInitialize", 0, ninput, C, g, nbeam, 0)
