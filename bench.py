@@ -1141,12 +1141,13 @@ def main():
                                             acc_pair[n & 1].ptr, 1 if n < 2 else 2))
                 ffi.call("xengXgpuSyncLag", 1)
             ffi.call("xengXgpuSync")
-            # the grouped flavour: the three dumps above, still in their spans, summed in one pass
+            corracc_fused = acc_pair[0].download(np.int32).astype(np.int64) + acc_pair[1].download(np.int32).astype(np.int64)
+            # the grouped flavour: the three dumps above, still in their spans, summed in one pass (acc_long is acc_pair[0]: read out first)
             g3 = (ctypes.c_void_p * 3)(*[outs3[n].ptr for n in range(3)])
             ffi.check("sum", L.xengMapSumI32(acc_long.ptr, g3, 3, 2 * matlen, 0))
             ffi.call("xengMapSync")
             verify = {"vis": outs3[2].download(np.int32), "corracc": corracc_sum,
-                      "corracc_fused": acc_pair[0].download(np.int32).astype(np.int64) + acc_pair[1].download(np.int32).astype(np.int64),
+                      "corracc_fused": corracc_fused,
                       "corracc_grouped": acc_long.download(np.int32).astype(np.int64),
                       "beams": dbeam.download(np.complex64).reshape(NCHAN, NB, NT_B), "weights": wts, "ntime_sum": NS,
                       "power": dpow.download(np.float32).reshape(NB // 2, NT_B // NS, NCHAN, 4)}

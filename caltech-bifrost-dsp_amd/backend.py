@@ -200,6 +200,14 @@ class HipBackend:
         return self._x.beam_pump(iring, iring._h, int(reader), oring, oring._h, int(oseq_id), int(igulp), int(ogulp), int(mode), int(row_bytes),
                                  int(ntime_sum), int(depth), int(bool(staged)))
 
+    def corr_pump(self, iring, reader, oring, igulp, ogulp, ntime_gulp):
+        """The per-gulp loop of Corr while it integrates, between two NATIVE rings, as an object whose run() works without the
+        interpreter lock (csrc/pyext/xfast.cpp CorrPump); None when the rings are not native or XENG_PUMP=0."""
+        import os
+        if os.environ.get("XENG_PUMP") == "0" or not (hasattr(iring, "_h") and hasattr(oring, "_h")):
+            return None
+        return self._x.corr_pump(iring, iring._h, int(reader), oring, oring._h, int(igulp), int(ogulp), int(ntime_gulp))
+
     def bfBeamformIntegrate(self, in_arr, out_arr, ntime_sum):
         # (bfBeamformIntegrate reads only the two data pointers from its structs: the raw entry point, no structs built per gulp)
         return self._x.beam_integrate(_dev(in_arr), _dev(out_arr), int(ntime_sum))

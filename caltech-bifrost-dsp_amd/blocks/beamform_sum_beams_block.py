@@ -51,7 +51,8 @@ class BeamformSumBeams(Block):
         # (round 4) the kernel writes a device buffer, and once ITS ticket is done the buffer goes to the pinned span on the
         # copy stream; the span is committed when that copy has completed.  A device output ring still takes the sums directly.
         streaming = (getattr(self.iring, 'span_memory_outlives_release', False) and getattr(self.oring, 'span_memory_outlives_release', False)
-                     and hasattr(self._bf, 'beam_mark') and self.oring.space in ('cuda', 'cuda_host'))
+                     and hasattr(self._bf, 'beam_mark')
+                     and (self.oring.space in ('cuda', 'cuda_host') or self.oring.space == self._bf.space_in))      # (the kernel writes the span)
         staged = streaming and self.oring.space == 'cuda_host' and hasattr(self._bf, 'copy_async')
         pending = collections.deque()           # (ticket, output span, input kept alive, device buffer or None)
         copying = collections.deque()           # (stamp of the copy, output span, device buffer)

@@ -11,6 +11,7 @@ through to `WriteSpan(oseq.ring ...)` with `oseq = None`, corr_block.py:424-435,
 zero for `start_time = -1`, :398); an integration interrupted by a new command is dropped with
 xengXgpuReset instead of leaking into the next one.
 """
+import ctypes
 import json
 import time
 
@@ -53,6 +54,7 @@ class Corr(Block):
         self.matlen = nchan * (nstand // 2 + 1) * (nstand // 4) * npol * npol * 4
         self.gpu = gpu
         self.test = test
+        self._pump_stop = ctypes.c_int(0)
         if self.gpu != -1:
             self._bf.set_device(self.gpu)
 
@@ -81,6 +83,19 @@ class Corr(Block):
         self.bl_is_conj = XArray(np.zeros([nstand, nstand, npol, npol], dtype=np.int32), space='system')
         if ant_to_input is not None:
             self.update_baseline_indices(ant_to_input)
+
+    # `update_pending` is set by the command thread; the native per-gulp loop (backend.corr_pump) watches the word behind
+    # `_pump_stop` and hands control back to this block's Python as soon as a gulp arrives with it up
+    @property
+    def update_pending(self):
+        return self.__dict__.get('_update_pending', False)
+
+    @update_pending.setter
+    def update_pending(self, value):
+        self.__dict__['_update_pending'] = value
+        stop = self.__dict__.get('_pump_stop')
+        if stop is not None and value:
+            stop.value = 1
 
     # --- the reference's numpy self-test (corr_block.py:265-315), vectorised -----------------------
     def _test(self, din, nchan, nstand, npol):
@@ -127,6 +142,7 @@ class Corr(Block):
 
         self.oring.resize(self.ogulp_size)
         time_tag = 1
+        self._time_tag = 1
         gate = IntegrationGate(recovery_skip=10, round_start_to_acc_len=True)
         self.update_stats({'state': 'starting'})
         self._held = []
@@ -201,6 +217,20 @@ class Corr(Block):
                     igulp_size = slab_npkt * slab_stride
                     for k in ('layout', 'slab_ntime', 'npkt_per_gulp', 'pkt_stride'):
                         ohdr.pop(k, None)
+                # The native per-gulp loop (csrc/pyext/xfast.cpp CorrPump; round 5): between native rings, streaming, with no CorrAcc
+                # fused into the dumps (its decisions are taken per dump in Python) and outside the self-test mode
+                pump = None
+                if (streaming and long_acc is None and not self.test and hasattr(self._bf, 'corr_pump') and hasattr(iseq, '_rid')
+                        and hasattr(self.oring, '_h')):
+                    pump = self._bf.corr_pump(self.iring, iseq._rid, self.oring, igulp_size, self.ogulp_size, self.ntime_gulp)
+                if pump is not None:
+                    if slab:
+                        pump.set_slabs(slab_npkt, slab_stride, slab_chan0)
+                    self.update_stats({'pump': True})
+                    time_tag = self._time_tag = max(time_tag, self._time_tag)
+                    self._pump_sequence(pump, iseq, ihdr, ohdr, gate, now, oring, igulp_size)
+                    time_tag = self._time_tag
+                    continue
                 for ispan in iseq.read(igulp_size):
                     if ispan.size < igulp_size:
                         self.log.info("CORR >>> Ignoring final gulp (expected %d bytes but got %d)" % (igulp_size, ispan.size))
@@ -320,6 +350,93 @@ class Corr(Block):
                 if oseq:
                     oseq.end()
                 oseq = None
+
+    PUMP_INTEGRATIONS = 4       # integrations per call of the native loop while no command is pending
+
+    def _pump_sequence(self, pump, iseq, ihdr, ohdr, gate, now, oring, igulp_size):
+        """One input sequence through the native per-gulp loop.  What stays here is what the loop above decides per integration or
+        rarer -- commands, the gate's start / stop / recovery, output sequences and their headers, statistics -- in the same order
+        per gulp: lost input, pending command, stop, start, waiting, running (corr_block.py:388-466)."""
+        g = self.ntime_gulp
+        stop_addr = ctypes.addressof(self._pump_stop)
+        FOREVER = 1 << 40
+        oseq = None
+        prev_time = time.time()
+        try:
+            while True:
+                self._pump_stop.value = 0       # (lowered BEFORE the flag is read: a command that comes in from here on raises it again)
+                if self.update_pending:
+                    self.update_command_vals()
+                    if gate.running:
+                        pump.abort()
+                    gate.configure(now, self.command_vals['acc_len'], self.command_vals['start_time'])
+                    self.log.info("CORR >> New start time set to %d. Accumulating %d samples" % (gate.start_time, gate.acc_len))
+                    ohdr['acc_len'] = gate.acc_len
+                    ohdr['seq0'] = gate.start_time
+                self.update_stats({'curr_sample': now})
+                nint = 0
+                if gate.acc_len == 0:
+                    # acc_len = 0 is the stop command (:423-428); a clean stop: gulps pass by until the next command
+                    self.update_stats({'state': 'stopped'})
+                    pump.finish()
+                    if oseq:
+                        oseq.end()
+                    oseq = None
+                    gate.running = False
+                    n, skipped, status, _ = pump.run(0, FOREVER, stop_addr, 0, 1, now)
+                elif not gate.running:
+                    if gate.try_start(now, g):
+                        self.log.info("CORR >> Start time %d reached." % gate.start_time)
+                        pump.finish()
+                        if oseq:
+                            oseq.end()
+                        self.sequence_proclog.update(ohdr)
+                        oseq = oring.begin_sequence(time_tag=self._time_tag, header=json.dumps(ohdr), nringlet=iseq.nringlet)
+                        self._time_tag += 1
+                        pump.set_output(oseq._seq_id)
+                        continue
+                    self.update_stats({'state': 'waiting'})
+                    n, skipped, status, _ = pump.run(0, (gate.start_time - now) // g if gate.start_time > now else FOREVER, stop_addr, 0, 1, now)
+                else:
+                    self.update_stats({'state': 'running'})
+                    gpi = gate.acc_len // g
+                    pos = (now - gate.first) // g
+                    n, skipped, status, nint = pump.run(1, self.PUMP_INTEGRATIONS * gpi - pos, stop_addr, pos, gpi, now)
+                now += n * g
+                if nint:
+                    for _ in range(nint):
+                        gate.advance(g)
+                    curr_time = time.time()
+                    process_time = (curr_time - prev_time) / nint
+                    gbps = 8 * gate.acc_len * ihdr['nchan'] * ihdr['nstand'] * ihdr['npol'] / max(process_time, 1e-9) / 1e9
+                    self.perf_proclog.update({'acquire_time': 0.0, 'reserve_time': 0.0, 'process_time': process_time, 'gbps': gbps})
+                    self.update_stats({'last_end_sample': gate.first - g, 'throughput': gbps})
+                prev_time = time.time()
+                if status == 3:
+                    # gulps this reader never saw (overwritten before it got to them; whole gulps): the sample count moves on with
+                    # them, and an integration they belonged to is lost -- realigned like a new upstream sequence (:360-371)
+                    now += (skipped // igulp_size) * g
+                    self.log.warning("CORR >> %d bytes of input were overwritten before they were read" % skipped)
+                    if gate.recover(now):
+                        pump.abort()
+                        ohdr['acc_len'] = gate.acc_len
+                        ohdr['seq0'] = gate.start_time
+                if status == 1:
+                    break
+            held = pump.state()
+            if held[1] or held[2]:
+                pump.abort()                    # upstream sequence ended mid-integration
+            pump.finish()
+            if oseq:
+                oseq.end()
+        except BaseException:
+            # (nothing in flight may still read a gulp or write a span when they go back to their rings)
+            try:
+                pump.close(False)
+            except Exception:
+                pass
+            raise
+        pump.close(True)
 
     def _finish_pending(self):
         """Streaming mode: wait for the dump in flight and commit its span."""

@@ -449,6 +449,60 @@ PyObject* ring_drain(PyObject*, PyObject* args) {
 }
 
 
+// ---------------------------------------------------------------- the compute calls the native per-gulp loops make
+// A table of function pointers, the library's own by default.  tests/fake_backend.py substitutes ctypes callbacks (the oracle on
+// system-space rings), so that the pumps' paths -- short tails, a Reserve that fails, an enqueue that fails mid-flight, the
+// stop-flag carry, skips on slab sequences -- run in the CPU suite and not only on the GPU box (round-4 review, W2).
+struct ComputeOps {
+    int (*beam_run_versioned)(const void*, void*, const void*, long long);
+    int (*beam_run_parts)(const void*, int, const void*, void*, const void*, long long);
+    int (*beam_run_slabs)(const void*, int, int, const void*, int, size_t, uint64_t, int, void*, const void*, long long);
+    int (*beam_integrate)(const void*, void*, int);
+    int (*beam_mark)(unsigned long long*);
+    int (*beam_wait)(unsigned long long);
+    int (*beam_sync)(void);
+    int (*memcpy_async)(void*, const void*, size_t);
+    int (*stamp_now_for)(xengStamp*, const void*, unsigned);
+    int (*stamp_done)(const xengStamp*, int*, int*);
+    int (*stamp_wait)(const xengStamp*);
+    int (*dev_malloc)(void**, size_t, int);
+    int (*dev_free)(void*, int);
+    int (*xgpu_try_kernel)(const void*, void*, int, void*, int);
+    int (*xgpu_try_kernel_slab)(const void*, int, size_t, uint64_t, int, void*, int, void*, int);
+    int (*xgpu_wait_slot)(void);
+    int (*xgpu_sync_lag)(int);
+    int (*xgpu_sync)(void);
+    int (*xgpu_reset)(void);
+};
+constexpr size_t NOPS = sizeof(ComputeOps) / sizeof(void*);
+
+ComputeOps default_ops() {
+    ComputeOps o;
+    o.beam_run_versioned = xengBeamformRunVersioned; o.beam_run_parts = xengBeamformRunParts; o.beam_run_slabs = xengBeamformRunSlabs;
+    o.beam_integrate = xengBeamformIntegrate; o.beam_mark = xengBeamformMark; o.beam_wait = xengBeamformWait; o.beam_sync = xengBeamformSync;
+    o.memcpy_async = xengMemcpyAsync; o.stamp_now_for = xengStampNowFor; o.stamp_done = xengStampDone; o.stamp_wait = xengStampWait;
+    o.dev_malloc = xengMalloc; o.dev_free = xengFree;
+    o.xgpu_try_kernel = xengXgpuTryKernelAsyncAcc; o.xgpu_try_kernel_slab = xengXgpuTryKernelAsyncSlab; o.xgpu_wait_slot = xengXgpuWaitLaunchSlot;
+    o.xgpu_sync_lag = xengXgpuSyncLag; o.xgpu_sync = xengXgpuSync; o.xgpu_reset = xengXgpuReset;
+    return o;
+}
+
+// `table`: None, or a bytes object of NOPS pointers in the order of ComputeOps (0 = the library's own)
+bool ops_from_arg(PyObject* table, ComputeOps* out) {
+    *out = default_ops();
+    if (!table || table == Py_None) return true;
+    char* p;
+    Py_ssize_t n;
+    if (PyBytes_AsStringAndSize(table, &p, &n) < 0) return false;
+    if (n != (Py_ssize_t)sizeof(ComputeOps)) { PyErr_Format(PyExc_ValueError, "compute table of %zd bytes, %zu expected", n, sizeof(ComputeOps)); return false; }
+    void* in[NOPS];
+    memcpy(in, p, sizeof(in));
+    void** dst = (void**)out;
+    for (size_t k = 0; k < NOPS; k++)
+        if (in[k]) dst[k] = in[k];
+    return true;
+}
+
 // ---------------------------------------------------------------- BeamPump: the per-gulp loop of Beamform / BeamformSumBeams
 // What the two blocks do per gulp in steady state -- take the next input gulp, reserve an output span, enqueue the kernel, mark
 // it, and retire the oldest gulp in flight (wait for its ticket, commit its span, give its input back) -- as one loop inside the
@@ -488,6 +542,7 @@ struct BeamPump {
     size_t carry_n[2];
     long long carry_span[2];
     int carry_nparts;
+    ComputeOps ops;
 };
 
 static void pump_release_item(PumpItem& it, bool commit, BeamPump* p) {
@@ -506,11 +561,11 @@ static int pump_finish_copies(BeamPump* p, size_t keep) {
     while (!p->copying->empty()) {
         PumpItem& it = p->copying->front();
         int done = 0;
-        int rc = xengStampDone(&it.copy_stamp, &done, nullptr);
+        int rc = p->ops.stamp_done(&it.copy_stamp, &done, nullptr);
         if (rc) return rc;
         if (!done) {
             if (p->copying->size() <= keep) break;
-            rc = xengStampWait(&it.copy_stamp);
+            rc = p->ops.stamp_wait(&it.copy_stamp);
             if (rc) return rc;
         }
         pump_release_item(it, true, p);
@@ -522,13 +577,13 @@ static int pump_finish_copies(BeamPump* p, size_t keep) {
 static int pump_retire(BeamPump* p, size_t keep) {
     while (p->pending->size() > keep) {
         PumpItem it = p->pending->front();
-        int rc = xengBeamformWait(it.ticket);
+        int rc = p->ops.beam_wait(it.ticket);
         if (rc) return rc;
         p->pending->pop_front();
         if (it.stage) {
             // the kernel's sums are in the device buffer: on to the pinned span on the copy stream; committed when that is done
-            rc = xengMemcpyAsync(it.out_ptr, it.stage, p->ogulp);
-            if (!rc) rc = xengStampNowFor(&it.copy_stamp, nullptr, XENG_STREAMS_COPY);
+            rc = p->ops.memcpy_async(it.out_ptr, it.stage, p->ogulp);
+            if (!rc) rc = p->ops.stamp_now_for(&it.copy_stamp, nullptr, XENG_STREAMS_COPY);
             if (rc) { pump_release_item(it, false, p); return rc; }
             for (int k = 0; k < it.nin; k++)
                 if (it.in_span[k]) { (void)xengRingSpanRelease(it.in_span[k]); it.in_span[k] = 0; }
@@ -543,8 +598,8 @@ static int pump_retire(BeamPump* p, size_t keep) {
 
 // after an error: nothing in flight may still touch a span when it goes back to its ring
 static void pump_abort(BeamPump* p) {
-    (void)xengBeamformSync();
-    for (auto& it : *p->copying) (void)xengStampWait(&it.copy_stamp);
+    (void)p->ops.beam_sync();
+    for (auto& it : *p->copying) (void)p->ops.stamp_wait(&it.copy_stamp);
     for (auto& it : *p->pending) pump_release_item(it, false, p);
     for (auto& it : *p->copying) pump_release_item(it, false, p);
     p->pending->clear();
@@ -560,7 +615,7 @@ void BeamPump_dealloc(BeamPump* self) {
         Py_BEGIN_ALLOW_THREADS
         pump_abort(self);
         Py_END_ALLOW_THREADS
-        for (void* st : *self->stages_free) (void)xengFree(st, XENG_SPACE_CUDA);
+        for (void* st : *self->stages_free) (void)self->ops.dev_free(st, XENG_SPACE_CUDA);
         delete self->pending;
         delete self->copying;
         delete self->stages_free;
@@ -573,17 +628,20 @@ void BeamPump_dealloc(BeamPump* self) {
 PyTypeObject BeamPumpType = {PyVarObject_HEAD_INIT(nullptr, 0)};
 
 // beam_pump(in_ring_obj, in_handle, reader, out_ring_obj, out_handle, out_seq, igulp, ogulp, mode (0 Beamform | 1 SumBeams), row_bytes,
-//           ntime_sum, depth, staged) -> BeamPump
+//           ntime_sum, depth, staged[, compute table]) -> BeamPump
 PyObject* beam_pump_new(PyObject*, PyObject* args) {
-    PyObject *rin_obj, *rout_obj;
+    PyObject *rin_obj, *rout_obj, *table = nullptr;
     unsigned long long hin, hout;
     int reader, mode, row_bytes, ntime_sum, depth, staged;
     long long oseq;
     Py_ssize_t igulp, ogulp;
-    if (!PyArg_ParseTuple(args, "OKiOKLnniiiii", &rin_obj, &hin, &reader, &rout_obj, &hout, &oseq, &igulp, &ogulp, &mode, &row_bytes, &ntime_sum, &depth, &staged))
+    if (!PyArg_ParseTuple(args, "OKiOKLnniiiii|O", &rin_obj, &hin, &reader, &rout_obj, &hout, &oseq, &igulp, &ogulp, &mode, &row_bytes, &ntime_sum, &depth, &staged, &table))
         return nullptr;
+    ComputeOps ops;
+    if (!ops_from_arg(table, &ops)) return nullptr;
     BeamPump* p = PyObject_New(BeamPump, &BeamPumpType);
     if (!p) return nullptr;
+    p->ops = ops;
     Py_INCREF(rin_obj); Py_INCREF(rout_obj);
     p->rin_obj = rin_obj; p->rout_obj = rout_obj;
     p->rin = (xengRing*)hin; p->rout = (xengRing*)hout;
@@ -650,26 +708,32 @@ PyObject* BeamPump_run(BeamPump* p, PyObject* args) {
             const size_t slab_bytes = (size_t)p->slab_npkt * p->slab_stride;
             const void* s0 = data[0];
             const void* s1 = nparts == 2 ? data[1] : (n[0] >= 2 * slab_bytes ? (const void*)((const char*)data[0] + slab_bytes) : nullptr);
-            rc = xengBeamformRunSlabs(s0, p->slab_npkt, p->slab_ntime, s1, p->slab_npkt, p->slab_stride, (uint64_t)seq0, p->slab_chan0, it.out_ptr,
-                                      (const void*)(uintptr_t)weights, version);
+            // (every part must be exactly one slab, or the one part one or two of them: anything else is not a slab sequence)
+            const bool whole = nparts == 2 ? (n[0] == slab_bytes && n[1] == slab_bytes) : (n[0] == slab_bytes || n[0] == 2 * slab_bytes);
+            if (!whole) { pump_release_item(it, false, p); rc = XENG_STATUS_INVALID_ARGUMENT; where = "BeamPump: a gulp that is not whole packet slabs"; break; }
+            rc = p->ops.beam_run_slabs(s0, p->slab_npkt, p->slab_ntime, s1, p->slab_npkt, p->slab_stride, (uint64_t)seq0, p->slab_chan0, it.out_ptr,
+                                       (const void*)(uintptr_t)weights, version);
             seq0 += (unsigned long long)p->ntime_gulp;
             where = "xengBeamformRunSlabs";
         } else if (p->mode == 0) {
-            if (nparts == 2) rc = xengBeamformRunParts(data[0], (int)(n[0] / (size_t)p->row_bytes), data[1], it.out_ptr, (const void*)(uintptr_t)weights, version);
-            else rc = xengBeamformRunVersioned(data[0], it.out_ptr, (const void*)(uintptr_t)weights, version);
+            if (nparts == 2) {
+                // (an upstream writer whose spans are not whole samples: the second part would be read from the wrong byte)
+                if (n[0] % (size_t)p->row_bytes) { pump_release_item(it, false, p); rc = XENG_STATUS_INVALID_ARGUMENT; where = "BeamPump: the first part of a two-part gulp is not a whole number of samples"; break; }
+                rc = p->ops.beam_run_parts(data[0], (int)(n[0] / (size_t)p->row_bytes), data[1], it.out_ptr, (const void*)(uintptr_t)weights, version);
+            } else rc = p->ops.beam_run_versioned(data[0], it.out_ptr, (const void*)(uintptr_t)weights, version);
             where = "xengBeamformRun";
         } else {
             void* target = it.out_ptr;
             if (p->staged) {
                 if (!p->stages_free->empty()) { it.stage = p->stages_free->back(); p->stages_free->pop_back(); }
-                else rc = xengMalloc(&it.stage, p->ogulp, XENG_SPACE_CUDA);
+                else rc = p->ops.dev_malloc(&it.stage, p->ogulp, XENG_SPACE_CUDA);
                 target = it.stage;
             }
-            if (!rc) rc = xengBeamformIntegrate(data[0], target, p->ntime_sum);
+            if (!rc) rc = p->ops.beam_integrate(data[0], target, p->ntime_sum);
             where = "xengBeamformIntegrate";
         }
-        if (!rc) { rc = xengBeamformMark(&it.ticket); if (rc) where = "xengBeamformMark"; }
-        if (rc) { (void)xengBeamformSync(); pump_release_item(it, false, p); break; }
+        if (!rc) { rc = p->ops.beam_mark(&it.ticket); if (rc) where = "xengBeamformMark"; }
+        if (rc) { (void)p->ops.beam_sync(); pump_release_item(it, false, p); break; }
         p->pending->push_back(it);
         ngulps++;
         rc = pump_retire(p, (size_t)p->depth);
@@ -716,6 +780,290 @@ PyMethodDef BeamPump_methods[] = {
     {"abort", (PyCFunction)BeamPump_abort, METH_NOARGS, "after an error elsewhere: wait for the stream, give every span back uncommitted"},
     {nullptr, nullptr, 0, nullptr}};
 
+// ---------------------------------------------------------------- CorrPump: the per-gulp loop of Corr (round 5)
+// What Corr does per gulp while it integrates -- take the next gulp, (first gulp of an integration: reserve the output span,)
+// register the gulp with the X-engine, keep its span until the dump has run, and on the dump gulp rotate: the dump of
+// integration n is enqueued, integration n-1's is waited for (xengXgpuSyncLag(1)), its span committed and its gulps given back
+// -- as one loop inside the extension with the interpreter lock released (corr_block.py:388-466 is one ctypes call per gulp on
+// bifrost's native ring; here the ring calls and the enqueue are native too).  The block's Python keeps what is decided per
+// integration or rarer: sequences and headers, commands (same stop flag as BeamPump: a gulp that arrives with the flag up is
+// handed back unprocessed), the integration gate's start / recovery, statistics.  mode 0 ("skip") only consumes gulps: the
+// states in which the reference's loop passes gulps by (waiting for the start sample, stopped).
+struct CorrPump {
+    PyObject_HEAD
+    PyObject* rin_obj;
+    PyObject* rout_obj;
+    xengRing* rin;
+    xengRing* rout;
+    int reader;
+    long long oseq;
+    size_t igulp, ogulp, advance;
+    int slab_npkt, slab_chan0, ntime_gulp;
+    size_t slab_stride;
+    ComputeOps ops;
+    // the integration in progress: its output span and the gulps registered so far
+    void* out_ptr;
+    long long out_span;
+    std::vector<long long>* held;
+    // the integration whose dump is in flight
+    int have_pending;
+    long long pend_out;
+    std::vector<long long>* pend_held;
+    // a gulp taken from the input ring but not processed (stop flag up, or the reader had lost data before it)
+    int have_carry;
+    void* carry_data;
+    size_t carry_n;
+    long long carry_span;
+};
+
+static void corr_release(std::vector<long long>* v) {
+    for (long long sp : *v) (void)xengRingSpanRelease(sp);
+    v->clear();
+}
+
+// the dump in flight has completed (the caller waited): its span is committed, its gulps go back to the input ring
+static void corr_commit_pending(CorrPump* p) {
+    if (!p->have_pending) return;
+    (void)xengRingCommit(p->rout, p->oseq, p->pend_out, p->ogulp);
+    (void)xengRingSpanRelease(p->pend_out);
+    corr_release(p->pend_held);
+    p->pend_out = 0;
+    p->have_pending = 0;
+}
+
+// wait for the dump in flight and commit it (Corr._finish_pending)
+static int corr_finish(CorrPump* p) {
+    if (!p->have_pending) return XENG_STATUS_SUCCESS;
+    const int rc = p->ops.xgpu_sync();
+    if (rc) return rc;
+    corr_commit_pending(p);
+    return XENG_STATUS_SUCCESS;
+}
+
+// drop the integration in progress (Corr._abort_integration): a completed one whose dump is in flight is still good; the
+// registered gulps are forgotten by the X-engine (xengXgpuReset synchronises: nothing reads them afterwards)
+static int corr_abort(CorrPump* p, bool commit_pending, bool always_reset = true) {
+    int rc = XENG_STATUS_SUCCESS;
+    const bool mid_integration = !p->held->empty() || p->out_span;
+    if (p->have_pending) {
+        rc = p->ops.xgpu_sync();
+        if (!rc && commit_pending) corr_commit_pending(p);
+        else {       // (after an error: nothing may be committed; the spans go back unpublished once the stream is idle)
+            if (p->pend_out) (void)xengRingSpanRelease(p->pend_out);
+            corr_release(p->pend_held);
+            p->pend_out = 0;
+            p->have_pending = 0;
+        }
+    }
+    if (mid_integration || always_reset) {
+        const int rc2 = p->ops.xgpu_reset();
+        if (!rc) rc = rc2;
+    }
+    corr_release(p->held);
+    if (p->out_span) { (void)xengRingSpanRelease(p->out_span); p->out_span = 0; p->out_ptr = nullptr; }
+    return rc;
+}
+
+void CorrPump_dealloc(CorrPump* self) {
+    if (self->held) {
+        Py_BEGIN_ALLOW_THREADS
+        if (self->have_pending || !self->held->empty() || self->out_span) (void)corr_abort(self, false);
+        if (self->have_carry) { (void)xengRingSpanRelease(self->carry_span); self->have_carry = 0; }
+        Py_END_ALLOW_THREADS
+        delete self->held;
+        delete self->pend_held;
+    }
+    Py_CLEAR(self->rin_obj);
+    Py_CLEAR(self->rout_obj);
+    Py_TYPE(self)->tp_free((PyObject*)self);
+}
+
+PyTypeObject CorrPumpType = {PyVarObject_HEAD_INIT(nullptr, 0)};
+
+// corr_pump(in_ring_obj, in_handle, reader, out_ring_obj, out_handle, igulp, ogulp, ntime_gulp[, compute table]) -> CorrPump
+PyObject* corr_pump_new(PyObject*, PyObject* args) {
+    PyObject *rin_obj, *rout_obj, *table = nullptr;
+    unsigned long long hin, hout;
+    int reader, ntime_gulp;
+    Py_ssize_t igulp, ogulp;
+    if (!PyArg_ParseTuple(args, "OKiOKnni|O", &rin_obj, &hin, &reader, &rout_obj, &hout, &igulp, &ogulp, &ntime_gulp, &table)) return nullptr;
+    ComputeOps ops;
+    if (!ops_from_arg(table, &ops)) return nullptr;
+    CorrPump* p = PyObject_New(CorrPump, &CorrPumpType);
+    if (!p) return nullptr;
+    Py_INCREF(rin_obj); Py_INCREF(rout_obj);
+    p->rin_obj = rin_obj; p->rout_obj = rout_obj;
+    p->rin = (xengRing*)hin; p->rout = (xengRing*)hout;
+    p->reader = reader; p->oseq = -1; p->igulp = (size_t)igulp; p->ogulp = (size_t)ogulp; p->advance = 0; p->ntime_gulp = ntime_gulp;
+    p->slab_npkt = 0; p->slab_chan0 = 0; p->slab_stride = 0;
+    p->ops = ops;
+    p->out_ptr = nullptr; p->out_span = 0; p->held = new std::vector<long long>();
+    p->have_pending = 0; p->pend_out = 0; p->pend_held = new std::vector<long long>();
+    p->have_carry = 0; p->carry_data = nullptr; p->carry_n = 0; p->carry_span = 0;
+    return (PyObject*)p;
+}
+
+// run(mode, max_gulps, stop_flag_address, pos, gulps_per_integration, now) -> (gulps consumed, bytes skipped, status, integrations dumped)
+//   mode 0: gulps are taken and given back (the gate is waiting / stopped); 1: gulps are registered, the one at position
+//   gulps_per_integration - 1 dumps.  `pos`: position of the next gulp in its integration; `now`: its sample number (slabs).
+//   status 0: max_gulps consumed;  1: the input sequence is over;  2: the stop flag was up when a gulp arrived -- kept, first of the
+//   next run();  3: the reader had lost `skipped` bytes before the gulp that arrived -- kept likewise, nothing else consumed.
+PyObject* CorrPump_run(CorrPump* p, PyObject* args) {
+    int mode, gpi, pos;
+    long long max_gulps;
+    unsigned long long stop_addr, now;
+    if (!PyArg_ParseTuple(args, "iLKiiK", &mode, &max_gulps, &stop_addr, &pos, &gpi, &now)) return nullptr;
+    if (gpi < 1 || pos < 0 || pos >= gpi) { PyErr_SetString(PyExc_ValueError, "CorrPump.run: bad position in the integration"); return nullptr; }
+    if (mode == 1 && p->oseq < 0) { PyErr_SetString(PyExc_ValueError, "CorrPump.run: no output sequence set"); return nullptr; }
+    volatile int* stop = (volatile int*)(uintptr_t)stop_addr;
+    long long ngulps = 0, nint = 0;
+    size_t skipped_total = 0;
+    int status = 0, rc = 0;
+    const char* where = "";
+    Py_BEGIN_ALLOW_THREADS
+    while (ngulps < max_gulps) {
+        void* data = nullptr;
+        size_t n = 0, skipped = 0;
+        long long span = 0;
+        if (p->have_carry) {
+            data = p->carry_data; n = p->carry_n; span = p->carry_span;
+            p->have_carry = 0;
+        } else {
+            rc = xengRingAcquire(p->rin, p->reader, p->advance, p->igulp, 1, &data, &n, &span, &skipped);
+            if (rc == XENG_STATUS_END_OF_DATA) { rc = 0; status = 1; break; }
+            if (rc) { where = "xengRingAcquire"; break; }
+            p->advance = n;
+            if (n < p->igulp) {              // the short tail of an ended sequence: not a gulp (corr_block.py:389-391)
+                (void)xengRingSpanRelease(span);
+                status = 1;
+                break;
+            }
+            if (skipped || (stop && *stop)) {
+                p->carry_data = data; p->carry_n = n; p->carry_span = span;
+                p->have_carry = 1;
+                skipped_total += skipped;
+                status = skipped ? 3 : 2;
+                break;
+            }
+        }
+        if (mode == 0) {
+            (void)xengRingSpanRelease(span);
+            ngulps++;
+            now += (unsigned long long)p->ntime_gulp;
+            continue;
+        }
+        if (pos == 0 && !p->out_span) {      // one output span per integration (corr_block.py:433-435)
+            rc = xengRingReserve(p->rout, p->oseq, p->ogulp, 0, 1, &p->out_ptr, &p->out_span);
+            if (rc) { where = "xengRingReserve"; (void)xengRingSpanRelease(span); p->out_span = 0; break; }
+        }
+        if (!p->out_span) { rc = XENG_STATUS_INVALID_STATE; where = "CorrPump: a gulp inside an integration that has no output span"; (void)xengRingSpanRelease(span); break; }
+        const int dump = pos == gpi - 1;
+        for (;;) {
+            if (p->slab_npkt > 0) rc = p->ops.xgpu_try_kernel_slab(data, p->slab_npkt, p->slab_stride, (uint64_t)now, p->slab_chan0, p->out_ptr, dump, nullptr, 0);
+            else rc = p->ops.xgpu_try_kernel(data, p->out_ptr, dump, nullptr, 0);
+            if (rc != XENG_STATUS_WOULD_BLOCK) break;
+            rc = p->ops.xgpu_wait_slot();    // 256 launches ahead of the GPU
+            if (rc) break;
+        }
+        if (rc) { where = "xengXgpuKernelAsync"; (void)xengRingSpanRelease(span); break; }     // (this gulp was not registered)
+        p->held->push_back(span);            // the gulp is read where it lies when the dump runs: its memory stays until then
+        ngulps++;
+        now += (unsigned long long)p->ntime_gulp;
+        if (dump) {
+            // the dump of this integration is enqueued; the previous one's has had a whole integration to run
+            const int had = p->have_pending;
+            long long prev_out = p->pend_out;
+            std::vector<long long> prev_held;
+            prev_held.swap(*p->pend_held);
+            p->pend_out = p->out_span; p->pend_held->swap(*p->held); p->have_pending = 1;
+            p->out_span = 0; p->out_ptr = nullptr;
+            if (had) {
+                rc = p->ops.xgpu_sync_lag(1);
+                if (rc) {                    // (cannot tell whether it completed: hand the spans to the abort below, uncommitted)
+                    where = "xengXgpuSyncLag";
+                    for (long long sp : prev_held) p->held->push_back(sp);
+                    p->held->push_back(prev_out);
+                    break;
+                }
+                (void)xengRingCommit(p->rout, p->oseq, prev_out, p->ogulp);
+                (void)xengRingSpanRelease(prev_out);
+                for (long long sp : prev_held) (void)xengRingSpanRelease(sp);
+            }
+            nint++;
+            pos = 0;
+        } else {
+            pos++;
+        }
+    }
+    if (rc) (void)corr_abort(p, false);
+    Py_END_ALLOW_THREADS
+    if (rc) return raise_xeng(where, rc);
+    return Py_BuildValue("(LniL)", ngulps, (Py_ssize_t)skipped_total, status, nint);
+}
+
+PyObject* CorrPump_finish(CorrPump* p, PyObject*) {
+    int rc;
+    Py_BEGIN_ALLOW_THREADS
+    rc = corr_finish(p);
+    if (rc) (void)corr_abort(p, false);
+    Py_END_ALLOW_THREADS
+    if (rc) return raise_xeng("CorrPump.finish", rc);
+    Py_RETURN_NONE;
+}
+
+PyObject* CorrPump_abort(CorrPump* p, PyObject*) {
+    int rc;
+    Py_BEGIN_ALLOW_THREADS
+    rc = corr_abort(p, true);
+    Py_END_ALLOW_THREADS
+    if (rc) return raise_xeng("CorrPump.abort", rc);
+    Py_RETURN_NONE;
+}
+
+// close(): at the end of the input sequence or after an error elsewhere -- everything in flight is waited for; the dump in flight is
+// committed (commit = 1) or dropped; gulps in hand go back
+PyObject* CorrPump_close(CorrPump* p, PyObject* args) {
+    int commit = 1;
+    if (!PyArg_ParseTuple(args, "|p", &commit)) return nullptr;
+    int rc;
+    Py_BEGIN_ALLOW_THREADS
+    rc = corr_abort(p, commit != 0, false);
+    if (p->have_carry) { (void)xengRingSpanRelease(p->carry_span); p->have_carry = 0; }
+    Py_END_ALLOW_THREADS
+    if (rc) return raise_xeng("CorrPump.close", rc);
+    Py_RETURN_NONE;
+}
+
+PyObject* CorrPump_set_output(CorrPump* p, PyObject* args) {
+    long long oseq;
+    if (!PyArg_ParseTuple(args, "L", &oseq)) return nullptr;
+    if (p->have_pending || p->out_span) { PyErr_SetString(PyExc_RuntimeError, "CorrPump.set_output with an integration in flight (finish() first)"); return nullptr; }
+    p->oseq = oseq;
+    Py_RETURN_NONE;
+}
+
+PyObject* CorrPump_set_slabs(CorrPump* p, PyObject* args) {
+    int npkt, chan0;
+    Py_ssize_t stride;
+    if (!PyArg_ParseTuple(args, "ini", &npkt, &stride, &chan0)) return nullptr;
+    p->slab_npkt = npkt; p->slab_stride = (size_t)stride; p->slab_chan0 = chan0;
+    Py_RETURN_NONE;
+}
+
+PyObject* CorrPump_state(CorrPump* p, PyObject*) {
+    return Py_BuildValue("(iniii)", p->have_pending, (Py_ssize_t)p->held->size(), p->out_span ? 1 : 0, p->have_carry, (int)p->pend_held->size());
+}
+
+PyMethodDef CorrPump_methods[] = {
+    {"run", (PyCFunction)CorrPump_run, METH_VARARGS, "(mode, max_gulps, stop_flag_address, pos, gulps_per_integration, now) -> (gulps, skipped bytes, status, integrations)"},
+    {"finish", (PyCFunction)CorrPump_finish, METH_NOARGS, "wait for the dump in flight and commit its span"},
+    {"abort", (PyCFunction)CorrPump_abort, METH_NOARGS, "drop the integration in progress (the dump in flight is still committed)"},
+    {"close", (PyCFunction)CorrPump_close, METH_VARARGS, "([commit = True]) end of the sequence / after an error: nothing stays in flight or in hand"},
+    {"set_output", (PyCFunction)CorrPump_set_output, METH_VARARGS, "(output sequence id)"},
+    {"set_slabs", (PyCFunction)CorrPump_set_slabs, METH_VARARGS, "(npkt, stride, chan0): gulps are packet slabs"},
+    {"state", (PyCFunction)CorrPump_state, METH_NOARGS, "-> (dump in flight, gulps held, output span open, gulp carried, gulps of the dump in flight)"},
+    {nullptr, nullptr, 0, nullptr}};
+
 PyObject* map_i32(PyObject*, PyObject* args) {
     unsigned long long a, b;
     Py_ssize_t n;
@@ -746,7 +1094,9 @@ PyMethodDef methods[] = {
     {"ring_feed_external", ring_feed_external, METH_VARARGS, "harness: (handle, seq, addresses, nbytes, count) -- a source that is not a Python thread"},
     {"ring_feed_slabs", ring_feed_slabs, METH_VARARGS, "harness: (handle, seq, addresses, nbytes, count, npkt, stride, pkts_per_seq, ntime) -- a receiver that reuses its slab buffers"},
     {"ring_drain", ring_drain, METH_VARARGS, "harness: (handle, reader, gulp, want_times) -> (spans, times) -- a sink that is not a Python thread"},
-    {"beam_pump", beam_pump_new, METH_VARARGS, "(in_ring, in_handle, reader, out_ring, out_handle, out_seq, igulp, ogulp, mode, row_bytes, ntime_sum, depth, staged) -> BeamPump"},
+    {"beam_pump", beam_pump_new, METH_VARARGS, "(in_ring, in_handle, reader, out_ring, out_handle, out_seq, igulp, ogulp, mode, row_bytes, ntime_sum, depth, staged[, compute table]) -> BeamPump"},
+    {"corr_pump", corr_pump_new, METH_VARARGS, "(in_ring, in_handle, reader, out_ring, out_handle, igulp, ogulp, ntime_gulp[, compute table]) -> CorrPump"},
+    {"compute_table_size", [](PyObject*, PyObject*) -> PyObject* { return PyLong_FromSize_t(NOPS); }, METH_NOARGS, "number of function pointers in a compute table"},
     {"copy_async", copy_async, METH_VARARGS, "(dst, src, nbytes) -> stamp of the enqueued copy (bytes)"},
     {"stamp_done", stamp_done, METH_VARARGS, "(stamp) -> bool"},
     {"stamp_wait", stamp_wait, METH_VARARGS, "(stamp): waits (interpreter lock released) unless it is done"},
@@ -770,6 +1120,13 @@ PyMODINIT_FUNC PyInit__xfast(void) {
     BeamPumpType.tp_methods = BeamPump_methods;
     BeamPumpType.tp_doc = "the steady-state per-gulp loop of Beamform / BeamformSumBeams, run without the interpreter lock";
     if (PyType_Ready(&BeamPumpType) < 0) return nullptr;
+    CorrPumpType.tp_name = "_xfast.CorrPump";
+    CorrPumpType.tp_basicsize = sizeof(CorrPump);
+    CorrPumpType.tp_flags = Py_TPFLAGS_DEFAULT;
+    CorrPumpType.tp_dealloc = (destructor)CorrPump_dealloc;
+    CorrPumpType.tp_methods = CorrPump_methods;
+    CorrPumpType.tp_doc = "the per-gulp loop of Corr while it integrates, run without the interpreter lock";
+    if (PyType_Ready(&CorrPumpType) < 0) return nullptr;
     PyObject* m = PyModule_Create(&moddef);
     if (!m) return nullptr;
     Py_INCREF(&SpanRefType);

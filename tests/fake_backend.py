@@ -218,3 +218,178 @@ class OracleBackend:
         out = orc.beamform_integrate(beams, ntime_sum)
         _np(out_arr, np.float32, out.size)[...] = out.ravel()
         return 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The native per-gulp loops (csrc/pyext/xfast.cpp BeamPump / CorrPump) on CPU rings: a table of ctypes callbacks in the order
+# of xfast.cpp's ComputeOps, so that the pumps call THIS backend (the oracle, on system-space span memory) where they would
+# call libxeng.  Round-4 review W2: their error paths were reached on the GPU box only.
+class _Ptr:
+    """what `_np` needs of an `as_BFarray()` reference: the address"""
+    def __init__(self, ptr):
+        self.data = ptr
+
+
+class _Bytes:
+    """what the slab / parts calls need of an XArray: numpy() and ptr"""
+    def __init__(self, ptr, nbytes):
+        self.ptr, self.nbytes = ptr, nbytes
+        self._a = np.frombuffer((ctypes.c_char * nbytes).from_address(ptr), dtype=np.uint8) if ptr else None
+
+    def numpy(self):
+        return self._a
+
+
+class _Stamp(ctypes.Structure):
+    _fields_ = [("w", ctypes.c_ulonglong * 16)]
+
+
+_vp, _i, _ll, _sz, _u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_size_t, ctypes.c_uint64
+_COMPUTE_SIGNATURES = [
+    ("beam_run_versioned", [_vp, _vp, _vp, _ll]), ("beam_run_parts", [_vp, _i, _vp, _vp, _vp, _ll]),
+    ("beam_run_slabs", [_vp, _i, _i, _vp, _i, _sz, _u64, _i, _vp, _vp, _ll]), ("beam_integrate", [_vp, _vp, _i]),
+    ("beam_mark", [ctypes.POINTER(ctypes.c_ulonglong)]), ("beam_wait", [ctypes.c_ulonglong]), ("beam_sync", []),
+    ("memcpy_async", [_vp, _vp, _sz]), ("stamp_now_for", [ctypes.POINTER(_Stamp), _vp, ctypes.c_uint]),
+    ("stamp_done", [ctypes.POINTER(_Stamp), ctypes.POINTER(_i), ctypes.POINTER(_i)]), ("stamp_wait", [ctypes.POINTER(_Stamp)]),
+    ("dev_malloc", [ctypes.POINTER(_vp), _sz, _i]), ("dev_free", [_vp, _i]),
+    ("xgpu_try_kernel", [_vp, _vp, _i, _vp, _i]), ("xgpu_try_kernel_slab", [_vp, _i, _sz, _u64, _i, _vp, _i, _vp, _i]),
+    ("xgpu_wait_slot", []), ("xgpu_sync_lag", [_i]), ("xgpu_sync", []), ("xgpu_reset", []),
+]
+
+
+class PumpOracleBackend(OracleBackend):
+    """OracleBackend whose beam_pump / corr_pump build the NATIVE pumps with a compute table that calls back into it.
+    `fail`: {entry name: call number (1-based) at which that entry returns an error status} -- failure injection."""
+    ERR = 5
+
+    def __init__(self, fail=None, slab=None):
+        super().__init__()
+        self.fail = dict(fail or {})
+        self.calls = {}
+        self.callback_errors = []
+        self.slab = slab                     # (npkt, stride, slab_ntime) of a slab sequence: sizes of the parts handed to run_slabs
+        self._staged = {}
+        self._tickets = 0
+        self._copies = 0
+        self._keep = []
+        self._table = None
+
+    # ---- the table
+    def compute_table(self):
+        if self._table is None:
+            ptrs = (ctypes.c_void_p * len(_COMPUTE_SIGNATURES))()
+            for k, (name, args) in enumerate(_COMPUTE_SIGNATURES):
+                cb = ctypes.CFUNCTYPE(ctypes.c_int, *args)(self._guard(name, getattr(self, "_op_" + name)))
+                self._keep.append(cb)
+                ptrs[k] = ctypes.cast(cb, ctypes.c_void_p).value
+            self._table = bytes(ptrs)
+        return self._table
+
+    def _guard(self, name, fn):
+        def call(*a):
+            n = self.calls[name] = self.calls.get(name, 0) + 1
+            if self.fail.get(name) == n:
+                return self.ERR
+            try:
+                return int(fn(*a) or 0)
+            except Exception as e:              # (an exception cannot cross the C frames of the pump)
+                self.callback_errors.append((name, repr(e)))
+                return 3
+        return call
+
+    def beam_pump(self, iring, reader, oring, oseq_id, igulp, ogulp, mode, row_bytes=0, ntime_sum=0, depth=8, staged=False):
+        if not (hasattr(iring, "_h") and hasattr(oring, "_h")):
+            return None
+        from caltech_bifrost_dsp_amd.ring import _xfast
+        self.pump_args = dict(igulp=igulp, ogulp=ogulp, mode=mode, row_bytes=row_bytes)
+        return _xfast().beam_pump(iring, iring._h, int(reader), oring, oring._h, int(oseq_id), int(igulp), int(ogulp), int(mode), int(row_bytes),
+                                  int(ntime_sum), int(depth), int(bool(staged)), self.compute_table())
+
+    def corr_pump(self, iring, reader, oring, igulp, ogulp, ntime_gulp):
+        if not (hasattr(iring, "_h") and hasattr(oring, "_h")):
+            return None
+        from caltech_bifrost_dsp_amd.ring import _xfast
+        self.corr_pumps = getattr(self, "corr_pumps", 0) + 1
+        return _xfast().corr_pump(iring, iring._h, int(reader), oring, oring._h, int(igulp), int(ogulp), int(ntime_gulp), self.compute_table())
+
+    # ---- beamformer entries
+    def _op_beam_run_versioned(self, vin, out, w, version):
+        return self.bfBeamformRun(_Ptr(vin), _Ptr(out), _Ptr(w), version=version)
+
+    def _op_beam_run_parts(self, in0, ntime0, in1, out, w, version):
+        b = self.beam
+        row = b["nchan"] * b["ninput"]
+        return self.bfBeamformRunParts(_Bytes(in0, ntime0 * row), _Bytes(in1, (b["ntime"] - ntime0) * row), _Ptr(out), _Ptr(w), version=version)
+
+    def _op_beam_run_slabs(self, pk0, npkt0, ntime0, pk1, npkt1, stride, seq0, chan0, out, w, version):
+        self.slab_seq0 = getattr(self, "slab_seq0", []) + [int(seq0)]
+        s0 = _Bytes(pk0, npkt0 * stride)
+        s1 = _Bytes(pk1, npkt1 * stride) if pk1 else None
+        return self.bfBeamformRunSlabs(s0, npkt0, ntime0, s1, npkt1, stride, seq0, chan0, _Ptr(out), _Ptr(w), version=version)
+
+    def _op_beam_integrate(self, vin, out, ntime_sum):
+        return self.bfBeamformIntegrate(_Ptr(vin), _Ptr(out), ntime_sum)
+
+    def _op_beam_mark(self, t):
+        self._tickets += 1
+        t[0] = self._tickets
+        return 0
+
+    def _op_beam_wait(self, t):
+        self.waits = getattr(self, "waits", []) + [int(t)]
+        return 0
+
+    def _op_beam_sync(self):
+        self.syncs = getattr(self, "syncs", 0) + 1
+        return 0
+
+    def _op_memcpy_async(self, dst, src, n):
+        ctypes.memmove(dst, src, n)
+        return 0
+
+    def _op_stamp_now_for(self, st, buf, classes):
+        self._copies += 1
+        st[0].w[0] = self._copies
+        return 0
+
+    def _op_stamp_done(self, st, done, waitable):
+        done[0] = 1
+        if waitable:
+            waitable[0] = 1
+        return 0
+
+    def _op_stamp_wait(self, st):
+        return 0
+
+    def _op_dev_malloc(self, out, n, space):
+        buf = (ctypes.c_char * max(int(n), 1))()
+        addr = ctypes.addressof(buf)
+        self._staged[addr] = buf
+        out[0] = addr
+        return 0
+
+    def _op_dev_free(self, p, space):
+        self._staged.pop(p, None)
+        return 0
+
+    # ---- X-engine entries
+    def _op_xgpu_try_kernel(self, vin, out, dump, acc, mode):
+        return self.bfXgpuKernelAsync(_Ptr(vin), _Ptr(out), dump)
+
+    def _op_xgpu_try_kernel_slab(self, pk, npkt, stride, seq0, chan0, out, dump, acc, mode):
+        self.slab_seq0 = getattr(self, "slab_seq0", []) + [int(seq0)]
+        return self.bfXgpuKernelSlab(_Bytes(pk, npkt * stride), npkt, stride, seq0, chan0, _Ptr(out), dump)
+
+    def _op_xgpu_wait_slot(self):
+        return 0
+
+    def _op_xgpu_sync_lag(self, lag):
+        self.lag_syncs = getattr(self, "lag_syncs", 0) + 1
+        return 0
+
+    def _op_xgpu_sync(self):
+        self.xsyncs = getattr(self, "xsyncs", 0) + 1
+        return 0
+
+    def _op_xgpu_reset(self):
+        return self.xgpu_reset()
