@@ -160,7 +160,8 @@ def corr_block_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=100):
                     "`throughput` stat of its last integration (corr_block.py:453 formula)"}
 
 
-def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=400, long_len=50, from_slabs=False, in_ring_integrations=4):
+def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=400, long_len=50, from_slabs=False, in_ring_integrations=4, chan0=0, seed=7,
+                       keep_span=None):
     """BASELINE config 5 through the BLOCKS on one GPU: Corr -> CorrAcc and Beamform -> BeamformSumBeams as four Python
     threads on in-repo rings (gpu-input read in place by Corr and Beamform), fed by a zero-copy replay source.  CorrAcc's
     long accumulation (`long_len` dumps) is done by the dumps' own epilogue (fused mode, blocks/corr_acc_block.py).  The warm-up
@@ -214,9 +215,9 @@ def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=4
     sb = BeamformSumBeams(log, r_bf, r_pow, nchan=NCHAN, ntime_gulp=nt_b, ntime_sum=ns, gpu=gpu)
     if os.environ.get("XENG_BENCH_VIS_SPANS"):       # (diagnosis: a deeper corr-output ring)
         r_vis.resize(corr.ogulp_size, total_span=int(os.environ["XENG_BENCH_VIS_SPANS"]) * corr.ogulp_size)
-    rng = np.random.default_rng(7)
+    rng = np.random.default_rng(seed)
     bf.gains_cpu[...] = (rng.uniform(-17, 17, bf.gains_cpu.shape) + 1j * rng.uniform(-17, 17, bf.gains_cpu.shape)).astype(np.complex64)
-    hdr = {'nchan': NCHAN, 'chan0': 0, 'bw_hz': NCHAN * 23925.78125, 'fs_hz': 196000000, 'sfreq': 0.0, 'nstand': NSTAND, 'npol': NPOL,
+    hdr = {'nchan': NCHAN, 'chan0': chan0, 'bw_hz': NCHAN * 23925.78125, 'fs_hz': 196000000, 'sfreq': chan0 * 23925.78125, 'nstand': NSTAND, 'npol': NPOL,
            'seq0': 0, 'sync_time': 0, 'pipeline_id': 0, 'system_nchan': 32 * NCHAN}
     if from_slabs:
         hdr.update({'layout': 'snap2_slab', 'slab_ntime': NTIME_GULP, 'npkt_per_gulp': npk, 'pkt_stride': stride})
@@ -249,8 +250,23 @@ def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=4
                             ffi.call("xengSnap2StampSeq", spans[k % ring_gulps].ptr, npk, stride, k * NTIME_GULP, nblk)
                         oseq.commit_external(spans[k % ring_gulps])
 
-    def drain(rg, gulp, on_span=None, times=None):
+    kept = {}
+
+    def drain(rg, gulp, on_span=None, times=None, keep=None):
         rg.declare_streams()        # (a sink that only counts spans)
+        if keep is not None:        # (the N-rank leg: span number `keep` is copied to the host for the check against the oracle)
+            gen_k = rg.read(guarantee=True)
+
+            def run_keep():
+                n = 0
+                for iseq in gen_k:
+                    for ispan in iseq.read(gulp):
+                        if times is not None:
+                            times.append(time.perf_counter())
+                        if n == keep:
+                            kept['vis'] = ispan.data.numpy().view(np.int32).copy()
+                        n += 1
+            return threading.Thread(target=run_keep, daemon=True)
         if native_harness:
             import ctypes as _ct
             rid = _ct.c_int()
@@ -277,7 +293,7 @@ def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=4
 
     def slow_span():
         nslow[0] += 1
-    ths = [drain(r_vis, corr.ogulp_size, times=stamps), drain(r_slow, cacc.ogulp_size, slow_span),
+    ths = [drain(r_vis, corr.ogulp_size, times=stamps, keep=keep_span), drain(r_slow, cacc.ogulp_size, slow_span),
            drain(r_pow, (nbeam // 2) * (nt_b // ns) * NCHAN * 16)]
     ths += [threading.Thread(target=f, daemon=True) for f in (corr.main, cacc.main, bf.main, sb.main, source)]
     # Four block threads (+ the harness threads on the Python ring) under one interpreter lock.  The blocks keep the lock across their enqueue-only library calls and ask
@@ -325,6 +341,8 @@ def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=4
         q = (n - 1 - nwarm) // 4
         wins = [round((stamps[nwarm + (k + 1) * q] - stamps[nwarm + k * q]) / q * 1e3, 4) for k in range(4)] if q > 0 else []
     return {"value": round(8 * NINPUT * ACC_LEN * NCHAN * (n - 1 - nwarm) / el / 1e9, 1) if ok else 0.0, "unit": "Gb/s",
+            **({"kept": kept} if keep_span is not None else {}),        # (the N-rank leg's span for the oracle: popped before anything is printed)
+            "seconds": round(el, 6), "timed_integrations": max(n - 1 - nwarm, 0),
             "ms_per_integration": round(el / max(n - 1 - nwarm, 1) * 1e3, 4) if ok else None, "integrations": n, "window_ms": wins,
             "long_integrations_published": nslow[0], "corracc_mode": "fused" if cacc.stats.get('fused') else ("grouped, %d dumps per pass" % cacc.group_dumps) if cacc.stats.get('grouped') else "map",
             # span allocations per ring over the whole leg: made, really freed, reissued from the free list, waits for a stamp at reissue
@@ -347,6 +365,69 @@ def beam_weights(chan0, seed):
         cal = (rng.uniform(-1, 1, (NCHAN, NINPUT)) + 1j * rng.uniform(-1, 1, (NCHAN, NINPUT))).astype(np.complex64)
         wts[:, b_, :] = amps * np.exp(1j * 2 * np.pi * freqs[:, None] * delays_ns * 1e-9) * cal
     return np.ascontiguousarray(wts.reshape(-1))
+
+
+def config5_blocks_workload(args, ffi, dist, rank, world, gpu, ring, gulp_bytes, pin, info, sh):
+    """`--workload config5_blocks`: config 5 through the BLOCKS on every rank -- the part of the pipeline with host threads, pinned-host
+    publishes and an interpreter, i.e. the part that could fail to scale (lwa352-start-pipeline.sh:1-8 runs four such pipeline
+    processes per server on pinned cores).  Every rank runs Corr -> CorrAcc and Beamform -> BeamformSumBeams on its own GPU, its own
+    96 channels (header chan0 / sfreq of channel block `rank`, input seed 0xdeadbeef + rank, gain seed 7 + rank); one step = one
+    integration of every rank, timed between visibility spans at a sink after `warmup` integrations; value = ingest of all ranks /
+    max-over-ranks time.  Outside the timed region every rank holds one visibility span to the oracle."""
+    if dist is not None:
+        dist.barrier()
+    leg = config5_blocks_leg(ffi, ring, gulp_bytes, args.ring_gulps, gpu, nint=args.steps, nwarm=max(args.warmup, 20), chan0=NCHAN * rank, seed=7 + rank,
+                             keep_span=2 * (args.ring_gulps // (ACC_LEN // NTIME_GULP)))
+    ffi.call("xengDeviceSynchronize")
+    el = leg["seconds"] * args.steps / max(leg["timed_integrations"], 1)          # (time of args.steps integrations at the measured rate)
+    ok = None
+    if not args.no_cpu_baseline:
+        from oracle import xeng_oracle as orc
+        orc.build()
+        gps = ACC_LEN // NTIME_GULP
+        rs5 = np.random.RandomState(0xdeadbeef + rank)                              # (the replay ring's gulps 0 .. gps-1 of this rank: main())
+        acc = None
+        for g in range(gps):
+            blk = rs5.randint(0, 255, size=gulp_bytes, dtype=np.uint8) if args.data == "random" else None
+            if blk is None:
+                break
+            acc = orc.xgpu_correlate(blk.reshape(NTIME_GULP, NCHAN, NSTAND, NPOL), NSTAND, NCHAN, acc)
+        vis = leg.pop("kept").get("vis")
+        ok = {"visibilities_bit_exact": bool(acc is not None and vis is not None and np.array_equal(vis.reshape(-1), acc.reshape(-1))),
+              "span": "integration %d of the stream = replay gulps 0..%d" % (2 * (args.ring_gulps // gps), gps - 1)}
+        ok["ok"] = ok["visibilities_bit_exact"]
+    leg.pop("kept", None)
+    per_rank_ms = [round(v / args.steps * 1e3, 4) for v in sh.gather_over_ranks(dist, el)]
+    oks, wins = [ok], [leg["window_ms"]]
+    if dist is not None:
+        import torch
+        oks, wins = [None] * world, [None] * world
+        dist.all_gather_object(oks, ok)
+        dist.all_gather_object(wins, leg["window_ms"])
+        t = torch.tensor([el], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+        dist.barrier()
+    units = ACC_LEN * NCHAN * args.steps * world
+    gbps = 8 * NINPUT * units / el / 1e9
+    return {
+        "metric": "xengine_ingest_gbps_704in_96ch", "value": round(gbps, 2), "unit": "Gb/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "int8 (4+4-bit samples) -> int32; beams fp32", "data": "synthetic",
+        "config": {"workload": "config 5 through the BLOCKS on every GPU: Corr -> CorrAcc (%s) and Beamform (960-sample gulps) -> BeamformSumBeams, four block threads per "
+                               "rank on in-repo rings, zero-copy replay source; 704 inputs, %d chan/GPU" % (leg.get("corracc_mode"), NCHAN),
+                   "nchan_total": NCHAN * world, "chan0_per_rank": [NCHAN * r for r in range(world)], "sharding": "channels, %d per GPU, no collective" % NCHAN},
+        "per_rank_ms": per_rank_ms, "per_rank_ms_min": min(per_rank_ms), "per_rank_ms_max": max(per_rank_ms), "per_rank_window_ms": wins,
+        "cmac_per_s": CMAC_PER_UNIT * units / el, "design_rate_x": round(gbps / world / 12.94, 1),
+        "roofline": {"kernel": "xcorr_fused_kernel", "bound": "mfma", "unit": "TFLOP/s",
+                     "achieved": round(OPS_PER_UNIT * ACC_LEN * NCHAN / (el / args.steps) / 1e12, 1), "peak": round(PEAK_INT8_OPS / 1e12, 1),
+                     "frac": round(OPS_PER_UNIT * ACC_LEN * NCHAN / (el / args.steps) / PEAK_INT8_OPS, 4), "traffic": None,
+                     "note": "the contraction's algorithmic int8 ops per integration / time per integration of the slowest rank, while the beamformer chain, CorrAcc "
+                             "and the host side of four blocks share the GPU and the interpreter (config 5 through the blocks: not the contraction alone)"},
+        "verified": {"ok": all(bool(o and o["ok"]) for o in oks) if oks[0] is not None else None, "per_rank": oks},
+        "rank_placement": {"numa_node": pin["numa_node"], "ncpus": len(pin["cpus"]), "source": pin["source"]},
+        "device": info,
+    }
 
 
 def config5_workload(args, ffi, dist, rank, world, gpu, ring, gulp_bytes, pin, info, sh):
@@ -488,7 +569,7 @@ def _leg(name):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--workload", default="correlator", choices=["correlator", "config5"],
+    ap.add_argument("--workload", default="correlator", choices=["correlator", "config5", "config5_blocks"],
                     help="correlator: BASELINE config 2 / 3 (the headline: one contraction per step); config5: the full X-engine per "
                          "GPU (Corr + fused CorrAcc + Beamform + power beams concurrently), sharded like config 3")
     # steady state of the streaming pipeline is reached after a few hundred integrations (clock / power ramp of a
@@ -616,8 +697,8 @@ def main():
         else:
             blk = np.full(gulp_bytes, 0 if args.data == "zeros" else 0x88, dtype=np.uint8)
         ring.upload(blk, offset=g * gulp_bytes)
-    if args.workload == "config5":
-        res = config5_workload(args, ffi, dist, rank, world, gpu, ring, gulp_bytes, pin, info, _sh)
+    if args.workload in ("config5", "config5_blocks"):
+        res = (config5_workload if args.workload == "config5" else config5_blocks_workload)(args, ffi, dist, rank, world, gpu, ring, gulp_bytes, pin, info, _sh)
         if rank == 0:
             print(json.dumps(res))
         ffi.call("xengXgpuDestroy")
@@ -839,8 +920,8 @@ def main():
             slabs_a.append(ffi.DeviceBuffer(slab_a.nbytes))
             ffi.call("xengMemcpy", slabs_a[k].ptr, slabs_a[0].ptr, slab_a.nbytes)
 
-        def packets_leg(direct):
-            nrep, nwarm, kk = 300, 100, 0
+        def packets_leg(direct, slabs=slabs, nrep=300, nwarm=100):
+            kk = 0
             for it in range(nwarm + nrep):
                 if it == nwarm:
                     ffi.call("xengXgpuSync")
@@ -898,6 +979,42 @@ def main():
         ingest["packets_to_visibilities_payloads_on_cache_lines"]["equals_scatter_path"] = bool(np.array_equal(slab_a_vis, want_vis))
         for b in slabs_a:
             b.free()
+        # ... and on a LOSSY link (the reference's transmitter has a deliberate-loss switch: test_tx_mt.c:22,108-118): the slot of
+        # a lost packet holds a duplicate of its neighbour (what a receiver that fills slots in arrival order is left with); a
+        # slab with a hole is not the gulp in another order any more -- it is zero-filled and scattered on the device (slab.hip)
+        def lossy_copy(nlost, seed):
+            rs = np.random.RandomState(seed)
+            out = []
+            for k, b in enumerate(slabs):
+                c = ffi.DeviceBuffer(b.nbytes)
+                ffi.call("xengMemcpy", c.ptr, b.ptr, b.nbytes)
+                for p in (rs.choice(npk - 1, size=nlost(k), replace=False) if nlost(k) else []):
+                    ffi.call("xengMemcpy", c.ptr + int(p) * stride, b.ptr + (int(p) + 1) * stride, stride)
+                out.append(c)
+            return out
+        lossy = {}
+        for name, nlost in (("one_packet_lost_per_integration", lambda k: 1 if k % gulps_per_step == 2 else 0), ("one_percent_lost", lambda k: npk // 100)):
+            _leg('packets in place, ' + name)
+            sl = lossy_copy(nlost, 11)
+            nfb = ctypes.c_int(-1)
+            ffi.call("xengXgpuGetSlabFallbacks", ctypes.byref(nfb))
+            el5, nrep5 = packets_leg(1, sl, nrep=200, nwarm=60)
+            ffi.call("xengXgpuGetSlabFallbacks", ctypes.byref(nfb))
+            got = outs[(200 + 60 - 1) & 1].download(np.int32)
+            for g in range(gulps_per_step):
+                dst = ring.ptr + g * gulp_bytes
+                slot = ((200 + 60 - 1) * gulps_per_step + g) % (2 * gulps_per_step)
+                ffi.check("unpack", L.xengSnap2UnpackAsync(sl[slot].ptr, npk, stride, dst, slot * NTIME_GULP, NTIME_GULP, 0, NCHAN, NINPUT, 1))
+                ffi.check(kern, L.xengXgpuKernelAsync(dst, outs[0].ptr, int(g == gulps_per_step - 1)))
+            ffi.call("xengXgpuSync")
+            lossy[name] = {"value": round(8 * NINPUT * units_per_step_c * nrep5 / el5 / 1e9, 1), "unit": "Gb/s", "ms_per_step": round(el5 / nrep5 * 1e3, 4),
+                           "gulps_scattered_after_all": int(nfb.value), "gulps": (200 + 60) * gulps_per_step,
+                           "equals_scatter_path": bool(np.array_equal(got, outs[0].download(np.int32)))}
+            for b in sl:
+                b.free()
+        lossy["note"] = ("packets_to_visibilities with packets lost (the lost packet's slot holds a duplicate of the next one): every gulp with a hole "
+                         "goes through zero-fill + scatter on the device, the others are read in place")
+        ingest["packets_to_visibilities"]["lossy"] = lossy
         dgulp.free()
     _leg('beamform')
     # outside the timed region: BASELINE config 4 -- Beamform (32 beams, 96 chan, 960 samples, fp32 weights)

@@ -140,6 +140,14 @@ static void launch_xcorr(const XcorrParams& p, hipStream_t s, bool raw, int grid
         const dim3 grid(grid_size);
 #ifdef XENG_DIAGNOSTICS
         const int fabl = getenv("XENG_ABLATE") ? atoi(getenv("XENG_ABLATE")) : 0;     // (diagnostic build: read per launch, so one process can alternate)
+#ifdef XENG_EXPERIMENTS
+        // XENG_KLOOP=16: the 16x16x64, eight-wave K loop inside the real kernel (experiments/xcorr_fused16.h: TIMING ONLY, results are wrong)
+        if (getenv("XENG_KLOOP") && atoi(getenv("XENG_KLOOP")) == 16 && !p.gdesc && !p.acc2_mode) {
+            if (fabl == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused16_kernel<16>), grid, dim3(512), 0, s, p);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused16_kernel<0>), grid, dim3(512), 0, s, p);
+            return;
+        }
+#endif
         switch (fabl) {
             case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<1>), grid, dim3(256), 0, s, p); return;
             case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<2>), grid, dim3(256), 0, s, p); return;

@@ -603,7 +603,8 @@ __device__ __forceinline__ void xcorr_mfma_cells(const Frags& u, bool skip1, v16
 // Epilogue of the fragment-tiled kernel: accumulator (m, n) is cell p = 2m + n with rows = inputs 32*row[p].., columns =
 // inputs 32*col[p].. (wave-uniform).  Same register-tile order, lane regrouping and masks as xcorr_store_tile.
 // fast: all four cells live, strictly below the diagonal, no padded inputs, nothing to add to -- exactly 32 stores.
-template <bool LACC>
+// MR: accumulator rows m in use (2: all four cells; 1: cells 0 and 1 only -- the two-cell wave tiles of experiments/xcorr_fused16.h)
+template <bool LACC, int MR = 2>
 __device__ __forceinline__ void xcorr_store_cells(const XcorrParams& p, int c, const int (&row)[4], const int (&col)[4],
                                                   int live, bool fast, bool accumulate, int lane, const v16i (&accR)[2][2],
                                                   const v16i (&accP)[2][2], const v16i (&accQ)[2][2]) {
@@ -639,7 +640,7 @@ __device__ __forceinline__ void xcorr_store_cells(const XcorrParams& p, int c, c
     if (fast) {
         // straight-line code: no per-cell branches, so the lane regrouping of one cell overlaps the arithmetic of the next
 #pragma unroll
-        for (int m = 0; m < 2; m++)
+        for (int m = 0; m < MR; m++)
 #pragma unroll
             for (int n = 0; n < 2; n++) {
                 const int ibase = row[2 * m + n] * 32, jbase = col[2 * m + n] * 32;
@@ -665,7 +666,7 @@ __device__ __forceinline__ void xcorr_store_cells(const XcorrParams& p, int c, c
         return;
     }
 #pragma unroll
-    for (int m = 0; m < 2; m++)
+    for (int m = 0; m < MR; m++)
 #pragma unroll
         for (int n = 0; n < 2; n++) {
             if (!((live >> (2 * m + n)) & 1)) continue;          // wave-uniform
@@ -1134,6 +1135,7 @@ __global__ __launch_bounds__(256) void packetize_kernel(const int32_t* __restric
 
 #ifdef XENG_EXPERIMENTS
 #include "experiments/xcorr_fp6.h"
+#include "experiments/xcorr_fused16.h"
 #endif
 
 }  // namespace xeng

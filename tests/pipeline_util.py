@@ -47,6 +47,38 @@ class Source(threading.Thread):
                             time.sleep(self.gap)
 
 
+class GatedSource(threading.Thread):
+    """Writes one sequence gulp by gulp; before gulp k it waits for gates[k] (a threading.Event) when there is one -- so a test
+    can make something happen between two named gulps by construction, not by timing."""
+
+    def __init__(self, ring, hdr, data, span, gates):
+        super().__init__(daemon=True)
+        self.ring, self.hdr, self.data, self.span, self.gates = ring, hdr, data.reshape(-1).view(np.uint8), span, gates
+        self.written = 0
+
+    def run(self):
+        t0 = time.time()
+        while len(self.ring._readers) < 1 and time.time() - t0 < 10:
+            time.sleep(0.002)
+        with self.ring.begin_writing() as oring:
+            with oring.begin_sequence(time_tag=0, header=json.dumps(self.hdr), nringlet=1) as oseq:
+                for k, off in enumerate(range(0, self.data.size, self.span)):
+                    ev = self.gates.get(k)
+                    if ev is not None:
+                        assert ev.wait(20), "gate %d never opened" % k
+                    n = min(self.span, self.data.size - off)
+                    with oseq.reserve(n) as sp:
+                        sp.data[...] = self.data[off:off + n]
+                    self.written = k + 1
+
+
+def wait_for(cond, what, timeout=20):
+    t0 = time.time()
+    while not cond():
+        assert time.time() - t0 < timeout, "timed out waiting for " + what
+        time.sleep(0.002)
+
+
 class Sink(threading.Thread):
     """Collects (header, time_tag, [span bytes as np.uint8 copies]) per sequence."""
 

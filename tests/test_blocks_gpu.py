@@ -129,7 +129,8 @@ def test_beamform_timed_coefficient_load_on_device_rings(pump, monkeypatch):
     """Forty gulps through Beamform -> BeamformSumBeams with coefficients that load at gulp 11 (beamform_block.py:416-429), on
     the native per-gulp loop (csrc/pyext/xfast.cpp BeamPump, which hands control back to the block when a load is pending) and
     on the Python loop (XENG_PUMP=0): zero beams before the load sample, the commanded ones from it on, every gulp against the
-    oracle, power sums included; a command that arrives WHILE the pipeline runs takes effect at its load sample too."""
+    oracle, power sums included; a command that arrives WHILE the pipeline runs takes effect at its load sample too.  No timing:
+    the source holds gulp 20 back until that command is in, so it lands between gulps 12 and 33 by construction."""
     import threading
     import time
     monkeypatch.setenv("XENG_PUMP", pump)
@@ -149,23 +150,25 @@ def test_beamform_timed_coefficient_load_on_device_rings(pump, monkeypatch):
     cmds2, _, _, _ = _beam_cmds(nchan, nbeam, ninput, np.random.default_rng(99), load_sample=33 * g)
     second = {}
 
+    from tests.pipeline_util import GatedSource, wait_for
+    gate20 = threading.Event()
+    src = GatedSource(r0, source_header(nchan, nstand, 2, sfreq=sfreq, chan_bw=bw), vin, g * nchan * ninput, {20: gate20})
+
     def late_command():
-        t0 = time.time()
-        while bf.stats.get('curr_sample', -1) < 12 * g and time.time() - t0 < 20:
-            time.sleep(0.0005)
+        wait_for(lambda: src.written == 20, "the source to have written gulps 0..19")       # (gulp 20 waits for the gate below)
         bf.process_command_strings(cmds2)
         second['gains'] = bf.gains_cpu_new.copy()
         second['at'] = bf.stats.get('curr_sample', -1)
+        gate20.set()
     s1, s2 = Sink(r1, g * nchan * nbeam * 8), Sink(r2, (nbeam // 2) * (g // ns) * nchan * 16)
     th = threading.Thread(target=late_command, daemon=True)
     th.start()
-    # (the source paces itself so that the late command finds the pipeline between gulps 12 and 33)
-    run_blocks([bf, sb], Source(r0, [(source_header(nchan, nstand, 2, sfreq=sfreq, chan_bw=bw), vin, g * nchan * ninput)], gap=0.015), [s1, s2])
+    run_blocks([bf, sb], src, [s1, s2])
     th.join(20)
     (h1, _, sp1), = s1.sequences
     (h2, _, sp2), = s2.sequences
     assert len(sp1) == ngulp and len(sp2) == ngulp
-    assert 'gains' in second and 12 * g <= second['at'] < 33 * g, second.get('at')
+    assert 'gains' in second and second['at'] < 20 * g, second.get('at')        # (commanded before gulp 20 was even written; loads at gulp 33)
     zero = np.zeros_like(first)
     for k in range(ngulp):
         w = zero if k < 11 else first if k < 33 else second['gains']

@@ -98,16 +98,17 @@ def test_bench_gpus_n_spawns_n_ranks():
     assert r3.returncode != 0
 
 
-def test_bench_workload_config5_on_the_spawn_path():
+@pytest.mark.parametrize("workload", ["config5", "config5_blocks"])
+def test_bench_workload_config5_on_the_spawn_path(workload):
     """`bench.py --gpus 2 --workload config5` (round 4: BASELINE config 5 as N ranks run it; lwa352-start-pipeline.sh:1-8 starts
     one pipeline process per channel block): the flag travels to every rank the launcher starts, each rank takes its own 96
     channels, and rank 0's line names the workload -- on the --selftest-spawn path (gloo, two ranks, no GPU work)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "config5", "--steps", "10",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", workload, "--steps", "10",
                         "--warmup", "1", "--selftest-spawn"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
-    assert res["n_gpus"] == 2 and res["config"]["workload"] == "selftest:config5"
+    assert res["n_gpus"] == 2 and res["config"]["workload"] == "selftest:" + workload
     assert res["config"]["nchan_total"] == 192 and res["config"]["chan0_per_rank"] == [0, 96]
     assert res["per_rank_ms"] == [0.1, 0.2]
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "nonsense", "--selftest-spawn"], cwd=ROOT, env=env,
