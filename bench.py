@@ -46,18 +46,26 @@ def cpu_baseline(budget_s=12.0, verify=None):
     rs = np.random.RandomState(0xdeadbeef)
     gulps = [rs.randint(0, 255, size=NTIME_GULP * NCHAN * NINPUT, dtype=np.uint8).reshape(NTIME_GULP, NCHAN, NSTAND, NPOL)
              for _ in range(ACC_LEN // NTIME_GULP)]
-    acc = None
+    # the checker first (untimed): the scalar oracle's integration of gulps 0..4
     first_int = None
+    for g in gulps:
+        first_int = orc.xgpu_correlate(g, NSTAND, NCHAN, first_int)
+    # ... then the baseline: the same contraction as the host cores can do it (oracle/xeng_cpu_fast.c: -march=native, AVX-512 VNNI where
+    # the host has it, built on THIS machine), held to the scalar oracle word for word on its first integration
+    fl = orc.fast_lib()
+    acc = None
+    fast_first = None
     t0 = time.time()
     ngulp = 0
     while True:
-        acc = orc.xgpu_correlate(gulps[ngulp % len(gulps)], NSTAND, NCHAN, acc)
+        acc = orc.xgpu_correlate_fast(gulps[ngulp % len(gulps)], NSTAND, NCHAN, acc)
         ngulp += 1
         if ngulp == len(gulps):
-            first_int = acc.copy()
+            fast_first = acc.copy()
         el = time.time() - t0
-        if (el > budget_s and ngulp >= len(gulps)) or ngulp >= 64:
+        if (el > budget_s and ngulp >= len(gulps)) or ngulp >= 4000:
             break
+    fast_ok = bool(np.array_equal(fast_first, first_int))
     units = ngulp * NTIME_GULP * NCHAN
     vin = gulps[0]
     # for honesty: the reference's own golden loop, restated in numpy (make_golden_inputs.py:156-158:
@@ -71,9 +79,12 @@ def cpu_baseline(budget_s=12.0, verify=None):
         g += x[t, :, :, None] * np.conj(x[t, :, None, :])
     el_np = time.time() - t1
     out = {"value": round(8 * NINPUT * units / el / 1e9, 4), "unit": "Gb/s",
-           "cores": int(orc.lib().orc_num_threads()), "kind": "port",
-           "kind_detail": "the oracle: scalar C restatement + OpenMP over channels (oracle/xeng_oracle.c); bifrost's own CPU "
-                          "correlator is not in /root/reference (empty submodule), so this is a stated baseline, not the reference's",
+           "cores": int(fl.fast_num_threads()), "kind": "port",
+           "kind_detail": "oracle/xeng_cpu_fast.c: the oracle's contraction written for this host (-march=native, %s, 4 x 32 register tiles, OpenMP over "
+                          "channels), built on this machine and held to the scalar oracle (oracle/xeng_oracle.c) word for word; bifrost's own CPU "
+                          "correlator is not in /root/reference (empty submodule), so this is a stated baseline, not the reference's"
+                          % ("AVX-512 VNNI vpdpwssd", "AVX-512 vpmaddwd", "no AVX-512: plain C")[2 - int(fl.fast_isa())],
+           "equals_scalar_oracle": fast_ok,
            "cmac_per_s": units * CMAC_PER_UNIT / el,
            "sample": "%d gulps of %d samples x %d chan x %d inputs (%.1f s)" % (ngulp, NTIME_GULP, NCHAN, NINPUT, el),
            "reference_numpy_golden_loop": {"cmac_per_s": round(nsp * ncg * NINPUT * NINPUT / el_np, 1), "cores": 1,
@@ -228,7 +239,7 @@ def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=4
     # The source and the three sinks are the harness, not the product: on the native ring they run as loops inside the
     # extension with the interpreter lock released (`_xfast.ring_feed_external` / `ring_drain`), so that the lock is shared by
     # the four block threads (+ CorrAcc's publish helper) only, as in a pipeline whose neighbours are not Python loops.
-    native_harness = hasattr(r_in, "_h") and hasattr(getattr(r_in, "_x", None), "ring_drain") and not os.environ.get("XENG_BENCH_PY_HARNESS")
+    native_harness = hasattr(r_in, "_h") and hasattr(getattr(r_in, "_x", None), "bench") and not os.environ.get("XENG_BENCH_PY_HARNESS")
 
     def source():
         import time as _t
@@ -241,9 +252,9 @@ def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=4
                 if native_harness:
                     ptrs = np.array([sp.ptr for sp in spans], dtype=np.uint64).tobytes()
                     if from_slabs:
-                        r_in._x.ring_feed_slabs(r_in._h, oseq._seq_id, ptrs, gulp_bytes, total, npk, stride, nblk, NTIME_GULP)
+                        r_in._x.bench.ring_feed_slabs(r_in._h, oseq._seq_id, ptrs, gulp_bytes, total, npk, stride, nblk, NTIME_GULP)
                     else:
-                        r_in._x.ring_feed_external(r_in._h, oseq._seq_id, ptrs, gulp_bytes, total)
+                        r_in._x.bench.ring_feed_external(r_in._h, oseq._seq_id, ptrs, gulp_bytes, total)
                 else:
                     for k in range(total):
                         if from_slabs:
@@ -273,7 +284,7 @@ def config5_blocks_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=4
             ffi.check("xengRingOpenReader", rg._enq.xengRingOpenReader(rg._h, 1, _ct.byref(rid)))       # (registered now, before any thread starts)
 
             def run_native():
-                nsp, tt = rg._x.ring_drain(rg._h, rid.value, gulp, times is not None)
+                nsp, tt = rg._x.bench.ring_drain(rg._h, rid.value, gulp, times is not None)
                 if times is not None:
                     times.extend(tt)
                 if on_span:

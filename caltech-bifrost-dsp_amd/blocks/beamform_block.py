@@ -178,19 +178,7 @@ class Beamform(Block):
             while True:
                 self._pump_stop.value = 0       # (lowered BEFORE the flag is read: a command that comes in from here on raises it again)
                 if self.update_pending:
-                    self.acquire_control_lock()
-                    for b in range(self.nbeam):
-                        if self.gains_load_sample[b] == 0:      # 0 = nothing pending for this beam
-                            continue
-                        if this_gulp_time >= self.gains_load_sample[b]:
-                            self.gains_cpu[:, b, :] = self.gains_cpu_new[:, b, :]
-                            self.gains_load_sample[b] = 0
-                            copy_pending = True
-                    if self.gains_load_sample.sum() == 0:
-                        self.update_pending = False
-                    self.stats['update_pending'] = self.update_pending
-                    self.stats['last_cmd_proc_time'] = time.time()
-                    self.release_control_lock()
+                    copy_pending = self._load_pending_gains(this_gulp_time) or copy_pending
                 if copy_pending:
                     pump.drain()                # (kernels in flight may still read the device copy of the weights)
                     self.gains_gpu[...] = self.gains_cpu
@@ -212,125 +200,153 @@ class Beamform(Block):
             raise
 
     def _main_loop(self, igulp_size, ogulp_size, streaming, pending, retire):
+        """Per input sequence: header work (_begin_sequence), then one of two per-gulp loops -- the native one (_pump_sequence) between
+        native rings, the Python one (_python_sequence) otherwise (bifrost / Python rings, XENG_PUMP=0)."""
         with self.oring.begin_writing() as oring:
             for iseq in self.iring.read(guarantee=self.guarantee):
-                # frequencies may have changed: rebuild and re-upload coefficients on every sequence
-                self.update_pending = True
-                copy_pending = True
-                ihdr = json.loads(iseq.header.tostring())
-                self.sequence_proclog.update(ihdr)
-                this_gulp_time = ihdr['seq0']
-                nchan, nstand, npol = ihdr['nchan'], ihdr['nstand'], ihdr['npol']
-                chan_bw = ihdr['bw_hz'] / nchan
-                assert nchan == self.nchan
-                assert self.ninput == nstand * npol
-                self.freqs = ihdr['sfreq'] + chan_bw * np.arange(nchan)
-                ohdr = ihdr.copy()
-                ohdr['nstand'] = self.nbeam
-                ohdr['nbit'] = 32
-                ohdr['npol'] = 1            # single-polarisation beams
-                ohdr['complex'] = True
-                ohdr['nbeam'] = self.nbeam
-                prev_time = time.time()
-                # A gulp that lies in two spans of the input ring (ntime_gulp = 2 x the writer's gulp, as the reference runs it:
-                # lwa352-pipeline.py:172,279-282) is taken as two windows and beamformed in ONE launch, without a gathered copy
-                read_parts = getattr(iseq, 'read_parts', None) if hasattr(self._bf, 'bfBeamformRunParts') else None
-                # A sequence of PACKET SLABS (Snap2Ingest(unpack=False), or a receiver that writes into a device ring): a gulp is
-                # one or two slabs of SNAP2 packets, handed to the library as they are (xengBeamformRunSlabs: read in place when
-                # complete and in order, scattered on the device otherwise)
-                slab = ihdr.get('layout') == 'snap2_slab'
-                igulp_size = self.ntime_gulp * self.nchan * self.ninput
-                if slab:
-                    slab_ntime, slab_npkt, slab_stride = ihdr['slab_ntime'], ihdr['npkt_per_gulp'], ihdr['pkt_stride']
-                    if self.ntime_gulp not in (slab_ntime, 2 * slab_ntime) or not hasattr(self._bf, 'bfBeamformRunSlabs'):
-                        raise RuntimeError("BEAMFORM: slabs of %d samples cannot make gulps of %d" % (slab_ntime, self.ntime_gulp))
-                    slab_bytes = slab_npkt * slab_stride
-                    igulp_size = (self.ntime_gulp // slab_ntime) * slab_bytes
-                    for k in ('layout', 'slab_ntime', 'npkt_per_gulp', 'pkt_stride'):
-                        ohdr.pop(k, None)
-                with oring.begin_sequence(time_tag=iseq.time_tag, header=json.dumps(ohdr)) as oseq:
+                seq = self._begin_sequence(iseq)
+                with oring.begin_sequence(time_tag=iseq.time_tag, header=json.dumps(seq['ohdr'])) as oseq:
                     pump = None
-                    if streaming and read_parts is not None and hasattr(self._bf, 'beam_pump') and hasattr(iseq, '_rid') and hasattr(oseq, '_seq_id'):
-                        pump = self._bf.beam_pump(self.iring, iseq._rid, self.oring, oseq._seq_id, igulp_size, ogulp_size, 0,
+                    if (streaming and seq['read_parts'] is not None and hasattr(self._bf, 'beam_pump') and hasattr(iseq, '_rid')
+                            and hasattr(oseq, '_seq_id')):
+                        pump = self._bf.beam_pump(self.iring, iseq._rid, self.oring, oseq._seq_id, seq['igulp_size'], ogulp_size, 0,
                                                   row_bytes=self.nchan * self.ninput, depth=self.STREAM_DEPTH)
                     if pump is not None:
-                        if slab:
-                            pump.set_slabs(slab_npkt, slab_stride, slab_ntime, ihdr['chan0'], self.ntime_gulp)
-                        this_gulp_time = self._pump_sequence(pump, this_gulp_time, igulp_size, copy_pending, slab)
-                        continue
-                    for ispan in (read_parts(igulp_size) if read_parts is not None else iseq.read(igulp_size)):
-                        self.update_stats({'curr_sample': this_gulp_time})
-                        if ispan.size < igulp_size:
-                            continue
-                        if getattr(ispan, 'skipped', 0):     # gulps overwritten before this reader got to them (ring.py)
-                            this_gulp_time += (ispan.skipped // igulp_size) * self.ntime_gulp
-                        if self.update_pending:
-                            self.acquire_control_lock()
-                            for b in range(self.nbeam):
-                                if self.gains_load_sample[b] == 0:      # 0 = nothing pending for this beam
-                                    continue
-                                if this_gulp_time >= self.gains_load_sample[b]:
-                                    self.gains_cpu[:, b, :] = self.gains_cpu_new[:, b, :]
-                                    self.gains_load_sample[b] = 0
-                                    copy_pending = True
-                            if self.gains_load_sample.sum() == 0:
-                                self.update_pending = False
-                            self.stats['update_pending'] = self.update_pending
-                            self.stats['last_cmd_proc_time'] = time.time()
-                            self.release_control_lock()
-                        if copy_pending:
-                            retire(0)           # (kernels in flight may still read the device copy of the weights)
-                            self.gains_gpu[...] = self.gains_cpu
-                            self._gains_version += 1
-                            copy_pending = False
-                        curr_time = time.time()
-                        acquire_time = curr_time - prev_time
-                        prev_time = curr_time
-                        ospan = oseq.reserve(ogulp_size)
-                        try:
-                            curr_time = time.time()
-                            reserve_time = curr_time - prev_time
-                            prev_time = curr_time
-                            # (the reference takes typed views, ispan.data_view('i8') / ospan.data_view(np.float32), :441-444; the
-                            # call only needs the spans' addresses, and two fewer objects per gulp is time under the interpreter lock)
-                            parts = getattr(ispan, 'parts', None)
-                            if slab:
-                                if parts is not None and len(parts) == 2:
-                                    held = parts
-                                    s0, s1 = parts
-                                elif igulp_size == slab_bytes:
-                                    held = s0 = ispan.data
-                                    s1 = None
-                                else:       # two slabs side by side in one span
-                                    held = ispan.data
-                                    s0 = XArray.window(held.ptr, slab_bytes, held.space, held)
-                                    s1 = XArray.window(held.ptr + slab_bytes, slab_bytes, held.space, held)
-                                rv = self._bf.bfBeamformRunSlabs(s0, slab_npkt, slab_ntime, s1, slab_npkt, slab_stride, this_gulp_time, ihdr['chan0'],
-                                                                 ospan.data.as_BFarray(), self.gains_gpu.as_BFarray(), version=self._gains_version)
-                            elif parts is not None and len(parts) == 2:
-                                held = parts
-                                rv = self._bf.bfBeamformRunParts(parts[0], parts[1], ospan.data.as_BFarray(), self.gains_gpu.as_BFarray(),
-                                                                 version=self._gains_version)
-                            else:
-                                held = ispan.data
-                                rv = self._bf.bfBeamformRun(held.as_BFarray(), ospan.data.as_BFarray(), self.gains_gpu.as_BFarray(),
-                                                            version=self._gains_version)
-                            if rv != self._bf.BF_STATUS_SUCCESS:
-                                raise RuntimeError("bfBeamformRun returned %d: %s" % (rv, self._bf.last_error()))
-                            if streaming:
-                                pending.append((self._bf.beam_mark(), ospan, held))
-                                ospan = None
-                                retire(self.STREAM_DEPTH)
-                            else:
-                                self._bf.beam_sync()          # BFSync() of beamform_block.py:450, this block's stream only
-                        finally:
-                            if ospan is not None:
-                                ospan.close()
-                        this_gulp_time += self.ntime_gulp
-                        curr_time = time.time()
-                        process_time = curr_time - prev_time
-                        prev_time = curr_time
-                        self.perf_proclog.update({'acquire_time': acquire_time, 'reserve_time': reserve_time,
-                                                  'process_time': process_time,
-                                                  'gbps': 8 * igulp_size / max(process_time, 1e-9) / 1e9})
-                    retire(0)                   # the sequence ends: every gulp in flight is committed first
+                        if seq['slab']:
+                            pump.set_slabs(seq['slab_npkt'], seq['slab_stride'], seq['slab_ntime'], seq['ihdr']['chan0'], self.ntime_gulp)
+                        self._pump_sequence(pump, seq['this_gulp_time'], seq['igulp_size'], True, seq['slab'])
+                    else:
+                        self._python_sequence(iseq, oseq, seq, ogulp_size, streaming, pending, retire)
+
+    def _begin_sequence(self, iseq):
+        """A new input sequence: frequencies (coefficients are rebuilt and re-uploaded on every sequence), the output header
+        (beamform_block.py:403-409), and how the gulps of this sequence are laid out."""
+        self.update_pending = True
+        ihdr = json.loads(iseq.header.tostring())
+        self.sequence_proclog.update(ihdr)
+        nchan, nstand, npol = ihdr['nchan'], ihdr['nstand'], ihdr['npol']
+        chan_bw = ihdr['bw_hz'] / nchan
+        assert nchan == self.nchan
+        assert self.ninput == nstand * npol
+        self.freqs = ihdr['sfreq'] + chan_bw * np.arange(nchan)
+        ohdr = ihdr.copy()
+        ohdr['nstand'] = self.nbeam
+        ohdr['nbit'] = 32
+        ohdr['npol'] = 1            # single-polarisation beams
+        ohdr['complex'] = True
+        ohdr['nbeam'] = self.nbeam
+        seq = {'ihdr': ihdr, 'ohdr': ohdr, 'this_gulp_time': ihdr['seq0'], 'igulp_size': self.ntime_gulp * self.nchan * self.ninput,
+               # A gulp that lies in two spans of the input ring (ntime_gulp = 2 x the writer's gulp, as the reference runs it:
+               # lwa352-pipeline.py:172,279-282) is taken as two windows and beamformed in ONE launch, without a gathered copy
+               'read_parts': getattr(iseq, 'read_parts', None) if hasattr(self._bf, 'bfBeamformRunParts') else None,
+               # A sequence of PACKET SLABS (Snap2Ingest(unpack=False), or a receiver that writes into a device ring): a gulp is one or
+               # two slabs of SNAP2 packets, handed to the library as they are (xengBeamformRunSlabs: read in place when complete and
+               # in order, scattered on the device otherwise)
+               'slab': ihdr.get('layout') == 'snap2_slab'}
+        if seq['slab']:
+            slab_ntime, slab_npkt, slab_stride = ihdr['slab_ntime'], ihdr['npkt_per_gulp'], ihdr['pkt_stride']
+            if self.ntime_gulp not in (slab_ntime, 2 * slab_ntime) or not hasattr(self._bf, 'bfBeamformRunSlabs'):
+                raise RuntimeError("BEAMFORM: slabs of %d samples cannot make gulps of %d" % (slab_ntime, self.ntime_gulp))
+            seq.update(slab_ntime=slab_ntime, slab_npkt=slab_npkt, slab_stride=slab_stride, slab_bytes=slab_npkt * slab_stride,
+                       igulp_size=(self.ntime_gulp // slab_ntime) * slab_npkt * slab_stride)
+            for k in ('layout', 'slab_ntime', 'npkt_per_gulp', 'pkt_stride'):
+                ohdr.pop(k, None)
+        return seq
+
+    # ---- one gulp on each input layout: returns (status, what has to stay alive until the kernel has run)
+    def _run_slabs(self, ispan, ospan, seq, this_gulp_time):
+        parts = getattr(ispan, 'parts', None)
+        slab_bytes = seq['slab_bytes']
+        if parts is not None and len(parts) == 2:
+            held = parts
+            s0, s1 = parts
+        elif seq['igulp_size'] == slab_bytes:
+            held = s0 = ispan.data
+            s1 = None
+        else:       # two slabs side by side in one span
+            held = ispan.data
+            s0 = XArray.window(held.ptr, slab_bytes, held.space, held)
+            s1 = XArray.window(held.ptr + slab_bytes, slab_bytes, held.space, held)
+        rv = self._bf.bfBeamformRunSlabs(s0, seq['slab_npkt'], seq['slab_ntime'], s1, seq['slab_npkt'], seq['slab_stride'], this_gulp_time,
+                                         seq['ihdr']['chan0'], ospan.data.as_BFarray(), self.gains_gpu.as_BFarray(), version=self._gains_version)
+        return rv, held
+
+    def _run_parts(self, parts, ospan):
+        return self._bf.bfBeamformRunParts(parts[0], parts[1], ospan.data.as_BFarray(), self.gains_gpu.as_BFarray(), version=self._gains_version), parts
+
+    def _run_plain(self, ispan, ospan):
+        # (the reference takes typed views, ispan.data_view('i8') / ospan.data_view(np.float32), :441-444; the call only needs the
+        # spans' addresses, and two fewer objects per gulp is time under the interpreter lock)
+        held = ispan.data
+        return self._bf.bfBeamformRun(held.as_BFarray(), ospan.data.as_BFarray(), self.gains_gpu.as_BFarray(), version=self._gains_version), held
+
+    def _load_pending_gains(self, this_gulp_time):
+        """beamform_block.py:416-429: coefficients whose load sample has come move from `new` to `cpu`; True when the device copy
+        has to be rewritten."""
+        copy_pending = False
+        self.acquire_control_lock()
+        for b in range(self.nbeam):
+            if self.gains_load_sample[b] == 0:      # 0 = nothing pending for this beam
+                continue
+            if this_gulp_time >= self.gains_load_sample[b]:
+                self.gains_cpu[:, b, :] = self.gains_cpu_new[:, b, :]
+                self.gains_load_sample[b] = 0
+                copy_pending = True
+        if self.gains_load_sample.sum() == 0:
+            self.update_pending = False
+        self.stats['update_pending'] = self.update_pending
+        self.stats['last_cmd_proc_time'] = time.time()
+        self.release_control_lock()
+        return copy_pending
+
+    def _python_sequence(self, iseq, oseq, seq, ogulp_size, streaming, pending, retire):
+        """The per-gulp loop in Python (beamform_block.py:411-461)."""
+        igulp_size, this_gulp_time, read_parts = seq['igulp_size'], seq['this_gulp_time'], seq['read_parts']
+        copy_pending = True
+        prev_time = time.time()
+        for ispan in (read_parts(igulp_size) if read_parts is not None else iseq.read(igulp_size)):
+            self.update_stats({'curr_sample': this_gulp_time})
+            if ispan.size < igulp_size:
+                continue
+            if getattr(ispan, 'skipped', 0):     # gulps overwritten before this reader got to them (ring.py)
+                this_gulp_time += (ispan.skipped // igulp_size) * self.ntime_gulp
+            if self.update_pending:
+                copy_pending = self._load_pending_gains(this_gulp_time) or copy_pending
+            if copy_pending:
+                retire(0)           # (kernels in flight may still read the device copy of the weights)
+                self.gains_gpu[...] = self.gains_cpu
+                self._gains_version += 1
+                copy_pending = False
+            curr_time = time.time()
+            acquire_time = curr_time - prev_time
+            prev_time = curr_time
+            ospan = oseq.reserve(ogulp_size)
+            try:
+                curr_time = time.time()
+                reserve_time = curr_time - prev_time
+                prev_time = curr_time
+                parts = getattr(ispan, 'parts', None)
+                if seq['slab']:
+                    rv, held = self._run_slabs(ispan, ospan, seq, this_gulp_time)
+                elif parts is not None and len(parts) == 2:
+                    rv, held = self._run_parts(parts, ospan)
+                else:
+                    rv, held = self._run_plain(ispan, ospan)
+                if rv != self._bf.BF_STATUS_SUCCESS:
+                    raise RuntimeError("bfBeamformRun returned %d: %s" % (rv, self._bf.last_error()))
+                if streaming:
+                    pending.append((self._bf.beam_mark(), ospan, held))
+                    ospan = None
+                    retire(self.STREAM_DEPTH)
+                else:
+                    self._bf.beam_sync()          # BFSync() of beamform_block.py:450, this block's stream only
+            finally:
+                if ospan is not None:
+                    ospan.close()
+            this_gulp_time += self.ntime_gulp
+            curr_time = time.time()
+            process_time = curr_time - prev_time
+            prev_time = curr_time
+            self.perf_proclog.update({'acquire_time': acquire_time, 'reserve_time': reserve_time, 'process_time': process_time,
+                                      'gbps': 8 * igulp_size / max(process_time, 1e-9) / 1e9})
+        retire(0)                   # the sequence ends: every gulp in flight is committed first

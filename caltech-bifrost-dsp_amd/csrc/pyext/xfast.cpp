@@ -352,7 +352,7 @@ PyObject* stamp_wait(PyObject*, PyObject* args) {
     Py_RETURN_NONE;
 }
 
-// ---------------------------------------------------------------- harness helpers (bench.py, probes): a data source and sinks that are not Python threads
+// ---------------------------------------------------------------- _xfast.bench: harness helpers (bench.py, probes): a data source and sinks that are not Python threads
 // ring_feed_external(h, seq, ptrs (bytes: uint64 each), nbytes, count): commits ptrs[k % n] as external spans, `count` times, waiting for
 // room like any writer; the interpreter lock is released for the whole loop
 PyObject* ring_feed_external(PyObject*, PyObject* args) {
@@ -1091,9 +1091,6 @@ PyMethodDef methods[] = {
     {"beam_mark", beam_mark, METH_NOARGS, "xengBeamformMark -> ticket | -status"},
     {"beam_ticket_done", beam_ticket_done, METH_VARARGS, "xengBeamformTicketDone -> -status | 0 | 1"},
     {"map_i32", map_i32, METH_VARARGS, "(a, b, nwords, add) -> status"},
-    {"ring_feed_external", ring_feed_external, METH_VARARGS, "harness: (handle, seq, addresses, nbytes, count) -- a source that is not a Python thread"},
-    {"ring_feed_slabs", ring_feed_slabs, METH_VARARGS, "harness: (handle, seq, addresses, nbytes, count, npkt, stride, pkts_per_seq, ntime) -- a receiver that reuses its slab buffers"},
-    {"ring_drain", ring_drain, METH_VARARGS, "harness: (handle, reader, gulp, want_times) -> (spans, times) -- a sink that is not a Python thread"},
     {"beam_pump", beam_pump_new, METH_VARARGS, "(in_ring, in_handle, reader, out_ring, out_handle, out_seq, igulp, ogulp, mode, row_bytes, ntime_sum, depth, staged[, compute table]) -> BeamPump"},
     {"corr_pump", corr_pump_new, METH_VARARGS, "(in_ring, in_handle, reader, out_ring, out_handle, igulp, ogulp, ntime_gulp[, compute table]) -> CorrPump"},
     {"compute_table_size", [](PyObject*, PyObject*) -> PyObject* { return PyLong_FromSize_t(NOPS); }, METH_NOARGS, "number of function pointers in a compute table"},
@@ -1103,6 +1100,15 @@ PyMethodDef methods[] = {
     {nullptr, nullptr, 0, nullptr}};
 
 PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_xfast", "direct binding of libxeng's per-gulp calls (include/xeng.h)", -1, methods};
+
+// _xfast.bench: what bench.py and the probes under profiles/ need and no pipeline does -- a source and sinks that are not Python
+// threads (so that the interpreter lock belongs to the blocks under test).  Kept apart from the product's bindings.
+PyMethodDef bench_methods[] = {
+    {"ring_feed_external", ring_feed_external, METH_VARARGS, "(handle, seq, addresses, nbytes, count) -- a source that is not a Python thread"},
+    {"ring_feed_slabs", ring_feed_slabs, METH_VARARGS, "(handle, seq, addresses, nbytes, count, npkt, stride, pkts_per_seq, ntime) -- a receiver that reuses its slab buffers"},
+    {"ring_drain", ring_drain, METH_VARARGS, "(handle, reader, gulp, want_times) -> (spans, times) -- a sink that is not a Python thread"},
+    {nullptr, nullptr, 0, nullptr}};
+PyModuleDef bench_moddef = {PyModuleDef_HEAD_INIT, "_xfast.bench", "harness helpers of bench.py / profiles (not used by the blocks)", -1, bench_methods};
 
 }  // namespace
 
@@ -1131,5 +1137,8 @@ PyMODINIT_FUNC PyInit__xfast(void) {
     if (!m) return nullptr;
     Py_INCREF(&SpanRefType);
     PyModule_AddObject(m, "SpanRef", (PyObject*)&SpanRefType);
+    PyObject* b = PyModule_Create(&bench_moddef);
+    if (!b) return nullptr;
+    PyModule_AddObject(m, "bench", b);
     return m;
 }

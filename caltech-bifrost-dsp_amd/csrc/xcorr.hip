@@ -29,6 +29,7 @@ struct XgpuContext {
     // transposes in LDS: asynchronous calls hand over the caller's buffer itself, synchronous calls a raw copy
     // of it in the staging area (except the dump call, which waits for the contraction anyway).
     bool raw = false;
+    bool kloop16 = false;      // raw: plain launches take the eight-wave 16x16x64 kernel (xcorr_fused16.h); XENG_KLOOP=32 keeps the four-wave one
     FragGroup* fgroups_dev = nullptr;          // fused kernel: fragment-level tile groups (xcorr_tiling.h) ...
     int nfg = 0;
     WorkList work;                             // ... and the persistent work-groups' item lists
@@ -135,19 +136,12 @@ template <int ABL>
 static void launch_abl(const XcorrParams& p, hipStream_t s) {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_mfma_kernel<ABL>), dim3(p.nchan * p.nwg), dim3(256), 0, s, p);
 }
-static void launch_xcorr(const XcorrParams& p, hipStream_t s, bool raw, int grid_size) {
+static void launch_xcorr(const XcorrParams& p, hipStream_t s, bool raw, int grid_size, bool kloop16) {
     if (raw) {
         const dim3 grid(grid_size);
 #ifdef XENG_DIAGNOSTICS
         const int fabl = getenv("XENG_ABLATE") ? atoi(getenv("XENG_ABLATE")) : 0;     // (diagnostic build: read per launch, so one process can alternate)
-#ifdef XENG_EXPERIMENTS
-        // XENG_KLOOP=16: the 16x16x64, eight-wave K loop inside the real kernel (experiments/xcorr_fused16.h: TIMING ONLY, results are wrong)
-        if (getenv("XENG_KLOOP") && atoi(getenv("XENG_KLOOP")) == 16 && !p.gdesc && !p.acc2_mode) {
-            if (fabl == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused16_kernel<16>), grid, dim3(512), 0, s, p);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused16_kernel<0>), grid, dim3(512), 0, s, p);
-            return;
-        }
-#endif
+        if (kloop16 && fabl == 16 && !p.gdesc && !p.acc2_mode) { hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused16_kernel<16>), grid, dim3(512), 0, s, p); return; }
         switch (fabl) {
             case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<1>), grid, dim3(256), 0, s, p); return;
             case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<2>), grid, dim3(256), 0, s, p); return;
@@ -168,6 +162,12 @@ static void launch_xcorr(const XcorrParams& p, hipStream_t s, bool raw, int grid
             default: break;
         }
 #endif
+        // the eight-wave 16x16x64 kernel (xcorr_fused16.h) for gulps by pointer without a long accumulator; the four-wave kernel otherwise
+        if (kloop16 && !p.acc2_mode) {
+            if (p.gdesc) hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused16_kernel<0, true>), grid, dim3(512), 0, s, p);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused16_kernel<0>), grid, dim3(512), 0, s, p);
+            return;
+        }
         if (p.gdesc) {          // gulps by descriptor (packet slabs)
             if (p.acc2_mode) hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<0, true, true>), grid, dim3(256), 0, s, p);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<0, false, true>), grid, dim3(256), 0, s, p);
@@ -296,7 +296,7 @@ static int flush_locked(void* out, bool dump, void* acc = nullptr, int acc_mode 
     if (x.fp6) hipLaunchKernelGGL(xcorr_fp6_kernel, dim3(p.nchan * p.nwg), dim3(256), 0, smm, p);
     else
 #endif
-    launch_xcorr(p, smm, x.raw, fused_grid(x.cfg.nchan, x.nfg, x.ncu));
+    launch_xcorr(p, smm, x.raw, fused_grid(x.cfg.nchan, x.nfg, x.ncu), x.kloop16);
     x.timer.end(smm, slot);
     XENG_HIP(hipGetLastError());
     XENG_HIP(hipEventRecord(x.ev_ring[seq % XgpuContext::NEV], smm));
@@ -542,6 +542,10 @@ static int initialize_locked(int gpu) {
                 // n * 8 rows: they stay non-negative -- the VGPR offset is unsigned -- only for rows of at least 128 bytes)
                 (size_t)x.cfg.nchan * x.ninput >= 128;
         if (x.raw) cap = std::min(cap, XC_MAX_GULPS);   // gulp pointers travel in the kernel arguments
+        // plain launches take the eight-wave 16x16x64 kernel (xcorr_fused16.h: -3 % per streaming step, profiles/r05/ab_kloop16_exact.txt);
+        // XENG_KLOOP=32 keeps the four-wave 32x32x32 kernel everywhere (the A/B switch)
+        const char* kl = getenv("XENG_KLOOP");
+        x.kloop16 = x.raw && !(kl && !strcmp(kl, "32"));
     }
     x.cap_gulps = cap;
     x.cap_kt = ((cap * x.gkt + x.kt_stage - 1) / x.kt_stage) * x.kt_stage;
@@ -1019,6 +1023,16 @@ int xengXgpuGetPath(int* fused_corner_turn, int* fp6) {
     if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized");
     if (fused_corner_turn) *fused_corner_turn = x.raw ? 1 : 0;
     if (fp6) *fp6 = x.fp6 ? 1 : 0;
+    return XENG_STATUS_SUCCESS;
+}
+
+int xengXgpuGetKernel(int* waves_per_group, int* mfma_k) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    XgpuContext& x = g_ctx;
+    if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized");
+    const bool k16 = x.raw && x.kloop16;
+    if (waves_per_group) *waves_per_group = k16 ? 8 : 4;
+    if (mfma_k) *mfma_k = k16 ? 64 : 32;
     return XENG_STATUS_SUCCESS;
 }
 

@@ -1133,9 +1133,10 @@ __global__ __launch_bounds__(256) void packetize_kernel(const int32_t* __restric
     }
 }
 
+#include "xcorr_fused16.h"
+
 #ifdef XENG_EXPERIMENTS
 #include "experiments/xcorr_fp6.h"
-#include "experiments/xcorr_fused16.h"
 #endif
 
 }  // namespace xeng

@@ -72,7 +72,7 @@ SYMBOLS = {
     "xengXgpuCorrelate": [_vp, _vp, _i], "xengXgpuGetOrder": [_vp, _vp, _vp],
     "xengXgpuSubSelect": [_vp, _vp, _vp, _vp, _i, _i], "xengXgpuReorder": [_vp, _vp, _vp, _vp],
     "xengXgpuGetInfo": [_pi, _pi, _pi, _pi, ctypes.POINTER(ctypes.c_int64), _pi],
-    "xengXgpuGetPath": [_pi, _pi],
+    "xengXgpuGetPath": [_pi, _pi], "xengXgpuGetKernel": [_pi, _pi],
     "xengXgpuPacketize": [_vp, _vp, _vp, _vp, _i],
     "xengSnap2Unpack": [_vp, _i, ctypes.c_size_t, _vp, ctypes.c_uint64, _i, _i, _i, _i, _i, _pi, _pi],
     "xengSnap2UnpackAsync": [_vp, _i, ctypes.c_size_t, _vp, ctypes.c_uint64, _i, _i, _i, _i, _i],

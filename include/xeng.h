@@ -277,6 +277,10 @@ int xengXgpuGetInfo(int *nstand, int *npol, int *nchan, int *ntime_gulp, int64_t
  * (ninput % 16 == 0, ntime_gulp % 96 == 0, not disabled with XENG_RAW=0), else the two-pass path
  * (corner turn into a fragment-major staging area); fp6 = 1 for the opt-in XENG_MFMA=fp6 experiment. */
 int xengXgpuGetPath(int *fused_corner_turn, int *fp6);
+/* the contraction kernel plain launches of the current context take: 8 waves per work-group on v_mfma_i32_16x16x64_i8
+ * (xcorr_fused16.h; mfma_k 64) or 4 waves on v_mfma_i32_32x32x32_i8 (mfma_k 32: XENG_KLOOP=32, the two-pass path, and always
+ * for gulps by descriptor and for dumps that feed a long accumulator) */
+int xengXgpuGetKernel(int *waves_per_group, int *mfma_k);
 
 /* profiling: HIP events around each kernel on the context's stream.  GetTimes returns and clears
  * the totals (ms) and launch counts since the last call: [0]=corner turn (two-pass path) or raw
@@ -304,9 +308,12 @@ int xengSnap2UnpackAsync(const void *packets_dev, int npkt, size_t pkt_stride, v
 /* Packets the enqueue-only calls have dropped (out of window / foreign / malformed) since this was last called; waits for
  * the staging stream and clears the count.  The synchronous call reports its own drops in *ndropped. */
 int xengSnap2GetAsyncDrops(int *ndropped);
-/* Emulator side (tests, bench): a receiver reuses its slab buffers; this re-stamps the sequence numbers of a device-resident slab
- * for its next window -- packet p gets seq0 + p / pkts_per_seq (big-endian, header bytes 0..7), nothing else changes.  Complete
- * on return. */
+
+/* ---------------------------------------------------------------- test / bench harness (no pipeline calls these)
+ * Emulator side of the F-engine link: a receiver reuses its slab buffers; this re-stamps the sequence numbers of a device-resident
+ * slab for its next window -- packet p gets seq0 + p / pkts_per_seq (big-endian, header bytes 0..7), nothing else changes.  Complete
+ * on return.  (The Python side of the harness lives in the extension's `_xfast.bench` sub-module: a source and sinks that are not
+ * Python threads.) */
 int xengSnap2StampSeq(void *packets_dev, int npkt, size_t pkt_stride, uint64_t seq0, int pkts_per_seq);
 
 /* ---------------------------------------------------------------- CorrAcc

@@ -141,6 +141,51 @@ def xgpu_correlate(vin, nstand, nchan, acc=None):
     return acc
 
 
+_FAST = None
+
+
+def fast_lib():
+    """oracle/xeng_cpu_fast.c built with -march=native ON THIS MACHINE: the library's file name carries a hash of the machine's CPU
+    flags, so a binary that travelled from another box (the build container, a different GPU host) is never loaded."""
+    global _FAST
+    if _FAST is None:
+        import hashlib
+        flags = ""
+        try:
+            with open("/proc/cpuinfo") as fh:
+                for line in fh:
+                    if line.startswith("flags"):
+                        flags = line
+                        break
+        except OSError:
+            pass
+        so = "libxeng_cpu_fast_%s.so" % hashlib.sha256(flags.encode()).hexdigest()[:12]
+        path = os.path.join(HERE, so)
+        src = os.path.join(HERE, "xeng_cpu_fast.c")
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", HERE, "-B", so, "FAST_SO=" + so], stdout=subprocess.DEVNULL)
+        L = ctypes.CDLL(path)
+        L.fast_xgpu_correlate.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.fast_xgpu_correlate.restype = ctypes.c_int
+        L.fast_num_threads.restype = ctypes.c_int
+        L.fast_isa.restype = ctypes.c_int
+        _FAST = L
+    return _FAST
+
+
+def xgpu_correlate_fast(vin, nstand, nchan, acc=None):
+    """xgpu_correlate through the vectorised translation unit (bench.py's cpu_baseline); same arguments, same words."""
+    vin = np.ascontiguousarray(vin, dtype=np.uint8)
+    ntime = vin.size // (nchan * nstand * 2)
+    assert ntime * nchan * nstand * 2 == vin.size
+    accumulate = acc is not None
+    if acc is None:
+        acc = np.empty(2 * per_chan(nstand) * nchan, dtype=np.int32)
+    rc = fast_lib().fast_xgpu_correlate(_p(vin), _p(acc), ntime, nchan, nstand, int(accumulate))
+    assert rc == 0, rc
+    return acc
+
+
 def xgpu_get_order(antpol_to_input):
     a = np.ascontiguousarray(antpol_to_input, dtype=np.int32)
     nstand, npol = a.shape

@@ -259,3 +259,16 @@ def test_snap2_oracle_is_pinned_by_the_reference_transmitter(golden_dir):
     out, placed, dropped = orc.snap2_unpack(pkts, 0, meta["ntime"], 0, meta["nchan"], meta["nstand"] * meta["npol"])
     assert placed == len(pkts) and dropped == 0
     assert np.array_equal(out.reshape(vin.shape), vin)
+
+
+def test_vectorised_cpu_baseline_equals_the_scalar_oracle():
+    """bench.py's cpu_baseline runs oracle/xeng_cpu_fast.c (the same contraction written for the host it runs on: -march=native, AVX-512
+    VNNI where there is one, built on this machine).  Word for word the scalar oracle -- every word of the planes, the diagonal
+    cells' unaddressed ones included -- for first gulps (assign) and following ones (accumulate)."""
+    for (T, C, S) in [(8, 4, 16), (96, 3, 48), (40, 2, 36), (32, 2, 352)]:
+        v = np.random.default_rng(T + S).integers(0, 256, (2 * T, C, S, 2), dtype=np.uint8)
+        a = orc.xgpu_correlate(v[:T], S, C)
+        b = orc.xgpu_correlate_fast(v[:T], S, C)
+        assert np.array_equal(a, b), (T, C, S)
+        assert np.array_equal(orc.xgpu_correlate(v[T:], S, C, a), orc.xgpu_correlate_fast(v[T:], S, C, b)), (T, C, S)
+    assert orc.fast_lib().fast_isa() in (0, 1, 2) and orc.fast_lib().fast_num_threads() >= 1

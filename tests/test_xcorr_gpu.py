@@ -490,6 +490,50 @@ def test_fragment_tiling_matches_tile_tiling(gpu, nstand, nchan, ntime, ngulp):
         del os.environ["XENG_TILING"]
 
 
+def _kernel_in_use(gpu):
+    import ctypes
+    w, k = ctypes.c_int(), ctypes.c_int()
+    gpu.ffi.call("xengXgpuGetKernel", ctypes.byref(w), ctypes.byref(k))
+    return w.value, k.value
+
+
+@pytest.mark.parametrize("nstand,nchan,ntime,ngulp", [
+    (352, 8, 96, 5),       # 704 inputs: 16 tile groups, all three operand patterns (2x2 waves, both halves of a Z wave); 5 stages: two pairs + an odd last stage
+    (352, 8, 192, 2),      # an even number of stages: no half K-tile at the end
+    (352, 8, 96, 1),       # a single stage: one K-tile and a half
+    (96, 8, 96, 3),        # 3 blocks: no squares at all
+    (344, 8, 96, 2),       # 688 inputs: padded fragments, clamped columns
+    (80, 8, 480, 2),       # 2.5 blocks, config-2 gulp length (5 stages per gulp)
+])
+def test_eight_wave_16x16x64_kernel_matches_the_four_wave_kernel_and_the_oracle(gpu, nstand, nchan, ntime, ngulp):
+    """Round 5: plain launches take xcorr_fused16_kernel (8 waves per work-group, v_mfma_i32_16x16x64_i8, K-tiles of 64 samples that
+    straddle the 96-sample stages, the half K-tile of an odd last stage zeroed in registers, accumulators brought into the 32x32
+    layout by lane swaps for the shared epilogue); XENG_KLOOP=32 keeps the four-wave 32x32x32 kernel.  Same words either way,
+    and the oracle's -- through the enqueue-only calls and the synchronous ones (raw copies + accumulate-into-stored flushes)."""
+    vin = gpu.synth_voltages(ntime * ngulp, nchan, nstand, "full", seed=5 + nstand + ntime)
+    exp = oracle_run(vin, nstand, nchan, ntime)
+    x = gpu.Xgpu(nstand, nchan, ntime)
+    if os.environ.get("XENG_RAW") == "0" or os.environ.get("XENG_KLOOP") == "32":
+        assert _kernel_in_use(gpu) == (4, 32)
+    else:
+        assert x.path() == (1, 0) and _kernel_in_use(gpu) == (8, 64)
+    assert np.array_equal(x.run(vin, use_async=True), exp)
+    assert np.array_equal(x.run(vin), exp)
+    x.close()
+    was = os.environ.get("XENG_KLOOP")
+    os.environ["XENG_KLOOP"] = "32"
+    try:
+        x = gpu.Xgpu(nstand, nchan, ntime)
+        assert _kernel_in_use(gpu) == (4, 32)
+        assert np.array_equal(x.run(vin, use_async=True), exp)
+        x.close()
+    finally:
+        if was is None:
+            del os.environ["XENG_KLOOP"]
+        else:
+            os.environ["XENG_KLOOP"] = was
+
+
 @pytest.mark.parametrize("nstand,nchan,ntime,ngulp,max_gulps,two_accs", [
     (80, 8, 96, 3, 3, True),      # 2.5 blocks: interior, diagonal and padded tiles; two accumulators (dumps may overlap)
     (80, 8, 96, 3, 3, False),     # one accumulator: the dumps are ordered by the library
