@@ -29,7 +29,7 @@ struct XgpuContext {
     // transposes in LDS: asynchronous calls hand over the caller's buffer itself, synchronous calls a raw copy
     // of it in the staging area (except the dump call, which waits for the contraction anyway).
     bool raw = false;
-    bool kloop16 = false;      // raw: plain launches take the eight-wave 16x16x64 kernel (xcorr_fused16.h); XENG_KLOOP=32 keeps the four-wave one
+    bool kloop16 = false;      // raw: XENG_KLOOP=16 -- plain and slab launches take the eight-wave 16x16x64 kernel (xcorr_fused16.h)
     FragGroup* fgroups_dev = nullptr;          // fused kernel: fragment-level tile groups (xcorr_tiling.h) ...
     int nfg = 0;
     WorkList work;                             // ... and the persistent work-groups' item lists
@@ -542,10 +542,12 @@ static int initialize_locked(int gpu) {
                 // n * 8 rows: they stay non-negative -- the VGPR offset is unsigned -- only for rows of at least 128 bytes)
                 (size_t)x.cfg.nchan * x.ninput >= 128;
         if (x.raw) cap = std::min(cap, XC_MAX_GULPS);   // gulp pointers travel in the kernel arguments
-        // plain launches take the eight-wave 16x16x64 kernel (xcorr_fused16.h: -3 % per streaming step, profiles/r05/ab_kloop16_exact.txt);
-        // XENG_KLOOP=32 keeps the four-wave 32x32x32 kernel everywhere (the A/B switch)
+        // XENG_KLOOP=16: plain and slab launches take the eight-wave 16x16x64 kernel (xcorr_fused16.h).  Exact and fully tested, but not the
+        // default: against the four-wave kernel its streaming step measured -3.0 % and -3.6 % on two boxes, +1.7 .. +7.8 % on three others
+        // (one launch alone: equal or 1-3 % faster everywhere; what differs is how consecutive persistent launches share the chip:
+        // profiles/r05/ab_kloop16_*.txt)
         const char* kl = getenv("XENG_KLOOP");
-        x.kloop16 = x.raw && !(kl && !strcmp(kl, "32"));
+        x.kloop16 = x.raw && kl && !strcmp(kl, "16");
     }
     x.cap_gulps = cap;
     x.cap_kt = ((cap * x.gkt + x.kt_stage - 1) / x.kt_stage) * x.kt_stage;

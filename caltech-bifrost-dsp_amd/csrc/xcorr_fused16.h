@@ -30,7 +30,10 @@
 #pragma once
 
 #ifndef XF16_SCHED
-#define XF16_SCHED 1          // 1: 2-2-2-3 VALU pinned behind the MFMAs; 2: the compiler's order (A/B builds)
+#define XF16_SCHED 1          // 1: 2-2-2-3 VALU pinned behind the MFMAs; 2: the compiler's order; 3: reads, MFMA burst, then the unpack (A/B builds)
+#endif
+#ifndef XF16_PRIO
+#define XF16_PRIO 0           // 1: the wave raises its issue priority for the MFMAs of a K-tile (A/B builds)
 #endif
 
 // sub-cell accumulators (i, j) -> idx 2 i + j of one 32x32 cell, 16x16 MFMA layout (column = lane & 15, row = 4 (lane >> 4) + reg)
@@ -233,6 +236,9 @@ __global__ __launch_bounds__(512, 1) void xcorr_fused16_kernel(XcorrParams p) {
         // the 32 MFMAs of one K-tile: per sub-cell R += xr*yr + xi*yi, P += xi*yr, Q += xr*yi (no negated operand: -(-8) x 16 overflows)
         auto mfma_tile = [&](const Ops& o, auto patc) {
             constexpr int PAT = decltype(patc)::value;
+#if XF16_PRIO
+            __builtin_amdgcn_s_setprio(2);
+#endif
             constexpr int RA[3][2] = {{0, 0}, {0, 1}, {0, 0}}, CB[3][2] = {{1, 2}, {0, 2}, {1, 0}};      // fragment of the cell's rows / columns
 #pragma unroll
             for (int cc = 0; cc < 2; cc++)
@@ -246,6 +252,9 @@ __global__ __launch_bounds__(512, 1) void xcorr_fused16_kernel(XcorrParams p) {
                         accQ[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(o.r[x], o.i[y], accQ[q], 0, 0, 0);
                         accR[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(o.i[x], o.i[y], accR[q], 0, 0, 0);
                     }
+#if XF16_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         };
         auto pin = [&]() {
 #if XF16_SCHED == 1
@@ -256,6 +265,10 @@ __global__ __launch_bounds__(512, 1) void xcorr_fused16_kernel(XcorrParams p) {
                 if ((i & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); // VALU 2-2-2-3
                 else __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
             }
+#elif XF16_SCHED == 3
+            __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);                      // the reads of the next K-tile
+            __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);                      // this K-tile's MFMAs back to back (the SIMD's other wave unpacks meanwhile)
+            __builtin_amdgcn_sched_group_barrier(0x002, 80, 0);                      // then the unpack
 #endif
         };
 

@@ -277,9 +277,9 @@ int xengXgpuGetInfo(int *nstand, int *npol, int *nchan, int *ntime_gulp, int64_t
  * (ninput % 16 == 0, ntime_gulp % 96 == 0, not disabled with XENG_RAW=0), else the two-pass path
  * (corner turn into a fragment-major staging area); fp6 = 1 for the opt-in XENG_MFMA=fp6 experiment. */
 int xengXgpuGetPath(int *fused_corner_turn, int *fp6);
-/* the contraction kernel plain launches of the current context take: 8 waves per work-group on v_mfma_i32_16x16x64_i8
- * (xcorr_fused16.h; mfma_k 64) or 4 waves on v_mfma_i32_32x32x32_i8 (mfma_k 32: XENG_KLOOP=32, the two-pass path, and always
- * for gulps by descriptor and for dumps that feed a long accumulator) */
+/* the contraction kernel plain and slab launches of the current context take: 4 waves per work-group on v_mfma_i32_32x32x32_i8
+ * (mfma_k 32: the default, the two-pass path, and always for dumps that feed a long accumulator) or, with XENG_KLOOP=16, 8 waves
+ * on v_mfma_i32_16x16x64_i8 (xcorr_fused16.h; mfma_k 64) */
 int xengXgpuGetKernel(int *waves_per_group, int *mfma_k);
 
 /* profiling: HIP events around each kernel on the context's stream.  GetTimes returns and clears

@@ -65,42 +65,52 @@ int fast_xgpu_correlate(const uint8_t *in, int32_t *acc, int ntime, int nchan, i
     const int ninput = 2 * nstand;
     if (nstand % 4 != 0 || nstand <= 0 || ntime <= 0 || nchan <= 0) return -1;
     const int np = (ninput + JB - 1) / JB * JB;                 /* inputs padded to whole column tiles */
+    const int nrow = (ninput + IB - 1) / IB * IB;               /* ... and to whole row strips */
     const int64_t per_chan = (int64_t)(nstand / 2 + 1) * (nstand / 4) * 16;
     const int64_t matlen = per_chan * nchan;
     const int64_t qs = ((int64_t)(nstand / 2 + 1) * nstand) / 4;
-    int fail = 0;
-#pragma omp parallel for schedule(dynamic, 1)
+    /* V[c][t][j] = (re_j, im_j) as int16 pairs (the column operand, 16 per vector); A1[c][i][t] = (re_i, im_i), A2[c][i][t] = (im_i, -re_i) */
+    const size_t vsz = (size_t)ntime * np, asz = (size_t)nrow * ntime;
+    int32_t *V = NULL, *A1 = NULL, *A2 = NULL;
+    if (posix_memalign((void **)&V, 64, vsz * nchan * 4) || posix_memalign((void **)&A1, 64, asz * nchan * 4) ||
+        posix_memalign((void **)&A2, 64, asz * nchan * 4)) { free(V); free(A1); free(A2); return -2; }
+#pragma omp parallel for schedule(static)
     for (int c = 0; c < nchan; c++) {
-        /* V[t][j] = (re_j, im_j) as int16 pairs (the column operand, 16 per vector); A1[i][t] = (re_i, im_i), A2[i][t] = (im_i, -re_i) */
-        int32_t *V = NULL, *A1 = NULL, *A2 = NULL;
-        if (posix_memalign((void **)&V, 64, (size_t)ntime * np * 4) || posix_memalign((void **)&A1, 64, (size_t)np * ntime * 4) ||
-            posix_memalign((void **)&A2, 64, (size_t)np * ntime * 4)) { fail = 1; free(V); free(A1); free(A2); continue; }
-        memset(V, 0, (size_t)ntime * np * 4);
-        memset(A1, 0, (size_t)np * ntime * 4);
-        memset(A2, 0, (size_t)np * ntime * 4);
+        int32_t *v = V + vsz * c, *a1 = A1 + asz * c, *a2 = A2 + asz * c;
+        memset(v, 0, vsz * 4);
+        memset(a1, 0, asz * 4);
+        memset(a2, 0, asz * 4);
         for (int t = 0; t < ntime; t++) {
             const uint8_t *row = in + ((size_t)t * nchan + c) * ninput;
             for (int i = 0; i < ninput; i++) {
                 const int re = nib_hi(row[i]), im = nib_lo(row[i]);
-                V[(size_t)t * np + i] = (int32_t)(((uint32_t)(uint16_t)(int16_t)im << 16) | (uint16_t)(int16_t)re);
-                A1[(size_t)i * ntime + t] = (int32_t)(((uint32_t)(uint16_t)(int16_t)im << 16) | (uint16_t)(int16_t)re);
-                A2[(size_t)i * ntime + t] = (int32_t)(((uint32_t)(uint16_t)(int16_t)(-re) << 16) | (uint16_t)(int16_t)im);
+                v[(size_t)t * np + i] = (int32_t)(((uint32_t)(uint16_t)(int16_t)im << 16) | (uint16_t)(int16_t)re);
+                a1[(size_t)i * ntime + t] = (int32_t)(((uint32_t)(uint16_t)(int16_t)im << 16) | (uint16_t)(int16_t)re);
+                a2[(size_t)i * ntime + t] = (int32_t)(((uint32_t)(uint16_t)(int16_t)(-re) << 16) | (uint16_t)(int16_t)im);
             }
         }
-        int32_t *out_r = acc + (size_t)c * per_chan, *out_i = acc + matlen + (size_t)c * per_chan;
-        for (int i0 = 0; i0 < ninput; i0 += IB)
-            for (int j0 = 0; j0 <= i0 + IB - 1 && j0 < ninput; j0 += JB) {
+    }
+    /* one task per (channel, block of 32 columns): its column operand (61 KB at 480 samples) stays in the core's cache while the row
+     * strips at and below the diagonal stream past; more tasks than cores, handed out dynamically (the triangle is uneven) */
+    const int njb = np / JB;
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
+    for (int c = 0; c < nchan; c++)
+        for (int jb = njb - 1; jb >= 0; jb--) {
+            const int j0 = jb * JB;
+            const int32_t *v = V + vsz * c, *a1 = A1 + asz * c, *a2 = A2 + asz * c;
+            int32_t *out_r = acc + (size_t)c * per_chan, *out_i = acc + matlen + (size_t)c * per_chan;
+            for (int i0 = j0 & ~(IB - 1); i0 < ninput; i0 += IB) {
                 int32_t tr[IB][JB], ti[IB][JB];
 #if FAST_AVX512
                 __m512i sr[IB][2], si[IB][2];
                 for (int a = 0; a < IB; a++)
-                    for (int v = 0; v < 2; v++) { sr[a][v] = _mm512_setzero_si512(); si[a][v] = _mm512_setzero_si512(); }
+                    for (int w = 0; w < 2; w++) { sr[a][w] = _mm512_setzero_si512(); si[a][w] = _mm512_setzero_si512(); }
                 for (int t = 0; t < ntime; t++) {
-                    const __m512i v0 = _mm512_load_si512((const void *)(V + (size_t)t * np + j0));
-                    const __m512i v1 = _mm512_load_si512((const void *)(V + (size_t)t * np + j0 + 16));
+                    const __m512i v0 = _mm512_load_si512((const void *)(v + (size_t)t * np + j0));
+                    const __m512i v1 = _mm512_load_si512((const void *)(v + (size_t)t * np + j0 + 16));
                     for (int a = 0; a < IB; a++) {
-                        const __m512i b1 = _mm512_set1_epi32(A1[(size_t)(i0 + a) * ntime + t]);
-                        const __m512i b2 = _mm512_set1_epi32(A2[(size_t)(i0 + a) * ntime + t]);
+                        const __m512i b1 = _mm512_set1_epi32(a1[(size_t)(i0 + a) * ntime + t]);
+                        const __m512i b2 = _mm512_set1_epi32(a2[(size_t)(i0 + a) * ntime + t]);
 #ifdef __AVX512VNNI__
                         sr[a][0] = _mm512_dpwssd_epi32(sr[a][0], v0, b1);
                         sr[a][1] = _mm512_dpwssd_epi32(sr[a][1], v1, b1);
@@ -115,19 +125,19 @@ int fast_xgpu_correlate(const uint8_t *in, int32_t *acc, int ntime, int nchan, i
                     }
                 }
                 for (int a = 0; a < IB; a++)
-                    for (int v = 0; v < 2; v++) {
-                        _mm512_storeu_si512((void *)&tr[a][16 * v], sr[a][v]);
-                        _mm512_storeu_si512((void *)&ti[a][16 * v], si[a][v]);
+                    for (int w = 0; w < 2; w++) {
+                        _mm512_storeu_si512((void *)&tr[a][16 * w], sr[a][w]);
+                        _mm512_storeu_si512((void *)&ti[a][16 * w], si[a][w]);
                     }
 #else
                 memset(tr, 0, sizeof(tr));
                 memset(ti, 0, sizeof(ti));
                 for (int t = 0; t < ntime; t++)
                     for (int a = 0; a < IB; a++) {
-                        const int32_t p1 = A1[(size_t)(i0 + a) * ntime + t];
+                        const int32_t p1 = a1[(size_t)(i0 + a) * ntime + t];
                         const int re_i = (int16_t)(p1 & 0xFFFF), im_i = (int16_t)((uint32_t)p1 >> 16);
                         for (int b = 0; b < JB; b++) {
-                            const int32_t pv = V[(size_t)t * np + j0 + b];
+                            const int32_t pv = v[(size_t)t * np + j0 + b];
                             const int re_j = (int16_t)(pv & 0xFFFF), im_j = (int16_t)((uint32_t)pv >> 16);
                             tr[a][b] += re_i * re_j + im_i * im_j;
                             ti[a][b] += im_i * re_j - re_i * im_j;
@@ -148,7 +158,7 @@ int fast_xgpu_correlate(const uint8_t *in, int32_t *acc, int ntime, int nchan, i
                     }
                 }
             }
-        free(V); free(A1); free(A2);
-    }
-    return fail ? -2 : 0;
+        }
+    free(V); free(A1); free(A2);
+    return 0;
 }

@@ -1,19 +1,24 @@
 #!/bin/bash
-# builds profiles/_ab/libxeng_k16_s<N>.so: the diagnostic library with the experimental 16x16x64 eight-wave K loop
-# (csrc/experiments/xcorr_fused16.h, selected per launch with XENG_KLOOP=16), one build per scheduling variant XF16_SCHED = N
-# (1: 2-2-2-3 VALU pinned behind the MFMAs, 2: the compiler's own order).  usage: bash profiles/build_kloop16.sh
+# builds variants of the diagnostic library around xcorr_fused16_kernel (csrc/xcorr_fused16.h) for A/B runs with profiles/ab_step.py:
+#   profiles/_ab/libxeng_k16_<name>.so   with the macros given as name=flags pairs, e.g.
+#   bash profiles/build_kloop16.sh s1="-DXF16_SCHED=1" s3="-DXF16_SCHED=3" p1="-DXF16_PRIO=1"
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p $R/profiles/_ab
 cd $R/caltech-bifrost-dsp_amd/csrc
-for sch in 1 2; do
-    B=${TMPDIR:-/tmp}/k16build_$sch
-    mkdir -p $B
-    for f in xeng_util corracc beamform ingest slab ring xeng_bfarray; do
-        /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -DXENG_DIAGNOSTICS -c $f.hip -o $B/$f.o &
-    done
-    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -DXENG_DIAGNOSTICS -DXENG_EXPERIMENTS -DXF16_SCHED=$sch -c xcorr.hip -o $B/xcorr.o &
-    wait
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/profiles/_ab/libxeng_k16_s$sch.so $B/*.o
+B0=${TMPDIR:-/tmp}/k16build_common
+mkdir -p $B0
+for f in xeng_util corracc beamform ingest slab ring xeng_bfarray; do
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -DXENG_DIAGNOSTICS -c $f.hip -o $B0/$f.o &
 done
-ls -la $R/profiles/_ab/
+wait
+for spec in "$@"; do
+    name=${spec%%=*}; flags=${spec#*=}
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -DXENG_DIAGNOSTICS $flags -c xcorr.hip -o $B0/xcorr_$name.o &
+done
+wait
+for spec in "$@"; do
+    name=${spec%%=*}
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/profiles/_ab/libxeng_k16_$name.so $B0/xeng_util.o $B0/corracc.o $B0/beamform.o $B0/ingest.o $B0/slab.o $B0/ring.o $B0/xeng_bfarray.o $B0/xcorr_$name.o
+done
+ls -la $R/profiles/_ab/libxeng_k16_*.so

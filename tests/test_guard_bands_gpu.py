@@ -77,7 +77,7 @@ XCORR_SHAPES = [
     (352, 96, 480, 5, {}),                       # config 2 / 5: the shipped fused kernel
     (352, 96, 480, 5, {"XENG_RAW": "0"}),        # two-pass path (corner turn + xcorr_mfma_kernel)
     (352, 96, 480, 5, {"XENG_TILING": "64"}),    # the 64x64 tiling
-    (352, 96, 480, 5, {"XENG_KLOOP": "32"}),     # the four-wave 32x32x32 kernel (the default is the eight-wave 16x16x64 one)
+    (352, 96, 480, 5, {"XENG_KLOOP": "16"}),     # the eight-wave 16x16x64 kernel (round 5, opt-in)
     (344, 8, 96, 2, {}),                         # 688 inputs: last block three quarters full
     (96, 8, 192, 2, {}),                         # 3 blocks
     (16, 4, 8, 2, {}),                           # config 1 shape: two-pass path (ntime not a multiple of 96)

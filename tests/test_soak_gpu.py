@@ -29,7 +29,7 @@ def _load_soak():
     ({"XENG_BEAM": "bf16x3"}, 60),      # bf16 MFMA beamformer beside the contraction's epilogue
     ({"XENG_BEAM": "f32"}, 60),         # fp32 MFMA beamformer
     ({"XENG_TILING": "64"}, 60),        # the 64x64-tile tiling of the fused kernel (17 groups, 7-vs-6 items)
-    ({"XENG_KLOOP": "32"}, 60),         # the four-wave 32x32x32 contraction kernel (round 5's default is the eight-wave 16x16x64 one)
+    ({"XENG_KLOOP": "16"}, 60),         # the eight-wave 16x16x64 contraction kernel (round 5, opt-in)
     ({"XENG_RAW": "0"}, 60),            # two-pass X-engine (corner turn + xcorr_mfma_kernel)
 ])
 def test_results_do_not_depend_on_concurrency(env, rounds):

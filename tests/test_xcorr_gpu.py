@@ -506,26 +506,28 @@ def _kernel_in_use(gpu):
     (80, 8, 480, 2),       # 2.5 blocks, config-2 gulp length (5 stages per gulp)
 ])
 def test_eight_wave_16x16x64_kernel_matches_the_four_wave_kernel_and_the_oracle(gpu, nstand, nchan, ntime, ngulp):
-    """Round 5: plain launches take xcorr_fused16_kernel (8 waves per work-group, v_mfma_i32_16x16x64_i8, K-tiles of 64 samples that
-    straddle the 96-sample stages, the half K-tile of an odd last stage zeroed in registers, accumulators brought into the 32x32
-    layout by lane swaps for the shared epilogue); XENG_KLOOP=32 keeps the four-wave 32x32x32 kernel.  Same words either way,
-    and the oracle's -- through the enqueue-only calls and the synchronous ones (raw copies + accumulate-into-stored flushes)."""
+    """Round 5: with XENG_KLOOP=16 plain and slab launches take xcorr_fused16_kernel (8 waves per work-group, v_mfma_i32_16x16x64_i8,
+    K-tiles of 64 samples that straddle the 96-sample stages, the half K-tile of an odd last stage zeroed in registers,
+    accumulators brought into the 32x32 layout by lane swaps for the shared epilogue); the default is the four-wave 32x32x32
+    kernel.  Same words either way, and the oracle's -- through the enqueue-only calls and the synchronous ones (raw copies +
+    accumulate-into-stored flushes)."""
     vin = gpu.synth_voltages(ntime * ngulp, nchan, nstand, "full", seed=5 + nstand + ntime)
     exp = oracle_run(vin, nstand, nchan, ntime)
     x = gpu.Xgpu(nstand, nchan, ntime)
-    if os.environ.get("XENG_RAW") == "0" or os.environ.get("XENG_KLOOP") == "32":
-        assert _kernel_in_use(gpu) == (4, 32)
-    else:
+    if os.environ.get("XENG_RAW") != "0" and os.environ.get("XENG_KLOOP") == "16":
         assert x.path() == (1, 0) and _kernel_in_use(gpu) == (8, 64)
+    else:
+        assert _kernel_in_use(gpu) == (4, 32)
     assert np.array_equal(x.run(vin, use_async=True), exp)
     assert np.array_equal(x.run(vin), exp)
     x.close()
     was = os.environ.get("XENG_KLOOP")
-    os.environ["XENG_KLOOP"] = "32"
+    os.environ["XENG_KLOOP"] = "16"
     try:
         x = gpu.Xgpu(nstand, nchan, ntime)
-        assert _kernel_in_use(gpu) == (4, 32)
+        assert _kernel_in_use(gpu) == ((8, 64) if os.environ.get("XENG_RAW") != "0" else (4, 32))
         assert np.array_equal(x.run(vin, use_async=True), exp)
+        assert np.array_equal(x.run(vin), exp)
         x.close()
     finally:
         if was is None:
