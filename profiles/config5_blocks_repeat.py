@@ -49,6 +49,6 @@ for r in range(runs * len(depths)):
               {k: (v["alloc"], v["stamp_wait"]) for k, v in res["ring_allocations"].items()}, flush=True)
         continue
     res = bench.config5_blocks_leg(ffi, ring, gulp_bytes, 10, 0, nint=nint, nwarm=nwarm, in_ring_integrations=depths[r % len(depths)])
-    print("input ring %2d integrations, run %d: %.4f ms per integration, windows %s, fused %s" % (depths[r % len(depths)], r, res["ms_per_integration"], res["window_ms"], res["corracc_fused_into_dumps"]),
+    print("input ring %2d integrations, run %d: %.4f ms per integration, windows %s, corracc %s" % (depths[r % len(depths)], r, res["ms_per_integration"], res["window_ms"], res.get("corracc_mode")),
           "gc collections per generation during the run:", [g["collections"] - a for g, a in zip(gc.get_stats(), n0)],
           "ring allocations:", {k: (v["alloc"], v["stamp_wait"]) for k, v in res["ring_allocations"].items()}, flush=True)

@@ -6,7 +6,7 @@ on one box:
    group   the dumps of a group of K stay in their spans and are summed in ONE pass (xengMapSumI32, round 5)
    none    no long accumulation at all (the floor: contraction + beamformer chain)
 Per 2400-sample integration: 5 gulps registered in place + 1 contraction, 2.5 beamformer gulps of 960 samples + power sums.
-usage: corracc_modes_probe.py [rounds] [integrations per leg] [K]"""
+usage: corracc_modes_probe.py [rounds] [integrations per leg] [K] [modes, comma-separated: none,map,fused,group]"""
 import ctypes
 import os
 import sys
@@ -88,7 +88,7 @@ def leg(mode, n0, nwarm=12):
     return (time.perf_counter() - t0) / nint * 1e3
 
 
-modes = ["none", "map", "fused", "group"]
+modes = sys.argv[4].split(",") if len(sys.argv) > 4 else ["none", "map", "fused", "group"]
 res = {m: [] for m in modes}
 n0 = 0
 for r in range(rounds):

@@ -122,8 +122,14 @@ def test_full_size_blocks_match_standalone_calls():
         assert not t.is_alive(), "pipeline thread did not finish: %r" % (t,)
     assert fast.verdicts == [True] * nrep, fast.verdicts
     assert slow.verdicts == [True] * (nrep // 2), slow.verdicts
-    # the long accumulation was done group by group, each group's spans summed in one pass (the block's default), beside everything else
-    assert corr.stats['fused_corracc'] is False and cacc.stats['grouped'] is True and cacc.fused_dumps == 0
+    # the long accumulation was done group by group, each group's spans summed in one pass (the block's default), beside everything
+    # else -- or, when the suite runs under XENG_CORRACC=fused (and the fused contraction kernel is in use), by the dumps themselves
+    if os.environ.get("XENG_CORRACC") == "fused" and os.environ.get("XENG_RAW") != "0":
+        assert corr.stats['fused_corracc'] is True and cacc.stats['fused'] is True and cacc.fused_dumps == nrep
+    elif os.environ.get("XENG_CORRACC") == "map":
+        assert corr.stats['fused_corracc'] is False and cacc.stats['grouped'] is False and cacc.fused_dumps == 0
+    else:
+        assert corr.stats['fused_corracc'] is False and cacc.stats['grouped'] is True and cacc.fused_dumps == 0
 
     # the beamformer calls alone, same weights, same gulps
     ffi.call("xengBeamformInitialize", 0, ninput, C, g, nbeam, 0)
