@@ -990,41 +990,71 @@ def main():
         ingest["packets_to_visibilities_payloads_on_cache_lines"]["equals_scatter_path"] = bool(np.array_equal(slab_a_vis, want_vis))
         for b in slabs_a:
             b.free()
-        # ... and on a LOSSY link (the reference's transmitter has a deliberate-loss switch: test_tx_mt.c:22,108-118): the slot of
-        # a lost packet holds a duplicate of its neighbour (what a receiver that fills slots in arrival order is left with); a
-        # slab with a hole is not the gulp in another order any more -- it is zero-filled and scattered on the device (slab.hip)
-        def lossy_copy(nlost, seed):
+        # ... and on a LOSSY link (the reference's transmitter has a deliberate-loss switch: test_tx_mt.c:22,108-118).  Two receiver
+        # models: "slot" -- the slot of a lost packet holds a duplicate of its neighbour (what the round-4 bench measured); "shift" -- the
+        # receiver stores packets in arrival order, so everything behind a loss sits one slot early and the slab is shorter.  Round 5:
+        # either way the contraction reads the packets where they lie, through the offset table built on the device (slab.hip);
+        # round 4 sent every such gulp through zero-fill + scatter (+8 % / +27 % on the slot model)
+        def lossy_copy(nlost, seed, shift):
             rs = np.random.RandomState(seed)
             out = []
             for k, b in enumerate(slabs):
                 c = ffi.DeviceBuffer(b.nbytes)
-                ffi.call("xengMemcpy", c.ptr, b.ptr, b.nbytes)
-                for p in (rs.choice(npk - 1, size=nlost(k), replace=False) if nlost(k) else []):
-                    ffi.call("xengMemcpy", c.ptr + int(p) * stride, b.ptr + (int(p) + 1) * stride, stride)
-                out.append(c)
+                lost = sorted(int(p) for p in rs.choice(npk - 1, size=nlost(k), replace=False)) if nlost(k) else []
+                if shift:
+                    dst, src = 0, 0
+                    for p in lost + [npk]:
+                        if p > src:
+                            ffi.call("xengMemcpy", c.ptr + dst * stride, b.ptr + src * stride, (p - src) * stride)
+                            dst += p - src
+                        src = p + 1
+                    out.append((c, dst))
+                else:
+                    ffi.call("xengMemcpy", c.ptr, b.ptr, b.nbytes)
+                    for p in lost:
+                        ffi.call("xengMemcpy", c.ptr + p * stride, b.ptr + (p + 1) * stride, stride)
+                    out.append((c, npk))
             return out
+
+        def lossy_leg(sl, nrep=200, nwarm=60):
+            kk = 0
+            for it in range(nwarm + nrep):
+                if it == nwarm:
+                    ffi.call("xengXgpuSync")
+                    t1 = time.perf_counter()
+                for g in range(gulps_per_step):
+                    slot = kk % (2 * gulps_per_step)
+                    ffi.check("slab", L.xengXgpuKernelAsyncSlab(sl[slot][0].ptr, sl[slot][1], stride, slot * NTIME_GULP, 0, outs[it & 1].ptr, int(g == gulps_per_step - 1), None, 0))
+                    kk += 1
+                ffi.call("xengXgpuSyncLag", 1)
+            ffi.call("xengXgpuSync")
+            return time.perf_counter() - t1, nrep
         lossy = {}
-        for name, nlost in (("one_packet_lost_per_integration", lambda k: 1 if k % gulps_per_step == 2 else 0), ("one_percent_lost", lambda k: npk // 100)):
+        for name, nlost, shift in (("one_packet_lost_per_integration", lambda k: 1 if k % gulps_per_step == 2 else 0, False),
+                                   ("one_percent_lost", lambda k: npk // 100, False),
+                                   ("one_percent_lost_arrival_order", lambda k: npk // 100, True)):
             _leg('packets in place, ' + name)
-            sl = lossy_copy(nlost, 11)
-            nfb = ctypes.c_int(-1)
-            ffi.call("xengXgpuGetSlabFallbacks", ctypes.byref(nfb))
-            el5, nrep5 = packets_leg(1, sl, nrep=200, nwarm=60)
-            ffi.call("xengXgpuGetSlabFallbacks", ctypes.byref(nfb))
+            sl = lossy_copy(nlost, 11, shift)
+            nfb, nirr = ctypes.c_int(-1), ctypes.c_int(-1)
+            ffi.call("xengXgpuGetSlabStats", ctypes.byref(nfb), ctypes.byref(nirr))
+            el5, nrep5 = lossy_leg(sl)
+            ffi.call("xengXgpuGetSlabStats", ctypes.byref(nfb), ctypes.byref(nirr))
             got = outs[(200 + 60 - 1) & 1].download(np.int32)
             for g in range(gulps_per_step):
                 dst = ring.ptr + g * gulp_bytes
                 slot = ((200 + 60 - 1) * gulps_per_step + g) % (2 * gulps_per_step)
-                ffi.check("unpack", L.xengSnap2UnpackAsync(sl[slot].ptr, npk, stride, dst, slot * NTIME_GULP, NTIME_GULP, 0, NCHAN, NINPUT, 1))
+                ffi.check("unpack", L.xengSnap2UnpackAsync(sl[slot][0].ptr, sl[slot][1], stride, dst, slot * NTIME_GULP, NTIME_GULP, 0, NCHAN, NINPUT, 1))
                 ffi.check(kern, L.xengXgpuKernelAsync(dst, outs[0].ptr, int(g == gulps_per_step - 1)))
             ffi.call("xengXgpuSync")
             lossy[name] = {"value": round(8 * NINPUT * units_per_step_c * nrep5 / el5 / 1e9, 1), "unit": "Gb/s", "ms_per_step": round(el5 / nrep5 * 1e3, 4),
-                           "gulps_scattered_after_all": int(nfb.value), "gulps": (200 + 60) * gulps_per_step,
+                           "gulps_scattered_after_all": int(nfb.value), "gulps_read_through_an_irregular_table": int(nirr.value), "gulps": (200 + 60) * gulps_per_step,
                            "equals_scatter_path": bool(np.array_equal(got, outs[0].download(np.int32)))}
-            for b in sl:
+            for b, _ in sl:
                 b.free()
-        lossy["note"] = ("packets_to_visibilities with packets lost (the lost packet's slot holds a duplicate of the next one): every gulp with a hole "
-                         "goes through zero-fill + scatter on the device, the others are read in place")
+        lossy["note"] = ("packets_to_visibilities with packets lost.  Slot model: the lost packet's slot holds a duplicate of the next one; arrival "
+                         "order: the packets behind a loss sit one slot early, the slab is shorter.  Every gulp is read where it lies through its "
+                         "offset table (round 4: zero-fill + scatter of every gulp with a hole); equals_scatter_path compares with "
+                         "xengSnap2UnpackAsync + xengXgpuKernelAsync on the same slabs")
         ingest["packets_to_visibilities"]["lossy"] = lossy
         dgulp.free()
     _leg('beamform')

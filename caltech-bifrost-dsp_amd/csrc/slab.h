@@ -26,10 +26,21 @@ namespace xeng {
 // (nblocks * pkt_stride, 64, pkt_stride): the contraction reads the packets where they lie, no scatter pass.
 struct GulpDesc {
     const uint8_t* base;
-    uint32_t t_stride, c_stride, b_stride, pad;
-    uint64_t pad2;
+    uint32_t t_stride, c_stride, b_stride, pad;      // pad: 0 read in place, 1 scratch gulp (clear + scatter precede), 2 the slab through its table
+    const uint32_t* table;                           // (round 5, the contraction's table kernel only) the offset table of this gulp, below
 };
 static_assert(sizeof(GulpDesc) == 32, "GulpDesc is read as eight aligned dwords");
+
+// (round 5) The contraction does not form addresses from the strides any more: it follows a TABLE, so that a slab with lost,
+// shifted, reordered or duplicated packets is read where it lies as well -- no scatter pass.  One row of 16 dwords per (64-input
+// block b, 96-sample stage sl, half h of the stage, row r8 of a piece): [n] for n = 0..5 the byte offset, from the gulp's base, of the
+// payload row of sample t = 96 sl + 48 h + 8 n + r8 (plus a bias that undoes the instruction's immediate offset: SLAB_OFF_BIAS -
+// 1024 (n & 3)); [6] bit n set: no packet carries that sample -- the offset then names valid bytes whose copy in LDS the kernel
+// overwrites with zeros.  A wave fetches the 2 x 512 bytes of its two blocks per stage with ONE LDS-DMA instruction, three stages
+// before it issues the pieces they describe.  Plain time-major gulps (scratch copies) use a static table of the same shape.
+constexpr int SLAB_ROW_U32 = 16;
+constexpr uint32_t SLAB_OFF_BIAS = 4096;
+inline size_t slab_table_u32(int ntime, int nblk) { return (size_t)nblk * (size_t)(ntime / 96) * 2 * 8 * SLAB_ROW_U32; }
 
 struct SlabArgs {
     const uint8_t* pkts;
@@ -59,5 +70,31 @@ int slab_prepare_enqueue(hipStream_t stream, const SlabSite& site, const SlabArg
 int slab_fallback_enqueue(hipStream_t stream, const GulpDesc* descs, const SlabArgs* args, int ngulp);
 // gulps that took the scratch path since the last call (waits for the stream)
 int slab_site_read_fallbacks(hipStream_t stream, const SlabSite& site, int* n);
+
+// ---- (round 5) the X-engine's passes: index, table, (rarely) scatter -- once per integration, grid.y = gulp --------------------------
+constexpr int SLAB_MAX_GULPS = 16;
+struct SlabIndexSite {
+    uint32_t* tab32 = nullptr;               // [gulp][ntime * nblk]: 1 + the LAST slab index that carries (sample, block); 0: nobody does
+    uint32_t* meta = nullptr;                // [gulp][4]: {packets with another geometry, rows not in place, -, -}
+    uint32_t* tables[2] = {nullptr, nullptr};// [area][gulp][slab_table_u32()]
+    uint32_t* plain_table = nullptr;         // the table of a time-major gulp u8[ntime][nchan][ninput] (scratch copies under the table kernel)
+    int* counters = nullptr;                 // {gulps scattered, gulps read through an irregular table} since they were last read
+    int* hint_host = nullptr;                // pinned: gulps that were not regular, ever -- read by the host without a wait (is the link losing packets?)
+    int ntime = 0, nblk = 0;
+};
+int slab_index_site_create(SlabIndexSite* s, int ntime, int nchan, int ninput);
+void slab_index_site_destroy(SlabIndexSite* s);
+struct SlabIndexJob {
+    SlabArgs a[SLAB_MAX_GULPS];
+    uint8_t* scratch[SLAB_MAX_GULPS];
+    int force[SLAB_MAX_GULPS];               // the host already knows that this slab cannot be read in place
+    int ngulp;
+};
+// enqueue on `stream`: descs[g] / args_out[g] for every gulp of the job (tables of staging area `area`); by_table: the contraction that
+// follows reads every gulp through its table (xcorr_fused_kernel<.., TAB>), else by strides (irregular slabs are scattered)
+int slab_index_enqueue(hipStream_t stream, const SlabIndexSite& site, int area, const SlabIndexJob& job, bool by_table, GulpDesc* descs, SlabArgs* args_out);
+int slab_index_site_read(hipStream_t stream, const SlabIndexSite& site, int* nscattered, int* nirregular);
+// could this slab be read through a table?  (whole 64-input blocks, payload rows of 64 bytes in 16-byte pieces, 31-bit offsets)
+bool slab_indexable(const SlabArgs& a);
 
 }  // namespace xeng

@@ -2,6 +2,7 @@
 #include "slab.h"
 
 #include <algorithm>
+#include <vector>
 
 #include "xeng_common.h"
 
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void slab_prepare_kernel(SlabJob job, unsigned
                 d.base = a.pkts + 32; d.t_stride = (uint32_t)a.nblk * a.stride; d.c_stride = 64; d.b_stride = a.stride;
             }
             d.pad = fb ? 1u : 0u;
-            d.pad2 = 0;
+            d.table = nullptr;
             descs[k] = d;
             args_out[k] = a;          // (for the scatter kernels, should this gulp need them)
             tallies[k] = 0;           // (re-armed for the next gulp: launches on one stream, in order)
@@ -129,15 +130,189 @@ __global__ __launch_bounds__(256) void slab_prepare_kernel(SlabJob job, unsigned
 // descriptor says "scratch"; the groups of every other gulp return at once.
 __global__ __launch_bounds__(256) void slab_clear_kernel(const GulpDesc* __restrict__ desc, const SlabArgs* __restrict__ args) {
     const GulpDesc& d = desc[blockIdx.y];
-    if (!d.pad) return;
+    if (d.pad != 1u) return;          // (0: read in place, 2: through its table)
     slab_clear_part(args[blockIdx.y], const_cast<uint8_t*>(d.base), (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
 }
 
 __global__ __launch_bounds__(256) void slab_scatter_kernel(const GulpDesc* __restrict__ desc, const SlabArgs* __restrict__ args) {
     const GulpDesc& d = desc[blockIdx.y];
-    if (!d.pad) return;
+    if (d.pad != 1u) return;          // (0: read in place, 2: through its table)
     const SlabArgs a = args[blockIdx.y];
     slab_scatter_part(a, const_cast<uint8_t*>(d.base), blockIdx.x * 4 + (threadIdx.x >> 6), gridDim.x * 4, threadIdx.x & 63);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// (round 5) The X-engine's passes.  Instead of deciding "regular or scatter", every slab gets an offset TABLE (slab.h): where the
+// payload row of every (sample, 64-input block) lies, whatever the order the packets arrived in, and which samples nobody carries.
+// While the link is clean the contraction addresses the slabs by their strides as before (and the first slab that is not regular goes
+// through the round-4 scatter); from then on it follows the tables, so lost, shifted, reordered and duplicated packets cost nothing but
+// the table; only packets of another geometry (two channel blocks per sample, 32 inputs per packet ...) still send a gulp through
+// zero-fill + scatter.
+//   slab_index_clear_kernel   tab32 = 0
+//   slab_index_kernel         one thread per packet: a valid packet of the deployed geometry takes its (sample, block) entry with
+//                             atomicMax(index + 1) -- the LAST packet that carries a sample wins, as in the oracle's scatter (later
+//                             packets overwrite earlier ones); a valid packet of another geometry flags the gulp
+//   slab_table_kernel         one thread per table row; notes whether any sample is not where a regular slab has it
+//   slab_index_finish_kernel  the gulp's descriptor -- by strides, by table, or the scratch gulp: see there --, counters; zero-fill of
+//                             the gulps that are scattered (slab_scatter_kernel follows)
+// ---------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void slab_index_clear_kernel(SlabIndexJob job, uint32_t* __restrict__ tab32, uint32_t* __restrict__ meta, int per_gulp) {
+    const int g = blockIdx.y;
+    const int n = job.a[g].ntime * job.a[g].nblk;
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) tab32[(size_t)g * per_gulp + k] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x < 4) meta[g * 4 + threadIdx.x] = (threadIdx.x == 0 && job.force[g]) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void slab_index_kernel(SlabIndexJob job, uint32_t* __restrict__ tab32, uint32_t* __restrict__ meta, int per_gulp) {
+    const int g = blockIdx.y;
+    if (job.force[g]) return;
+    const SlabArgs& a = job.a[g];
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= a.npkt) return;
+    const SlabHeader h = slab_header(a.pkts + (size_t)p * a.stride, a.chan0);
+    const int payload_max = (int)a.stride - 32;
+    const bool ok = h.seq >= a.seq0 && h.seq - a.seq0 < (unsigned long long)a.ntime && h.npol > 0 && h.nchan > 0 && h.chan0 >= 0 &&
+                    h.chan0 + h.nchan <= a.nchan && h.pol0 + h.npol <= a.ninput && (long long)h.nchan * h.npol <= payload_max;
+    if (!ok) return;                                            // (dropped, as the scatter drops it)
+    if (h.npol != 64 || h.nchan != a.nchan || h.chan0 != 0 || (h.pol0 & 63) != 0) { atomicOr(&meta[g * 4], 1u); return; }
+    const unsigned int home = (unsigned int)(h.seq - a.seq0) * (unsigned int)a.nblk + (unsigned int)(h.pol0 >> 6);
+    atomicMax(&tab32[(size_t)g * per_gulp + home], (uint32_t)p + 1u);
+}
+
+__global__ __launch_bounds__(256) void slab_table_kernel(SlabIndexJob job, const uint32_t* __restrict__ tab32, uint32_t* __restrict__ meta, int per_gulp,
+                                                         uint32_t* __restrict__ tables, size_t table_u32) {
+    const int g = blockIdx.y;
+    const SlabArgs& a = job.a[g];
+    if (meta[g * 4] != 0) return;                             // (packets of another geometry: this gulp is scattered)
+    const int spg = a.ntime / 96, nrow = a.nblk * spg * 16;
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    bool irregular = false;
+    if (row < nrow) {
+        const int r8 = row & 7, h = (row >> 3) & 1, sl = (row >> 4) % spg, b = (row >> 4) / spg;
+        uint32_t w[SLAB_ROW_U32];
+#pragma unroll
+        for (int k = 0; k < SLAB_ROW_U32; k++) w[k] = 0u;
+#pragma unroll
+        for (int n = 0; n < 6; n++) {
+            const int t = sl * 96 + 48 * h + 8 * n + r8;
+            const uint32_t e = tab32[(size_t)g * per_gulp + (size_t)t * a.nblk + b];
+            const uint32_t slot = e ? e - 1u : 0u;               // (nobody carries it: any valid bytes -- the kernel zeroes their copy)
+            if (!e) w[6] |= 1u << n;
+            irregular = irregular || !e || slot != (uint32_t)(t * a.nblk + b);
+            w[n] = slot * a.stride + 32u + SLAB_OFF_BIAS - 1024u * (uint32_t)(n & 3);
+        }
+        uint4* dst = reinterpret_cast<uint4*>(tables + (size_t)g * table_u32 + (size_t)row * SLAB_ROW_U32);
+#pragma unroll
+        for (int k = 0; k < 4; k++) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+    }
+    if (__ballot(irregular) != 0ull && (threadIdx.x & 63) == 0) atomicOr(&meta[g * 4 + 1], 1u);
+}
+
+// the verdict (one thread per gulp).  by_table = 0 (the contraction kernel that follows addresses gulps by strides: the link has been
+// clean): every packet in place -> the slab by its strides, as in round 4; anything else -> the scratch gulp, zero-filled here and
+// scattered by the next launch, and the host is told (a counter in pinned memory, read there without a wait: its next launches read
+// every gulp through its table).  by_table = 1: a slab -> through its table, whatever the order of its packets; only packets of another
+// geometry -> the scratch gulp, through the static table of a time-major gulp.
+__global__ __launch_bounds__(256) void slab_index_finish_kernel(SlabIndexJob job, int by_table, const uint32_t* __restrict__ meta, uint32_t* __restrict__ tables,
+                                                                size_t table_u32, const uint32_t* __restrict__ plain_table, GulpDesc* __restrict__ descs,
+                                                                SlabArgs* __restrict__ args_out, int* __restrict__ counters, int* __restrict__ hint_host) {
+    const int g = blockIdx.y;
+    const SlabArgs& a = job.a[g];
+    const bool partial = meta[g * 4] != 0, irregular = meta[g * 4 + 1] != 0;
+    const bool scatter = partial || (irregular && !by_table);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        GulpDesc d;
+        if (scatter) {
+            d.base = job.scratch[g]; d.t_stride = (uint32_t)a.nchan * (uint32_t)a.ninput; d.c_stride = (uint32_t)a.ninput; d.b_stride = 64; d.pad = 1u;
+            d.table = plain_table;
+            atomicAdd(&counters[0], 1);
+        } else if (by_table) {
+            d.base = a.pkts; d.t_stride = (uint32_t)a.nblk * a.stride; d.c_stride = 64; d.b_stride = a.stride; d.pad = 2u;
+            d.table = tables + (size_t)g * table_u32;
+            if (irregular) atomicAdd(&counters[1], 1);
+        } else {
+            d.base = a.pkts + 32; d.t_stride = (uint32_t)a.nblk * a.stride; d.c_stride = 64; d.b_stride = a.stride; d.pad = 0u;
+            d.table = nullptr;
+        }
+        descs[g] = d;
+        args_out[g] = a;
+        if (partial || irregular) __hip_atomic_fetch_add(hint_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (!scatter) return;
+    slab_clear_part(a, job.scratch[g], (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
+}
+
+int slab_index_site_create(SlabIndexSite* s, int ntime, int nchan, int ninput) {
+    s->ntime = ntime; s->nblk = ninput / 64;
+    const size_t per_gulp = (size_t)ntime * s->nblk, tu = slab_table_u32(ntime, s->nblk);
+    XENG_HIP(hipMalloc((void**)&s->tab32, SLAB_MAX_GULPS * per_gulp * 4));
+    XENG_HIP(hipMalloc((void**)&s->meta, SLAB_MAX_GULPS * 4 * 4 + 16));
+    XENG_HIP(hip_memset_now(s->meta, 0, SLAB_MAX_GULPS * 4 * 4 + 16));
+    s->counters = (int*)(s->meta + SLAB_MAX_GULPS * 4);
+    for (int b = 0; b < 2; b++) {
+        XENG_HIP(hipMalloc((void**)&s->tables[b], SLAB_MAX_GULPS * tu * 4));
+        XENG_HIP(hip_memset_now(s->tables[b], 0, SLAB_MAX_GULPS * tu * 4));
+    }
+    // the table of a time-major gulp (scratch copies): sample t, block b at t * nchan * ninput + 64 b
+    std::vector<uint32_t> pt(tu, 0u);
+    const int spg = ntime / 96;
+    for (int b = 0; b < s->nblk; b++)
+        for (int sl = 0; sl < spg; sl++)
+            for (int h = 0; h < 2; h++)
+                for (int r8 = 0; r8 < 8; r8++) {
+                    uint32_t* w = pt.data() + ((((size_t)b * spg + sl) * 2 + h) * 8 + r8) * SLAB_ROW_U32;
+                    for (int n = 0; n < 6; n++) {
+                        const size_t t = (size_t)sl * 96 + 48 * h + 8 * n + r8;
+                        w[n] = (uint32_t)(t * nchan * ninput + 64u * b) + SLAB_OFF_BIAS - 1024u * (uint32_t)(n & 3);
+                    }
+                }
+    XENG_HIP(hipMalloc((void**)&s->plain_table, tu * 4));
+    XENG_HIP(hipMemcpy(s->plain_table, pt.data(), tu * 4, hipMemcpyHostToDevice));
+    XENG_HIP(hipHostMalloc((void**)&s->hint_host, sizeof(int)));
+    *s->hint_host = 0;
+    return XENG_STATUS_SUCCESS;
+}
+
+void slab_index_site_destroy(SlabIndexSite* s) {
+    if (s->plain_table) (void)hipFree(s->plain_table);
+    if (s->hint_host) (void)hipHostFree(s->hint_host);
+    if (s->tab32) (void)hipFree(s->tab32);
+    if (s->meta) (void)hipFree(s->meta);
+    for (int b = 0; b < 2; b++) if (s->tables[b]) (void)hipFree(s->tables[b]);
+    *s = SlabIndexSite();
+}
+
+bool slab_indexable(const SlabArgs& a) {
+    return a.ninput > 0 && a.ninput % 64 == 0 && a.ntime % 96 == 0 && a.npkt > 0 && a.npkt < (1 << 24) && a.stride >= 32 + (size_t)a.nchan * 64 &&
+           a.stride % 16 == 0 && ((uintptr_t)a.pkts & 15) == 0 && (uint64_t)a.npkt * a.stride + SLAB_OFF_BIAS + 64 < (1ull << 31) &&
+           (uint64_t)a.nblk * a.stride * 96 < (1ull << 31);       // (a regular slab by its strides: 32-bit per-lane offsets over the rows of a stage)
+}
+
+int slab_index_enqueue(hipStream_t stream, const SlabIndexSite& site, int area, const SlabIndexJob& job, bool by_table, GulpDesc* descs, SlabArgs* args_out) {
+    const int per_gulp = site.ntime * site.nblk;
+    const size_t tu = slab_table_u32(site.ntime, site.nblk);
+    int npkt_max = 1;
+    for (int g = 0; g < job.ngulp; g++) npkt_max = std::max(npkt_max, job.a[g].npkt);
+    const int nrow = site.nblk * (site.ntime / 96) * 16;
+    hipLaunchKernelGGL(slab_index_clear_kernel, dim3((per_gulp + 1023) / 1024, job.ngulp), dim3(256), 0, stream, job, site.tab32, site.meta, per_gulp);
+    hipLaunchKernelGGL(slab_index_kernel, dim3((npkt_max + 255) / 256, job.ngulp), dim3(256), 0, stream, job, site.tab32, site.meta, per_gulp);
+    hipLaunchKernelGGL(slab_table_kernel, dim3((nrow + 255) / 256, job.ngulp), dim3(256), 0, stream, job, (const uint32_t*)site.tab32, site.meta, per_gulp,
+                       site.tables[area], tu);
+    hipLaunchKernelGGL(slab_index_finish_kernel, dim3(512, job.ngulp), dim3(256), 0, stream, job, by_table ? 1 : 0, (const uint32_t*)site.meta, site.tables[area], tu,
+                       (const uint32_t*)site.plain_table, descs, args_out, site.counters, site.hint_host);
+    hipLaunchKernelGGL(slab_scatter_kernel, dim3(512, job.ngulp), dim3(256), 0, stream, (const GulpDesc*)descs, (const SlabArgs*)args_out);
+    XENG_HIP(hipGetLastError());
+    return XENG_STATUS_SUCCESS;
+}
+
+int slab_index_site_read(hipStream_t stream, const SlabIndexSite& site, int* nscattered, int* nirregular) {
+    int v[2] = {0, 0};
+    XENG_HIP(hipMemcpyAsync(v, site.counters, sizeof(v), hipMemcpyDeviceToHost, stream));
+    XENG_HIP(hipMemsetAsync(site.counters, 0, sizeof(v), stream));
+    XENG_HIP(hipStreamSynchronize(stream));
+    if (nscattered) *nscattered = v[0];
+    if (nirregular) *nirregular = v[1];
+    return XENG_STATUS_SUCCESS;
 }
 
 int slab_site_create(SlabSite* s) {

@@ -87,7 +87,13 @@ struct XgpuContext {
     // packet slabs as gulps (xengXgpuKernelAsyncSlab): per staging area one descriptor per gulp, written on the staging stream
     GulpDesc* gdesc_dev[2] = {nullptr, nullptr};
     SlabArgs* gargs_dev[2] = {nullptr, nullptr};   // ... and what the scatter of a gulp that turns out irregular needs (slab.h)
-    SlabSite slab_site;                     // the verify pass's tally + the count of gulps that took the scratch path (slab.h)
+    SlabSite slab_site;                     // input counts that are not whole 64-input blocks: every slab is scattered (slab_prepare_kernel, forced)
+    SlabIndexSite slab_index;               // (round 5) otherwise: every slab is read in place through its offset table (slab.h)
+    SlabIndexJob slab_job;                  // the slabs staged since the last flush
+    int slab_forced = 0;                    // gulps of the legacy path since they were last read (counted on the host: all of them are scattered)
+    int slab_hint_seen = 0;                 // slab_index.hint_host at the last look ...
+    int slab_recent_irr[8] = {}, slab_recent_n[8] = {}, slab_recent_pos = 0;   // ... what it moved by at each of the last eight launches, and their gulps
+    int slab_force_tables = -1;             // XENG_SLAB_TABLES=1 / 0: always / never (tests, A/B); unset: by the hint
     bool slab_mode = false;                 // the gulps staged since the last flush are slabs (no mixing inside one flush)
     EventTimer timer;
 };
@@ -125,6 +131,7 @@ static int destroy_locked() {
     for (int b = 0; b < 2; b++)
         if (x.gargs_dev[b]) (void)hipFree(x.gargs_dev[b]);
     slab_site_destroy(&x.slab_site);
+    slab_index_site_destroy(&x.slab_index);
     x.timer.destroy();
     x = XgpuContext();
     g_epoch++;
@@ -163,12 +170,17 @@ static void launch_xcorr(const XcorrParams& p, hipStream_t s, bool raw, int grid
         }
 #endif
         // the eight-wave 16x16x64 kernel (xcorr_fused16.h) for gulps by pointer without a long accumulator; the four-wave kernel otherwise
-        if (kloop16 && !p.acc2_mode) {
-            if (p.gdesc) hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused16_kernel<0, true>), grid, dim3(512), 0, s, p);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused16_kernel<0>), grid, dim3(512), 0, s, p);
+        // (round 5: also for gulps by descriptor -- the offset tables are laid out for the four-wave kernel's pieces)
+        if (kloop16 && !p.acc2_mode && !p.gdesc) {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused16_kernel<0>), grid, dim3(512), 0, s, p);
             return;
         }
-        if (p.gdesc) {          // gulps by descriptor (packet slabs)
+        if (p.gdesc && p.by_table) {          // gulps by descriptor, every one through its offset table (packet slabs on a lossy link)
+            if (p.acc2_mode) hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<0, true, true, true>), grid, dim3(256), 0, s, p);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<0, false, true, true>), grid, dim3(256), 0, s, p);
+            return;
+        }
+        if (p.gdesc) {          // gulps by descriptor, by strides (packet slabs)
             if (p.acc2_mode) hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<0, true, true>), grid, dim3(256), 0, s, p);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused_kernel<0, false, true>), grid, dim3(256), 0, s, p);
             return;
@@ -239,9 +251,30 @@ static int flush_locked(void* out, bool dump, void* acc = nullptr, int acc_mode 
         stream_tick(STREAM_XGPU);
         nkt += padk;
     }
-    if (x.slab_mode && !diag_env("XENG_SLAB_SKIP")) {
-        // packet slabs: zero-fill + scatter of the gulps that turned out irregular (slab.h); for every other gulp the
-        // groups return at once
+    const bool slab_tables = x.slab_mode && x.slab_index.tab32 != nullptr;
+    bool slab_by_table = false;
+    if (slab_tables) {
+        // packet slabs: index + offset table of every gulp, descriptors (slab.h); zero-fill + scatter only of gulps that carry packets of
+        // another geometry -- five short launches per integration on the staging stream, beside the previous contraction
+        x.slab_job.ngulp = x.nfilled;
+        // By strides while the link is clean or nearly so (round 4's kernel: nothing extra in its K loop; an irregular gulp costs a
+        // zero-fill + scatter, about 15 % of a gulp), through the tables (3-4 % on every gulp, irregular or not) once more than a quarter
+        // of the gulps of the last eight launches were not regular.  The device counts them in pinned memory, read here without a
+        // wait: a hint that lags by a launch or two -- either kernel is exact on any slab.
+        {
+            const int seen = *(volatile int*)x.slab_index.hint_host;
+            x.slab_recent_irr[x.slab_recent_pos] = seen - x.slab_hint_seen;
+            x.slab_recent_n[x.slab_recent_pos] = x.nfilled;
+            x.slab_recent_pos = (x.slab_recent_pos + 1) & 7;
+            x.slab_hint_seen = seen;
+            int irr = 0, n = 0;
+            for (int k = 0; k < 8; k++) { irr += x.slab_recent_irr[k]; n += x.slab_recent_n[k]; }
+            slab_by_table = x.slab_force_tables > 0 || (x.slab_force_tables < 0 && 4 * irr > n);
+        }
+        if (int rcs = slab_index_enqueue(x.stream, x.slab_index, x.cur, x.slab_job, slab_by_table, x.gdesc_dev[x.cur], x.gargs_dev[x.cur])) return rcs;
+        staging_stream_touched();
+    } else if (x.slab_mode) {
+        // (inputs that are not whole 64-input blocks: every gulp was forced to its scratch copy by slab_prepare_kernel; plain launch from there)
         if (int rcs = slab_fallback_enqueue(x.stream, x.gdesc_dev[x.cur], x.gargs_dev[x.cur], x.nfilled)) return rcs;
         staging_stream_touched();
     }
@@ -255,8 +288,9 @@ static int flush_locked(void* out, bool dump, void* acc = nullptr, int acc_mode 
     p.ninput = x.ninput;
     p.fgroups = x.fgroups_dev; p.work = x.work.dev; p.maxi = x.work.maxi; p.nstage = nkt / XC_KT;
     p.acc2 = (int32_t*)acc; p.acc2_mode = acc ? acc_mode : 0;
-    p.gdesc = x.slab_mode ? x.gdesc_dev[x.cur] : nullptr;
-    if (x.slab_mode && !diag_env("XENG_SLAB_PLAIN_ORDER")) { p.work = x.work_pairs.dev; p.maxi = x.work_pairs.maxi; }    // (diagnostic builds: A/B switch)
+    p.gdesc = slab_tables ? x.gdesc_dev[x.cur] : nullptr;
+    p.by_table = slab_by_table ? 1 : 0;
+    if (slab_tables && !diag_env("XENG_SLAB_PLAIN_ORDER")) { p.work = x.work_pairs.dev; p.maxi = x.work_pairs.maxi; }    // (diagnostic builds: A/B switch)
     for (int g = 0; g < XC_MAX_GULPS; g++) p.gulps[g] = g < x.nfilled ? x.gulp_ptr[g] : nullptr;
     // the contraction starts when this area's corner turns are done and runs beside the next area's
     const int si = (int)(x.nlaunch++ % x.nmm);
@@ -548,6 +582,11 @@ static int initialize_locked(int gpu) {
         // profiles/r05/ab_kloop16_*.txt)
         const char* kl = getenv("XENG_KLOOP");
         x.kloop16 = x.raw && kl && !strcmp(kl, "16");
+        // XENG_SLAB_TABLES=1 / 0: packet slabs always / never through their offset tables (default: by strides until a gulp was not regular)
+        const char* st = getenv("XENG_SLAB_TABLES");
+        x.slab_force_tables = st ? (strcmp(st, "0") ? 1 : 0) : -1;
+        x.slab_hint_seen = 0; x.slab_recent_pos = 0;
+        for (int k = 0; k < 8; k++) x.slab_recent_irr[k] = x.slab_recent_n[k] = 0;
     }
     x.cap_gulps = cap;
     x.cap_kt = ((cap * x.gkt + x.kt_stage - 1) / x.kt_stage) * x.kt_stage;
@@ -737,14 +776,23 @@ static int kernel_slab(const void* packets_dev, int npkt, size_t pkt_stride, uin
     SlabArgs a;
     a.pkts = (const uint8_t*)packets_dev; a.npkt = npkt; a.stride = (uint32_t)pkt_stride; a.seq0 = seq0;
     a.ntime = x.cfg.ntime_gulp; a.chan0 = chan0_pipeline; a.nchan = x.cfg.nchan; a.ninput = x.ninput; a.nblk = x.ninput / 64;
-    const bool maybe = slab_maybe_regular(a, 48);       // (the kernel's 32-bit per-lane offsets hold 48 sample rows)
     uint8_t* scratch = x.stash[x.cur] + (size_t)k * x.gulp_bytes;
-    const char* skip = diag_env("XENG_SLAB_SKIP");      // (diagnostic builds, timing only: any value drops the clear / scatter launches, "all" also this one -- descriptors of earlier launches are reused)
-    if (!skip || skip[0] != 'a')
+    if (x.ninput % 64 == 0) {
+        // read in place through an offset table, whatever order the packets are in: nothing is launched per call -- the index and
+        // table passes of all gulps of the integration go onto the staging stream with the flush (slab_index_enqueue)
+        if (!x.slab_index.tab32)
+            if (int rcs = slab_index_site_create(&x.slab_index, x.cfg.ntime_gulp, x.cfg.nchan, x.ninput)) return rcs;
+        x.slab_job.a[k] = a; x.slab_job.scratch[k] = scratch; x.slab_job.force[k] = slab_indexable(a) ? 0 : 1;
+        x.gulp_ptr[k] = nullptr;
+    } else {
+        // (the contraction reads whole 64-input blocks through a table; other input counts: scattered, then a plain launch)
+        const bool maybe = false;
         if (int rcs = slab_prepare_enqueue(x.stream, x.slab_site, &a, &maybe, 1, x.gdesc_dev[x.cur] + k, x.gargs_dev[x.cur] + k, &scratch, false)) return rcs;
-    XENG_HIP(hipGetLastError());
-    staging_stream_touched();
-    x.gulp_ptr[k] = nullptr;
+        XENG_HIP(hipGetLastError());
+        staging_stream_touched();
+        x.slab_forced++;
+        x.gulp_ptr[k] = scratch;
+    }
     x.slab_mode = true;
     x.nfilled++;
     if (doDump || x.nfilled == x.cap_gulps) return flush_locked(out_dev, doDump != 0, acc_dev, acc_dev ? acc_mode : 0);
@@ -762,19 +810,42 @@ int xengXgpuTryKernelAsyncSlab(const void* packets_dev, int npkt, size_t pkt_str
     return kernel_slab(packets_dev, npkt, pkt_stride, seq0, chan0_pipeline, out_dev, doDump, acc_dev, acc_mode, false);
 }
 
-// gulps handed over as slabs that took the scratch path (lost / reordered / foreign packets) since the last call; waits for the
-// staging stream
+static int slab_stats_locked(int* nscattered, int* nirregular) {
+    XgpuContext& x = g_ctx;
+    int ns = x.slab_forced, ni = 0;
+    x.slab_forced = 0;
+    if (x.slab_index.tab32) {
+        XENG_HIP(hipSetDevice(x.gpu));
+        stream_tick(STREAM_XGPU);
+        int a = 0, b = 0;
+        if (int rcs = slab_index_site_read(x.stream, x.slab_index, &a, &b)) return rcs;
+        ns += a; ni += b;
+    }
+    if (nscattered) *nscattered = ns;
+    if (nirregular) *nirregular = ni;
+    return XENG_STATUS_SUCCESS;
+}
+
+// gulps handed over as slabs that went through zero-fill + scatter (packets of another geometry; round 4: any irregular slab) since
+// the last call; waits for the staging stream
 int xengXgpuGetSlabFallbacks(int* nfallback) {
     std::lock_guard<std::mutex> lk(g_mu);
     XgpuContext& x = g_ctx;
     if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized");
     if (!nfallback) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "GetSlabFallbacks: null pointer");
     *nfallback = 0;
-    if (!x.slab_site.tally) return XENG_STATUS_SUCCESS;
-    XENG_HIP(hipSetDevice(x.gpu));
-    stream_tick(STREAM_XGPU);
-    if (int rcs = slab_site_read_fallbacks(x.stream, x.slab_site, nfallback)) return rcs;
-    return XENG_STATUS_SUCCESS;
+    return slab_stats_locked(nfallback, nullptr);
+}
+
+// ... and (round 5) the gulps that were read in place although their packets were not all in place (lost, shifted, reordered,
+// duplicated, foreign): through their offset table, no scatter
+int xengXgpuGetSlabStats(int* nscattered, int* nirregular) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    XgpuContext& x = g_ctx;
+    if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "xgpu: not initialized");
+    if (!nscattered || !nirregular) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "GetSlabStats: null pointer");
+    *nscattered = *nirregular = 0;
+    return slab_stats_locked(nscattered, nirregular);
 }
 
 int xengXgpuSync(void) {

@@ -204,6 +204,7 @@ struct XcorrParams {
     // DESC instantiation (round 4): the gulps of this launch are described in DEVICE memory, one GulpDesc each, written on the
     // staging stream before the launch -- a gulp may then be a slab of F-engine packets read where it lies (xengXgpuKernelAsyncSlab)
     const GulpDesc* gdesc;
+    int by_table;                 // (round 5, host side only: launch the TAB instantiation -- every gulp through its offset table)
 };
 
 
@@ -709,15 +710,30 @@ __device__ __forceinline__ void xcorr_store_cells(const XcorrParams& p, int c, c
 // channels of a round (an experiment: results stay right).
 // DESC: gulps by descriptor (GulpDesc above) instead of by pointer: strides are per gulp and read with scalar loads; the default
 // instantiation is untouched.
-template <int ABL, bool LACC = false, bool DESC = false>
+// TAB (round 5; a third instantiation, the DESC one is what it was): every gulp of the launch is read through its offset TABLE
+// (slab.h) -- a slab of packets with lost, shifted, reordered or duplicated packets is read where it lies, like a regular one:
+//   * per stage a wave brings the 1 KiB of table rows of its two 64-input blocks into a small LDS ring with ONE more LDS-DMA
+//     instruction (the stage walker runs SIX stages ahead of the MFMAs for it; the pieces still run three stages ahead),
+//   * one iteration before it issues the pieces of a stage, every lane reads its six offsets from there (ds_read_b128 + b64, under
+//     the MFMAs of the stage's last K-tile: the rows landed two stages ago, nothing waits),
+//   * when the pieces of a stage have landed, lanes whose sample nobody carries overwrite their 16 bytes with zeros (a flag word in
+//     the same row, read when the stage begins; a wave-uniform branch per stage when nothing is missing).
+// Every stage costs NVM = 7 operations on the vmcnt counter instead of 6.
+template <int ABL, bool LACC = false, bool DESC = false, bool TAB = false>
 __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
     constexpr int KT_STAGE = XC_KT;
     constexpr int SLOT_BYTES = KT_STAGE * KT_BYTES;
     constexpr int STAGE_BYTES = XC_NSLOT * SLOT_BYTES;
     constexpr int NLOAD = 2 * KT_STAGE;  // 1 KiB LDS-DMA pieces per wave per stage
+#ifndef XT_EXPERIMENT
+#define XT_EXPERIMENT 0       // timing-only A/B builds of the TAB path (results wrong): 1 no hole flags / fix, 2 no table fetch in the loop, 3 both
+#endif
+    constexpr int NVM = NLOAD + ((TAB && !(XT_EXPERIMENT & 2)) ? 1 : 0);    // vector-memory operations per wave and stage (TAB: + the table rows)
     constexpr int DEPTH = XF_DEPTH;          // the LDS-DMA of stage S+DEPTH is issued while stage S is contracted
     constexpr int RING = DEPTH + 1;          // LDS ring (stages)
+    static_assert(!TAB || (DESC && DEPTH == 3), "the table ring (flags of S+2, offsets of S+3 and S+4, S+5 landed, S+6 in flight) assumes DEPTH 3");
     __shared__ __attribute__((aligned(16))) uint8_t lds[RING * STAGE_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t idx_lds[TAB ? 8 * 4096 : 16];   // [stage & 7][wave][block of the pair][row r8][64 B]
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -748,9 +764,21 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
     uint32_t is_blk = 0, is_sub = 0, d_t = row_stride, d_c = (uint32_t)p.ninput;
     const uint8_t* d_base = nullptr;
     const DescPtr gdesc = (DescPtr)(uintptr_t)p.gdesc;
+    // TAB: what next_stage() made of the walker's stage -- base of its pieces, source of its table rows --, the bases of the three stages in
+    // between (the pieces run three stages behind the walker), and per lane: its 16 bytes of the wave's table rows (per item), its row
+    // in the LDS copy and its 16-byte piece of a 64-byte payload row (constants), the flags of the stage that lands
+    const int lchunk = (lane & 7) ^ (((lane >> 4) & 3) << 1);            // source chunk 0..7 of the 128-byte pair row
+    const uint32_t t_sub = (uint32_t)(lchunk & 3) * 16u, ix_row = (uint32_t)(wave * 1024 + (lchunk >> 2) * 512 + (lane >> 3) * 64);
+    uint32_t ix_voff = 0, hole_flags = 0;
+    const uint8_t *d_tab = nullptr, *nx_sb = nullptr, *nx_ix = nullptr, *sb_q0 = nullptr, *sb_q1 = nullptr, *sb_q2 = nullptr, *sb_now = nullptr;
     auto load_desc = [&](int g) {          // gulp g's layout (scalar loads) -> this lane's six piece offsets
         const uint32_t lo = gdesc[g * 8], hi = gdesc[g * 8 + 1];
         d_base = (const uint8_t*)(((uint64_t)hi << 32) | lo);
+        if (TAB) {
+            d_c = gdesc[g * 8 + 3];
+            d_tab = (const uint8_t*)(((uint64_t)gdesc[g * 8 + 7] << 32) | gdesc[g * 8 + 6]);
+            return;
+        }
         d_t = gdesc[g * 8 + 2];
         d_c = gdesc[g * 8 + 3];
         const uint32_t d_b = gdesc[g * 8 + 4];
@@ -764,7 +792,10 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
         const uint32_t slots = groups[it.wg * 8];                         // slot_blk[0..3]
         const int chunk = (lane & 7) ^ (((lane >> 4) & 3) << 1);          // source chunk 0..7 of the 128-byte pair row
         const int blk0 = (slots >> (8 * (wave & 2))) & 0xFF, blk1 = (slots >> (8 * (wave & 2) + 8)) & 0xFF;
-        if (DESC) {
+        if (TAB) {
+            // (whole 64-input blocks only: the host hands this kernel nothing else)
+            ix_voff = (uint32_t)((lane & 32) ? blk1 : blk0) * (uint32_t)p.spg * 1024u + (uint32_t)(lane & 31) * 16u;
+        } else if (DESC) {
             is_blk = (uint32_t)((chunk >> 2) ? blk1 : blk0);
             is_sub = (uint32_t)(chunk & 3) * 16u;
             if (is_blk * 64u + is_sub + 16u > (uint32_t)p.ninput) { is_blk = 0; is_sub = 0; }
@@ -787,7 +818,11 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
             is_k++;
             is_setup(nx);
         }
-        if (DESC) {
+        if (TAB) {
+            if (is_sl == 0) load_desc(is_g);
+            nx_sb = d_base + (size_t)is_c * d_c - SLAB_OFF_BIAS;      // (never dereferenced as it stands: every table offset carries the bias)
+            nx_ix = d_tab + (size_t)(is_sl * 2 + (wave & 1)) * 512;
+        } else if (DESC) {
             // (a new gulp may be laid out differently: its descriptor is loaded here, when its first stage is set up -- not when
             // the previous gulp's last stage was, whose pieces are still to be issued with the old offsets)
             if (is_sl == 0 && is_g > 0) load_desc(is_g);
@@ -811,8 +846,33 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
     // (raw_voff[n] = lane offset + n * 8 rows - imm) the pieces share one scalar base per stage and M0 is written
     // twice per stage (pieces 0-3: imm 0..3072, pieces 4-5: M0 + 4096, imm 0, 1024) instead of once per piece.
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(const __attribute__((address_space(3))) void*)lds);
+    const uint32_t idx_base = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(const __attribute__((address_space(3))) void*)idx_lds);
+    // TAB: the table rows of the stage last returned by next_stage(): 2 x 512 B (the wave's two blocks), one instruction
+    auto issue_table = [&](int slot) {
+        const uint32_t la = idx_base + slot * 4096 + wave * 1024;
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(ix_voff), "s"(nx_ix), "s"(la) : "memory");
+    };
+    // ... this lane's six offsets out of a landed table block
+    auto load_offsets = [&](int slot) {
+        const uint8_t* row = idx_lds + slot * 4096 + ix_row;
+        const uint4 e = *reinterpret_cast<const uint4*>(row);
+        const uint2 f = *reinterpret_cast<const uint2*>(row + 16);
+        is_voff[0] = e.x + t_sub; is_voff[1] = e.y + t_sub; is_voff[2] = e.z + t_sub; is_voff[3] = e.w + t_sub;
+        is_voff[4] = f.x + t_sub; is_voff[5] = f.y + t_sub;
+    };
+    // ... and, once the pieces of that stage have landed in ring slot `ring_slot`: zeros where no packet carries the sample
+    auto load_flags = [&](int slot) { hole_flags = *reinterpret_cast<const uint32_t*>(idx_lds + slot * 4096 + ix_row + 24); };
+    auto fix_holes = [&](int ring_slot) {
+        if (__builtin_amdgcn_ballot_w64(hole_flags != 0u) != 0ull) {
+            uint8_t* own = lds + ring_slot * STAGE_BYTES + wave * SLOT_BYTES + lane * 16;
+#pragma unroll
+            for (int n = 0; n < NLOAD; n++)
+                if ((hole_flags >> n) & 1u) *reinterpret_cast<uint4*>(own + n * 1024) = make_uint4(0u, 0u, 0u, 0u);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the barrier that publishes the stage does not wait for LDS writes)
+        }
+    };
     auto issue_piece = [&](int ring_slot, int n) {
-        const uint8_t* sb = is_stage + (size_t)(48 * (wave & 1)) * (DESC ? d_t : row_stride);   // scalar base of this wave's rows
+        const uint8_t* sb = TAB ? sb_now : is_stage + (size_t)(48 * (wave & 1)) * (DESC ? d_t : row_stride);   // scalar base of this wave's rows
         const uint32_t la = lds_base + ring_slot * STAGE_BYTES + wave * SLOT_BYTES + (n < 4 ? 0 : 4096);
         const uint32_t vo = is_voff[n];
         if (n == 0) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(vo), "s"(sb), "s"(la) : "memory");
@@ -839,6 +899,29 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
         }
     }
     is_setup(it);
+    if (TAB) {
+        // table rows of stages 0-5, then the pieces of stages 0-2 from them
+        const uint8_t* sbs[6];
+#pragma unroll
+        for (int st = 0; st < 6; st++) {
+            next_stage();
+            sbs[st] = nx_sb;
+            issue_table(st);
+        }
+        wait_vmcnt<0>();
+#pragma unroll
+        for (int st = 0; st < DEPTH; st++) {
+            load_offsets(st);
+            sb_now = sbs[st];
+#pragma unroll
+            for (int n = 0; n < NLOAD; n++) issue_piece(st, n);
+        }
+        wait_vmcnt<NLOAD>();                 // stages 0 and 1 have landed
+        load_flags(0); fix_holes(0);
+        load_flags(1); fix_holes(1);
+        load_offsets(3);                     // for the pieces of stage 3, issued while stage 0 is contracted
+        sb_q0 = sbs[3]; sb_q1 = sbs[4]; sb_q2 = sbs[5];
+    } else {
 #pragma unroll
     for (int st = 0; st < DEPTH; st++) {
         next_stage();
@@ -846,12 +929,47 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
         for (int n = 0; n < NLOAD; n++) issue_piece(st, n);
     }
     wait_vmcnt<(DEPTH - 2) * NLOAD>();       // stages 0 and 1 have landed
+    }
     __builtin_amdgcn_s_barrier();
 
     // ring slots of the stage being contracted (rs), the next one (rs1) and the one being filled (rf):
     // the stage counter is continuous across items
     int rs = 0, rs1 = 1, rf = DEPTH;
     auto bump = [&](int& r) { r = (r + 1 == RING) ? 0 : r + 1; };
+    // TAB: q = (number of the stage being contracted) & 7, the table ring's phase
+    int q = 0;
+    // what a stage begins with: the walker moves on (TAB: six stages ahead; the base of the pieces issued now was made three stages
+    // ago), the flags of the stage that lands meanwhile are fetched
+    auto stage_begin = [&]() {
+        if (TAB) { sb_now = sb_q0; sb_q0 = sb_q1; sb_q1 = sb_q2; }
+        next_stage();
+        if (TAB) {
+            sb_q2 = nx_sb;
+            if (!(ABL & 1) && !(XT_EXPERIMENT & 2)) issue_table((q + 6) & 7);
+            if (!(XT_EXPERIMENT & 1)) load_flags((q + 2) & 7);
+        }
+    };
+    // TAB, once the last piece of the stage has been issued: the offsets of the pieces that the NEXT stage issues (their rows landed
+    // two stages ago; the reads run under the MFMAs of this K-tile)
+    auto stage_offsets = [&]() {
+        if (TAB) load_offsets((q + 4) & 7);
+    };
+    // ... and ends with: this wave's pieces of stage S+2 (and everything older) have landed; TAB: zeros for its missing samples; one barrier
+    auto stage_end = [&](bool relaxed) {
+        if (!(ABL & 8)) {
+            // (first stage behind a straight-line epilogue: the 32 tile stores of that epilogue sit between the DMA of
+            // stage S+2, which this wait is for, and the pieces just issued; vmcnt retires in issue order, so
+            // allowing them to stay in flight does not let stage S+2 slip -- and the wave does not stall for the
+            // write acknowledgements of the previous item)
+            if (!(ABL & 1)) { if (relaxed && !XF_NO_RELAX) wait_vmcnt<(DEPTH - 2) * NVM + 32>(); else wait_vmcnt<(DEPTH - 2) * NVM>(); }
+            if (TAB) {
+                if (!(XT_EXPERIMENT & 1)) fix_holes(rs1 + 1 == RING ? 0 : rs1 + 1);
+                q = (q + 1) & 7;
+            }
+            __builtin_amdgcn_s_barrier();
+        }
+        bump(rs); bump(rs1); bump(rf);
+    };
     bool stores_in_flight = false;            // the previous item of this wave ended with the 32-store epilogue
     for (int k = 0; item(k, it); k++) {
         const int c = it.c, wg = it.wg;
@@ -861,16 +979,13 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
             // A wave without a cell only keeps the stage stream and the barriers going (no MFMAs on dummy data: the
             // kernel is power-limited).  Nothing is live across this branch.
             for (int s = 0; s < p.nstage; s++) {
-                next_stage();
+                stage_begin();
                 if (!(ABL & 1)) {
 #pragma unroll
                     for (int n = 0; n < NLOAD; n++) issue_piece(rf, n);
                 }
-                if (!(ABL & 8)) {
-                    if (!(ABL & 1)) wait_vmcnt<(DEPTH - 2) * NLOAD>();
-                    __builtin_amdgcn_s_barrier();
-                }
-                bump(rs); bump(rs1); bump(rf);
+                stage_offsets();
+                stage_end(false);
             }
             stores_in_flight = false;
             continue;
@@ -935,13 +1050,14 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
             Frags cur = unpack_frags(load_raw(rs, 0));
             RawFrags raw = load_raw(rs, 1);
             for (int s = 0; s < p.nstage; s++) {
-                next_stage();
+                stage_begin();
 #pragma unroll
                 for (int j = 0; j < KT_STAGE; j++) {
                     if (!(ABL & 1)) {
                         issue_piece(rf, 2 * j);
                         issue_piece(rf, 2 * j + 1);
                     }
+                    if (j == KT_STAGE - 1) stage_offsets();
                     xcorr_mfma_cells<Z>(cur, skip1, accR, accP, accQ, (ABL & 128) && Z && ((s * KT_STAGE + j) & 3) == 3);
                     if (ABL & 256) {
                         cur = unpack_frags_offset_binary(raw);
@@ -964,15 +1080,7 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
                         if (i >= 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // DS read
                     }
                 }
-                if (!(ABL & 8)) {
-                    // (first stage behind a straight-line epilogue: the 32 tile stores of that epilogue sit between the DMA of
-                    // stage S+2, which this wait is for, and the 6 pieces just issued; vmcnt retires in issue order, so
-                    // allowing them to stay in flight does not let stage S+2 slip -- and the wave does not stall for the
-                    // write acknowledgements of the previous item)
-                    if (!(ABL & 1)) { if (s == 0 && stores_in_flight && !XF_NO_RELAX) wait_vmcnt<(DEPTH - 2) * NLOAD + 32>(); else wait_vmcnt<(DEPTH - 2) * NLOAD>(); }
-                    __builtin_amdgcn_s_barrier();
-                }
-                bump(rs); bump(rs1); bump(rf);
+                stage_end(s == 0 && stores_in_flight);
             }
         };
         if (zpat) kloop(std::true_type{});

@@ -68,7 +68,7 @@ SYMBOLS = {
     "xengMemcpyAsync": [_vp, _vp, _sz], "xengMemset": [_vp, _i, _sz], "xengStreamSynchronize": [],
     "xengXgpuConfigure": [_i, _i, _i, _i, _i], "xengXgpuInitialize": [_i], "xengXgpuDestroy": [],
     "xengXgpuKernel": [_vp, _vp, _i], "xengXgpuKernelAsync": [_vp, _vp, _i], "xengXgpuKernelAsyncAcc": [_vp, _vp, _i, _vp, _i], "xengXgpuTryKernelAsyncAcc": [_vp, _vp, _i, _vp, _i], "xengXgpuWaitLaunchSlot": [],
-    "xengXgpuKernelAsyncSlab": [_vp, _i, _sz, ctypes.c_uint64, _i, _vp, _i, _vp, _i], "xengXgpuTryKernelAsyncSlab": [_vp, _i, _sz, ctypes.c_uint64, _i, _vp, _i, _vp, _i], "xengXgpuGetSlabFallbacks": [_pi], "xengXgpuSync": [], "xengXgpuSyncLag": [_i], "xengXgpuDumpDone": [_i, _pi], "xengXgpuReset": [],
+    "xengXgpuKernelAsyncSlab": [_vp, _i, _sz, ctypes.c_uint64, _i, _vp, _i, _vp, _i], "xengXgpuTryKernelAsyncSlab": [_vp, _i, _sz, ctypes.c_uint64, _i, _vp, _i, _vp, _i], "xengXgpuGetSlabFallbacks": [_pi], "xengXgpuGetSlabStats": [_pi, _pi], "xengXgpuSync": [], "xengXgpuSyncLag": [_i], "xengXgpuDumpDone": [_i, _pi], "xengXgpuReset": [],
     "xengXgpuCorrelate": [_vp, _vp, _i], "xengXgpuGetOrder": [_vp, _vp, _vp],
     "xengXgpuSubSelect": [_vp, _vp, _vp, _vp, _i, _i], "xengXgpuReorder": [_vp, _vp, _vp, _vp],
     "xengXgpuGetInfo": [_pi, _pi, _pi, _pi, ctypes.POINTER(ctypes.c_int64), _pi],
@@ -106,6 +106,8 @@ def lib():
                               "(or make -C caltech-bifrost-dsp_amd/csrc). There is no CPU fallback." % LIB_PATH)
         L = ctypes.CDLL(LIB_PATH)
         for name, args in SYMBOLS.items():
+            if os.environ.get("XENG_LIB") and not hasattr(L, name):
+                continue            # (an older build loaded for an A/B by profiles/: calling what it lacks raises AttributeError there)
             f = getattr(L, name)
             f.argtypes = args
             f.restype = ctypes.c_int

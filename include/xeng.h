@@ -219,17 +219,22 @@ int xengXgpuWaitLaunchSlot(void);
 /* A gulp handed over as the SLAB OF PACKETS it arrived in (round 4; layout: "Ingest" below; the gulp's window starts at seq0,
  * channel 0 of the pipeline is chan0_pipeline).  Enqueue-only like xengXgpuKernelAsync[Acc], same rules for out_dev / acc_dev /
  * doDump, and the slab must stay valid and unchanged until the dump that consumes it has completed.  On the device, without a host
- * round trip: if the slab is REGULAR -- packet (sample t, 64-input block b) at index t * (ninput / 64) + b, every packet covering
- * all channels -- the contraction kernel reads the voltages out of the packets where they lie (no scatter pass, no copy of the
- * gulp at all); any lost, reordered, duplicated or foreign packet sends the gulp through a scatter into the library's staging area
- * instead, with the rules of xengSnap2Unpack (missing samples read as zero), and the results are those of unpack + correlate
- * either way.  Slabs and plain gulps cannot be mixed inside one integration.  xengXgpuGetSlabFallbacks: gulps that took the
- * scatter since it was last called (waits for the staging stream).  No reference counterpart: bifrost's capture scatters on the CPU. */
+ * round trip (round 5): every packet of the deployed geometry (one packet per sample and 64-input block, all channels) is entered
+ * into an index -- the last packet that carries a (sample, block) wins, as in xengSnap2Unpack -- and the contraction kernel reads the
+ * voltages out of the packets WHERE THEY LIE, through a table of their offsets: in order, shifted by lost packets, reordered,
+ * duplicated, mixed with foreign or out-of-window packets, any packet count -- no scatter pass, no copy of the gulp at all;
+ * samples nobody carries read as zero.  Only a slab that holds valid packets of ANOTHER geometry (several channel blocks per sample,
+ * fewer inputs per packet), or one the table cannot describe (stride not a multiple of 16, unaligned, >= 2 GiB), goes through
+ * zero-fill + scatter into the library's staging area, with the rules of xengSnap2Unpack.  The results are those of unpack +
+ * correlate either way.  Slabs and plain gulps cannot be mixed inside one integration.  xengXgpuGetSlabFallbacks: gulps that took
+ * the scatter since it was last called; xengXgpuGetSlabStats: those, and the gulps read in place whose packets were not all in
+ * place (both wait for the staging stream).  No reference counterpart: bifrost's capture scatters on the CPU. */
 int xengXgpuKernelAsyncSlab(const void *packets_dev, int npkt, size_t pkt_stride, uint64_t seq0, int chan0_pipeline, void *out_dev,
                             int doDump, void *acc_dev, int acc_mode);
 int xengXgpuTryKernelAsyncSlab(const void *packets_dev, int npkt, size_t pkt_stride, uint64_t seq0, int chan0_pipeline, void *out_dev,
                                int doDump, void *acc_dev, int acc_mode);      /* never waits: see xengXgpuTryKernelAsyncAcc */
 int xengXgpuGetSlabFallbacks(int *nfallback);
+int xengXgpuGetSlabStats(int *nscattered, int *nirregular);
 int xengXgpuSync(void);
 /* Wait until all but the last `lag` (0..3) dumps are complete -- lag 1 lets a streaming caller enqueue
  * integration n+1 (into a different out_dev) before it waits for integration n, so the contraction of

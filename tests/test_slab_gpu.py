@@ -1,9 +1,11 @@
 """Packet slabs as gulps (round 4, SURVEY 8(f) row 3 + the north star's "throughput on synthetic F-engine packets"): through the C ABI.
 
 `xengXgpuKernelAsyncSlab` takes a gulp as the slab of SNAP2 packets it arrived in (format pinned by the reference's
-transmitters: test_tx_vectors.py:38-48,103-108).  A regular slab is read by the contraction where it lies; anything else goes
-through a scatter into the library's staging area.  Either way the visibilities are, bit for bit, those of the oracle's
-unpack (`snap2_unpack`: missing samples read as zero, foreign / out-of-window packets dropped) followed by its correlation."""
+transmitters: test_tx_vectors.py:38-48,103-108).  Round 5: every slab of the deployed packet geometry is read by the contraction
+where it lies, through a table of packet offsets built on the device -- in order, with lost, shifted, reordered, duplicated,
+foreign or out-of-window packets alike; only packets of another geometry send a gulp through a scatter into the library's
+staging area.  Either way the visibilities are, bit for bit, those of the oracle's unpack (`snap2_unpack`: missing samples read as
+zero, foreign / out-of-window packets dropped, the last packet that carries a sample wins) followed by its correlation."""
 import ctypes
 
 import numpy as np
@@ -48,11 +50,27 @@ def _expected(pkt_lists, ntime, nchan, nstand):
     return acc
 
 
-def _run(gpu, pkt_lists, nstand, nchan, ntime, acc_mode=0):
-    """one integration of len(pkt_lists) slabs; returns (visibilities, accumulator or None, fallbacks)"""
+def _init(ffi, tables, *cfg):
+    """Configure + Initialize under XENG_SLAB_TABLES = tables ("1": the contraction follows the offset tables from the first launch
+    on; "0": never; None: the shipped default -- by strides until a gulp was not regular)"""
+    import os
+    old = os.environ.pop("XENG_SLAB_TABLES", None)
+    if tables is not None:
+        os.environ["XENG_SLAB_TABLES"] = tables
+    try:
+        ffi.call("xengXgpuConfigure", *cfg)
+        ffi.call("xengXgpuInitialize", 0)
+    finally:
+        os.environ.pop("XENG_SLAB_TABLES", None)
+        if old is not None:
+            os.environ["XENG_SLAB_TABLES"] = old
+
+
+def _run(gpu, pkt_lists, nstand, nchan, ntime, acc_mode=0, tables=None):
+    """one integration of len(pkt_lists) slabs; returns (visibilities, accumulator or None, gulps scattered); _run.irregular: gulps
+    read in place through a table that was not regular"""
     ffi = gpu.ffi
-    ffi.call("xengXgpuConfigure", nstand, 2, nchan, ntime, len(pkt_lists))
-    ffi.call("xengXgpuInitialize", 0)
+    _init(ffi, tables, nstand, 2, nchan, ntime, len(pkt_lists))
     fused, fp6 = ctypes.c_int(), ctypes.c_int()
     ffi.call("xengXgpuGetPath", ctypes.byref(fused), ctypes.byref(fp6))
     if fused.value != 1:        # (XENG_RAW=0: the two-pass X-engine has no descriptor kernel -- the call says UNSUPPORTED, unpack instead)
@@ -72,30 +90,37 @@ def _run(gpu, pkt_lists, nstand, nchan, ntime, acc_mode=0):
         ffi.call("xengXgpuKernelAsyncSlab", d.ptr, len(pk), stride, SEQ0 + g * ntime, CHAN0, out.ptr, int(g == len(pkt_lists) - 1),
                  acc.ptr if acc else None, acc_mode)
     ffi.call("xengXgpuSync")
-    nfb = ctypes.c_int(-1)
-    ffi.call("xengXgpuGetSlabFallbacks", ctypes.byref(nfb))
+    nfb, nirr = ctypes.c_int(-1), ctypes.c_int(-1)
+    ffi.call("xengXgpuGetSlabStats", ctypes.byref(nfb), ctypes.byref(nirr))
+    again = ctypes.c_int(-1)
+    ffi.call("xengXgpuGetSlabFallbacks", ctypes.byref(again))
+    assert again.value == 0                     # (reading the counters resets them)
     vis = out.download(np.int32)
     accv = acc.download(np.int32) if acc else None
     ffi.call("xengXgpuDestroy")
     for b in bufs + [out] + ([acc] if acc else []):
         b.free()
+    _run.irregular = nirr.value
     return vis, accv, nfb.value
 
 
+@pytest.mark.parametrize("tables", [None, "1"])
 @pytest.mark.parametrize("nstand,nchan,ntime,ngulp", [(352, 96, 480, 5), (96, 8, 96, 2), (64, 4, 192, 3), (32, 16, 96, 1)])
-def test_regular_slabs_are_read_in_place(gpu, nstand, nchan, ntime, ngulp):
+def test_regular_slabs_are_read_in_place(gpu, nstand, nchan, ntime, ngulp, tables):
     vin = gpu.synth_voltages(ngulp * ntime, nchan, nstand, "full", seed=nstand + ntime)
     pk = [orc.snap2_packets(vin[g * ntime:(g + 1) * ntime], seq0=SEQ0 + g * ntime, sync_time=3, nchan_blocks=1, nstand_per_pkt=32, chan0_pipeline=CHAN0)
           for g in range(ngulp)]
-    vis, acc, nfb = _run(gpu, pk, nstand, nchan, ntime, acc_mode=1)
+    vis, acc, nfb = _run(gpu, pk, nstand, nchan, ntime, acc_mode=1, tables=tables)
     want = orc.xgpu_correlate(vin, nstand, nchan)
-    assert nfb == 0, "a regular slab took the scatter path"
+    assert nfb == 0 and _run.irregular == 0, "a regular slab took the scatter path / was counted irregular"
     assert np.array_equal(vis, want) and np.array_equal(acc, want)
 
 
-def test_irregular_slabs_take_the_scatter_and_give_the_unpacked_result(gpu):
+@pytest.mark.parametrize("tables", [None, "1"])
+def test_irregular_slabs_give_the_unpacked_result(gpu, tables):
     """lost, reordered, duplicated, foreign and out-of-window packets, one kind per gulp, beside a regular gulp in the same
-    integration: every irregular gulp is counted, and the integration equals unpack + correlate of what was received"""
+    integration: following the tables no gulp is scattered, every irregular gulp is counted; by strides (a link that has been clean so
+    far) the five take the round-4 scatter; the integration equals unpack + correlate of what was received either way"""
     nstand, nchan, ntime = 96, 8, 96
     rng = np.random.default_rng(5)
     vin = gpu.synth_voltages(6 * ntime, nchan, nstand, "full", seed=11)
@@ -112,9 +137,103 @@ def test_irregular_slabs_take_the_scatter_and_give_the_unpacked_result(gpu):
     late = mk(5)
     late[10] = orc.snap2_packets(vin[:1], seq0=SEQ0 + 99 * ntime, sync_time=3, nchan_blocks=1, nstand_per_pkt=32, chan0_pipeline=CHAN0)[0]              # outside the window
     lists = [regular, shuffled, lost, dup, foreign, late]
-    vis, _, nfb = _run(gpu, lists, nstand, nchan, ntime)
-    assert nfb == 5
+    vis, _, nfb = _run(gpu, lists, nstand, nchan, ntime, tables=tables)
+    assert (nfb, _run.irregular) == ((0, 5) if tables else (5, 0))
     assert np.array_equal(vis, _expected(lists, ntime, nchan, nstand))
+
+
+def _mk(gpu, vin, g, ntime, **kw):
+    return orc.snap2_packets(vin[g * ntime:(g + 1) * ntime], seq0=SEQ0 + g * ntime, sync_time=3, nchan_blocks=1, nstand_per_pkt=32, chan0_pipeline=CHAN0, **kw)
+
+
+@pytest.mark.parametrize("tables", ["1", None])
+@pytest.mark.parametrize("nstand,nchan,ntime", [(96, 8, 96), (352, 96, 480)])
+def test_lossy_links_shifted_slabs_and_last_duplicate_wins(gpu, nstand, nchan, ntime, tables):
+    """what receivers really leave behind, one kind per gulp (the reference's transmitter has a deliberate-loss switch,
+    test_tx_mt.c:22,108-118):
+      0  arrival order with 1 % of the packets lost: everything behind a loss sits one slot early, the slab is SHORTER
+      1  slots by index, a lost packet's slot keeps a stale packet of an older window
+      2  a lost packet's slot holds a copy of the next packet (bench.py's model), two of them adjacent: the first then holds the
+         only copy of a packet whose own slot is taken
+      3  two packets carry the same (sample, block) with DIFFERENT payloads: the later one wins, as in the oracle's scatter
+      4  a whole sample and a whole 64-input block missing
+      5  nothing but foreign packets: the gulp reads as zeros
+    Following the tables all are read in place, none is scattered; by strides all six take the scatter (two different payloads for one
+    sample make that path's result depend on the order of its waves: that gulp is left out there)."""
+    rng = np.random.default_rng(nstand)
+    vin = gpu.synth_voltages(6 * ntime, nchan, nstand, "full", seed=21)
+    nblk = nstand * 2 // 64
+    lists = []
+    full = _mk(gpu, vin, 0, ntime)
+    lost = set(rng.choice(len(full), size=max(2, len(full) // 100), replace=False).tolist())
+    lists.append([pk for i, pk in enumerate(full) if i not in lost])
+    full = _mk(gpu, vin, 1, ntime)
+    stale = orc.snap2_packets(vin[:1], seq0=SEQ0 - 7 * ntime, sync_time=3, nchan_blocks=1, nstand_per_pkt=32, chan0_pipeline=CHAN0)
+    for i in rng.choice(len(full), size=5, replace=False):
+        full[i] = stale[i % nblk]
+    lists.append(full)
+    full = _mk(gpu, vin, 2, ntime)
+    orig = list(full)
+    for i in (9, 10, 40):
+        full[i] = orig[i + 1]
+    lists.append(full)
+    full = _mk(gpu, vin, 3, ntime)
+    other = _mk(gpu, vin[::-1], 3, ntime)                      # same headers, other payloads
+    full[5] = other[20]                                       # an early copy of (sample, block) 20 that loses against slot 20 ...
+    full[len(full) - 3] = other[33]                           # ... and a late one of 33 that wins
+    lists.append(full)
+    full = _mk(gpu, vin, 4, ntime)
+    lists.append([pk for i, pk in enumerate(full) if i // nblk != 17 and i % nblk != 1])
+    lists.append(orc.snap2_packets(vin[:ntime], seq0=SEQ0 + 5 * ntime, sync_time=3, nchan_blocks=1, nstand_per_pkt=32, chan0_pipeline=CHAN0 + 5000))
+    if not tables:
+        lists[3] = _mk(gpu, vin, 3, ntime)[::-1]              # (reversed instead: the scatter has no order among duplicates)
+    vis, acc, nfb = _run(gpu, lists, nstand, nchan, ntime, acc_mode=1, tables=tables)
+    want = _expected(lists, ntime, nchan, nstand)
+    assert (nfb, _run.irregular) == ((0, 6) if tables else (6, 0))
+    assert np.array_equal(vis, want) and np.array_equal(acc, want)
+
+
+def test_the_contraction_follows_the_tables_on_a_lossy_link(gpu):
+    """the shipped default: slabs are addressed by their strides while the link is clean or nearly so -- a gulp that is not regular
+    takes the round-4 scatter and is counted in pinned memory --; once more than a quarter of the recent gulps were not regular the
+    host's launches read every gulp through its table; when the link is clean again they go back.  Exact at every step."""
+    ffi = gpu.ffi
+    nstand, nchan, ntime = 96, 8, 96
+    vin = gpu.synth_voltages(3 * ntime, nchan, nstand, "full", seed=31)
+    full = [_mk(gpu, vin, g, ntime) for g in range(3)]
+    lossy = [full[0][:7] + full[0][8:], full[1][:30] + full[1][31:], full[2][1:]]
+    want_full, want_lossy = _expected(full, ntime, nchan, nstand), _expected(lossy, ntime, nchan, nstand)
+    _init(ffi, None, nstand, 2, nchan, ntime, 3)
+    _need_fused(ffi)
+    out = ffi.DeviceBuffer(orc.per_chan(nstand) * nchan * 8)
+    bufs = {}
+
+    def integrate(lists):
+        for g, pk in enumerate(lists):
+            raw, stride = _slab(pk)
+            d = bufs.setdefault(id(pk), ffi.DeviceBuffer(raw.size).upload(raw))
+            ffi.call("xengXgpuKernelAsyncSlab", d.ptr, len(pk), stride, SEQ0 + g * ntime, CHAN0, out.ptr, int(g == 2), None, 0)
+        ffi.call("xengXgpuSync")
+        ns, ni = ctypes.c_int(-1), ctypes.c_int(-1)
+        ffi.call("xengXgpuGetSlabStats", ctypes.byref(ns), ctypes.byref(ni))
+        return out.download(np.int32), ns.value, ni.value
+
+    vis, ns, ni = integrate(full)
+    assert (ns, ni) == (0, 0) and np.array_equal(vis, want_full)
+    seen = []
+    for _ in range(4):                                       # every gulp lossy: scattered at first, then read through the tables
+        vis, ns, ni = integrate(lossy)
+        assert ns + ni == 3 and np.array_equal(vis, want_lossy), (ns, ni)
+        seen.append((ns, ni))
+    assert seen[0] == (3, 0) and seen[-1] == (0, 3), seen
+    for k in range(12):                                      # clean again: regular tables at first, then back to the strides
+        vis, ns, ni = integrate(full)
+        assert (ns, ni) == (0, 0) and np.array_equal(vis, want_full), k
+    vis, ns, ni = integrate(lossy)
+    assert (ns, ni) == (3, 0) and np.array_equal(vis, want_lossy), (ns, ni)
+    ffi.call("xengXgpuDestroy")
+    for b in list(bufs.values()) + [out]:
+        b.free()
 
 
 def test_other_packet_geometries_take_the_scatter(gpu):
@@ -123,10 +242,11 @@ def test_other_packet_geometries_take_the_scatter(gpu):
     nstand, nchan, ntime = 64, 8, 96
     vin = gpu.synth_voltages(ntime, nchan, nstand, "full", seed=2)
     want = orc.xgpu_correlate(vin, nstand, nchan)
-    for kw in (dict(nchan_blocks=2, nstand_per_pkt=32), dict(nchan_blocks=1, nstand_per_pkt=16)):
-        pk = orc.snap2_packets(vin, seq0=SEQ0, sync_time=3, chan0_pipeline=CHAN0, **kw)
-        vis, _, nfb = _run(gpu, [pk], nstand, nchan, ntime)
-        assert nfb == 1 and np.array_equal(vis, want), kw
+    for tables in (None, "1"):
+        for kw in (dict(nchan_blocks=2, nstand_per_pkt=32), dict(nchan_blocks=1, nstand_per_pkt=16)):
+            pk = orc.snap2_packets(vin, seq0=SEQ0, sync_time=3, chan0_pipeline=CHAN0, **kw)
+            vis, _, nfb = _run(gpu, [pk], nstand, nchan, ntime, tables=tables)
+            assert nfb == 1 and np.array_equal(vis, want), (kw, tables)
 
 
 def test_slabs_and_plain_gulps_do_not_mix_inside_an_integration(gpu):
