@@ -727,6 +727,7 @@ __global__ __launch_bounds__(256, 1) void xcorr_fused_kernel(XcorrParams p) {
     constexpr int NLOAD = 2 * KT_STAGE;  // 1 KiB LDS-DMA pieces per wave per stage
 #ifndef XT_EXPERIMENT
 #define XT_EXPERIMENT 0       // timing-only A/B builds of the TAB path (results wrong): 1 no hole flags / fix, 2 no table fetch in the loop, 3 both
+                              // (profiles/r05/slab_tables_ablation.txt: the fetch costs ~3 %, the flags ~1-2 %, everything else nothing)
 #endif
     constexpr int NVM = NLOAD + ((TAB && !(XT_EXPERIMENT & 2)) ? 1 : 0);    // vector-memory operations per wave and stage (TAB: + the table rows)
     constexpr int DEPTH = XF_DEPTH;          // the LDS-DMA of stage S+DEPTH is issued while stage S is contracted
