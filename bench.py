@@ -1222,15 +1222,16 @@ def main():
             nslab = 2 * gulps_per_step
 
             def full_step_packets(n, first, in_place):
-                o = outs3[n % 3]
+                # (CorrAcc as in the leg above and in the CorrAcc block: the spans of a group of KG dumps summed in one pass)
+                o = outs_g[n % len(outs_g)]
                 for g in range(gulps_per_step):
                     slot = gi[0] % nslab
                     if in_place:
-                        ffi.check("slab", sfn(slabs[slot].ptr, npk, stride, slot * NTIME_GULP, 0, o.ptr, int(g == gulps_per_step - 1), acc_pair[n & 1].ptr, 1 if first else 2))
+                        ffi.check("slab", sfn(slabs[slot].ptr, npk, stride, slot * NTIME_GULP, 0, o.ptr, int(g == gulps_per_step - 1), None, 0))
                     else:
                         dst = ring.ptr + slot * gulp_bytes
                         ffi.check("unpack", ufn(slabs[slot].ptr, npk, stride, dst, slot * NTIME_GULP, NTIME_GULP, 0, NCHAN, NINPUT, 1))
-                        ffi.check("kernel", afn(dst, o.ptr, int(g == gulps_per_step - 1), acc_pair[n & 1].ptr, 1 if first else 2))
+                        ffi.check(kern, kfn(dst, o.ptr, int(g == gulps_per_step - 1)))
                     gi[0] += 1
                 for _ in range(2 + (n & 1)):
                     k0 = (2 * bi[0]) % nslab
@@ -1241,28 +1242,89 @@ def main():
                     ffi.check("int", L.xengBeamformIntegrate(dbeam.ptr, dpow.ptr, NS))
                     bi[0] += 1
                 ffi.call("xengXgpuSyncLag", 1)
+                if n >= KG and n % KG == 0:
+                    srcs = SrcArr(*[outs_g[(n - KG + j) % len(outs_g)].ptr for j in range(KG)])
+                    ffi.check("sum", L.xengMapSumI32(acc_long.ptr, srcs, KG, 2 * matlen, int(n > KG)))
+                elif n % KG == 1:
+                    ffi.call("xengMapSync")
             pk = {}
             snap = {}
             for in_place in (False, True):
                 gi[0] = bi[0] = 0
-                for n in range(6):
-                    full_step_packets(n, n < 2, in_place)
+                for n in range(KG, KG + 6):
+                    full_step_packets(n, False, in_place)
                 ffi.call("xengDeviceSynchronize")
                 tf = time.perf_counter()
-                for n in range(6, 6 + nfull):
+                for n in range(2 * KG, 2 * KG + nfull):
                     full_step_packets(n, False, in_place)
                 ffi.call("xengDeviceSynchronize")
                 elp = time.perf_counter() - tf
                 pk["in_place" if in_place else "through_scatter"] = {
                     "ingest_gbps": round(8 * NINPUT * units_per_step_c * nfull / elp / 1e9, 1), "ms_per_integration": round(elp / nfull * 1e3, 4)}
-                snap[in_place] = (outs3[(6 + nfull - 1) % 3].download(np.int32), dbeam.download(np.uint32), dpow.download(np.uint32))
+                snap[in_place] = (outs_g[(2 * KG + nfull - 1) % len(outs_g)].download(np.int32), dbeam.download(np.uint32), dpow.download(np.uint32))
             nfx, nfb = ctypes.c_int(-1), ctypes.c_int(-1)
             ffi.call("xengXgpuGetSlabFallbacks", ctypes.byref(nfx))
             ffi.call("xengBeamformGetSlabFallbacks", ctypes.byref(nfb))
             pk["slabs_scattered_after_all"] = {"corr": int(nfx.value), "beamform": int(nfb.value)}
+            # ... and on a lossy link (round 5): the same ten slabs in arrival order with 1 % of their packets lost (everything behind a
+            # loss one slot early, the slabs shorter).  Both consumers read them where they lie -- the contraction through offset tables,
+            # the beamformer through packet indices -- once the device has told the host that the link is lossy (XENG_SLAB_TABLES=0:
+            # round 4's zero-fill + scatter of every gulp, for both)
+            rsl = np.random.RandomState(23)
+            lossy_slabs = []
+            for b in slabs:
+                cbuf = ffi.DeviceBuffer(b.nbytes)
+                lost = sorted(int(q) for q in rsl.choice(npk - 1, size=npk // 100, replace=False))
+                dstp = srcp = 0
+                for q in lost + [npk]:
+                    if q > srcp:
+                        ffi.call("xengMemcpy", cbuf.ptr + dstp * stride, b.ptr + srcp * stride, (q - srcp) * stride)
+                        dstp += q - srcp
+                    srcp = q + 1
+                lossy_slabs.append((cbuf, dstp))
+
+            def full_step_lossy(n):
+                o = outs_g[n % len(outs_g)]
+                for g in range(gulps_per_step):
+                    slot = gi[0] % nslab
+                    ffi.check("slab", sfn(lossy_slabs[slot][0].ptr, lossy_slabs[slot][1], stride, slot * NTIME_GULP, 0, o.ptr, int(g == gulps_per_step - 1), None, 0))
+                    gi[0] += 1
+                for _ in range(2 + (n & 1)):
+                    k0 = (2 * bi[0]) % nslab
+                    ffi.check("run", bsl(lossy_slabs[k0][0].ptr, lossy_slabs[k0][1], NTIME_GULP, lossy_slabs[k0 + 1][0].ptr, lossy_slabs[k0 + 1][1], stride,
+                                         k0 * NTIME_GULP, 0, dbeam.ptr, dw.ptr, 1))
+                    ffi.check("int", L.xengBeamformIntegrate(dbeam.ptr, dpow.ptr, NS))
+                    bi[0] += 1
+                ffi.call("xengXgpuSyncLag", 1)
+                if n >= KG and n % KG == 0:
+                    srcs = SrcArr(*[outs_g[(n - KG + j) % len(outs_g)].ptr for j in range(KG)])
+                    ffi.check("sum", L.xengMapSumI32(acc_long.ptr, srcs, KG, 2 * matlen, int(n > KG)))
+                elif n % KG == 1:
+                    ffi.call("xengMapSync")
+            gi[0] = bi[0] = 0
+            for n in range(KG, 2 * KG):
+                full_step_lossy(n)
+            ffi.call("xengDeviceSynchronize")
+            st = [ctypes.c_int(-1) for _ in range(4)]
+            ffi.call("xengXgpuGetSlabStats", ctypes.byref(st[0]), ctypes.byref(st[1]))
+            ffi.call("xengBeamformGetSlabStats", ctypes.byref(st[2]), ctypes.byref(st[3]))
+            tf = time.perf_counter()
+            for n in range(2 * KG, 2 * KG + nfull):
+                full_step_lossy(n)
+            ffi.call("xengDeviceSynchronize")
+            elp = time.perf_counter() - tf
+            ffi.call("xengXgpuGetSlabStats", ctypes.byref(st[0]), ctypes.byref(st[1]))
+            ffi.call("xengBeamformGetSlabStats", ctypes.byref(st[2]), ctypes.byref(st[3]))
+            pk["one_percent_lost_arrival_order"] = {
+                "ingest_gbps": round(8 * NINPUT * units_per_step_c * nfull / elp / 1e9, 1), "ms_per_integration": round(elp / nfull * 1e3, 4),
+                "corr": {"gulps_scattered": int(st[0].value), "gulps_through_an_irregular_table": int(st[1].value)},
+                "beamform": {"parts_scattered": int(st[2].value), "parts_through_an_irregular_index": int(st[3].value)},
+                "slab_tables_env": os.environ.get("XENG_SLAB_TABLES", "unset: by the device's hint")}
+            for b, _ in lossy_slabs:
+                b.free()
             pk["in_place_equals_through_scatter"] = {"visibilities": bool(np.array_equal(snap[0][0], snap[1][0])), "beams": bool(np.array_equal(snap[0][1], snap[1][1])),
                                                      "power_sums": bool(np.array_equal(snap[0][2], snap[1][2]))}
-            pk["note"] = ("config 5 with fused CorrAcc, fed from ten device-resident slabs of 5280 SNAP2 packets each: per integration 5 slabs "
+            pk["note"] = ("config 5 (grouped CorrAcc, as above), fed from ten device-resident slabs of 5280 SNAP2 packets each: per integration 5 slabs "
                           "to the correlator and 2.5 slab pairs to the beamformer; in_place = both read the packets where they lie")
             beam["full_xengine_concurrent"]["from_packet_slabs"] = pk
             del snap

@@ -49,6 +49,13 @@ struct BeamContext {
     // (profiles/r04/slab_paths.txt) four short launches in front of a 35 us kernel pair cost 18 us, the same passes on a
     // stream of their own with an event each way 9-12 us, one launch 5 us.
     SlabSite slab_site;
+    // (round 5) on a lossy link the parts are read through packet indices instead (slab.h, SlabIndexPrep; the TAB instantiations of the
+    // int8x3 / bf16x3 kernels): chosen per call like the X-engine's table kernel -- more than a quarter of the parts of the last eight
+    // calls not regular (a counter in pinned memory, read without a wait); XENG_SLAB_TABLES=1 / 0 pins it
+    SlabIndexPrep slab_ix;
+    uint8_t* zero_page = nullptr;       // 64 bytes of zeros: what the rows of a lost packet read
+    int slab_irr_seen = 0, slab_recent_irr[8] = {}, slab_recent_n[8] = {}, slab_recent_pos = 0, slab_force_tables = -1;
+    unsigned long long slab_tab_until = 0;
     int slab_seen = 0;                  // slab_site.fallbacks_host at the last look ...
     unsigned long long nslab_calls = 0, slab_lossy_until = 0;   // ... and until which call the scatter passes are launched as grids
     GulpDesc* gdesc = nullptr;          // [part]
@@ -81,6 +88,9 @@ static int beam_destroy_locked() {
         if (g_b.marks[k]) (void)hipEventDestroy(g_b.marks[k]);
     if (g_b.stamps) (void)hipFree(g_b.stamps);
     slab_site_destroy(&g_b.slab_site);
+    slab_index_prep_destroy(&g_b.slab_ix);
+    if (g_b.zero_page) (void)hipFree(g_b.zero_page);
+    g_b.zero_page = nullptr;
     if (g_b.gdesc) (void)hipFree(g_b.gdesc);
     if (g_b.gargs) (void)hipFree(g_b.gargs);
     if (g_b.slab_scratch) (void)hipFree(g_b.slab_scratch);
@@ -93,8 +103,9 @@ static int beam_destroy_locked() {
 // *fused = false when the caller has to run the voltage mode into its scratch and integrate separately
 // in1 / split: the gulp in two parts (samples [split, ntime) at in1; beamform_kernels.h GulpAddr); one part: in1 null
 // gd: the parts are described on the device (packet slabs; in / in1 unused), split as above
+// tab: (with gd) parts may be named by packet indices: the TAB instantiations
 static int run_locked(const void* in, float* out, const void* w, long long version, float* pow_out = nullptr, int ntime_sum = 0,
-                      bool* fused = nullptr, bool may_wait = true, const void* in1v = nullptr, int split = 0, const GulpDesc* gd = nullptr) {
+                      bool* fused = nullptr, bool may_wait = true, const void* in1v = nullptr, int split = 0, const GulpDesc* gd = nullptr, bool tab = false) {
     BeamContext& x = g_b;
     if (fused) *fused = false;
     const uint8_t* in1 = (const uint8_t*)in1v;
@@ -158,13 +169,15 @@ static int run_locked(const void* in, float* out, const void* w, long long versi
             XENG_HIP(hipMemsetAsync(pow_out, 0, (size_t)(x.nbeam / 2) * (x.ntime / ntime_sum) * x.nchan * 4 * sizeof(float), x.stream));
             *fused = true;
         }
-        hipLaunchKernelGGL(gd ? beamform_i8x3_kernel<true> : beamform_i8x3_kernel<false>, grid, dim3(256), 0, x.stream, (const uint8_t*)in, x.wq, x.wscale, x.wsum, out,
+        hipLaunchKernelGGL(gd ? (tab ? beamform_i8x3_kernel<true, true> : beamform_i8x3_kernel<true>) : beamform_i8x3_kernel<false>, grid, dim3(256), 0, x.stream,
+                           (const uint8_t*)in, x.wq, x.wscale, x.wsum, out,
                            x.ntime, x.nchan, x.ninput, x.nbeam, x.nchunk_i8, x.nbtile, x.route, x.out_n, x.out_idx, x.out_R, x.stamps,
-                           fuse ? pow_out : (float*)nullptr, ntime_sum, in1, split, gd);
+                           fuse ? pow_out : (float*)nullptr, ntime_sum, in1, split, gd, (const uint8_t*)x.zero_page);
         if (x.need_bf16) {
             dim3 grid3(((x.ntime + BF3_NT - 1) / BF3_NT) * x.nchan * x.nbtile);
-            hipLaunchKernelGGL(gd ? beamform_bf16x3_kernel<true> : beamform_bf16x3_kernel<false>, grid3, dim3(64 * BF3_NW), 0, x.stream, (const uint8_t*)in, x.wprep, out,
-                               x.ntime, x.nchan, x.ninput, x.nbeam, x.nchunk, x.nbtile, x.route, in1, split, gd);
+            hipLaunchKernelGGL(gd ? (tab ? beamform_bf16x3_kernel<true, true> : beamform_bf16x3_kernel<true>) : beamform_bf16x3_kernel<false>, grid3, dim3(64 * BF3_NW), 0,
+                               x.stream, (const uint8_t*)in, x.wprep, out,
+                               x.ntime, x.nchan, x.ninput, x.nbeam, x.nchunk, x.nbtile, x.route, in1, split, gd, (const uint8_t*)x.zero_page);
         }
         x.timer.end(x.stream, slot);
     stream_tick(STREAM_BEAM);
@@ -181,8 +194,9 @@ static int run_locked(const void* in, float* out, const void* w, long long versi
     }
     dim3 grid(((x.ntime + BF3_NT - 1) / BF3_NT) * x.nchan * x.nbtile);
     int slot = x.timer.begin(x.stream, 0);
-    hipLaunchKernelGGL(gd ? beamform_bf16x3_kernel<true> : beamform_bf16x3_kernel<false>, grid, dim3(64 * BF3_NW), 0, x.stream, (const uint8_t*)in, x.wprep, out,
-                       x.ntime, x.nchan, x.ninput, x.nbeam, x.nchunk, x.nbtile, (const int*)nullptr, in1, split, gd);
+    hipLaunchKernelGGL(gd ? (tab ? beamform_bf16x3_kernel<true, true> : beamform_bf16x3_kernel<true>) : beamform_bf16x3_kernel<false>, grid, dim3(64 * BF3_NW), 0, x.stream,
+                       (const uint8_t*)in, x.wprep, out,
+                       x.ntime, x.nchan, x.ninput, x.nbeam, x.nchunk, x.nbtile, (const int*)nullptr, in1, split, gd, (const uint8_t*)x.zero_page);
     x.timer.end(x.stream, slot);
     stream_tick(STREAM_BEAM);
     XENG_HIP(hipGetLastError());
@@ -232,6 +246,9 @@ int xengBeamformInitialize(int gpu, int ninput, int nchan, int ntime, int nbeam,
     const char* mode = getenv("XENG_BEAM");
     x.use_f32 = getenv("XENG_BEAM_F32") != nullptr || (mode && !strcmp(mode, "f32")) || (ninput % 16) != 0;
     x.use_i8 = !x.use_f32 && !(mode && !strcmp(mode, "bf16x3"));     // default; XENG_BEAM=bf16x3 | f32 select the others
+    // XENG_SLAB_TABLES=1 / 0: packet slabs always / never through their packet indices (default: by strides until the link loses packets)
+    const char* st = getenv("XENG_SLAB_TABLES");
+    x.slab_force_tables = st ? (strcmp(st, "0") ? 1 : 0) : -1;
     if (x.use_i8) {
         x.nchunk_i8 = (ninput + BI_KC - 1) / BI_KC;
         const size_t qb = (size_t)nchan * x.nbtile * x.nchunk_i8 * BI_WCHUNK;
@@ -280,6 +297,23 @@ int xengBeamformRun(const void* in_dev, void* out_dev, const void* weights_dev) 
     return xengBeamformRunVersioned(in_dev, out_dev, weights_dev, 0);
 }
 
+// ... and (round 5) the parts that were read where they lay although their packets were not all in place, through their index
+int xengBeamformGetSlabStats(int* nscattered, int* nirregular) {
+    std::lock_guard<std::mutex> lk(g_bmu);
+    BeamContext& x = g_b;
+    if (!x.live) XENG_FAIL(XENG_STATUS_INVALID_STATE, "Beamform: not initialized");
+    if (!nscattered || !nirregular) XENG_FAIL(XENG_STATUS_INVALID_ARGUMENT, "GetSlabStats: null pointer");
+    *nscattered = *nirregular = 0;
+    if (!x.slab_site.tally) return XENG_STATUS_SUCCESS;
+    XENG_HIP(hipSetDevice(x.gpu));
+    stream_tick(STREAM_BEAM);
+    if (x.slab_ix.irregular) {
+        XENG_HIP(hipMemcpyAsync(nirregular, x.slab_ix.irregular, sizeof(int), hipMemcpyDeviceToHost, x.stream));
+        XENG_HIP(hipMemsetAsync(x.slab_ix.irregular, 0, sizeof(int), x.stream));
+    }
+    return slab_site_read_fallbacks(x.stream, x.slab_site, nscattered);
+}
+
 static int run_versioned(const void* in_dev, void* out_dev, const void* weights_dev, long long weights_version, bool may_wait,
                          const void* in1_dev = nullptr, int ntime0 = 0);
 
@@ -325,6 +359,13 @@ static int run_slabs(const void* packets0_dev, int npkt0, int ntime0, const void
         XENG_HIP(hipMalloc((void**)&x.gargs, 2 * sizeof(SlabArgs)));
         XENG_HIP(hip_memset_now(x.gargs, 0, 2 * sizeof(SlabArgs)));
         XENG_HIP(hipMalloc((void**)&x.slab_scratch, (size_t)x.ntime * row));
+        if (x.ninput % 64 == 0 && !x.use_f32) {
+            if (int rc = slab_index_prep_create(&x.slab_ix, x.ntime, x.ninput)) return rc;
+            XENG_HIP(hipMalloc((void**)&x.zero_page, 64));
+            XENG_HIP(hip_memset_now(x.zero_page, 0, 64));
+        }
+        x.slab_irr_seen = 0; x.slab_recent_pos = 0; x.slab_tab_until = 0;
+        for (int k = 0; k < 8; k++) x.slab_recent_irr[k] = x.slab_recent_n[k] = 0;
     }
     const int nparts = packets1_dev ? 2 : 1;
     SlabArgs a[2];
@@ -341,13 +382,33 @@ static int run_slabs(const void* packets0_dev, int npkt0, int ntime0, const void
     // scatter passes as grids behind the verify pass instead (two more short launches, 9 us per call; 20 x faster when needed).
     if (const int seen = *(volatile int*)x.slab_site.fallbacks_host; seen != x.slab_seen) { x.slab_seen = seen; x.slab_lossy_until = x.nslab_calls + 64; }
     const bool lossy = x.nslab_calls++ < x.slab_lossy_until;
-    if (int rc = slab_prepare_enqueue(x.stream, x.slab_site, a, maybe, nparts, x.gdesc, x.gargs, scratch, !lossy)) return rc;
+    // (round 5) through the packet indices once more than a quarter of the parts of the last eight calls were not regular (the verify
+    // pass and the index pass both count them in pinned memory); by strides -- round 4's kernels, an irregular part scattered -- below that
+    bool tab = false;
+    if (x.slab_ix.tab[0]) {
+        const int seen = *(volatile int*)x.slab_ix.irregular_host + x.slab_seen;     // (by index: irregular or scattered; by strides: scattered)
+        x.slab_recent_irr[x.slab_recent_pos] = seen - x.slab_irr_seen;
+        x.slab_recent_n[x.slab_recent_pos] = nparts;
+        x.slab_recent_pos = (x.slab_recent_pos + 1) & 7;
+        x.slab_irr_seen = seen;
+        int irr = 0, n = 0;
+        for (int k = 0; k < 8; k++) { irr += x.slab_recent_irr[k]; n += x.slab_recent_n[k]; }
+        // (the beam stream may run many calls behind its enqueuer, so the counts arrive late and in bursts: once over the threshold the
+        // next 64 calls stay on the indices)
+        if (4 * irr > n) x.slab_tab_until = x.nslab_calls + 64;
+        tab = x.slab_force_tables > 0 || (x.slab_force_tables < 0 && x.nslab_calls < x.slab_tab_until);
+    }
+    if (tab) {
+        bool ok[2] = {false, false};
+        for (int k = 0; k < nparts; k++) ok[k] = slab_index_prep_ok(a[k]);
+        if (int rc = slab_index_prepare_enqueue(x.stream, x.slab_site, x.slab_ix, a, ok, nparts, x.gdesc, x.gargs, scratch, !lossy)) return rc;
+    } else if (int rc = slab_prepare_enqueue(x.stream, x.slab_site, a, maybe, nparts, x.gdesc, x.gargs, scratch, !lossy)) return rc;
     if (lossy)
         if (int rc = slab_fallback_enqueue(x.stream, x.gdesc, x.gargs, nparts)) return rc;
     stream_tick(STREAM_BEAM);
-    if (x.ntime_blocks == 0) return run_locked(nullptr, (float*)out_dev, weights_dev, weights_version, nullptr, 0, nullptr, true, nullptr, ntime0, x.gdesc);
+    if (x.ntime_blocks == 0) return run_locked(nullptr, (float*)out_dev, weights_dev, weights_version, nullptr, 0, nullptr, true, nullptr, ntime0, x.gdesc, tab);
     bool fused = false;
-    int rc = run_locked(nullptr, x.scratch, weights_dev, weights_version, (float*)out_dev, x.ntime / x.ntime_blocks, &fused, may_wait, nullptr, ntime0, x.gdesc);
+    int rc = run_locked(nullptr, x.scratch, weights_dev, weights_version, (float*)out_dev, x.ntime / x.ntime_blocks, &fused, may_wait, nullptr, ntime0, x.gdesc, tab);
     if (rc || fused) return rc;
     return integrate_locked(x.scratch, out_dev, x.ntime / x.ntime_blocks, 0, x.nbeam / 2);
 }

@@ -38,16 +38,27 @@ constexpr int BF_NT = 128;                // samples per work-group
 // are per part: sample, channel and 64-input block steps come from the descriptor (scalar loads), and a row of inputs is no
 // longer contiguous: input i sits (i >> 6) * b_stride + (i & 63) bytes into its row (16-byte pieces never straddle a block).
 // The default instantiations compile to the code they were before.
-template <bool DESC>
+// TAB instantiations (round 5, a lossy link): a part may be a slab read through its packet INDEX (descriptor pad 2, slab.h: SlabIndexPrep) --
+// the row of (sample t, block b) lies in the packet whose slot the index names, or nowhere (then: a page of zeros).  For such a part
+// row() returns the address of the sample's index row instead of its data, and piece() turns an entry into an address.
+template <bool DESC, bool TAB = false>
 struct GulpAddr {
     const uint8_t* p[2];
     uint32_t ts[2], cs[2], bs[2];
     int split;
+    uint32_t mode[2];                 // TAB: the descriptors' pad (2: by index)
+    const uint32_t* tab[2];
+    int nblk;
     __device__ __forceinline__ GulpAddr(const uint8_t* in, const uint8_t* in1, int split_, const GulpDesc* __restrict__ gd, int nchan, int ninput) {
         split = split_;
+        nblk = ninput >> 6;
+        mode[0] = mode[1] = 0; tab[0] = tab[1] = nullptr;
         if (DESC) {
 #pragma unroll
-            for (int k = 0; k < 2; k++) { p[k] = gd[k].base; ts[k] = gd[k].t_stride; cs[k] = gd[k].c_stride; bs[k] = gd[k].b_stride; }
+            for (int k = 0; k < 2; k++) {
+                p[k] = gd[k].base; ts[k] = gd[k].t_stride; cs[k] = gd[k].c_stride; bs[k] = gd[k].b_stride;
+                if (TAB) { mode[k] = gd[k].pad; tab[k] = gd[k].table; }
+            }
         } else {
             p[0] = in; p[1] = in1;
             ts[0] = ts[1] = (uint32_t)nchan * (uint32_t)ninput; cs[0] = cs[1] = (uint32_t)ninput; bs[0] = bs[1] = 64;
@@ -59,7 +70,24 @@ struct GulpAddr {
         const uint8_t* base = second ? p[1] : p[0];
         const uint32_t tstr = DESC ? (second ? ts[1] : ts[0]) : ts[0], cstr = DESC ? (second ? cs[1] : cs[0]) : cs[0];
         *bstride = DESC ? (second ? bs[1] : bs[0]) : 64u;
+        if (TAB && (second ? mode[1] : mode[0]) == 2u)      // (the sample's index row: see piece())
+            return reinterpret_cast<const uint8_t*>((second ? tab[1] : tab[0]) + (size_t)(second ? t - split : t) * nblk);
         return base + (size_t)(second ? t - split : t) * tstr + (size_t)c * cstr;
+    }
+    // TAB: is the part that holds sample t read through its index?  (uniform over the 16 rows of an LDS-DMA piece: parts begin on
+    // 16-sample boundaries)
+    __device__ __forceinline__ bool indexed(int t) const { return TAB && (t >= split ? mode[1] : mode[0]) == 2u; }
+    // ... then: the 16 bytes at input i of (sample t, channel c), given the sample's index row (what row() returned) -- in the packet
+    // the entry names if it is of this call's generation, else in the page of zeros
+    __device__ __forceinline__ const uint8_t* piece(const uint8_t* row_, int t, int c, int i, const uint8_t* zeros) const {
+        return piece_from(reinterpret_cast<const uint32_t*>(row_)[i >> 6], t, c, i, zeros);
+    }
+    __device__ __forceinline__ const uint8_t* piece_from(uint32_t e, int t, int c, int i, const uint8_t* zeros) const {
+        const bool second = t >= split;
+        const uint32_t gen = second ? ts[1] : ts[0], stride = second ? bs[1] : bs[0];
+        const uint8_t* base = second ? p[1] : p[0];
+        const bool have = (e >> SLAB_GEN_SHIFT) == gen && (e & SLAB_SLOT_MASK) != 0u;
+        return have ? base + (size_t)((e & SLAB_SLOT_MASK) - 1u) * stride + 32u + (size_t)c * 64u + (size_t)(i & 63) : zeros + (i & 63);
     }
 };
 template <bool DESC>
@@ -256,13 +284,13 @@ __device__ __forceinline__ v8bf as_v8bf(uint32_t a, uint32_t b, uint32_t c, uint
 // bound by how well the staging latency hides, not by MFMA throughput.  So the LDS-DMA runs two chunks
 // ahead on a ring of three 16 KiB stages (counted vmcnt, one barrier per chunk), and three work-groups per
 // CU (48 KiB each) interleave on every SIMD.
-template <bool DESC = false>
+template <bool DESC = false, bool TAB = false>
 __global__ __launch_bounds__(64 * BF3_NW, BF3_NW == 8 ? 2 : 3) void beamform_bf16x3_kernel(const uint8_t* __restrict__ in,
                                                                  const uint8_t* __restrict__ wp,
                                                                  float* __restrict__ out, int ntime, int nchan,
                                                                  int ninput, int nbeam, int nchunk, int nbtile,
                                                                  const int* __restrict__ route, const uint8_t* __restrict__ in1, int split,
-                                                                 const GulpDesc* __restrict__ gd) {
+                                                                 const GulpDesc* __restrict__ gd, const uint8_t* __restrict__ zeros = nullptr) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[BF3_RING * BF3_STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -285,9 +313,12 @@ __global__ __launch_bounds__(64 * BF3_NW, BF3_NW == 8 ? 2 : 3) void beamform_bf1
     // makes the 8-byte fragment reads below bank-conflict-free.  Rows past ntime: any valid row (never stored).
     int xt = t0 + wave * 32 + (lane >> 1);
     if (xt >= ntime) xt = ntime - 1;
-    const GulpAddr<DESC> ga(in, in1, split, gd, nchan, ninput);
+    const GulpAddr<DESC, TAB> ga(in, in1, split, gd, nchan, ninput);
     uint32_t xbstr;
     const uint8_t* xsrc = ga.row(xt, c, &xbstr);
+    // TAB: the part of this wave's rows is read through its index (xsrc: the sample's index row).  The entry is looked up when the
+    // piece is issued -- this kernel only runs the few routed tiles, its staging pipeline is not worth a prefetch register
+    const bool xidx = TAB && __builtin_amdgcn_readfirstlane((int)ga.indexed(xt)) != 0;
     const int xhalf = ((lane & 1) ^ ((lane >> 4) & 1)) * 16;
     // every stage costs exactly BF3_WSLOTS + 1 pieces per wave on the vmcnt counter (chunks past the end re-read
     // the last one; weight slots past the 12th piece re-copy an earlier piece onto itself)
@@ -301,7 +332,7 @@ __global__ __launch_bounds__(64 * BF3_NW, BF3_NW == 8 ? 2 : 3) void beamform_bf1
         }
         int i = cs * BF3_KC + xhalf;
         if (i + 16 > ninput) i = 0;                    // columns past the end meet zero weights
-        lds_dma16(xsrc + gulp_col<DESC>(i, xbstr), l + BF3_WCHUNK + wave * 1024);
+        lds_dma16(xidx ? ga.piece(xsrc, xt, c, i, zeros) : xsrc + gulp_col<DESC>(i, xbstr), l + BF3_WCHUNK + wave * 1024);
     };
     v16f acc_r = (v16f)(0.f), acc_i = (v16f)(0.f);
     issue(0, 0);
@@ -619,7 +650,7 @@ __global__ __launch_bounds__(256) void beam_weights_prep_i8_kernel(const float* 
     }
 }
 
-template <bool DESC = false>
+template <bool DESC = false, bool TAB = false>
 __global__ __launch_bounds__(256, 3) void beamform_i8x3_kernel(const uint8_t* __restrict__ in,
                                                                const uint8_t* __restrict__ wq,
                                                                const float* __restrict__ scale, const int* __restrict__ wsum,
@@ -630,7 +661,7 @@ __global__ __launch_bounds__(256, 3) void beamform_i8x3_kernel(const uint8_t* __
                                                                unsigned long long* __restrict__ stamps,
                                                                float* __restrict__ pow_out, int ntime_sum,
                                                                const uint8_t* __restrict__ in1, int split,
-                                                               const GulpDesc* __restrict__ gd) {
+                                                               const GulpDesc* __restrict__ gd, const uint8_t* __restrict__ zeros = nullptr) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[BI_RING * BI_STAGE];
     const unsigned long long r0 = stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;   // diagnostic (XENG_BEAM_STAMPS=1)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -651,15 +682,29 @@ __global__ __launch_bounds__(256, 3) void beamform_i8x3_kernel(const uint8_t* __
     // X pieces 2*wave, 2*wave+1 of a chunk = samples 32*wave .. +31, 64 B each (16 rows per 1 KiB piece); lane: row
     // lane/4 of the piece, 16-byte position lane&3 holding source piece (lane&3) ^ ((row>>2)&1): the swizzle (on the
     // source side; the LDS side of the DMA is lane-linear) makes the 16-byte operand reads conflict-free at 64-byte pitch
-    const GulpAddr<DESC> ga(in, in1, split, gd, nchan, ninput);
+    const GulpAddr<DESC, TAB> ga(in, in1, split, gd, nchan, ninput);
     const uint8_t* xsrc[BI_XSLOTS];
     uint32_t xbstr[BI_XSLOTS];
+    // TAB: piece n's part is read through its index (xsrc[n]: the sample's index row; a chunk is one 64-input block, i.e. one entry);
+    // the entry of the chunk that the NEXT issue() brings is fetched right after this one's -- it arrives under the MFMAs
+    bool xidx[BI_XSLOTS];
+    int xtt[BI_XSLOTS];
+    uint32_t e_nx[BI_XSLOTS] = {};
 #pragma unroll
     for (int n = 0; n < BI_XSLOTS; n++) {
         int xt = t0 + wave * 32 + n * 16 + (lane >> 2);
         if (xt >= ntime) xt = ntime - 1;
         xsrc[n] = ga.row(xt, c, &xbstr[n]);
+        xtt[n] = xt;
+        xidx[n] = TAB && __builtin_amdgcn_readfirstlane((int)ga.indexed(xt)) != 0;
     }
+    auto load_entries = [&](int ch) {
+        if (!TAB) return;
+        const int cs = ch < nchunk ? ch : nchunk - 1;
+#pragma unroll
+        for (int n = 0; n < BI_XSLOTS; n++)
+            if (xidx[n]) e_nx[n] = reinterpret_cast<const uint32_t*>(xsrc[n])[(cs * BI_KC) >> 6];
+    };
     const int xpiece = ((lane & 3) ^ ((lane >> 4) & 1)) * 16;
     // every stage costs exactly BI_WSLOTS + BI_XSLOTS pieces per wave on the vmcnt counter (chunks past the end
     // re-read the last one; digit slots past the last piece re-copy an earlier piece onto itself)
@@ -675,11 +720,13 @@ __global__ __launch_bounds__(256, 3) void beamform_i8x3_kernel(const uint8_t* __
         for (int n = 0; n < BI_XSLOTS; n++) {
             int i = cs * BI_KC + xpiece;
             if (i + 16 > ninput) i = 0;                // columns past the end meet zero digits
-            lds_dma16(xsrc[n] + gulp_col<DESC>(i, xbstr[n]), l + BI_WCHUNK + (wave * BI_XSLOTS + n) * 1024);
+            lds_dma16(xidx[n] ? ga.piece_from(e_nx[n], xtt[n], c, i, zeros) : xsrc[n] + gulp_col<DESC>(i, xbstr[n]), l + BI_WCHUNK + (wave * BI_XSLOTS + n) * 1024);
         }
     };
+    static_assert(!TAB || BI_KC == 64, "TAB: one chunk = one 64-input block = one index entry");
 #pragma unroll
-    for (int k = 0; k < BI_RING - 1; k++) issue(k, k);          // first: the DMA of the first chunk(s) is the critical path
+    for (int k = 0; k < BI_RING - 1; k++) { load_entries(k); issue(k, k); }          // first: the DMA of the first chunk(s) is the critical path
+    load_entries(BI_RING - 1);
     if (routed) {                                                // (the route flag's load has travelled beside the DMA)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // no LDS-DMA may be in flight when the wave ends
         return;
@@ -708,6 +755,7 @@ __global__ __launch_bounds__(256, 3) void beamform_i8x3_kernel(const uint8_t* __
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"((BI_WSLOTS + BI_XSLOTS) * (BI_RING - 2)) : "memory");
         __builtin_amdgcn_s_barrier();                  // ... for all waves; and everybody is done reading chunk ch-1,
         issue(ch + BI_RING - 1, nbuf);                 // whose buffer the DMA of chunk ch+BI_RING-1 now overwrites
+        load_entries(ch + BI_RING);
         if (stamps && ch == 0) r1 = __builtin_amdgcn_s_memrealtime();
         const v4i_ M = (v4i_)(0xF0F0F0F0);
 #pragma unroll
@@ -751,7 +799,8 @@ __global__ __launch_bounds__(256, 3) void beamform_i8x3_kernel(const uint8_t* __
         const uint8_t* xcol = ga.row(t < ntime ? t : ntime - 1, c, &cbstr);
         const int tile = c * nbtile + bt;
         for (int k = 0; k < n_outl; k++) {
-            const int xb = xcol[gulp_col<DESC>(out_idx[(size_t)tile * BI_TILE_OUT + k], cbstr)];
+            const int oi = out_idx[(size_t)tile * BI_TILE_OUT + k];
+            const int xb = (TAB && ga.indexed(t < ntime ? t : ntime - 1)) ? ga.piece(xcol, t < ntime ? t : ntime - 1, c, oi, zeros)[0] : xcol[gulp_col<DESC>(oi, cbstr)];
             const float xr = (float)(int)__builtin_amdgcn_sbfe(xb, 4, 4), xi = (float)(int)__builtin_amdgcn_sbfe(xb, 0, 4);
             const float2* Rk = out_R + ((size_t)tile * BI_TILE_OUT + k) * 32;
 #pragma unroll

@@ -57,6 +57,26 @@ struct SlabSite {
     int* fallbacks_host = nullptr;           // ... and ever, in pinned host memory: read by the host without a wait (a hint: is the link losing packets?)
 };
 int slab_site_create(SlabSite* s);
+// (round 5) the beamformer on a lossy link: ONE launch per call as before, but instead of "regular or scatter" it enters every packet
+// of the deployed geometry into the part's index -- u32[ntime][nblk], entry = generation << 20 | 1 + the LAST slab index that carries
+// (sample, block); entries of earlier calls carry older generations and read as "nobody carries it", so nothing is cleared per call --
+// and the part's descriptor names that index (pad 2: base = the slab, t_stride = the generation, b_stride = the packet stride): the
+// beamformer kernels' TAB instantiations look every row up there and read it where it lies, or zeros.  Only packets of another geometry
+// still send a part through zero-fill + scatter.
+constexpr uint32_t SLAB_GEN_SHIFT = 20, SLAB_SLOT_MASK = (1u << SLAB_GEN_SHIFT) - 1u, SLAB_GEN_MAX = (1u << (32 - SLAB_GEN_SHIFT)) - 1u;
+struct SlabIndexPrep {
+    uint32_t* tab[2] = {nullptr, nullptr};   // [part][ntime_max * nblk]
+    size_t tab_u32 = 0;
+    uint32_t gen = 0;                        // generation of the last call (1 .. SLAB_GEN_MAX; at the wrap the indices are cleared)
+    int* irregular = nullptr;                // parts read through an index that was not regular, since they were last read
+    int* irregular_host = nullptr;           // ... and ever, in pinned host memory (the host's hint: is the link losing packets?)
+};
+int slab_index_prep_create(SlabIndexPrep* s, int ntime, int ninput);
+void slab_index_prep_destroy(SlabIndexPrep* s);
+// could this part be read through an index?  (whole 64-input blocks, 16-byte pieces, slot numbers below 2^20)
+bool slab_index_prep_ok(const SlabArgs& a);
+int slab_index_prepare_enqueue(hipStream_t stream, const SlabSite& site, SlabIndexPrep& ix, const SlabArgs* a, const bool* ok, int ngulp, GulpDesc* descs,
+                               SlabArgs* args_out, uint8_t* const* scratch, bool inline_fallback);
 void slab_site_destroy(SlabSite* s);
 // could this slab be regular at all?  (whole 64-input blocks, one packet per (sample, block), payload rows of 64 bytes, 16-byte
 // pieces, and 32-bit per-lane offsets that hold `rows` sample rows)

@@ -126,6 +126,82 @@ __global__ __launch_bounds__(256) void slab_prepare_kernel(SlabJob job, unsigned
     slab_scatter_part(a, job.scratch[k], threadIdx.x >> 6, blockDim.x >> 6, threadIdx.x & 63);
 }
 
+// (round 5) the same launch for the beamformer's TAB kernels (slab.h, SlabIndexPrep): every packet of the deployed geometry is entered
+// into the part's index; the wave that takes the last ticket knows whether any valid packet had another geometry (then: the scratch
+// gulp, as above) and whether every (sample, block) sits in its regular slot (statistics and the host's hint only: the kernels follow
+// the index either way).  Tally word: packets in place << 32 | waves that saw another geometry << 16 | ticket.
+struct SlabIndexPrepJob {
+    SlabArgs a[2];
+    uint8_t* scratch[2];
+    int force[2];
+    uint32_t* tab[2];
+    uint32_t gen;
+};
+template <bool INLINE>
+__global__ __launch_bounds__(256) void slab_index_prepare_kernel(SlabIndexPrepJob job, unsigned long long* __restrict__ tallies, int* __restrict__ fallbacks,
+                                                                 int* __restrict__ fallbacks_host, int* __restrict__ irregular, int* __restrict__ irregular_host,
+                                                                 GulpDesc* __restrict__ descs, SlabArgs* __restrict__ args_out) {
+    __shared__ int s_fallback_here;
+    const int k = blockIdx.y;
+    const SlabArgs& a = job.a[k];
+    const int force_scratch = job.force[k];
+    const unsigned int nblocks = force_scratch ? 1u : (unsigned int)((a.npkt + (int)blockDim.x - 1) / (int)blockDim.x);
+    if (blockIdx.x >= nblocks) return;
+    if (INLINE) {
+        if (threadIdx.x == 0) s_fallback_here = 0;
+        __syncthreads();
+    }
+    bool in_place = false, other = false;
+    if (!force_scratch) {
+        const int p = blockIdx.x * blockDim.x + threadIdx.x;
+        if (p < a.npkt) {
+            const SlabHeader h = slab_header(a.pkts + (size_t)p * a.stride, a.chan0);
+            const int payload_max = (int)a.stride - 32;
+            const bool ok = h.seq >= a.seq0 && h.seq - a.seq0 < (unsigned long long)a.ntime && h.npol > 0 && h.nchan > 0 && h.chan0 >= 0 &&
+                            h.chan0 + h.nchan <= a.nchan && h.pol0 + h.npol <= a.ninput && (long long)h.nchan * h.npol <= payload_max;
+            if (ok) {
+                if (h.npol != 64 || h.nchan != a.nchan || h.chan0 != 0 || (h.pol0 & 63) != 0) other = true;
+                else {
+                    const unsigned int home = (unsigned int)(h.seq - a.seq0) * (unsigned int)a.nblk + (unsigned int)(h.pol0 >> 6);
+                    atomicMax(&job.tab[k][home], (job.gen << SLAB_GEN_SHIFT) | ((uint32_t)p + 1u));
+                    in_place = home == (unsigned int)p;
+                }
+            }
+        }
+    }
+    const unsigned long long nin = (unsigned long long)__popcll(__ballot(in_place)), noth = __ballot(other) != 0ull ? 1ull : 0ull;
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned long long nwaves = (unsigned long long)nblocks * (blockDim.x >> 6);
+        const unsigned long long before = atomicAdd(&tallies[k], (nin << 32) | (noth << 16) | 1ull);
+        if ((before & 0xFFFFull) == nwaves - 1) {
+            const bool fb = force_scratch || (((before >> 16) & 0xFFFFull) + noth) != 0;
+            const bool regular = (before >> 32) + nin == (unsigned long long)a.ntime * a.nblk;
+            GulpDesc d;
+            if (fb) {
+                d.base = job.scratch[k]; d.t_stride = (uint32_t)a.nchan * (uint32_t)a.ninput; d.c_stride = (uint32_t)a.ninput; d.b_stride = 64; d.pad = 1u;
+                d.table = nullptr;
+                atomicAdd(fallbacks, 1);
+                __hip_atomic_fetch_add(fallbacks_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            } else {
+                d.base = a.pkts; d.t_stride = job.gen; d.c_stride = 64; d.b_stride = a.stride; d.pad = 2u;
+                d.table = job.tab[k];
+                if (!regular) atomicAdd(irregular, 1);
+            }
+            if (fb || !regular) __hip_atomic_fetch_add(irregular_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            descs[k] = d;
+            args_out[k] = a;
+            tallies[k] = 0;
+            if (INLINE && fb) s_fallback_here = 1;
+        }
+    }
+    if (!INLINE) return;
+    __syncthreads();
+    if (!s_fallback_here) return;
+    slab_clear_part(a, job.scratch[k], threadIdx.x, blockDim.x);
+    __syncthreads();
+    slab_scatter_part(a, job.scratch[k], threadIdx.x >> 6, blockDim.x >> 6, threadIdx.x & 63);
+}
+
 // Once per integration, behind the prepare kernels of its gulps (grid.y = gulp): zero-fill and scatter of the gulps whose
 // descriptor says "scratch"; the groups of every other gulp return at once.
 __global__ __launch_bounds__(256) void slab_clear_kernel(const GulpDesc* __restrict__ desc, const SlabArgs* __restrict__ args) {
@@ -360,6 +436,54 @@ int slab_fallback_enqueue(hipStream_t stream, const GulpDesc* descs, const SlabA
     // (both return at once for every gulp whose descriptor does not say "scratch": small grids, grid-stride loops)
     hipLaunchKernelGGL(slab_clear_kernel, dim3(512, ngulp), dim3(256), 0, stream, descs, args);
     hipLaunchKernelGGL(slab_scatter_kernel, dim3(512, ngulp), dim3(256), 0, stream, descs, args);
+    XENG_HIP(hipGetLastError());
+    return XENG_STATUS_SUCCESS;
+}
+
+int slab_index_prep_create(SlabIndexPrep* s, int ntime, int ninput) {
+    s->tab_u32 = (size_t)ntime * (size_t)(ninput / 64);
+    for (int k = 0; k < 2; k++) {
+        XENG_HIP(hipMalloc((void**)&s->tab[k], s->tab_u32 * 4));
+        XENG_HIP(hip_memset_now(s->tab[k], 0, s->tab_u32 * 4));
+    }
+    XENG_HIP(hipMalloc((void**)&s->irregular, 16));
+    XENG_HIP(hip_memset_now(s->irregular, 0, 16));
+    XENG_HIP(hipHostMalloc((void**)&s->irregular_host, sizeof(int)));
+    *s->irregular_host = 0;
+    s->gen = 0;
+    return XENG_STATUS_SUCCESS;
+}
+
+void slab_index_prep_destroy(SlabIndexPrep* s) {
+    for (int k = 0; k < 2; k++) if (s->tab[k]) (void)hipFree(s->tab[k]);
+    if (s->irregular) (void)hipFree(s->irregular);
+    if (s->irregular_host) (void)hipHostFree(s->irregular_host);
+    *s = SlabIndexPrep();
+}
+
+bool slab_index_prep_ok(const SlabArgs& a) {
+    return a.ninput > 0 && a.ninput % 64 == 0 && a.npkt > 0 && (uint32_t)a.npkt < SLAB_SLOT_MASK && a.stride >= 32 + (size_t)a.nchan * 64 && a.stride % 16 == 0 &&
+           ((uintptr_t)a.pkts & 15) == 0;
+}
+
+int slab_index_prepare_enqueue(hipStream_t stream, const SlabSite& site, SlabIndexPrep& ix, const SlabArgs* a, const bool* ok, int ngulp, GulpDesc* descs,
+                               SlabArgs* args_out, uint8_t* const* scratch, bool inline_fallback) {
+    if (ix.gen >= SLAB_GEN_MAX) {            // the generation wraps: entries of 4095 calls ago must not come back to life
+        for (int k = 0; k < 2; k++) XENG_HIP(hipMemsetAsync(ix.tab[k], 0, ix.tab_u32 * 4, stream));
+        ix.gen = 0;
+    }
+    ix.gen++;
+    SlabIndexPrepJob job;
+    const int bs = 256;
+    unsigned int nblocks = 1;
+    for (int k = 0; k < 2; k++) {
+        const int kk = k < ngulp ? k : 0;
+        job.a[k] = a[kk]; job.scratch[k] = scratch[kk]; job.force[k] = ok[kk] ? 0 : 1; job.tab[k] = ix.tab[k];
+        if (ok[kk]) nblocks = std::max(nblocks, (unsigned int)((a[kk].npkt + bs - 1) / bs));
+    }
+    job.gen = ix.gen;
+    hipLaunchKernelGGL(inline_fallback ? slab_index_prepare_kernel<true> : slab_index_prepare_kernel<false>, dim3(nblocks, ngulp), dim3(bs), 0, stream, job, site.tally,
+                       site.fallbacks, site.fallbacks_host, ix.irregular, ix.irregular_host, descs, args_out);
     XENG_HIP(hipGetLastError());
     return XENG_STATUS_SUCCESS;
 }

@@ -93,6 +93,7 @@ struct XgpuContext {
     int slab_forced = 0;                    // gulps of the legacy path since they were last read (counted on the host: all of them are scattered)
     int slab_hint_seen = 0;                 // slab_index.hint_host at the last look ...
     int slab_recent_irr[8] = {}, slab_recent_n[8] = {}, slab_recent_pos = 0;   // ... what it moved by at each of the last eight launches, and their gulps
+    unsigned long long slab_tables_until = 0;
     int slab_force_tables = -1;             // XENG_SLAB_TABLES=1 / 0: always / never (tests, A/B); unset: by the hint
     bool slab_mode = false;                 // the gulps staged since the last flush are slabs (no mixing inside one flush)
     EventTimer timer;
@@ -269,7 +270,8 @@ static int flush_locked(void* out, bool dump, void* acc = nullptr, int acc_mode 
             x.slab_hint_seen = seen;
             int irr = 0, n = 0;
             for (int k = 0; k < 8; k++) { irr += x.slab_recent_irr[k]; n += x.slab_recent_n[k]; }
-            slab_by_table = x.slab_force_tables > 0 || (x.slab_force_tables < 0 && 4 * irr > n);
+            if (4 * irr > n) x.slab_tables_until = x.nlaunch + 16;      // (a little hysteresis: the counts lag by a launch or two)
+            slab_by_table = x.slab_force_tables > 0 || (x.slab_force_tables < 0 && x.nlaunch < x.slab_tables_until);
         }
         if (int rcs = slab_index_enqueue(x.stream, x.slab_index, x.cur, x.slab_job, slab_by_table, x.gdesc_dev[x.cur], x.gargs_dev[x.cur])) return rcs;
         staging_stream_touched();
@@ -585,7 +587,7 @@ static int initialize_locked(int gpu) {
         // XENG_SLAB_TABLES=1 / 0: packet slabs always / never through their offset tables (default: by strides until a gulp was not regular)
         const char* st = getenv("XENG_SLAB_TABLES");
         x.slab_force_tables = st ? (strcmp(st, "0") ? 1 : 0) : -1;
-        x.slab_hint_seen = 0; x.slab_recent_pos = 0;
+        x.slab_hint_seen = 0; x.slab_recent_pos = 0; x.slab_tables_until = 0;
         for (int k = 0; k < 8; k++) x.slab_recent_irr[k] = x.slab_recent_n[k] = 0;
     }
     x.cap_gulps = cap;

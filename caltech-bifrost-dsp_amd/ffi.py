@@ -83,7 +83,7 @@ SYMBOLS = {
     "xengBeamformInitialize": [_i, _i, _i, _i, _i, _i], "xengBeamformDestroy": [],
     "xengBeamformRun": [_vp, _vp, _vp], "xengBeamformRunVersioned": [_vp, _vp, _vp, ctypes.c_longlong], "xengBeamformTryRunVersioned": [_vp, _vp, _vp, ctypes.c_longlong],
     "xengBeamformRunParts": [_vp, _i, _vp, _vp, _vp, ctypes.c_longlong], "xengBeamformTryRunParts": [_vp, _i, _vp, _vp, _vp, ctypes.c_longlong],
-    "xengBeamformRunSlabs": [_vp, _i, _i, _vp, _i, _sz, ctypes.c_uint64, _i, _vp, _vp, ctypes.c_longlong], "xengBeamformTryRunSlabs": [_vp, _i, _i, _vp, _i, _sz, ctypes.c_uint64, _i, _vp, _vp, ctypes.c_longlong], "xengBeamformGetSlabFallbacks": [_pi],
+    "xengBeamformRunSlabs": [_vp, _i, _i, _vp, _i, _sz, ctypes.c_uint64, _i, _vp, _vp, ctypes.c_longlong], "xengBeamformTryRunSlabs": [_vp, _i, _i, _vp, _i, _sz, ctypes.c_uint64, _i, _vp, _vp, ctypes.c_longlong], "xengBeamformGetSlabFallbacks": [_pi], "xengBeamformGetSlabStats": [_pi, _pi],
     "xengBeamformIntegrate": [_vp, _vp, _i],
     "xengBeamformIntegrateSingleBeam": [_vp, _vp, _i, _i], "xengBeamformMark": [ctypes.POINTER(ctypes.c_ulonglong)], "xengBeamformWait": [ctypes.c_ulonglong], "xengBeamformTicketDone": [ctypes.c_ulonglong, _pi], "xengBeamformSync": [],
     "xengBeamformSetProfiling": [_i], "xengBeamformGetTimes": [ctypes.POINTER(ctypes.c_double), _pi],

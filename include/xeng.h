@@ -374,6 +374,11 @@ int xengBeamformRunSlabs(const void *packets0_dev, int npkt0, int ntime0, const 
 int xengBeamformTryRunSlabs(const void *packets0_dev, int npkt0, int ntime0, const void *packets1_dev, int npkt1, size_t pkt_stride,
                             uint64_t seq0, int chan0_pipeline, void *out_dev, const void *weights_dev, long long weights_version);   /* never waits: see xengBeamformTryRunVersioned */
 int xengBeamformGetSlabFallbacks(int *nfallback);
+/* (round 5) On a lossy link -- more than a quarter of the parts of the last eight calls not regular -- the beamformer reads the parts
+ * where they lie as well, through a packet index built by the verify launch (lost, shifted, reordered, duplicated packets; samples
+ * nobody carries read as zero; the int8 and bf16 kernels, not the fp32 one); XENG_SLAB_TABLES=1 / 0 pins that on / off.
+ * xengBeamformGetSlabStats: parts scattered, and parts read through an index that was not regular, since the last call. */
+int xengBeamformGetSlabStats(int *nscattered, int *nirregular);
 
 /* beamform_sum_beams_block.py:243-246.  in_dev cf32[nchan][nbeam][ntime];
  * out_dev f32[nbeam/2][ntime/ntime_sum][nchan][4] = [XX, YY, Re XY*, Im XY*]. */

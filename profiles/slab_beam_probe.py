@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Diagnostic (round 4): the beamformer pair (Beamform 960 samples + power sums, config 4 shape) on plain gulps, on packed packet
 slabs (stride 6176), on slabs whose payloads start on 128-byte lines (stride 6272) and on slabs with two packets out of order (the
-slow path: both parts scattered by one work-group each), alone on the GPU.
+slow path: both parts scattered by one work-group each), and (round 5) on slabs in arrival order with 1 % of the packets lost
+(everything behind a loss one slot early, the slab shorter), alone on the GPU.  XENG_SLAB_TABLES=1 / 0: through the packet indices /
+by strides + scatter.
 usage: slab_beam_probe.py [rounds] [gulps per round]"""
 import os
 import struct
@@ -43,6 +45,17 @@ for k in range(10):
     a = np.zeros(LEAD_A + npk * STRIDE_A, dtype=np.uint8)
     a[LEAD_A:].reshape(npk, STRIDE_A)[:, :stride] = slab
     slabs_a.append(ffi.DeviceBuffer(a.nbytes).upload(a))
+slabs_lossy = []
+for k, b in enumerate(slabs):
+    c = ffi.DeviceBuffer(npk * stride)
+    lost = sorted(int(p) for p in rs.choice(npk - 1, size=npk // 100, replace=False))
+    dst = src = 0
+    for p in lost + [npk]:
+        if p > src:
+            ffi.call("xengMemcpy", c.ptr + dst * stride, b.ptr + src * stride, (p - src) * stride)
+            dst += p - src
+        src = p + 1
+    slabs_lossy.append((c, dst))
 gulp = NT * NCHAN * NINPUT
 ring = ffi.DeviceBuffer(10 * gulp)
 for k in range(10):
@@ -64,6 +77,9 @@ def run(mode, n):
             ffi.check("r", L.xengBeamformRunVersioned(ring.ptr + k0 * gulp, dbeam.ptr, dw.ptr, 1))
         elif mode == "irregular":
             ffi.check("r", L.xengBeamformRunSlabs(slabs_irr[k0].ptr, npk, NT, slabs_irr[k0 + 1].ptr, npk, stride, k0 * NT, 0, dbeam.ptr, dw.ptr, 1))
+        elif mode == "lossy":
+            (b0, n0), (b1, n1) = slabs_lossy[k0], slabs_lossy[k0 + 1]
+            ffi.check("r", L.xengBeamformRunSlabs(b0.ptr, n0, NT, b1.ptr, n1, stride, k0 * NT, 0, dbeam.ptr, dw.ptr, 1))
         elif mode == "packed":
             ffi.check("r", L.xengBeamformRunSlabs(slabs[k0].ptr, npk, NT, slabs[k0 + 1].ptr, npk, stride, k0 * NT, 0, dbeam.ptr, dw.ptr, 1))
         else:
@@ -75,7 +91,7 @@ def run(mode, n):
 
 res = {}
 for r in range(rounds):
-    for mode in ("plain", "packed", "aligned", "irregular"):
+    for mode in ("plain", "packed", "aligned", "lossy", "irregular"):
         res.setdefault(mode, []).append(run(mode, ngulp if mode != "irregular" else max(10, ngulp // 10)))
 for mode, v in res.items():
     v = sorted(v)

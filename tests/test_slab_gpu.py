@@ -226,7 +226,7 @@ def test_the_contraction_follows_the_tables_on_a_lossy_link(gpu):
         assert ns + ni == 3 and np.array_equal(vis, want_lossy), (ns, ni)
         seen.append((ns, ni))
     assert seen[0] == (3, 0) and seen[-1] == (0, 3), seen
-    for k in range(12):                                      # clean again: regular tables at first, then back to the strides
+    for k in range(30):                                      # clean again: regular tables at first, then back to the strides
         vis, ns, ni = integrate(full)
         assert (ns, ni) == (0, 0) and np.array_equal(vis, want_full), k
     vis, ns, ni = integrate(lossy)
@@ -319,18 +319,21 @@ def test_streaming_slabs_with_alternating_outputs(gpu):
 
 # ---- the beamformer on packet slabs (xengBeamformRunSlabs) ----
 
-def _beam_init(ffi, mode, ninput, nchan, ntime, nbeam, ntime_blocks=0):
+def _beam_init(ffi, mode, ninput, nchan, ntime, nbeam, ntime_blocks=0, tables=None):
+    """tables: XENG_SLAB_TABLES for this context ("1": the parts are read through their packet indices from the first call on)"""
     import os
-    old = os.environ.get("XENG_BEAM")
+    old = {k: os.environ.pop(k, None) for k in ("XENG_BEAM", "XENG_SLAB_TABLES")}
     if mode:
         os.environ["XENG_BEAM"] = mode
+    if tables is not None:
+        os.environ["XENG_SLAB_TABLES"] = tables
     try:
         ffi.call("xengBeamformInitialize", 0, ninput, nchan, ntime, nbeam, ntime_blocks)
     finally:
-        if mode:
-            os.environ.pop("XENG_BEAM")
-            if old is not None:
-                os.environ["XENG_BEAM"] = old
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
 
 
 def _beam_weights(rng, nchan, nbeam, ninput):
@@ -340,9 +343,10 @@ def _beam_weights(rng, nchan, nbeam, ninput):
     return w
 
 
+@pytest.mark.parametrize("tables", [None, "1"])
 @pytest.mark.parametrize("mode", ["", "bf16x3", "f32"])
 @pytest.mark.parametrize("nstand,nchan,ntime,nbeam,ntime0", [(352, 96, 960, 32, 480), (96, 8, 256, 32, 64), (64, 5, 192, 6, 0)])
-def test_beamformer_reads_regular_slabs_in_place(gpu, mode, nstand, nchan, ntime, nbeam, ntime0):
+def test_beamformer_reads_regular_slabs_in_place(gpu, mode, nstand, nchan, ntime, nbeam, ntime0, tables):
     """one or two regular slabs as a beamformer gulp: no part takes the scatter, and the beams are BIT-IDENTICAL to
     xengBeamformRun on the unpacked gulp (the same kernels do the arithmetic; only the addresses differ) -- on all three
     kernel routes, with outlier inputs and routed tiles in play"""
@@ -351,7 +355,7 @@ def test_beamformer_reads_regular_slabs_in_place(gpu, mode, nstand, nchan, ntime
     rng = np.random.default_rng(nstand + ntime0)
     vin = gpu.synth_voltages(ntime, nchan, nstand, "full", seed=ntime + nchan)
     w = _beam_weights(rng, nchan, nbeam, ninput)
-    _beam_init(ffi, mode, ninput, nchan, ntime, nbeam)
+    _beam_init(ffi, mode, ninput, nchan, ntime, nbeam, tables=tables)
     mk = lambda lo, hi: _slab(orc.snap2_packets(vin[lo:hi], seq0=SEQ0 + lo, sync_time=1, nchan_blocks=1, nstand_per_pkt=32, chan0_pipeline=CHAN0))
     parts = [mk(0, ntime0), mk(ntime0, ntime)] if ntime0 else [mk(0, ntime)]
     stride = parts[0][1]
@@ -367,26 +371,28 @@ def test_beamformer_reads_regular_slabs_in_place(gpu, mode, nstand, nchan, ntime
     else:
         ffi.call("xengBeamformRunSlabs", bufs[0].ptr, parts[0][0].size // stride, ntime, None, 0, stride, SEQ0, CHAN0, o2.ptr, dw.ptr, 1)
     ffi.call("xengBeamformSync")
-    nfb = ctypes.c_int(-1)
-    ffi.call("xengBeamformGetSlabFallbacks", ctypes.byref(nfb))
-    assert nfb.value == 0
+    nfb, nir = ctypes.c_int(-1), ctypes.c_int(-1)
+    ffi.call("xengBeamformGetSlabStats", ctypes.byref(nfb), ctypes.byref(nir))
+    assert nfb.value == 0 and nir.value == 0
     assert np.array_equal(o1.download(np.uint32), o2.download(np.uint32))
     ffi.call("xengBeamformDestroy")
     for d in bufs + [dfull, dw, o1, o2]:
         d.free()
 
 
-@pytest.mark.parametrize("mode", ["", "f32"])
-def test_beamformer_irregular_slabs_give_the_unpacked_result(gpu, mode):
+@pytest.mark.parametrize("mode,tables", [("", None), ("f32", None), ("", "1"), ("bf16x3", "1"), ("f32", "1")])
+def test_beamformer_irregular_slabs_give_the_unpacked_result(gpu, mode, tables):
     """a regular first part and a second part with lost, reordered and foreign packets; then both parts irregular: the beams
-    equal xengBeamformRun on what snap2_unpack makes of the packets (missing samples zero), bit for bit"""
+    equal xengBeamformRun on what snap2_unpack makes of the packets (missing samples zero), bit for bit -- scattered first (a link that
+    has been clean; always with the fp32 kernel) or, through the packet indices (round 5), read where they lie"""
     ffi = gpu.ffi
     nstand, nchan, ntime, nbeam, ntime0 = 96, 8, 256, 32, 128
     ninput = nstand * 2
     rng = np.random.default_rng(77)
     vin = gpu.synth_voltages(ntime, nchan, nstand, "full", seed=5)
     w = _beam_weights(rng, nchan, nbeam, ninput)
-    _beam_init(ffi, mode, ninput, nchan, ntime, nbeam)
+    _beam_init(ffi, mode, ninput, nchan, ntime, nbeam, tables=tables)
+    by_index = tables == "1" and mode != "f32"
     mk = lambda lo, hi: orc.snap2_packets(vin[lo:hi], seq0=SEQ0 + lo, sync_time=1, nchan_blocks=1, nstand_per_pkt=32, chan0_pipeline=CHAN0)
     p0, p1 = mk(0, ntime0), mk(ntime0, ntime)
     bad1 = [p1[i] for i in rng.permutation(len(p1))]
@@ -407,9 +413,9 @@ def test_beamformer_irregular_slabs_give_the_unpacked_result(gpu, mode):
         ffi.call("xengBeamformRunVersioned", dfull.ptr, o1.ptr, dw.ptr, 1)
         ffi.call("xengBeamformRunSlabs", d0.ptr, r0.size // stride, ntime0, d1.ptr, r1.size // stride, stride, SEQ0, CHAN0, o2.ptr, dw.ptr, 1)
         ffi.call("xengBeamformSync")
-        nfb = ctypes.c_int(-1)
-        ffi.call("xengBeamformGetSlabFallbacks", ctypes.byref(nfb))
-        assert nfb.value == nexp
+        nfb, nir = ctypes.c_int(-1), ctypes.c_int(-1)
+        ffi.call("xengBeamformGetSlabStats", ctypes.byref(nfb), ctypes.byref(nir))
+        assert (nfb.value, nir.value) == ((0, nexp) if by_index else (nexp, 0))
         assert np.array_equal(o1.download(np.uint32), o2.download(np.uint32)), nexp
         for d in (dfull, d0, d1):
             d.free()
@@ -418,6 +424,51 @@ def test_beamformer_irregular_slabs_give_the_unpacked_result(gpu, mode):
     ffi.call("xengBeamformDestroy")
     for d in (dw, o1, o2):
         d.free()
+
+
+def test_beamformer_shifted_and_lossy_parts_through_the_indices(gpu):
+    """what a lossy link leaves (round 5): part 0 in arrival order with 2 % of its packets lost (everything behind a loss one slot
+    early, the slab shorter), part 1 with a whole sample, a whole 64-input block and an outlier input's packets missing and one sample
+    carried twice with different payloads (the later wins) -- read where they lie through the packet indices, bit-identical to
+    xengBeamformRun on what snap2_unpack makes of them; then the default context: scattered at first, by index from the second call on"""
+    ffi = gpu.ffi
+    nstand, nchan, ntime, nbeam, ntime0 = 96, 8, 256, 32, 128
+    ninput, nblk = nstand * 2, nstand * 2 // 64
+    rng = np.random.default_rng(8)
+    vin = gpu.synth_voltages(ntime, nchan, nstand, "full", seed=15)
+    w = _beam_weights(rng, nchan, nbeam, ninput)
+    mk = lambda lo, hi, v=vin: orc.snap2_packets(v[lo:hi], seq0=SEQ0 + lo, sync_time=1, nchan_blocks=1, nstand_per_pkt=32, chan0_pipeline=CHAN0)
+    p0, p1 = mk(0, ntime0), mk(ntime0, ntime)
+    lost = set(rng.choice(len(p0), size=len(p0) // 50, replace=False).tolist())
+    q0 = [pk for i, pk in enumerate(p0) if i not in lost]
+    other = mk(ntime0, ntime, vin[::-1])
+    q1 = [pk for i, pk in enumerate(p1) if i // nblk != 5 and i % nblk != 0]
+    q1[3] = other[40 * nblk + 1]                             # an early copy of (sample 40, block 1) that loses ...
+    q1.append(other[50 * nblk + 2])                          # ... and a late one of (sample 50, block 2) that wins
+    g0, _, _ = orc.snap2_unpack(q0, SEQ0, ntime0, CHAN0, nchan, ninput)
+    g1, _, _ = orc.snap2_unpack(q1, SEQ0 + ntime0, ntime - ntime0, CHAN0, nchan, ninput)
+    unpacked = np.concatenate([g0, g1])
+    (r0, stride), (r1, _) = _slab(q0), _slab(q1)
+    for mode, tables in (("", "1"), ("bf16x3", "1"), ("", None)):
+        _beam_init(ffi, mode, ninput, nchan, ntime, nbeam, tables=tables)
+        dfull = ffi.DeviceBuffer(unpacked.size).upload(unpacked.reshape(-1))
+        d0, d1 = ffi.DeviceBuffer(r0.size).upload(r0), ffi.DeviceBuffer(r1.size).upload(r1)
+        dw = ffi.DeviceBuffer(w.nbytes).upload(w)
+        o1, o2 = ffi.DeviceBuffer(nchan * nbeam * ntime * 8), ffi.DeviceBuffer(nchan * nbeam * ntime * 8)
+        ffi.call("xengBeamformRunVersioned", dfull.ptr, o1.ptr, dw.ptr, 1)
+        seen = []
+        for call in range(3):
+            ffi.call("xengMemset", o2.ptr, 0x5A, o2.nbytes)
+            ffi.call("xengBeamformRunSlabs", d0.ptr, r0.size // stride, ntime0, d1.ptr, r1.size // stride, stride, SEQ0, CHAN0, o2.ptr, dw.ptr, 1)
+            ffi.call("xengBeamformSync")
+            nfb, nir = ctypes.c_int(-1), ctypes.c_int(-1)
+            ffi.call("xengBeamformGetSlabStats", ctypes.byref(nfb), ctypes.byref(nir))
+            seen.append((nfb.value, nir.value))
+            assert np.array_equal(o1.download(np.uint32), o2.download(np.uint32)), (mode, tables, call)
+        assert seen == ([(0, 2)] * 3 if tables else [(2, 0), (0, 2), (0, 2)]), (mode, tables, seen)
+        ffi.call("xengBeamformDestroy")
+        for d in (dfull, d0, d1, dw, o1, o2):
+            d.free()
 
 
 def test_beamformer_slabs_in_the_integrated_power_mode(gpu):
