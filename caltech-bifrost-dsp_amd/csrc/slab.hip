@@ -2,6 +2,7 @@
 #include "slab.h"
 
 #include <algorithm>
+#include <stdlib.h>
 #include <vector>
 
 #include "xeng_common.h"
@@ -451,6 +452,8 @@ int slab_index_prep_create(SlabIndexPrep* s, int ntime, int ninput) {
     XENG_HIP(hipHostMalloc((void**)&s->irregular_host, sizeof(int)));
     *s->irregular_host = 0;
     s->gen = 0;
+    // (test hook: start near the wrap of the 12-bit generation, 4095 calls away otherwise -- tests/test_slab_gpu.py)
+    if (const char* g0 = getenv("XENG_SLAB_GEN0")) s->gen = (uint32_t)std::min<long>(std::max<long>(atol(g0), 0), (long)SLAB_GEN_MAX);
     return XENG_STATUS_SUCCESS;
 }
 

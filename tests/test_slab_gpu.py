@@ -471,6 +471,49 @@ def test_beamformer_shifted_and_lossy_parts_through_the_indices(gpu):
             d.free()
 
 
+def test_beamformer_index_generations_wrap(gpu):
+    """the packet indices are never cleared per call: an entry is valid only if it carries the call's 12-bit generation.  At the
+    wrap the indices are cleared, so that an entry written 4095 calls ago does not come back to life.  Started three calls before
+    the wrap (test hook XENG_SLAB_GEN0), alternating a part with (sample 9, block 1) present and the same part without it:
+    the lost row must read as zero on every call, also on the calls right after the wrap."""
+    import os
+    ffi = gpu.ffi
+    nstand, nchan, ntime, nbeam = 96, 8, 128, 32
+    ninput, nblk = nstand * 2, nstand * 2 // 64
+    rng = np.random.default_rng(12)
+    vin = gpu.synth_voltages(ntime, nchan, nstand, "full", seed=19)
+    w = _beam_weights(rng, nchan, nbeam, ninput)
+    full = orc.snap2_packets(vin, seq0=SEQ0, sync_time=1, nchan_blocks=1, nstand_per_pkt=32, chan0_pipeline=CHAN0)
+    holed = [pk for i, pk in enumerate(full) if i != 9 * nblk + 1]
+    os.environ["XENG_SLAB_GEN0"] = str(4095 - 3)
+    try:
+        _beam_init(ffi, "", ninput, nchan, ntime, nbeam, tables="1")
+        dw = ffi.DeviceBuffer(w.nbytes).upload(w)
+        o1, o2 = ffi.DeviceBuffer(nchan * nbeam * ntime * 8), ffi.DeviceBuffer(nchan * nbeam * ntime * 8)
+        wants, bufs = {}, {}
+        for name, pk in (("full", full), ("holed", holed)):
+            g, _, _ = orc.snap2_unpack(pk, SEQ0, ntime, CHAN0, nchan, ninput)
+            d = ffi.DeviceBuffer(g.size).upload(g.reshape(-1))
+            ffi.call("xengBeamformRunVersioned", d.ptr, o1.ptr, dw.ptr, 1)
+            ffi.call("xengBeamformSync")
+            wants[name] = o1.download(np.uint32)
+            raw, stride = _slab(pk)
+            bufs[name] = (ffi.DeviceBuffer(raw.size).upload(raw), len(pk), stride)
+            d.free()
+        assert not np.array_equal(wants["full"], wants["holed"])
+        for call in range(8):                                 # generations 4093, 4094, 4095, (wrap) 1, 2, ...
+            name = "full" if call % 2 == 0 else "holed"
+            d, npk, stride = bufs[name]
+            ffi.call("xengBeamformRunSlabs", d.ptr, npk, ntime, None, 0, stride, SEQ0, CHAN0, o2.ptr, dw.ptr, 1)
+            ffi.call("xengBeamformSync")
+            assert np.array_equal(o2.download(np.uint32), wants[name]), (call, name)
+    finally:
+        os.environ.pop("XENG_SLAB_GEN0", None)
+    ffi.call("xengBeamformDestroy")
+    for b in [dw, o1, o2] + [v[0] for v in bufs.values()]:
+        b.free()
+
+
 def test_beamformer_slabs_in_the_integrated_power_mode(gpu):
     """ntime_blocks > 0 (power sums formed in the kernel's epilogue): slabs give the same words as the unpacked gulp"""
     ffi = gpu.ffi
