@@ -30,6 +30,8 @@ def _load_soak():
     ({"XENG_BEAM": "f32"}, 60),         # fp32 MFMA beamformer
     ({"XENG_TILING": "64"}, 60),        # the 64x64-tile tiling of the fused kernel (17 groups, 7-vs-6 items)
     ({"XENG_KLOOP": "16"}, 60),         # the eight-wave 16x16x64 contraction kernel (round 5, opt-in)
+    ({"XENG_SLAB_TABLES": "1"}, 60),    # packet slabs through offset tables / packet indices from the first launch (round 5)
+    ({"XENG_SLAB_TABLES": "0"}, 60),    # ... and never (round 4's zero-fill + scatter of every irregular slab)
     ({"XENG_RAW": "0"}, 60),            # two-pass X-engine (corner turn + xcorr_mfma_kernel)
 ])
 def test_results_do_not_depend_on_concurrency(env, rounds):
