@@ -50,8 +50,8 @@ struct BeamContext {
     // stream of their own with an event each way 9-12 us, one launch 5 us.
     SlabSite slab_site;
     // (round 5) on a lossy link the parts are read through packet indices instead (slab.h, SlabIndexPrep; the TAB instantiations of the
-    // int8x3 / bf16x3 kernels): chosen per call like the X-engine's table kernel -- more than a quarter of the parts of the last eight
-    // calls not regular (a counter in pinned memory, read without a wait); XENG_SLAB_TABLES=1 / 0 pins it
+    // int8x3 / bf16x3 kernels): chosen per call by a counter in pinned memory, read without a wait -- any part of the last eight calls
+    // not regular, then 64 calls of hysteresis; XENG_SLAB_TABLES=1 / 0 pins it
     SlabIndexPrep slab_ix;
     uint8_t* zero_page = nullptr;       // 64 bytes of zeros: what the rows of a lost packet read
     int slab_irr_seen = 0, slab_recent_irr[8] = {}, slab_recent_n[8] = {}, slab_recent_pos = 0, slab_force_tables = -1;
@@ -382,8 +382,8 @@ static int run_slabs(const void* packets0_dev, int npkt0, int ntime0, const void
     // scatter passes as grids behind the verify pass instead (two more short launches, 9 us per call; 20 x faster when needed).
     if (const int seen = *(volatile int*)x.slab_site.fallbacks_host; seen != x.slab_seen) { x.slab_seen = seen; x.slab_lossy_until = x.nslab_calls + 64; }
     const bool lossy = x.nslab_calls++ < x.slab_lossy_until;
-    // (round 5) through the packet indices once more than a quarter of the parts of the last eight calls were not regular (the verify
-    // pass and the index pass both count them in pinned memory); by strides -- round 4's kernels, an irregular part scattered -- below that
+    // (round 5) through the packet indices once a part of the last eight calls was not regular (the verify pass and the index pass both
+    // count them in pinned memory); by strides -- round 4's kernels, an irregular part scattered -- on a clean link
     bool tab = false;
     if (x.slab_ix.tab[0]) {
         const int seen = *(volatile int*)x.slab_ix.irregular_host + x.slab_seen;     // (by index: irregular or scattered; by strides: scattered)
@@ -395,7 +395,9 @@ static int run_slabs(const void* packets0_dev, int npkt0, int ntime0, const void
         for (int k = 0; k < 8; k++) { irr += x.slab_recent_irr[k]; n += x.slab_recent_n[k]; }
         // (the beam stream may run many calls behind its enqueuer, so the counts arrive late and in bursts: once over the threshold the
         // next 64 calls stay on the indices)
-        if (4 * irr > n) x.slab_tab_until = x.nslab_calls + 64;
+        // (by index a regular part costs 3 % more than by strides, a scattered part 40 %: any irregular part among the last eight calls
+        // is enough)
+        if (irr > 0 && n > 0) x.slab_tab_until = x.nslab_calls + 64;
         tab = x.slab_force_tables > 0 || (x.slab_force_tables < 0 && x.nslab_calls < x.slab_tab_until);
     }
     if (tab) {

@@ -698,12 +698,19 @@ __global__ __launch_bounds__(256, 3) void beamform_i8x3_kernel(const uint8_t* __
         xtt[n] = xt;
         xidx[n] = TAB && __builtin_amdgcn_readfirstlane((int)ga.indexed(xt)) != 0;
     }
+    // (from inline asm, like the LDS-DMA: a load the compiler knows about gets `s_waitcnt vmcnt(0)` in front of the next one -- it
+    // cannot count the asm LDS-DMA pieces in between -- and that wait would sit between a chunk's pieces and its MFMAs.  The register
+    // is tied in and out, so the value lives in one register from the load to the kernel's own vmcnt(0) at the top of the next chunk,
+    // which is what makes it valid; nothing reads it before.)
     auto load_entries = [&](int ch) {
         if (!TAB) return;
         const int cs = ch < nchunk ? ch : nchunk - 1;
 #pragma unroll
         for (int n = 0; n < BI_XSLOTS; n++)
-            if (xidx[n]) e_nx[n] = reinterpret_cast<const uint32_t*>(xsrc[n])[(cs * BI_KC) >> 6];
+            if (xidx[n]) {
+                const uint32_t* ep = reinterpret_cast<const uint32_t*>(xsrc[n]) + ((cs * BI_KC) >> 6);
+                asm volatile("global_load_dword %0, %1, off" : "+v"(e_nx[n]) : "v"(ep) : "memory");
+            }
     };
     const int xpiece = ((lane & 3) ^ ((lane >> 4) & 1)) * 16;
     // every stage costs exactly BI_WSLOTS + BI_XSLOTS pieces per wave on the vmcnt counter (chunks past the end
@@ -723,9 +730,13 @@ __global__ __launch_bounds__(256, 3) void beamform_i8x3_kernel(const uint8_t* __
             lds_dma16(xidx[n] ? ga.piece_from(e_nx[n], xtt[n], c, i, zeros) : xsrc[n] + gulp_col<DESC>(i, xbstr[n]), l + BI_WCHUNK + (wave * BI_XSLOTS + n) * 1024);
         }
     };
-    static_assert(!TAB || BI_KC == 64, "TAB: one chunk = one 64-input block = one index entry");
+    static_assert(!TAB || (BI_KC == 64 && BI_RING == 2), "TAB: one chunk = one 64-input block = one index entry; the entry fetched behind a chunk's pieces is "
+                                                          "covered by the vmcnt(0) at the top of the next chunk (ring of two stages)");
 #pragma unroll
-    for (int k = 0; k < BI_RING - 1; k++) { load_entries(k); issue(k, k); }          // first: the DMA of the first chunk(s) is the critical path
+    for (int k = 0; k < BI_RING - 1; k++) {          // first: the DMA of the first chunk(s) is the critical path
+        if (TAB) { load_entries(k); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        issue(k, k);
+    }
     load_entries(BI_RING - 1);
     if (routed) {                                                // (the route flag's load has travelled beside the DMA)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // no LDS-DMA may be in flight when the wave ends

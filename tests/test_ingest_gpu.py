@@ -240,12 +240,13 @@ def test_ingest_leaves_slabs_and_corr_and_beamform_read_them_in_place():
         exp = orc.beamform_integrate(beams, ntime_sum)
         got = sp.view(np.float32).reshape(exp.shape)
         assert np.max(np.abs(got - exp)) <= 2e-5 * np.sqrt(np.mean(exp[..., :2] ** 2)), k
-    nfx, nix, nfb = ctypes.c_int(-1), ctypes.c_int(-1), ctypes.c_int(-1)
+    nfx, nix, nfb, nib = ctypes.c_int(-1), ctypes.c_int(-1), ctypes.c_int(-1), ctypes.c_int(-1)
     ffi.call("xengXgpuGetSlabStats", ctypes.byref(nfx), ctypes.byref(nix))
-    ffi.call("xengBeamformGetSlabFallbacks", ctypes.byref(nfb))
-    # windows 2 and 5 are irregular: the beamformer scatters them; the X-engine scatters the first and, once its host side has seen
-    # the device's hint, reads the next in place through its offset table (round 5); the other six are read in place by both
-    assert nfx.value + nix.value == 2 and nfx.value >= 1 and nfb.value == 2
+    ffi.call("xengBeamformGetSlabStats", ctypes.byref(nfb), ctypes.byref(nib))
+    # windows 2 and 5 are irregular: each consumer scatters the first and, if its host side has seen the device's hint by then, reads
+    # the next where it lies -- through an offset table (X-engine) / a packet index (beamformer), round 5; the other six are read in
+    # place by both
+    assert nfx.value + nix.value == 2 and nfx.value >= 1 and nfb.value + nib.value == 2 and nfb.value >= 1
 
 
 def test_stamp_seq_rewrites_the_sequence_numbers_only():

@@ -403,6 +403,7 @@ def test_beamformer_irregular_slabs_give_the_unpacked_result(gpu, mode, tables):
     bad0[11] = bad0[12]
     dw = ffi.DeviceBuffer(w.nbytes).upload(w)
     o1, o2 = ffi.DeviceBuffer(nchan * nbeam * ntime * 8), ffi.DeviceBuffer(nchan * nbeam * ntime * 8)
+    ncall = 0
     for first, second, nexp in ((p0, bad1, 1), (bad0, bad1, 2), (p0, p1, 0)):       # (the last: the scratch gulp of earlier calls is not read)
         g0, _, _ = orc.snap2_unpack(first, SEQ0, ntime0, CHAN0, nchan, ninput)
         g1, _, _ = orc.snap2_unpack(second, SEQ0 + ntime0, ntime - ntime0, CHAN0, nchan, ninput)
@@ -415,7 +416,10 @@ def test_beamformer_irregular_slabs_give_the_unpacked_result(gpu, mode, tables):
         ffi.call("xengBeamformSync")
         nfb, nir = ctypes.c_int(-1), ctypes.c_int(-1)
         ffi.call("xengBeamformGetSlabStats", ctypes.byref(nfb), ctypes.byref(nir))
-        assert (nfb.value, nir.value) == ((0, nexp) if by_index else (nexp, 0))
+        # (the shipped default goes over to the indices once a part was not regular: the first call scatters, the later ones do not)
+        index_now = by_index or (tables is None and mode != "f32" and ncall > 0)
+        assert (nfb.value, nir.value) == ((0, nexp) if index_now else (nexp, 0)), (ncall, nfb.value, nir.value)
+        ncall += 1
         assert np.array_equal(o1.download(np.uint32), o2.download(np.uint32)), nexp
         for d in (dfull, d0, d1):
             d.free()
