@@ -1418,7 +1418,7 @@ def main():
     # taken from are the ones this library was built from, else traffic is null)
     traffic = traffic_slabs = None
     import hashlib
-    for rnd in ("r04", "r03"):                     # (the latest PMC pass whose X-engine sources are the ones this library was built from)
+    for rnd in ("r05", "r04", "r03"):              # (the latest PMC pass whose X-engine sources are the ones this library was built from)
         try:
             with open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")) as fh:
                 pmc = json.load(fh)

@@ -7,7 +7,7 @@ out = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        k = row["Kernel_Name"].split("(")[0][-40:]
+        k = row["Kernel_Name"].split("(")[0][-56:]
         a = agg[k][row["Counter_Name"]]
         a[0] += float(row["Counter_Value"]); a[1] += 1
 with open(out + "/summary.txt", "w") as fh:
@@ -27,10 +27,11 @@ res = {"xcorr_sources_sha256": h.hexdigest(), "xcorr_sources": srcs,
        "correction": "FETCH_SIZE x2 (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md HBM section); "
                      "WRITE_SIZE exact for 16-B-per-lane stores; separate --pmc passes (profiles/pmc_run.sh)"}
 for k, d in agg.items():
-    if "xcorr_" in k and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
-        if "fused_kernel<" in k:      # template arguments <ABL, LACC, DESC>: long accumulation in the epilogue; gulps by descriptor (packet slabs)
+    if ("xcorr_" in k or "fused_kernel<" in k) and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+        if "fused_kernel<" in k:      # template arguments <ABL, LACC, DESC, TAB>: long accumulation in the epilogue; gulps by descriptor (packet slabs); through offset tables
             targs = [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")]
-            name = "xcorr_fused_kernel" + ("_lacc" if targs[1] == "true" else "") + ("_slabs" if len(targs) > 2 and targs[2] == "true" else "")
+            name = ("xcorr_fused_kernel" + ("_lacc" if targs[1] == "true" else "") + ("_slabs" if len(targs) > 2 and targs[2] == "true" else "") +
+                    ("_tables" if len(targs) > 3 and targs[3] == "true" else ""))
         else:
             name = k.strip()
         f, w = d["FETCH_SIZE"][0] / d["FETCH_SIZE"][1], d["WRITE_SIZE"][0] / d["WRITE_SIZE"][1]
