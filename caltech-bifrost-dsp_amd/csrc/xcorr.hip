@@ -751,8 +751,9 @@ int xengXgpuTryKernelAsyncAcc(const void* in_dev, void* out_dev, int doDump, voi
 
 int xengXgpuWaitLaunchSlot(void) { return wait_for_event_slot(true); }
 
-// A gulp handed over as the slab of packets it arrived in (slab.h): verified on the device; read in place by the
-// contraction when it is regular, scattered into the library's staging area (and read from there) when it is not.
+// A gulp handed over as the slab of packets it arrived in (slab.h).  Nothing is launched here: the slabs of an integration are indexed
+// on the device when the integration is flushed (slab_index_enqueue) and read where they lie -- by strides, or through their offset
+// tables -- or, holding packets of another geometry, scattered into the library's staging area and read from there.
 static int kernel_slab(const void* packets_dev, int npkt, size_t pkt_stride, uint64_t seq0, int chan0_pipeline, void* out_dev,
                        int doDump, void* acc_dev, int acc_mode, bool may_block) {
     int rc0 = wait_for_event_slot(may_block);

@@ -249,6 +249,20 @@ def test_other_packet_geometries_take_the_scatter(gpu):
             assert nfb == 1 and np.array_equal(vis, want), (kw, tables)
 
 
+def test_input_counts_that_are_not_whole_64_input_blocks_are_scattered(gpu):
+    """80 inputs (16 inputs per packet): the table kernel reads whole 64-input blocks, so every slab is scattered and the plain kernel
+    contracts the copies -- same visibilities"""
+    nstand, nchan, ntime = 40, 8, 96
+    vin = gpu.synth_voltages(2 * ntime, nchan, nstand, "full", seed=4)
+    want = orc.xgpu_correlate(vin, nstand, nchan)
+    for tables in (None, "1"):
+        pk = [orc.snap2_packets(vin[g * ntime:(g + 1) * ntime], seq0=SEQ0 + g * ntime, sync_time=3, nchan_blocks=1, nstand_per_pkt=8, chan0_pipeline=CHAN0)
+              for g in range(2)]
+        pk[1] = pk[1][::-1]
+        vis, _, nfb = _run(gpu, pk, nstand, nchan, ntime, tables=tables)
+        assert nfb == 2 and _run.irregular == 0 and np.array_equal(vis, want), tables
+
+
 def test_slabs_and_plain_gulps_do_not_mix_inside_an_integration(gpu):
     ffi = gpu.ffi
     nstand, nchan, ntime = 64, 4, 96
