@@ -116,7 +116,10 @@ def config5_check(verify, first_int, gulps):
     return chk
 
 
-def corr_block_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=100):
+def corr_block_leg(ffi, ring, gulp_bytes, ring_gulps, gpu, nint=400, nwarm=600):
+    # (nwarm: the output ring grows its pool of 191 MB span buffers during the first few hundred integrations -- every allocation is a
+    # 3 ms hole in the kernel trace, profiles/r05/trace_corr_block.txt; with 100 warm-up integrations they fell into the timed window and
+    # the leg read 10 % above the C-ABI loop, which it equals in steady state)
     """Corr.main on in-repo 'cuda' rings at config-2 size.  The source publishes the replay ring's gulps as spans without
     copying them (WriteSequence.commit_external); the sink discards the visibility spans."""
     import json as _json
