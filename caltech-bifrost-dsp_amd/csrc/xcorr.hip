@@ -171,9 +171,10 @@ static void launch_xcorr(const XcorrParams& p, hipStream_t s, bool raw, int grid
         }
 #endif
         // the eight-wave 16x16x64 kernel (xcorr_fused16.h) for gulps by pointer without a long accumulator; the four-wave kernel otherwise
-        // (round 5: also for gulps by descriptor -- the offset tables are laid out for the four-wave kernel's pieces)
-        if (kloop16 && !p.acc2_mode && !p.gdesc) {
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused16_kernel<0>), grid, dim3(512), 0, s, p);
+        // (round 5: and for gulps through their offset tables -- those are laid out for the four-wave kernel's pieces)
+        if (kloop16 && !p.acc2_mode && !(p.gdesc && p.by_table)) {
+            if (p.gdesc) hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused16_kernel<0, true>), grid, dim3(512), 0, s, p);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(xcorr_fused16_kernel<0>), grid, dim3(512), 0, s, p);
             return;
         }
         if (p.gdesc && p.by_table) {          // gulps by descriptor, every one through its offset table (packet slabs on a lossy link)
