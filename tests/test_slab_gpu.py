@@ -249,6 +249,38 @@ def test_other_packet_geometries_take_the_scatter(gpu):
             assert nfb == 1 and np.array_equal(vis, want), (kw, tables)
 
 
+@pytest.mark.parametrize("tables", [None, "1"])
+def test_an_integration_longer_than_the_staging_depth_on_lossy_slabs(gpu, tables):
+    """five slabs per integration with room for two in the library: the contraction runs after the second and the fourth slab (partial
+    sums read-modify-written in `out`) and at the dump -- every launch with its own tables / descriptors, regular and lossy slabs mixed"""
+    ffi = gpu.ffi
+    nstand, nchan, ntime, ng = 96, 8, 96, 5
+    vin = gpu.synth_voltages(ng * ntime, nchan, nstand, "full", seed=41)
+    lists = [_mk(gpu, vin, g, ntime) for g in range(ng)]
+    lists[1] = lists[1][:11] + lists[1][12:]
+    lists[2] = lists[2][::-1]
+    lists[4] = lists[4][:50] + lists[4][53:] + [lists[4][0]]
+    want = _expected(lists, ntime, nchan, nstand)
+    _init(ffi, tables, nstand, 2, nchan, ntime, 2)
+    _need_fused(ffi)
+    out = ffi.DeviceBuffer(orc.per_chan(nstand) * nchan * 8)
+    ffi.call("xengMemset", out.ptr, 0x5A, out.nbytes)
+    bufs = []
+    for g, pk in enumerate(lists):
+        raw, stride = _slab(pk)
+        d = ffi.DeviceBuffer(raw.size).upload(raw)
+        bufs.append(d)
+        ffi.call("xengXgpuKernelAsyncSlab", d.ptr, len(pk), stride, SEQ0 + g * ntime, CHAN0, out.ptr, int(g == ng - 1), None, 0)
+    ffi.call("xengXgpuSync")
+    ns, ni = ctypes.c_int(-1), ctypes.c_int(-1)
+    ffi.call("xengXgpuGetSlabStats", ctypes.byref(ns), ctypes.byref(ni))
+    assert ns.value + ni.value == 3 and (ns.value == 0 if tables else ns.value >= 1)
+    assert np.array_equal(out.download(np.int32), want)
+    ffi.call("xengXgpuDestroy")
+    for b in bufs + [out]:
+        b.free()
+
+
 def test_input_counts_that_are_not_whole_64_input_blocks_are_scattered(gpu):
     """80 inputs (16 inputs per packet): the table kernel reads whole 64-input blocks, so every slab is scattered and the plain kernel
     contracts the copies -- same visibilities"""
