@@ -36,6 +36,16 @@ int fast_num_threads(void) {
 #endif
 }
 
+/* threads of the following calls (bench.py picks the count that is fastest on the host it runs on: a container's CPU quota can be far
+ * below the number of cores it sees) */
+void fast_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 /* 2: AVX-512 VNNI, 1: AVX-512 BW, 0: plain C */
 int fast_isa(void) {
 #if FAST_AVX512 && defined(__AVX512VNNI__)

@@ -168,6 +168,8 @@ def fast_lib():
         L.fast_xgpu_correlate.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         L.fast_xgpu_correlate.restype = ctypes.c_int
         L.fast_num_threads.restype = ctypes.c_int
+        L.fast_set_threads.argtypes = [ctypes.c_int]
+        L.fast_set_threads.restype = None
         L.fast_isa.restype = ctypes.c_int
         _FAST = L
     return _FAST
