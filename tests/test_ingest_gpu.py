@@ -184,8 +184,10 @@ def test_ingest_corr_on_device_rings():
     assert ing.stats['packets_placed'] == len(pk) and ing.stats['missing_frac'] == 0.0
 
 
-def test_ingest_leaves_slabs_and_corr_and_beamform_read_them_in_place():
-    """pinned packet slabs -> Snap2Ingest(unpack=False): one H2D per slab, nothing else -> a device ring of SLABS -> Corr
+@pytest.mark.parametrize("tables", [None, "1"])
+def test_ingest_leaves_slabs_and_corr_and_beamform_read_them_in_place(tables, monkeypatch):
+    """(tables "1": XENG_SLAB_TABLES=1 -- both consumers follow their offset tables / packet indices from the first launch on.)
+    pinned packet slabs -> Snap2Ingest(unpack=False): one H2D per slab, nothing else -> a device ring of SLABS -> Corr
     (xengXgpuKernelAsyncSlab, with a CorrAcc fed from its dumps) and Beamform (xengBeamformRunSlabs, two slabs per gulp) ->
     BeamformSumBeams.  Regular windows are read where they lie; one window arrives in another order and one has lost a packet
     (scattered on the device).  Every product equals the oracle on what was received."""
@@ -195,6 +197,10 @@ def test_ingest_leaves_slabs_and_corr_and_beamform_read_them_in_place():
     from caltech_bifrost_dsp_amd.blocks import Beamform, BeamformSumBeams, CorrAcc
     if os.environ.get("XENG_RAW") == "0":
         pytest.skip("packet slabs need the fused contraction kernel (the two-pass X-engine refuses them)")
+    if tables is not None:
+        monkeypatch.setenv("XENG_SLAB_TABLES", tables)
+    else:
+        monkeypatch.delenv("XENG_SLAB_TABLES", raising=False)
     T, C, S, g, acc, nbeam, ntime_sum = 768, 8, 64, 96, 192, 32, 16           # (gulps of 96 samples: the fused contraction kernel)
     ninput = S * 2
     rng = np.random.default_rng(14)
@@ -246,7 +252,10 @@ def test_ingest_leaves_slabs_and_corr_and_beamform_read_them_in_place():
     # windows 2 and 5 are irregular: each consumer scatters the first and, if its host side has seen the device's hint by then, reads
     # the next where it lies -- through an offset table (X-engine) / a packet index (beamformer), round 5; the other six are read in
     # place by both
-    assert nfx.value + nix.value == 2 and nfx.value >= 1 and nfb.value + nib.value == 2 and nfb.value >= 1
+    if tables == "1":
+        assert (nfx.value, nix.value, nfb.value, nib.value) == (0, 2, 0, 2)
+    else:
+        assert nfx.value + nix.value == 2 and nfx.value >= 1 and nfb.value + nib.value == 2 and nfb.value >= 1
 
 
 def test_stamp_seq_rewrites_the_sequence_numbers_only():
