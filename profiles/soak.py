@@ -264,8 +264,8 @@ def soak(N=1500, packets=None, log=print):
         log("  slabs not regular: correlator %d scattered + %d through a table (expected %d in all); beamformer %d scattered + %d through an index (expected %d in all)"
             % (nfx.value, nix.value, want[0], nfb.value, nib.value, want[1]))
         bad = int(nfx.value + nix.value != want[0]) + int(nfb.value + nib.value != want[1])
-        if forced == "1":
-            bad += int(nfx.value != 0) + int(nfb.value != 0)
+        if forced == "1":          # (the fp32 beamformer kernel has no index path: its irregular parts are scattered whatever the switch says)
+            bad += int(nfx.value != 0) + int(nfb.value != 0 and os.environ.get("XENG_BEAM") != "f32" and not os.environ.get("XENG_BEAM_F32"))
         elif forced == "0":
             bad += int(nix.value != 0) + int(nib.value != 0)
         else:
